@@ -1,0 +1,53 @@
+"""Tiny configurations shared by the golden generator and the tests (kept in sync with
+tests/golden/make_golden.py::TINY; the state-dict checksum stored in each fixture guards drift)."""
+import json
+import os
+
+import numpy as np
+
+from oracle import teo_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+TINY_STD = 0.08
+
+TINY = {
+    "tinyA": dict(
+        vit=dict(hidden_size=64, num_attention_heads=4, intermediate_size=128, num_hidden_layers=3,
+                 hidden_act="quick_gelu"),
+        llm=dict(hidden_size=64, num_attention_heads=4, num_key_value_heads=2, intermediate_size=128,
+                 num_hidden_layers=2, vocab_size=300),
+    ),
+    "tinyB": dict(
+        vit=dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=3,
+                 hidden_act="gelu"),
+        llm=dict(hidden_size=256, num_attention_heads=2, num_key_value_heads=2, intermediate_size=512,
+                 num_hidden_layers=2, vocab_size=512),
+    ),
+}
+
+
+def cfgs(name):
+    t = TINY[name]
+    v = O.VitCfg(**t["vit"])
+    l = O.LlamaCfg(**t["llm"])
+    mm = O.MMCfg(mm_hidden_size=v.hidden_size)
+    return v, l, mm
+
+
+def state_dict(name, dtype=None):
+    import torch
+    v, l, mm = cfgs(name)
+    return O.make_state_dict(v, l, mm, seed=2, std=TINY_STD, dtype=dtype or torch.float32)
+
+
+def sd_checksum(sd):
+    return float(sum(v.double().abs().sum() for v in sd.values()))
+
+
+def load_npz(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def load_json(name):
+    return json.load(open(os.path.join(GOLDEN, name + ".json")))

@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REFERENCE ITSELF (build container only).
+
+Usage:  python tests/golden/make_golden.py          (writes tests/golden/*.npz / *.json)
+
+The reference (/root/reference, read-only) is imported unmodified through tests/golden/ref_import.py
+and executed on CPU with tiny seeded configurations.  Only inputs/outputs (data) are stored; weights
+are re-derived from seeds by oracle.teo_oracle.make_state_dict and guarded by a checksum.
+The arithmetic underneath the reference here is transformers 5.15.0 (pin is 4.31.0; not installable).
+
+Fixtures (SURVEY.md section 8c list):
+  host.json        G1 prompts + G2 tokenizer_image_token ids (through the reference's run_inference_single)
+                   G8 KeywordsStoppingCriteria truth table
+  splice.json      G3 prepare_inputs_labels_for_multimodal index plans / masks / positions / labels
+  tinyA.npz/tinyB.npz  G4 ViT features, G5 projector, G6 LLaMA prefill+decode, G7 end-to-end logits
+"""
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_import  # noqa: E402
+from oracle import teo_oracle as O  # noqa: E402
+from teochat_amd.tokenizer_stub import ByteTokenizer  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+TINY = {
+    # generic dims (exercise the shape-agnostic kernels); GQA; quick_gelu
+    "tinyA": dict(
+        vit=dict(hidden_size=64, num_attention_heads=4, intermediate_size=128, num_hidden_layers=3,
+                 hidden_act="quick_gelu"),
+        llm=dict(hidden_size=64, num_attention_heads=4, num_key_value_heads=2, intermediate_size=128,
+                 num_hidden_layers=2, vocab_size=300),
+    ),
+    # MFMA-friendly dims (head_dim 64 / 128 like the real model); MHA; gelu
+    "tinyB": dict(
+        vit=dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=3,
+                 hidden_act="gelu"),
+        llm=dict(hidden_size=256, num_attention_heads=2, num_key_value_heads=2, intermediate_size=512,
+                 num_hidden_layers=2, vocab_size=512),
+    ),
+}
+
+
+TINY_STD = 0.08   # large enough that attention is peaked and greedy tokens vary at tiny dims
+
+
+def cfgs(name):
+    t = TINY[name]
+    v = O.VitCfg(**t["vit"])
+    l = O.LlamaCfg(**t["llm"])
+    mm = O.MMCfg(mm_hidden_size=v.hidden_size)
+    return v, l, mm
+
+
+def sd_checksum(sd):
+    return float(sum(v.double().abs().sum() for v in sd.values()))
+
+
+# ----------------------------------------------------------------------------------------------
+# reference model assembly
+# ----------------------------------------------------------------------------------------------
+def ref_tower_class():
+    """Compile the reference's LanguageBindImageTower class body from its own source file without
+    running that file's top-level imports (they pull in video/audio deps that are absent here)."""
+    path = os.path.join(ref_import.REF_ROOT, "videollava/model/multimodal_encoder/languagebind/__init__.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LanguageBindImageTower"][0]
+    mod = ast.Module(body=[node], type_ignores=[])
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["LanguageBindImageTower"]
+
+
+def build_reference(name):
+    ref_import.install()
+    LL = ref_import.import_llava_llama()
+    from videollava.model.multimodal_encoder.languagebind.image import modeling_image as MI
+    from videollava.model.multimodal_encoder.languagebind.image import configuration_image as CI
+    import videollava.model.multimodal_encoder.builder as EB
+
+    vcfg, lcfg, mm = cfgs(name)
+    Tower = ref_tower_class()
+
+    def factory(cfg):
+        t = Tower.__new__(Tower)
+        torch.nn.Module.__init__(t)
+        t.is_loaded = True
+        t.image_tower_name = "stub/LanguageBind_Image"
+        t.select_layer = cfg.mm_vision_select_layer
+        t.select_feature = getattr(cfg, "mm_vision_select_feature", "patch")
+        vc = CI.CLIPVisionConfig(hidden_size=vcfg.hidden_size, intermediate_size=vcfg.intermediate_size,
+                                 num_hidden_layers=vcfg.num_hidden_layers,
+                                 num_attention_heads=vcfg.num_attention_heads, image_size=vcfg.image_size,
+                                 patch_size=vcfg.patch_size, hidden_act=vcfg.hidden_act,
+                                 layer_norm_eps=vcfg.layer_norm_eps, add_time_attn=False, lora_r=0)
+        vc._attn_implementation = "eager"
+        t.image_tower = MI.CLIPVisionTransformer(vc)
+        return t
+
+    EB._tower_factory = factory
+    cfg = LL.LlavaConfig(hidden_size=lcfg.hidden_size, intermediate_size=lcfg.intermediate_size,
+                         num_hidden_layers=lcfg.num_hidden_layers, num_attention_heads=lcfg.num_attention_heads,
+                         num_key_value_heads=lcfg.num_key_value_heads, vocab_size=lcfg.vocab_size,
+                         rms_norm_eps=lcfg.rms_norm_eps, max_position_embeddings=4096,
+                         rope_theta=lcfg.rope_theta, attention_bias=False, tie_word_embeddings=False)
+    cfg.pretraining_tp = 1
+    cfg.mm_image_tower = "stub/LanguageBind_Image"
+    cfg.mm_hidden_size = mm.mm_hidden_size
+    cfg.mm_projector_type = mm.mm_projector_type
+    cfg.mm_vision_select_layer = mm.mm_vision_select_layer
+    cfg.mm_vision_select_feature = mm.mm_vision_select_feature
+    cfg._attn_implementation = "eager"
+    model = LL.LlavaLlamaForCausalLM(cfg)
+    model.eval()
+    sd = O.make_state_dict(vcfg, lcfg, mm, seed=2, std=TINY_STD)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    bad = [k for k in missing if "post_layernorm" not in k and "inv_freq" not in k and "position_ids" not in k]
+    assert not bad, bad
+    return model, sd, (vcfg, lcfg, mm)
+
+
+# ----------------------------------------------------------------------------------------------
+# G1/G2/G8: host-side fixtures through the reference's own run_inference_single
+# ----------------------------------------------------------------------------------------------
+class _RecTok(ByteTokenizer):
+    def __init__(self, add_bos=True):
+        super().__init__(add_bos)
+        self.calls = []
+
+    def __call__(self, text, **kw):
+        self.calls.append(text)
+        return super().__call__(text, **kw)
+
+
+class _FakeProc:
+    def preprocess(self, path, return_tensors=None):
+        return {"pixel_values": [torch.zeros(3, 2, 2)]}
+
+
+class _FakeModel:
+    device = torch.device("cpu")
+
+    def __init__(self, reply_ids):
+        self.reply_ids = reply_ids
+        self.seen = None
+
+    def generate(self, input_ids=None, images=None, **kw):
+        self.seen = dict(input_ids=input_ids.clone(), n_images=len(images), kw={k: v for k, v in kw.items()
+                                                                               if k != "stopping_criteria"})
+        return torch.cat([input_ids, torch.tensor([self.reply_ids], dtype=torch.long)], dim=1)
+
+
+def gen_host():
+    ref_import.install()
+    import videollava.eval.inference as INF
+    import videollava.mm_utils as MU
+
+    out = {"run_inference_single": [], "tokenizer_image_token": [], "stopping": []}
+    reply = ByteTokenizer(add_bos=False)("Two new buildings.</s>").input_ids
+    cases = []
+    for T in (1, 2, 8, 16):
+        for strat in (None, "interleave"):
+            for chrono in (True, False):
+                cases.append(dict(inp="<video>\nThese images were taken at times: 2016, 2018. What changed?",
+                                  T=T, strategy=strat, chrono=chrono, timestamps=[]))
+    cases.append(dict(inp="<video>\nDescribe.", T=3, strategy="interleave", chrono=True,
+                      timestamps=["2020-05-01", "2018-01-31", "2019-07-04"]))
+    cases.append(dict(inp="No frames token here.", T=0, strategy="interleave", chrono=True, timestamps=[]))
+    for c in cases:
+        tok = _RecTok()
+        fm = _FakeModel(reply)
+        paths = ["frame_%d.png" % i for i in range(c["T"])]
+        text = INF.run_inference_single(fm, _FakeProc(), tok, c["inp"], paths, conv_mode="v1",
+                                        timestamps=list(c["timestamps"]), prompt_strategy=c["strategy"],
+                                        chronological_prefix=c["chrono"], temperature=0.2, max_new_tokens=16)
+        n_chunks = c["inp"].count("<video>") * max(c["T"], 0) + 1 if "<video>" in c["inp"] else 1
+        rec = dict(c)
+        rec["prompt_chunks"] = tok.calls[:n_chunks]
+        rec["input_ids"] = fm.seen["input_ids"][0].tolist()
+        rec["n_images"] = fm.seen["n_images"]
+        rec["generate_kwargs"] = {k: (v if not torch.is_tensor(v) else v.tolist()) for k, v in fm.seen["kw"].items()}
+        rec["output_text"] = text
+        out["run_inference_single"].append(rec)
+
+    # G2 edge cases straight into tokenizer_image_token
+    edge = ["<image>", "<image><image>", "a<image>", "<image>a", "a<image><image>b<image>", "", "plain text",
+            "x<image>y<image>z", "Image 1: <image>Image 2: <image> end"]
+    for add_bos in (True, False):
+        for p in edge:
+            tok = ByteTokenizer(add_bos=add_bos)
+            ids = MU.tokenizer_image_token(p, tok, -200, return_tensors=None)
+            out["tokenizer_image_token"].append(dict(prompt=p, add_bos=add_bos, ids=list(map(int, ids))))
+
+    # G8 stopping criterion
+    tok = ByteTokenizer()
+    base = tok("USER: hi ASSISTANT:").input_ids
+    ok = ByteTokenizer(add_bos=False)
+    tails = ["", "a", "ab</s>", "</s>", "abc</s>d", "hello", "</s></s>", "x</", "</s"]
+    for kw in (["</s>"], ["###"], ["</s>", "END"]):
+        for tl in tails + ["##", "###", "a###b", "EN", "END"]:
+            ids = torch.tensor([base + ok(tl).input_ids], dtype=torch.long)
+            crit = MU.KeywordsStoppingCriteria(kw, tok, torch.tensor([base]))
+            res = bool(crit(ids, None))
+            out["stopping"].append(dict(keywords=kw, prompt_len=len(base), row=ids[0].tolist(), stop=res))
+    # batch semantics: all() over rows
+    crit = MU.KeywordsStoppingCriteria(["</s>"], tok, torch.tensor([base]))
+    rows = torch.tensor([base + ok("ab</s>").input_ids, base + ok("abc").input_ids])
+    out["stopping_batch"] = dict(keywords=["</s>"], prompt_len=len(base), rows=rows.tolist(),
+                                 stop=bool(crit(rows, None)))
+    json.dump(out, open(os.path.join(HERE, "host.json"), "w"), indent=0)
+    print("host.json", len(out["run_inference_single"]), len(out["tokenizer_image_token"]), len(out["stopping"]))
+
+
+# ----------------------------------------------------------------------------------------------
+# G3: splice index plans (integer work -> bit exact)
+# ----------------------------------------------------------------------------------------------
+def gen_splice():
+    model, sd, (vcfg, lcfg, mm) = build_reference("tinyA")
+    V, D = lcfg.vocab_size, lcfg.hidden_size
+    NV = 5      # visual rows per image for the coded encoder
+    # coded tables: embed row v -> value v ; feature (img i, row j) -> -(1000*i + j + 1)
+    with torch.no_grad():
+        model.model.embed_tokens.weight.copy_(torch.arange(V, dtype=torch.float32).view(V, 1).expand(V, D))
+
+    def coded_encode(images_minibatch):
+        n = images_minibatch.shape[0]
+        f = torch.zeros(n, NV, D)
+        for i in range(n):
+            for j in range(NV):
+                f[i, j] = -(1000 * i + j + 1)
+        return f
+
+    model.encode_images = coded_encode
+    IMG = -200
+    cases = {
+        "single_T2": dict(ids=[[1, 10, IMG, 11, 12, IMG, 13]], n_images=2),
+        "lead_trail": dict(ids=[[IMG, 10, 11, IMG]], n_images=2),
+        "adjacent": dict(ids=[[1, IMG, IMG, IMG, 7]], n_images=3),
+        "batch_unequal": dict(ids=[[1, 10, IMG, 11, 0, 0, 0], [1, IMG, 20, IMG, 21, IMG, 22]], n_images=4,
+                              mask=[[1, 1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1]]),
+        "batch_zero_image": dict(ids=[[1, 30, 31, 32], [1, IMG, 40, 41]], n_images=2),
+        "truncate": dict(ids=[[1, 10, IMG, 11, 12, IMG, 13, 14]], n_images=2, max_len=9),
+        "left_pad": dict(ids=[[1, 10, IMG, 11], [1, IMG, 20, IMG]], n_images=3, padding_side="left"),
+        "labels": dict(ids=[[1, 10, IMG, 11, 12]], n_images=1, labels=[[-100, -100, -100, 11, 12]]),
+        "labels_batch_mask": dict(ids=[[1, IMG, 11, 12, 0], [1, 5, IMG, 6, 7]], n_images=2,
+                                  mask=[[1, 1, 1, 1, 0], [1, 1, 1, 1, 1]],
+                                  labels=[[-100, -100, 11, 12, -100], [-100, -100, -100, 6, 7]],
+                                  pos=True),
+    }
+    out = {"NV": NV}
+    for name, c in cases.items():
+        model.config.tokenizer_model_max_length = c.get("max_len")
+        model.config.tokenizer_padding_side = c.get("padding_side", "right")
+        ids = torch.tensor(c["ids"], dtype=torch.long)
+        mask = torch.tensor(c["mask"], dtype=torch.long) if "mask" in c else None
+        labels = torch.tensor(c["labels"], dtype=torch.long) if "labels" in c else None
+        pos = torch.arange(ids.shape[1]).unsqueeze(0).expand(ids.shape[0], -1).clone() if c.get("pos") else None
+        images = [torch.zeros(3, 224, 224) for _ in range(c["n_images"])]
+        r = model.prepare_inputs_labels_for_multimodal(ids.clone(), pos, mask, None, labels, images)
+        assert r[0] is None
+        emb = r[4]
+        code = emb[:, :, 0].round().long()
+        assert torch.equal(emb, emb[:, :, :1].expand_as(emb))
+        rec = dict(c)
+        rec["plan"] = code.tolist()           # >=0: vocab id (0 may be a pad row); <0: -(1000*img + row + 1)
+        rec["embeds_is_zero_row"] = (emb.abs().sum(-1) == 0).tolist()
+        rec["position_ids"] = None if r[1] is None else r[1].tolist()
+        rec["attention_mask"] = None if r[2] is None else r[2].long().tolist()
+        rec["attention_mask_dtype"] = None if r[2] is None else str(r[2].dtype)
+        rec["labels_out"] = None if r[5] is None else r[5].tolist()
+        out[name] = rec
+    # error convention: more <image> than images -> IndexError (llava_arch.py:284)
+    model.config.tokenizer_model_max_length = None
+    model.config.tokenizer_padding_side = "right"
+    try:
+        model.prepare_inputs_labels_for_multimodal(torch.tensor([[1, IMG, IMG]]), None, None, None, None,
+                                                   [torch.zeros(3, 224, 224)])
+        out["too_few_images_error"] = None
+    except Exception as e:  # noqa: BLE001
+        out["too_few_images_error"] = type(e).__name__
+
+    # decode branch (llava_arch.py:154-163) with a legacy tuple cache
+    past = ((torch.zeros(2, 2, 9, 4), torch.zeros(2, 2, 9, 4)),)
+    am = torch.tensor([[1, 1, 1, 1], [0, 1, 1, 1]], dtype=torch.long)
+    r = model.prepare_inputs_labels_for_multimodal(torch.tensor([[5], [6]]), None, am, past, None,
+                                                   [torch.zeros(3, 224, 224)])
+    out["decode_branch"] = dict(past_len=9, mask_in=am.tolist(), input_ids=[[5], [6]],
+                                position_ids=r[1].tolist(), attention_mask=r[2].tolist(),
+                                embeds_is_none=r[4] is None)
+    # images=None passthrough
+    r = model.prepare_inputs_labels_for_multimodal(torch.tensor([[1, 2, 3]]), None, None, None, None, None)
+    out["no_images_passthrough"] = dict(input_ids=r[0].tolist(), rest_none=all(x is None for x in r[1:]))
+    json.dump(out, open(os.path.join(HERE, "splice.json"), "w"), indent=0)
+    print("splice.json", list(out.keys()))
+
+
+# ----------------------------------------------------------------------------------------------
+# G4-G7 numeric fixtures
+# ----------------------------------------------------------------------------------------------
+SEL_ROWS = 16     # logits rows kept (evenly spaced) for prefill
+
+
+def gen_numeric(name):
+    model, sd, (vcfg, lcfg, mm) = build_reference(name)
+    T, n_text, n_new = 2, 24, 8
+    frames = O.synthetic_frames(T, vcfg.image_size, seed=0)
+    ids = O.synthetic_prompt_ids(n_text, T, lcfg.vocab_size, seed=1).unsqueeze(0)
+    out = {"sd_checksum": np.float64(sd_checksum(sd)), "input_ids": ids.numpy(), "T": np.int64(T),
+           "frames_checksum": np.float64(float(sum(f.double().abs().sum() for f in frames)))}
+
+    tower = model.get_model().get_image_tower()
+    pix = torch.stack(frames)
+    # G4: tower output = hidden_states[-2][:, 1:]
+    feats = tower(pix)
+    out["vit_features"] = feats.numpy()
+    hs = tower.image_tower(pix, output_hidden_states=True).hidden_states
+    out["vit_hidden0_row0"] = hs[0][:, :4].numpy()           # pre_layrnorm(embeddings), first rows incl. CLS
+    out["vit_n_states"] = np.int64(len(hs))
+    # G5: projector
+    proj = model.get_model().mm_projector(feats)
+    out["projector_rows"] = proj[:, ::8].numpy()
+    enc = model.encode_images(pix)
+    assert torch.equal(enc, proj)
+
+    # G7: end-to-end prefill through the reference forward
+    res = model(input_ids=ids, images=frames, use_cache=True)
+    logits = res.logits[0]
+    L = logits.shape[0]
+    sel = torch.linspace(0, L - 1, SEL_ROWS).long()
+    out["e2e_L"] = np.int64(L)
+    out["e2e_sel"] = sel.numpy()
+    out["e2e_logits_sel"] = logits[sel].numpy()
+    out["e2e_logits_sum_abs"] = np.float64(float(logits.double().abs().sum()))
+    out["e2e_argmax_all"] = logits.argmax(-1).numpy()
+
+    # G6: greedy decode, manual loop around the reference forward (generate() is broken under tf-5.15)
+    cache = res.past_key_values
+    nxt = int(logits[-1].argmax())
+    toks, dec_logits = [nxt], [logits[-1].numpy()]
+    for _ in range(n_new - 1):
+        r2 = model(input_ids=torch.tensor([[nxt]]), past_key_values=cache, use_cache=True)
+        cache = r2.past_key_values
+        nxt = int(r2.logits[0, -1].argmax())
+        toks.append(nxt)
+        dec_logits.append(r2.logits[0, -1].numpy())
+    out["greedy_tokens"] = np.array(toks, dtype=np.int64)
+    out["greedy_logits"] = np.stack(dec_logits)
+    # KV snapshot (layer 0 and last), selected positions
+    try:
+        k0, v0 = cache.layers[0].keys, cache.layers[0].values
+        k1, v1 = cache.layers[-1].keys, cache.layers[-1].values
+    except AttributeError:
+        k0, v0 = cache[0]
+        k1, v1 = cache[-1]
+    ks = torch.linspace(0, k0.shape[2] - 1, 12).long()
+    out["kv_sel"] = ks.numpy()
+    out["kv_len"] = np.int64(k0.shape[2])
+    out["k_layer0"] = k0[0][:, ks].numpy()
+    out["v_layer0"] = v0[0][:, ks].numpy()
+    out["k_last"] = k1[0][:, ks].numpy()
+    out["v_last"] = v1[0][:, ks].numpy()
+
+    # LLaMA alone from given embeddings (G6 first half): text-only prompt, no images
+    tids = O.synthetic_prompt_ids(20, 0, lcfg.vocab_size, seed=5).unsqueeze(0)
+    r3 = model(input_ids=tids, images=None)
+    out["text_only_ids"] = tids.numpy()
+    out["text_only_logits"] = r3.logits[0].numpy()
+
+    # information only: the reference run in bf16 on CPU (its low-precision path), last-row logits
+    m16 = model.to(torch.bfloat16)
+    r16 = m16(input_ids=ids, images=[f.to(torch.bfloat16) for f in frames])
+    out["e2e_bf16_last_logits"] = r16.logits[0, -1].float().numpy()
+    out["e2e_bf16_logits_sel"] = r16.logits[0][sel].float().numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "L=%d" % L, "greedy", toks, "size KB",
+          os.path.getsize(os.path.join(HERE, name + ".npz")) // 1024)
+
+
+if __name__ == "__main__":
+    assert ref_import.available(), "reference tree required"
+    torch.manual_seed(0)
+    gen_host()
+    gen_splice()
+    for nm in TINY:
+        gen_numeric(nm)

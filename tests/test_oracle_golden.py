@@ -1,0 +1,154 @@
+"""Pin the CPU oracle (oracle/teo_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import teo_oracle as O
+from teochat_amd.tokenizer_stub import ByteTokenizer
+from tests import _tiny as TY
+
+FP32_TOL = 2e-5     # reference (tf-5.15 op order) vs restatement, fp32, tiny configs
+
+
+def test_prompts_and_token_packing_bit_exact():
+    g = TY.load_json("host")
+    for c in g["run_inference_single"]:
+        T = c["T"]
+        prompt = O.build_prompt(c["inp"], T, c["strategy"], c["chrono"])
+        ids = O.tokenizer_image_token(prompt, ByteTokenizer(), O.IMAGE_TOKEN_INDEX)
+        assert ids == c["input_ids"], c
+        assert prompt.split("<image>") == c["prompt_chunks"], c
+        assert ids.count(-200) == (T if "<video>" in c["inp"] else 0)
+    for c in g["tokenizer_image_token"]:
+        ids = O.tokenizer_image_token(c["prompt"], ByteTokenizer(add_bos=c["add_bos"]), -200)
+        assert ids == c["ids"], c
+
+
+def test_stopping_truth_table():
+    g = TY.load_json("host")
+    tok = ByteTokenizer()
+    for c in g["stopping"]:
+        crit = O.KeywordsStop(c["keywords"], tok, c["prompt_len"])
+        assert crit([c["row"]]) == c["stop"], c
+    b = g["stopping_batch"]
+    assert O.KeywordsStop(b["keywords"], tok, b["prompt_len"])(b["rows"]) == b["stop"]
+
+
+def _coded_tables(V, D, n_images, NV):
+    emb = torch.arange(V, dtype=torch.float32).view(V, 1).expand(V, D).contiguous()
+    feats = []
+    for i in range(n_images):
+        f = torch.zeros(NV, D)
+        for j in range(NV):
+            f[j] = -(1000 * i + j + 1)
+        feats.append(f)
+    return emb, feats
+
+
+def test_splice_plans_bit_exact():
+    g = TY.load_json("splice")
+    NV = g["NV"]
+    _, lcfg, _ = TY.cfgs("tinyA")
+    for name, c in g.items():
+        if not isinstance(c, dict) or "plan" not in c:
+            continue
+        mm = O.MMCfg(tokenizer_model_max_length=c.get("max_len"), tokenizer_padding_side=c.get("padding_side", "right"))
+        emb, feats = _coded_tables(lcfg.vocab_size, 8, c["n_images"], NV)
+        ids = torch.tensor(c["ids"], dtype=torch.long)
+        mask = torch.tensor(c["mask"], dtype=torch.long) if "mask" in c else None
+        labels = torch.tensor(c["labels"], dtype=torch.long) if "labels" in c else None
+        pos = torch.arange(ids.shape[1]).unsqueeze(0).expand(ids.shape[0], -1).clone() if c.get("pos") else None
+        r = O.prepare_inputs_labels_for_multimodal(ids, pos, mask, None, labels, feats, emb, mm)
+        assert r[0] is None
+        assert r[4][:, :, 0].round().long().tolist() == c["plan"], name
+        assert (r[4].abs().sum(-1) == 0).tolist() == c["embeds_is_zero_row"], name
+        assert (None if r[1] is None else r[1].tolist()) == c["position_ids"], name
+        assert (None if r[2] is None else r[2].long().tolist()) == c["attention_mask"], name
+        assert (None if r[5] is None else r[5].tolist()) == c["labels_out"], name
+    # error convention
+    emb, feats = _coded_tables(lcfg.vocab_size, 8, 1, NV)
+    with pytest.raises(IndexError):
+        O.prepare_inputs_labels_for_multimodal(torch.tensor([[1, -200, -200]]), None, None, None, None, feats, emb,
+                                               O.MMCfg())
+    assert g["too_few_images_error"] == "IndexError"
+    d = g["decode_branch"]
+    r = O.prepare_inputs_labels_for_multimodal(torch.tensor(d["input_ids"]), None, torch.tensor(d["mask_in"]),
+                                               ((None, None),), None, feats, emb, O.MMCfg(), past_len=d["past_len"])
+    assert r[1].tolist() == d["position_ids"] and r[2].tolist() == d["attention_mask"] and r[4] is None
+    p = g["no_images_passthrough"]
+    r = O.prepare_inputs_labels_for_multimodal(torch.tensor(p["input_ids"]), None, None, None, None, None, emb, O.MMCfg())
+    assert r[0].tolist() == p["input_ids"] and all(x is None for x in r[1:])
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_numeric_fixtures(name):
+    g = TY.load_npz(name)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd = TY.state_dict(name)
+    assert abs(TY.sd_checksum(sd) - float(g["sd_checksum"])) < 1e-6 * float(g["sd_checksum"])
+    T = int(g["T"])
+    frames = O.synthetic_frames(T, vcfg.image_size, seed=0)
+    assert abs(float(sum(f.double().abs().sum() for f in frames)) - float(g["frames_checksum"])) < 1e-3
+    ids = torch.from_numpy(g["input_ids"])
+    assert torch.equal(ids[0], O.synthetic_prompt_ids(ids.shape[1], T, lcfg.vocab_size, seed=1))
+    pix = torch.stack(frames)
+
+    # G4 ViT
+    states = O.vit_hidden_states(pix, sd, vcfg)
+    assert len(states) == int(g["vit_n_states"])
+    np.testing.assert_allclose(states[0][:, :4].numpy(), g["vit_hidden0_row0"], atol=FP32_TOL, rtol=0)
+    feats = O.vit_features(pix, sd, vcfg, -2, "patch")
+    np.testing.assert_allclose(feats.numpy(), g["vit_features"], atol=FP32_TOL, rtol=1e-5)
+    # G5 projector
+    proj = O.projector(feats, sd, mm.mm_projector_type)
+    np.testing.assert_allclose(proj[:, ::8].numpy(), g["projector_rows"], atol=FP32_TOL, rtol=1e-5)
+
+    # G7 end-to-end prefill
+    logits, cache, embeds = O.mm_forward(ids, frames, sd, vcfg, lcfg, mm)
+    L = int(g["e2e_L"])
+    assert logits.shape[1] == L == ids.shape[1] - T + 256 * T
+    sel = torch.from_numpy(g["e2e_sel"])
+    np.testing.assert_allclose(logits[0][sel].numpy(), g["e2e_logits_sel"], atol=FP32_TOL, rtol=1e-5)
+    assert abs(float(logits.double().abs().sum()) - float(g["e2e_logits_sum_abs"])) < 1e-5 * float(g["e2e_logits_sum_abs"])
+    am = logits[0].argmax(-1).numpy()
+    assert (am == g["e2e_argmax_all"]).mean() > 0.995   # ties aside
+
+    # G6 greedy decode + KV snapshots
+    toks, step_logits, cache = O.greedy_generate(ids, frames, sd, vcfg, lcfg, mm, max_new_tokens=len(g["greedy_tokens"]))
+    assert toks == g["greedy_tokens"].tolist()
+    np.testing.assert_allclose(step_logits.numpy(), g["greedy_logits"], atol=FP32_TOL, rtol=1e-5)
+    ks = torch.from_numpy(g["kv_sel"])
+    # after n_new tokens the reference cache holds L + n_new - 1 entries (the last token is never fed back)
+    assert cache.length == int(g["kv_len"])
+    np.testing.assert_allclose(cache.k[0][0][:, ks].numpy(), g["k_layer0"], atol=FP32_TOL, rtol=1e-5)
+    np.testing.assert_allclose(cache.v[0][0][:, ks].numpy(), g["v_layer0"], atol=FP32_TOL, rtol=1e-5)
+    np.testing.assert_allclose(cache.k[-1][0][:, ks].numpy(), g["k_last"], atol=FP32_TOL, rtol=1e-5)
+    np.testing.assert_allclose(cache.v[-1][0][:, ks].numpy(), g["v_last"], atol=FP32_TOL, rtol=1e-5)
+
+    # text-only forward (no images)
+    tids = torch.from_numpy(g["text_only_ids"])
+    emb = sd["model.embed_tokens.weight"][tids]
+    lg, _ = O.llama_forward(emb, None, None, None, sd, lcfg)
+    np.testing.assert_allclose(lg[0].numpy(), g["text_only_logits"], atol=FP32_TOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tinyB"])
+def test_bf16_boundary_mode_is_close_to_reference_bf16(name):
+    """Information-level check: the oracle's bf16-boundary mode (what the HIP bf16 path stores) stays as
+    close to the fp32 truth as the reference's own bf16 CPU run does (different rounding points)."""
+    g = TY.load_npz(name)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd = TY.state_dict(name)
+    sd16 = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    frames = O.synthetic_frames(int(g["T"]), vcfg.image_size, seed=0)
+    ids = torch.from_numpy(g["input_ids"])
+    sel = torch.from_numpy(g["e2e_sel"])
+    lo, _, _ = O.mm_forward(ids, frames, sd16, vcfg, lcfg, mm, rounding="bf16")
+    ours = lo[0][sel].numpy()
+    truth = g["e2e_logits_sel"]
+    ref16 = g["e2e_bf16_logits_sel"]
+    scale = np.abs(truth).max()
+    err_ours = np.abs(ours - truth).max() / scale
+    err_ref = np.abs(ref16 - truth).max() / scale
+    assert err_ours < 0.05 and err_ours < 2.0 * err_ref + 1e-2, (err_ours, err_ref)
