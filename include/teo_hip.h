@@ -1,0 +1,252 @@
+/*
+ * teo_hip.h -- C ABI of libteo_hip.so: the MI355X (gfx950) compute library beneath the
+ * videollava-compatible Python surface of teochat_amd.
+ *
+ * Boundary rules:
+ *   - extern "C", plain pointers + sizes, no torch / C++ types in any signature;
+ *   - every entry point returns 0 (TEO_OK) or a negative teo_status; it never throws.
+ *     teo_last_error() returns a thread-local message for the last failure;
+ *   - all pointers named d_* are DEVICE pointers owned by the caller (torch tensors on the
+ *     Python side); the library allocates nothing on the device: composed entry points take a
+ *     caller-provided workspace whose size comes from the matching *_workspace_bytes() query;
+ *   - work is enqueued asynchronously on the caller's stream (hipStream_t passed as void*);
+ *   - dtype arguments are teo_dtype; "T" below means the element type that dtype selects.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * repo; "tf" = transformers modelling files the reference delegates its arithmetic to,
+ * pyproject.toml:17).
+ */
+#ifndef TEO_HIP_H
+#define TEO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEO_ABI_VERSION 1
+
+typedef void* teo_stream_t; /* hipStream_t */
+
+typedef enum { TEO_F32 = 0, TEO_BF16 = 1 } teo_dtype;
+typedef enum { TEO_ACT_NONE = 0, TEO_ACT_GELU_ERF = 1, TEO_ACT_QUICK_GELU = 2 } teo_act;
+typedef enum {
+    TEO_OK = 0,
+    TEO_ERR_ARG = -1,         /* bad argument (null pointer, negative size, misaligned) */
+    TEO_ERR_UNSUPPORTED = -2, /* shape / dtype combination not implemented */
+    TEO_ERR_HIP = -3,         /* a HIP runtime call failed (message in teo_last_error) */
+    TEO_ERR_WORKSPACE = -4    /* workspace too small */
+} teo_status;
+
+/* GEMM epilogue flags (teo_gemm `flags`) */
+#define TEO_GEMM_SWIGLU16 1u /* W rows are [gate16|up16] interleaved; C[M, N/2] = silu(g) * u */
+#define TEO_GEMM_FORCE_SIMPLE 2u /* use the shape-agnostic VALU kernel even when the MFMA kernel applies */
+
+int teo_version(void);
+const char* teo_last_error(void);
+/* 1 when the MFMA (fast) kernel would be used for this GEMM, 0 when the generic kernel would. */
+int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags);
+
+/* ---------------------------------------------------------------------------------------------
+ * Primitive operators (each one parity-tested on its own against oracle/teo_oracle.py)
+ * ------------------------------------------------------------------------------------------- */
+
+/* y[r,:] = LayerNorm(x[r,:]) * w + b.   Replaces nn.LayerNorm at
+ * languagebind/image/modeling_image.py:70,72 (layer_norm1/2) and :601 (pre_layrnorm). */
+int teo_layernorm(const void* d_x, const void* d_w, const void* d_b, void* d_y, int rows, int dim, float eps,
+                  int dtype, teo_stream_t stream);
+
+/* y[r,:] = x[r,:] * rsqrt(mean(x^2) + eps) * w.   Replaces tf llama LlamaRMSNorm.forward
+ * (constructed by LlamaModel, reached from language_model/llava_llama.py:88-99). */
+int teo_rmsnorm(const void* d_x, const void* d_w, void* d_y, int rows, int dim, float eps, int dtype,
+                teo_stream_t stream);
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]   (bias/residual may be NULL).
+ * A rows have stride lda, C/residual rows stride ldc (elements).  out_dtype may be TEO_F32 with
+ * bf16 inputs (logits).  Replaces every nn.Linear on the path: tf CLIPAttention q/k/v/out_proj,
+ * CLIPMLP fc1/fc2 (constructed at modeling_image.py:69,71), the projector Linear layers
+ * (multimodal_projector/builder.py:42-46), tf LlamaAttention q/k/v/o_proj, LlamaMLP, lm_head. */
+int teo_gemm(const void* d_A, const void* d_W, const void* d_bias, const void* d_residual, void* d_C, int M,
+             int N, int K, int lda, int ldc, int act, unsigned flags, int dtype, int out_dtype,
+             teo_stream_t stream);
+
+/* Patch extraction for the CLIP patch-embedding conv (kernel = stride = patch, no bias):
+ * cols[t*g*g + py*g + px, c*P*P + ky*P + kx] = pixels[t, c, py*P+ky, px*P+kx], zero padded to ldcols.
+ * Replaces the im2col half of CLIPVisionEmbeddings.patch_embedding (used at modeling_image.py:602,645). */
+int teo_im2col_patches(const void* d_pixels, void* d_cols, int T, int channels, int image, int patch, int ldcols,
+                       int dtype, teo_stream_t stream);
+
+/* hidden0[t, 0, :] = LN(cls + pos[0]); hidden0[t, 1+p, :] = LN(patch[t*NP + p] + pos[1+p]).
+ * Replaces the cat/+position_embedding of CLIPVisionEmbeddings.forward and pre_layrnorm
+ * (modeling_image.py:645-649). */
+int teo_vit_embed_ln(const void* d_patch, const void* d_cls, const void* d_pos, const void* d_w, const void* d_b,
+                     void* d_out, int T, int n_patches, int dim, float eps, int dtype, teo_stream_t stream);
+
+/* Attention over explicitly strided operands (element strides):
+ *   Q[b][h][i][:]  at q  + b*q_bs  + h*q_hs  + i*q_rs          (i < q_len, head_dim contiguous)
+ *   K[b][hk][j][:] at k  + b*k_bs  + hk*k_hs + j*k_rs          (j < kv_len)
+ *   V[b][hk][j][:] at v  + b*v_bs  + hk*v_hs + j*v_rs          (row-major values)
+ *   VT[b][hk][:][j] at vt + b*vt_bs + hk*vt_hs + d*vt_rs + j   (transposed values; may be NULL)
+ *   O[b][i][h*head_dim + :] at o + b*o_bs + i*o_rs
+ * out = softmax(scale * Q K^T + causal mask) V;  causal: key j visible to query i iff j <= i + (kv_len - q_len).
+ * hk = h / (heads / kv_heads).  The MFMA kernel needs VT, bf16 and head_dim in {64,128}; otherwise the
+ * generic kernel runs (reads V).  Replaces tf CLIPAttention / LlamaAttention eager attention. */
+typedef struct {
+    const void* q; const void* k; const void* v; const void* vt; void* o;
+    long long q_bs, q_hs, q_rs;
+    long long k_bs, k_hs, k_rs;
+    long long v_bs, v_hs, v_rs;
+    long long vt_bs, vt_hs, vt_rs;
+    long long o_bs, o_rs;
+    int batch, heads, kv_heads, head_dim, q_len, kv_len;
+    int causal;
+    float scale;
+    unsigned flags; /* TEO_ATTN_FORCE_SIMPLE */
+} teo_attn_args;
+#define TEO_ATTN_FORCE_SIMPLE 1u
+int teo_attention(const teo_attn_args* args, int dtype, teo_stream_t stream);
+
+/* ViT helper: VT[t][h][d][j] = qkv[t*N + j][2*D + h*hd + d], rows padded with zeros to ldv.
+ * (layout change only; lets the MFMA attention kernel read key-contiguous values.) */
+int teo_vit_value_transpose(const void* d_qkv, void* d_vt, int T, int N, int heads, int head_dim, int ldv,
+                            int dtype, teo_stream_t stream);
+
+/* RoPE + KV append for S new positions of one sequence (LLaMA prefill or decode):
+ *   qkv[s, :] = [q (H*hd) | k (Hk*hd) | v (Hk*hd)] rows with stride ld_qkv; q is rotated IN PLACE;
+ *   k rotated -> K cache [Hk][S_max][hd] at position past+s; v -> V cache (same layout) and,
+ *   when d_vt_cache != NULL, VT cache [Hk][hd][S_max].
+ *   cos/sin tables: fp32 [max_pos][hd/2] (built on the host exactly as tf LlamaRotaryEmbedding does);
+ *   positions: int32 [S] (position_ids of the new tokens).
+ * Replaces tf apply_rotary_pos_emb + the KV-cache torch.cat in LlamaAttention.forward. */
+int teo_rope_kv_append(void* d_qkv, int ld_qkv, const int* d_positions, const float* d_cos, const float* d_sin,
+                       void* d_k_cache, void* d_v_cache, void* d_vt_cache, int S, int past, int S_max, int heads,
+                       int kv_heads, int head_dim, int dtype, teo_stream_t stream);
+
+/* Embedding splice (the data movement of prepare_inputs_labels_for_multimodal, llava_arch.py:254-293):
+ * out[r,:] = plan[r] >= 0 ? embed[plan[r],:] : (plan[r] == INT32_MIN ? 0 : visual[-plan[r]-1,:]).
+ * The int32 plan is built on the host by the bit-exact index logic. */
+int teo_embed_splice(const int* d_plan, const void* d_embed, const void* d_visual, void* d_out, int rows, int dim,
+                     int dtype, teo_stream_t stream);
+
+/* out[t, p, :] = in[t, 1+p, :]  (feature_select 'patch', languagebind/__init__.py:121-129) */
+int teo_drop_cls(const void* d_in, void* d_out, int T, int n_tokens, int dim, int dtype, teo_stream_t stream);
+
+/* token[r] = argmax_j logits[r, j] (first index on ties, like torch.argmax); int64 out.
+ * Replaces the greedy branch of GenerationMixin (call at eval/inference.py:64-72 with do_sample=False). */
+int teo_argmax(const float* d_logits, long long* d_token, int rows, int vocab, teo_stream_t stream);
+
+/* Decode GEMV: y[N] = W[N,K] . f(x) (+ residual), x one row.
+ *   norm_w != NULL : f(x) = rmsnorm(x) * norm_w (rounded to dtype), else f(x) = x
+ *   flags & TEO_GEMM_SWIGLU16 : W is gate/up interleaved-16; y[N/2] = silu(g)*u
+ *   out_dtype TEO_F32 allowed (logits).
+ * Same Linear layers as teo_gemm, for the q_len == 1 decode step (HBM-bound, no MFMA). */
+int teo_gemv(const void* d_x, const void* d_W, const void* d_norm_w, const void* d_residual, void* d_y, int N, int K,
+             float eps, unsigned flags, int dtype, int out_dtype, teo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Composed runtime entry points (the layer loops live in C++, not Python)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int hidden, heads, inter, layers_run; /* layers_run = number of encoder layers actually executed */
+    int image, patch, channels;
+    int act;        /* teo_act of CLIPMLP */
+    float eps;
+    int dtype;
+    int k_pad;      /* padded K of the patch GEMM (multiple of 64) */
+    const void* patch_w;  /* [hidden, k_pad] (zero padded) */
+    const void* cls;      /* [hidden] */
+    const void* pos;      /* [n_patches+1, hidden] */
+    const void* pre_ln_w; const void* pre_ln_b;
+    /* per layer arrays of device pointers (host arrays of length layers_run) */
+    const void* const* ln1_w; const void* const* ln1_b;
+    const void* const* qkv_w; const void* const* qkv_b;   /* fused [3*hidden, hidden], [3*hidden] */
+    const void* const* out_w; const void* const* out_b;
+    const void* const* ln2_w; const void* const* ln2_b;
+    const void* const* fc1_w; const void* const* fc1_b;
+    const void* const* fc2_w; const void* const* fc2_b;
+} teo_vit_desc;
+
+size_t teo_vit_workspace_bytes(const teo_vit_desc* d, int T);
+/* features[T, n_patches, hidden] = hidden_states[layers_run][:, 1:]  (H7-H11 of SURVEY.md section 8a):
+ * LanguageBindImageTower.forward + feature_select (languagebind/__init__.py:121-146). */
+int teo_vit_encode(const teo_vit_desc* d, const void* d_pixels, int T, void* d_features, void* d_workspace,
+                   size_t workspace_bytes, teo_stream_t stream);
+
+typedef struct {
+    int in_dim, out_dim, depth; /* depth 1 = linear, 2 = mlp2x_gelu */
+    int dtype;
+    const void* w[4]; const void* b[4];
+} teo_proj_desc;
+size_t teo_projector_workspace_bytes(const teo_proj_desc* d, int rows);
+/* build_vision_projector (multimodal_projector/builder.py:33-51) applied to [rows, in_dim]. */
+int teo_projector(const teo_proj_desc* d, const void* d_x, int rows, void* d_y, void* d_workspace,
+                  size_t workspace_bytes, teo_stream_t stream);
+
+typedef struct {
+    int hidden, heads, kv_heads, head_dim, inter, layers, vocab;
+    float eps;
+    int dtype;
+    int max_seq;           /* S_max of the KV cache */
+    const void* embed;     /* [vocab, hidden] */
+    const void* final_norm_w;
+    const void* lm_head;   /* [vocab, hidden] */
+    const float* rope_cos; const float* rope_sin;   /* [max_pos, head_dim/2] fp32 */
+    int max_pos;
+    const void* const* in_norm_w;
+    const void* const* qkv_w;      /* fused [(heads+2*kv_heads)*head_dim, hidden] */
+    const void* const* o_w;
+    const void* const* post_norm_w;
+    const void* const* gateup_w;   /* [2*inter, hidden], gate/up interleaved in blocks of 16 rows */
+    const void* const* down_w;
+    /* KV cache, per layer device pointers */
+    void* const* k_cache;  /* [kv_heads][max_seq][head_dim] */
+    void* const* v_cache;  /* [kv_heads][max_seq][head_dim] */
+    void* const* vt_cache; /* [kv_heads][head_dim][max_seq] */
+} teo_llama_desc;
+
+size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
+/* LlamaModel.forward + lm_head over S new positions given inputs_embeds (llava_llama.py:88-99).
+ *   d_embeds [S, hidden] (dtype), d_positions int32 [S], past = tokens already in the cache.
+ *   logits_rows: 0 -> logits for all S positions [S, vocab] fp32; 1 -> last position only [1, vocab].
+ *   d_hidden_out (may be NULL): final-normed hidden states of the rows logits were computed for. */
+int teo_llama_prefill(const teo_llama_desc* d, const void* d_embeds, const int* d_positions, int S, int past,
+                      int last_only, float* d_logits, void* d_workspace, size_t workspace_bytes,
+                      teo_stream_t stream);
+
+/* Persistent decode state: greedy decode of one sequence with everything (token, position, stop flag) on the device. */
+typedef struct {
+    long long* d_token;      /* [1] current token id (input of the step; overwritten with the next token) */
+    int* d_pos;              /* [1] position of d_token == number of tokens in the cache */
+    long long* d_out_tokens; /* [max_new] generated ids, written at d_out_count */
+    int* d_out_count;        /* [1] */
+    int* d_stop;             /* [1] set to 1 when the generated tail equals d_stop_ids (id-suffix match) */
+    const long long* d_stop_ids; int n_stop_ids; /* may be NULL/0 */
+    float* d_logits;         /* [vocab] fp32 logits of the last step */
+} teo_decode_state;
+
+size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d);
+/* One greedy decode step (embedding lookup -> 32 layers -> lm_head -> argmax -> append), all on device.
+ * Replaces one iteration of GenerationMixin's loop around LlavaLlamaForCausalLM.forward with
+ * input_ids [1,1] (llava_arch.py:154-163 decode branch; position = past length). */
+int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace,
+                          size_t workspace_bytes, teo_stream_t stream);
+
+/* hipGraph form of the same step: capture once, replay per token. */
+typedef struct teo_graph teo_graph;
+int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace,
+                                  size_t workspace_bytes, teo_stream_t stream, teo_graph** out);
+int teo_graph_launch(teo_graph* g, int n_times, teo_stream_t stream);
+int teo_graph_destroy(teo_graph* g);
+
+/* Bench helper: run the decode gate/up GEMV (the dominant kernel by bytes) over n weight matrices
+ * back to back between two HIP events on `stream`; returns the average milliseconds per launch. */
+int teo_time_gemv_chain(const void* d_x, const void* const* d_Ws, int n, const void* d_norm_w, void* d_y, int N,
+                        int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out,
+                        teo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEO_HIP_H */

@@ -1,0 +1,145 @@
+"""ctypes binding of libteo_hip.so (C ABI declared in include/teo_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it cannot be loaded, importing
+callers get a TeoLibraryError telling them to run `python -c "import __graft_entry__ as g; g.build()"`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libteo_hip.so")
+
+TEO_F32, TEO_BF16 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
+GEMM_SWIGLU16, GEMM_FORCE_SIMPLE = 1, 2
+ATTN_FORCE_SIMPLE = 1
+INT32_MIN = -(2 ** 31)
+
+
+class TeoLibraryError(RuntimeError):
+    pass
+
+
+class TeoError(RuntimeError):
+    pass
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
+                ("q_bs", C.c_longlong), ("q_hs", C.c_longlong), ("q_rs", C.c_longlong),
+                ("k_bs", C.c_longlong), ("k_hs", C.c_longlong), ("k_rs", C.c_longlong),
+                ("v_bs", C.c_longlong), ("v_hs", C.c_longlong), ("v_rs", C.c_longlong),
+                ("vt_bs", C.c_longlong), ("vt_hs", C.c_longlong), ("vt_rs", C.c_longlong),
+                ("o_bs", C.c_longlong), ("o_rs", C.c_longlong),
+                ("batch", C.c_int), ("heads", C.c_int), ("kv_heads", C.c_int), ("head_dim", C.c_int),
+                ("q_len", C.c_int), ("kv_len", C.c_int), ("causal", C.c_int), ("scale", C.c_float),
+                ("flags", C.c_uint)]
+
+
+PP = C.POINTER(C.c_void_p)
+
+
+class VitDesc(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("inter", C.c_int), ("layers_run", C.c_int),
+                ("image", C.c_int), ("patch", C.c_int), ("channels", C.c_int), ("act", C.c_int),
+                ("eps", C.c_float), ("dtype", C.c_int), ("k_pad", C.c_int),
+                ("patch_w", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
+                ("pre_ln_w", C.c_void_p), ("pre_ln_b", C.c_void_p),
+                ("ln1_w", PP), ("ln1_b", PP), ("qkv_w", PP), ("qkv_b", PP), ("out_w", PP), ("out_b", PP),
+                ("ln2_w", PP), ("ln2_b", PP), ("fc1_w", PP), ("fc1_b", PP), ("fc2_w", PP), ("fc2_b", PP)]
+
+
+class ProjDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int), ("out_dim", C.c_int), ("depth", C.c_int), ("dtype", C.c_int),
+                ("w", C.c_void_p * 4), ("b", C.c_void_p * 4)]
+
+
+class LlamaDesc(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("heads", C.c_int), ("kv_heads", C.c_int), ("head_dim", C.c_int),
+                ("inter", C.c_int), ("layers", C.c_int), ("vocab", C.c_int), ("eps", C.c_float),
+                ("dtype", C.c_int), ("max_seq", C.c_int),
+                ("embed", C.c_void_p), ("final_norm_w", C.c_void_p), ("lm_head", C.c_void_p),
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("max_pos", C.c_int),
+                ("in_norm_w", PP), ("qkv_w", PP), ("o_w", PP), ("post_norm_w", PP), ("gateup_w", PP),
+                ("down_w", PP), ("k_cache", PP), ("v_cache", PP), ("vt_cache", PP)]
+
+
+class DecodeState(C.Structure):
+    _fields_ = [("d_token", C.c_void_p), ("d_pos", C.c_void_p), ("d_out_tokens", C.c_void_p),
+                ("d_out_count", C.c_void_p), ("d_stop", C.c_void_p), ("d_stop_ids", C.c_void_p),
+                ("n_stop_ids", C.c_int), ("d_logits", C.c_void_p)]
+
+
+_SIGS = {
+    "teo_version": (C.c_int, []),
+    "teo_last_error": (C.c_char_p, []),
+    "teo_gemm_uses_mfma": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
+    "teo_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "teo_rmsnorm": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "teo_gemm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_uint, C.c_int, C.c_int, C.c_void_p]),
+    "teo_im2col_patches": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "teo_vit_embed_ln": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "teo_attention": (C.c_int, [C.POINTER(AttnArgs), C.c_int, C.c_void_p]),
+    "teo_vit_value_transpose": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "teo_rope_kv_append": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
+    "teo_embed_splice": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "teo_drop_cls": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "teo_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "teo_gemv": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_uint, C.c_int, C.c_int, C.c_void_p]),
+    "teo_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitDesc), C.c_int]),
+    "teo_vit_encode": (C.c_int, [C.POINTER(VitDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_projector_workspace_bytes": (C.c_size_t, [C.POINTER(ProjDesc), C.c_int]),
+    "teo_projector": (C.c_int, [C.POINTER(ProjDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_prefill_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc), C.c_int]),
+    "teo_llama_prefill": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_decode_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc)]),
+    "teo_llama_decode_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_decode_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t,
+                                                C.c_void_p, C.POINTER(C.c_void_p)]),
+    "teo_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "teo_graph_destroy": (C.c_int, [C.c_void_p]),
+    "teo_time_gemv_chain": (C.c_int, [C.c_void_p, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                      C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+_lib = None
+
+
+def load():
+    """Load libteo_hip.so and attach signatures.  Raises TeoLibraryError if it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TeoLibraryError(
+            f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). Build it with "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` or `make -C teochat_amd/csrc`.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise TeoLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TeoLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.teo_version() != 1:
+        raise TeoLibraryError(f"ABI version mismatch: library {lib.teo_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().teo_last_error()
+        raise TeoError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (kept alive by the caller)."""
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return arr, C.cast(arr, PP)

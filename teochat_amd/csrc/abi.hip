@@ -1,0 +1,227 @@
+// extern "C" surface of libteo_hip.so (declared in include/teo_hip.h).  Argument validation + dispatch only.
+#include <stdarg.h>
+
+#include "ops.h"
+
+namespace teo {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return TEO_ERR_HIP;
+}
+
+size_t vit_workspace_bytes(const teo_vit_desc* d, int T);
+int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features, void* ws, size_t ws_bytes, hipStream_t st);
+size_t projector_workspace_bytes(const teo_proj_desc* d, int rows);
+int projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws, size_t ws_bytes, hipStream_t st);
+size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
+int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
+                  float* logits, void* ws, size_t ws_bytes, hipStream_t st);
+size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
+int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
+int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
+                        teo_graph** out);
+
+static bool dtype_ok(int dt) { return dt == TEO_F32 || dt == TEO_BF16; }
+
+}  // namespace teo
+
+using namespace teo;
+
+#define ST(s) ((hipStream_t)(s))
+#define NEED(p, name) TEO_CHECK_ARG((p) != nullptr, "%s: null %s", __func__, name)
+#define NEED_DT(dt) TEO_CHECK_ARG(dtype_ok(dt), "%s: bad dtype %d", __func__, dt)
+
+extern "C" {
+
+int teo_version(void) { return TEO_ABI_VERSION; }
+const char* teo_last_error(void) { return g_err; }
+
+int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags) {
+    return gemm_mfma_ok(M, N, K, K, (flags & TEO_GEMM_SWIGLU16) ? N / 2 : N, dtype, flags, nullptr, nullptr, nullptr,
+                        nullptr, nullptr) ? 1 : 0;
+}
+
+int teo_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, int dtype,
+                  teo_stream_t s) {
+    NEED_DT(dtype); TEO_CHECK_ARG(rows >= 0 && dim > 0, "teo_layernorm: rows %d dim %d", rows, dim);
+    if (rows) { NEED(x, "x"); NEED(w, "w"); NEED(b, "b"); NEED(y, "y"); }
+    return layernorm(x, w, b, y, rows, dim, eps, dtype, ST(s));
+}
+
+int teo_rmsnorm(const void* x, const void* w, void* y, int rows, int dim, float eps, int dtype, teo_stream_t s) {
+    NEED_DT(dtype); TEO_CHECK_ARG(rows >= 0 && dim > 0, "teo_rmsnorm: rows %d dim %d", rows, dim);
+    if (rows) { NEED(x, "x"); NEED(w, "w"); NEED(y, "y"); }
+    return rmsnorm(x, w, y, rows, dim, eps, dtype, ST(s));
+}
+
+int teo_gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
+             int ldc, int act, unsigned flags, int dtype, int out_dtype, teo_stream_t s) {
+    NEED_DT(dtype); NEED_DT(out_dtype);
+    TEO_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && lda >= K, "teo_gemm: M %d N %d K %d lda %d", M, N, K, lda);
+    TEO_CHECK_ARG(ldc >= ((flags & TEO_GEMM_SWIGLU16) ? N / 2 : N), "teo_gemm: ldc %d too small", ldc);
+    TEO_CHECK_ARG(act >= TEO_ACT_NONE && act <= TEO_ACT_QUICK_GELU, "teo_gemm: act %d", act);
+    if (M && N) { NEED(A, "A"); NEED(W, "W"); NEED(C, "C"); }
+    return gemm(A, W, bias, res, C, M, N, K, lda, ldc, act, flags, dtype, out_dtype, ST(s));
+}
+
+int teo_im2col_patches(const void* px, void* cols, int T, int channels, int image, int patch, int ldcols, int dtype,
+                       teo_stream_t s) {
+    NEED_DT(dtype); TEO_CHECK_ARG(T >= 0 && patch > 0 && image > 0, "teo_im2col_patches: bad sizes");
+    if (T) { NEED(px, "pixels"); NEED(cols, "cols"); }
+    return im2col_patches(px, cols, T, channels, image, patch, ldcols, dtype, ST(s));
+}
+
+int teo_vit_embed_ln(const void* patch, const void* cls, const void* pos, const void* w, const void* b, void* out, int T,
+                     int n_patches, int dim, float eps, int dtype, teo_stream_t s) {
+    NEED_DT(dtype);
+    TEO_CHECK_ARG(T >= 0 && n_patches > 0 && dim > 0 && dim <= 16384, "teo_vit_embed_ln: bad sizes");
+    if (T) { NEED(patch, "patch"); NEED(cls, "cls"); NEED(pos, "pos"); NEED(w, "w"); NEED(b, "b"); NEED(out, "out"); }
+    return vit_embed_ln(patch, cls, pos, w, b, out, T, n_patches, dim, eps, dtype, ST(s));
+}
+
+int teo_attention(const teo_attn_args* a, int dtype, teo_stream_t s) {
+    NEED_DT(dtype); NEED(a, "args");
+    TEO_CHECK_ARG(a->batch >= 0 && a->heads > 0 && a->kv_heads > 0 && a->head_dim > 0 && a->q_len >= 0 && a->kv_len >= 0,
+                  "teo_attention: bad sizes");
+    if (a->batch && a->q_len) { NEED(a->q, "q"); NEED(a->k, "k"); NEED(a->o, "o"); TEO_CHECK_ARG(a->kv_len > 0, "teo_attention: kv_len 0"); }
+    return attention(a, dtype, ST(s));
+}
+
+int teo_vit_value_transpose(const void* qkv, void* vt, int T, int N, int heads, int head_dim, int ldv, int dtype,
+                            teo_stream_t s) {
+    NEED_DT(dtype); TEO_CHECK_ARG(T >= 0 && N > 0 && ldv >= N, "teo_vit_value_transpose: bad sizes");
+    if (T) { NEED(qkv, "qkv"); NEED(vt, "vt"); }
+    return vit_value_transpose(qkv, vt, T, N, heads, head_dim, ldv, dtype, ST(s));
+}
+
+int teo_rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
+                       void* vtc, int S, int past, int S_max, int heads, int kv_heads, int head_dim, int dtype,
+                       teo_stream_t s) {
+    NEED_DT(dtype);
+    TEO_CHECK_ARG(S >= 0 && past >= 0 && past + S <= S_max, "teo_rope_kv_append: S %d past %d S_max %d", S, past, S_max);
+    if (S) { NEED(qkv, "qkv"); NEED(cs, "cos"); NEED(sn, "sin"); NEED(kc, "k_cache"); NEED(vc, "v_cache"); }
+    return rope_kv_append(qkv, ld, positions, cs, sn, kc, vc, vtc, S, past, nullptr, S_max, heads, kv_heads, head_dim,
+                          dtype, ST(s));
+}
+
+int teo_embed_splice(const int* plan, const void* embed, const void* visual, void* out, int rows, int dim, int dtype,
+                     teo_stream_t s) {
+    NEED_DT(dtype); TEO_CHECK_ARG(rows >= 0 && dim > 0, "teo_embed_splice: bad sizes");
+    if (rows) { NEED(plan, "plan"); NEED(embed, "embed"); NEED(out, "out"); }
+    return embed_splice(plan, embed, visual, out, rows, dim, dtype, ST(s));
+}
+
+int teo_drop_cls(const void* in, void* out, int T, int n_tokens, int dim, int dtype, teo_stream_t s) {
+    NEED_DT(dtype); TEO_CHECK_ARG(T >= 0 && n_tokens >= 1 && dim > 0, "teo_drop_cls: bad sizes");
+    if (T && n_tokens > 1) { NEED(in, "in"); NEED(out, "out"); }
+    return drop_cls(in, out, T, n_tokens, dim, dtype, ST(s));
+}
+
+int teo_argmax(const float* logits, long long* tok, int rows, int vocab, teo_stream_t s) {
+    TEO_CHECK_ARG(rows >= 0 && vocab > 0, "teo_argmax: bad sizes");
+    if (rows) { NEED(logits, "logits"); NEED(tok, "token"); }
+    return argmax(logits, tok, rows, vocab, ST(s));
+}
+
+int teo_gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
+             unsigned flags, int dtype, int out_dtype, teo_stream_t s) {
+    NEED_DT(dtype); NEED_DT(out_dtype); TEO_CHECK_ARG(N >= 0 && K > 0, "teo_gemv: N %d K %d", N, K);
+    if (N) { NEED(x, "x"); NEED(W, "W"); NEED(y, "y"); }
+    return gemv(x, W, norm_w, res, y, N, K, eps, flags, dtype, out_dtype, ST(s));
+}
+
+size_t teo_vit_workspace_bytes(const teo_vit_desc* d, int T) { return d ? vit_workspace_bytes(d, T) : 0; }
+int teo_vit_encode(const teo_vit_desc* d, const void* px, int T, void* feat, void* ws, size_t wsb, teo_stream_t s) {
+    NEED(d, "desc"); NEED_DT(d->dtype);
+    TEO_CHECK_ARG(T >= 0 && d->hidden % d->heads == 0 && d->image % d->patch == 0, "teo_vit_encode: bad config");
+    if (T) { NEED(px, "pixels"); NEED(feat, "features"); NEED(ws, "workspace"); }
+    return vit_encode(d, px, T, feat, ws, wsb, ST(s));
+}
+
+size_t teo_projector_workspace_bytes(const teo_proj_desc* d, int rows) { return d ? projector_workspace_bytes(d, rows) : 0; }
+int teo_projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws, size_t wsb, teo_stream_t s) {
+    NEED(d, "desc"); NEED_DT(d->dtype);
+    if (rows) { NEED(x, "x"); NEED(y, "y"); }
+    return projector(d, x, rows, y, ws, wsb, ST(s));
+}
+
+size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S) { return d ? llama_prefill_workspace_bytes(d, S) : 0; }
+int teo_llama_prefill(const teo_llama_desc* d, const void* emb, const int* pos, int S, int past, int last_only,
+                      float* logits, void* ws, size_t wsb, teo_stream_t s) {
+    NEED(d, "desc"); NEED_DT(d->dtype);
+    TEO_CHECK_ARG(S >= 0 && past >= 0, "teo_llama_prefill: S %d past %d", S, past);
+    if (S) { NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace"); }
+    return llama_prefill(d, emb, pos, S, past, last_only, logits, ws, wsb, ST(s));
+}
+
+size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d) { return d ? llama_decode_workspace_bytes(d) : 0; }
+int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, teo_stream_t s) {
+    NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
+    NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
+    NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
+    return llama_decode_step(d, st, ws, wsb, ST(s));
+}
+
+int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb,
+                                  teo_stream_t s, teo_graph** out) {
+    NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED(out, "out"); NEED_DT(d->dtype);
+    TEO_CHECK_ARG(s != nullptr, "teo_llama_decode_graph_create: needs a non-default stream to capture on");
+    return decode_graph_create(d, st, ws, wsb, ST(s), out);
+}
+
+int teo_graph_launch(teo_graph* g, int n_times, teo_stream_t s) {
+    NEED(g, "graph");
+    for (int i = 0; i < n_times; ++i) {
+        hipError_t e = hipGraphLaunch(g->exec, ST(s));
+        if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
+    }
+    return TEO_OK;
+}
+
+int teo_graph_destroy(teo_graph* g) {
+    if (!g) return TEO_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return TEO_OK;
+}
+
+int teo_time_gemv_chain(const void* x, const void* const* Ws, int n, const void* norm_w, void* y, int N, int K,
+                        float eps, unsigned flags, int dtype, int reps, float* avg_ms_out, teo_stream_t s) {
+    NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
+    TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_gemv_chain: n %d reps %d", n, reps);
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return hip_fail(e, "hipEventCreate"); }
+    int rc = TEO_OK;
+    for (int i = 0; i < n && rc == TEO_OK; ++i)   // warm-up pass (not timed)
+        rc = gemv(x, Ws[i], norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
+    (void)hipEventRecord(e0, ST(s));
+    for (int r = 0; r < reps && rc == TEO_OK; ++r)
+        for (int i = 0; i < n && rc == TEO_OK; ++i)
+            rc = gemv(x, Ws[i], norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
+    (void)hipEventRecord(e1, ST(s));
+    e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != TEO_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "teo_time_gemv_chain events");
+    *avg_ms_out = ms / (float)(n * reps);
+    return TEO_OK;
+}
+
+}  // extern "C"

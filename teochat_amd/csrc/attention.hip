@@ -1,0 +1,397 @@
+// Attention kernels.
+//
+//  attn_simple_kernel<T>   : one wave per (query, head); scores in LDS, exact two-pass softmax.  fp32 parity path,
+//                            fallback for head dims the MFMA kernel does not take, and the on-GPU cross-check of it.
+//  attn_mfma_kernel<D,C>   : flash-style bf16 kernel on v_mfma_f32_16x16x32_bf16, D in {64,128}, causal or not.
+//                            One workgroup = 64 queries of one head (4 waves x 16 queries), KV tiles of 64 keys staged
+//                            in LDS (K row-major XOR-swizzled for ds_read_b128; V^T key-contiguous, swizzled for
+//                            ds_read_b64).  The score MFMA is SWAPPED (S^T = K . Q^T): a lane then owns ONE query and
+//                            16 keys of the tile, so the online-softmax row max/sum is an in-lane reduction plus two
+//                            cross-lane steps, the rescale factor is a per-lane scalar, and the exponentiated tile
+//                            is already in the B-operand layout of O^T += V^T . P^T -- no LDS round trip for P.
+//  attn_decode_*           : q_len == 1 (decode).  Split over the KV length (grid heads x splits, fixed for hipGraph
+//                            replay; kv_len comes from device memory), then a combine kernel.  HBM-bound:
+//                            algorithmic bytes = 2 * kv_heads * kv_len * head_dim * sizeof(T) per layer.
+#include "common.h"
+
+namespace teo {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ------------------------------------------------------------------------------------------------
+// generic kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void attn_simple_kernel(teo_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qs = sm;                   // [head_dim]
+    float* sc = sm + a.head_dim;      // [kv_len]
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int hk = h / (a.heads / a.kv_heads);
+    const int hd = a.head_dim;
+    const T* q = (const T*)a.q + b * a.q_bs + h * a.q_hs + (long long)i * a.q_rs;
+    const T* k = (const T*)a.k + b * a.k_bs + hk * a.k_hs;
+    const T* v = (const T*)a.v + b * a.v_bs + hk * a.v_hs;
+    for (int d = lane; d < hd; d += 64) qs[d] = Elem<T>::ld(q + d);
+    __syncthreads();
+    const int lim = a.causal ? min(a.kv_len, i + (a.kv_len - a.q_len) + 1) : a.kv_len;
+    float mx = -INFINITY;
+    for (int j = lane; j < lim; j += 64) {
+        const T* kr = k + (long long)j * a.k_rs;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(qs[d], Elem<T>::ld(kr + d), s);
+        s *= a.scale;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < lim; j += 64) {
+        const float p = expf(sc[j] - mx);
+        sum += p;
+        sc[j] = Elem<T>::round(p);    // P is fed to the PV product in the storage type
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    T* o = (T*)a.o + b * a.o_bs + (long long)i * a.o_rs + h * hd;
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < lim; ++j) acc = fmaf(sc[j], Elem<T>::ld(v + (long long)j * a.v_rs + d), acc);
+        Elem<T>::st(o + d, acc / sum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA flash kernel
+// ------------------------------------------------------------------------------------------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(teo_attn_args a) {
+    constexpr int CH = D / 8;              // 16-byte chunks per K row
+    constexpr int KROW = D * 2;            // bytes per K row in LDS
+    constexpr int KT_BYTES = 64 * KROW;    // K tile
+    constexpr int NDF = D / 16;            // d-fragments of the output
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sK = smem;              // [64 keys][D] bf16, chunk c of row r at c ^ (r & (CH-1))
+    unsigned char* sV = smem + KT_BYTES;   // [D][64 keys] bf16 (128 B rows), 16-B chunk c of row d at c ^ ((d>>1)&7)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hk = h / (a.heads / a.kv_heads);
+    const int qb = blockIdx.x * 64;
+    const int off = a.kv_len - a.q_len;
+    const bf16_t* Q = (const bf16_t*)a.q + b * a.q_bs + h * a.q_hs;
+    const bf16_t* K = (const bf16_t*)a.k + b * a.k_bs + hk * a.k_hs;
+    const bf16_t* VT = (const bf16_t*)a.vt + b * a.vt_bs + hk * a.vt_hs;
+
+    // this lane's query (B operand of the swapped score MFMA): Q[q][kk*32 + fg*8 .. +8]
+    const int qi = qb + wid * 16 + fr;
+    const int qrow = min(qi, a.q_len - 1);
+    bf16x8 qf[D / 32];
+#pragma unroll
+    for (int kk = 0; kk < D / 32; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8*>(Q + (long long)qrow * a.q_rs + kk * 32 + fg * 8);
+    const int qpos = qi + off;             // last visible key (causal)
+
+    f32x4 acc_o[NDF];
+#pragma unroll
+    for (int i = 0; i < NDF; ++i) acc_o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl2 = a.scale * 1.44269504088896340736f;   // scores in log2 units
+
+    int kv_end = a.kv_len;
+    if (CAUSAL) kv_end = min(a.kv_len, qb + 63 + off + 1);
+    const int ntiles = (kv_end + 63) >> 6;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 64;
+        __syncthreads();   // previous tile fully consumed
+        // ---- stage K tile: 64 rows x CH chunks
+#pragma unroll
+        for (int i = 0; i < (64 * CH) / 256; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CH, c = id % CH;
+            const int gj = min(j0 + r, a.kv_len - 1);
+            const uint4 val = *reinterpret_cast<const uint4*>(K + (long long)gj * a.k_rs + c * 8);
+            *reinterpret_cast<uint4*>(sK + r * KROW + ((c ^ (r & (CH - 1))) << 4)) = val;
+        }
+        // ---- stage V^T tile: D rows x 8 chunks (64 keys); keys >= kv_len must read as zero
+#pragma unroll
+        for (int i = 0; i < (D * 8) / 256; ++i) {
+            const int id = tid + 256 * i;
+            const int d = id >> 3, c = id & 7;
+            uint4 val = *reinterpret_cast<const uint4*>(VT + (long long)d * a.vt_rs + j0 + c * 8);
+            const int valid = a.kv_len - (j0 + c * 8);     // number of valid keys in this chunk
+            if (valid < 8) {
+                unsigned w[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (2 * e >= valid) w[e] = 0u;
+                    else if (2 * e + 1 >= valid) w[e] &= 0xffffu;
+                }
+                val = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(sV + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = val;
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T : 4 key fragments x (D/32) k-steps
+        f32x4 s[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < D / 32; ++kk) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int r = f * 16 + fr;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + r * KROW + (((kk * 4 + fg) ^ (r & (CH - 1))) << 4));
+                s[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[f], 0, 0, 0);
+            }
+        }
+        // lane holds S[key = j0 + f*16 + fg*4 + r][query = fr]
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = j0 + f * 16 + fg * 4 + r;
+                float v = s[f][r] * sl2;
+                const bool ok = (key < a.kv_len) && (!CAUSAL || key <= qpos);
+                v = ok ? v : -INFINITY;
+                s[f][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);           // m_run = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(s[f][r] - m_use);
+                psum += p;
+                s[f][r] = p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDF; ++i) {
+            acc_o[i][0] *= alpha; acc_o[i][1] *= alpha; acc_o[i][2] *= alpha; acc_o[i][3] *= alpha;
+        }
+        // ---- O^T += V^T . P^T : 2 key blocks of 32 x NDF d-fragments
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            union { bf16x8 v; unsigned u[4]; } pf;
+            pf.u[0] = pack_bf2(s[2 * kb][0], s[2 * kb][1]);
+            pf.u[1] = pack_bf2(s[2 * kb][2], s[2 * kb][3]);
+            pf.u[2] = pack_bf2(s[2 * kb + 1][0], s[2 * kb + 1][1]);
+            pf.u[3] = pack_bf2(s[2 * kb + 1][2], s[2 * kb + 1][3]);
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) {
+                const int d = df * 16 + fr;
+                const int sw = (d >> 1) & 7;
+                // keys (2kb)*16 + fg*4 .. +4  -> 8-byte unit u0 = 8*kb + fg ; keys (2kb+1)*16 + fg*4 -> u1 = u0 + 4
+                const int u0 = 8 * kb + fg, u1 = u0 + 4;
+                const unsigned char* rowp = sV + d * 128;
+                const uint2 lo = *reinterpret_cast<const uint2*>(rowp + (((u0 >> 1) ^ sw) << 4) + ((u0 & 1) << 3));
+                const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((u1 >> 1) ^ sw) << 4) + ((u1 & 1) << 3));
+                union { bf16x8 v; unsigned u[4]; } vf;
+                vf.u[0] = lo.x; vf.u[1] = lo.y; vf.u[2] = hi.x; vf.u[3] = hi.y;
+                acc_o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, acc_o[df], 0, 0, 0);
+            }
+        }
+    }
+    // ---- finish: l over the four lanes that share a query, normalise, store O[q][h*D + df*16 + fg*4 + r]
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (qi < a.q_len) {
+        const float inv = 1.0f / l_run;
+        bf16_t* o = (bf16_t*)a.o + b * a.o_bs + (long long)qi * a.o_rs + h * D;
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+            const uint2 pk = make_uint2(pack_bf2(acc_o[df][0] * inv, acc_o[df][1] * inv),
+                                        pack_bf2(acc_o[df][2] * inv, acc_o[df][3] * inv));
+            *reinterpret_cast<uint2*>(o + df * 16 + fg * 4) = pk;
+        }
+    }
+}
+
+bool attn_mfma_ok(const teo_attn_args& a, int dtype) {
+    if (dtype != TEO_BF16 || (a.flags & TEO_ATTN_FORCE_SIMPLE) || a.vt == nullptr) return false;
+    if (a.head_dim != 64 && a.head_dim != 128) return false;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al16(a.q) || !al16(a.k) || !al16(a.vt) || (reinterpret_cast<uintptr_t>(a.o) & 7)) return false;
+    if (a.q_rs % 8 || a.q_hs % 8 || a.q_bs % 8 || a.k_rs % 8 || a.k_hs % 8 || a.k_bs % 8) return false;
+    if (a.vt_rs % 8 || a.vt_hs % 8 || a.vt_bs % 8 || a.o_rs % 4 || a.o_bs % 4) return false;
+    // V^T rows are read in whole 64-key tiles
+    if (a.vt_rs < (long long)((a.kv_len + 63) / 64) * 64) return false;
+    return true;
+}
+
+int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
+    const teo_attn_args& a = *ap;
+    if (a.q_len == 0 || a.batch == 0) return TEO_OK;
+    TEO_CHECK_ARG(a.heads % a.kv_heads == 0, "teo_attention: heads %d not a multiple of kv_heads %d", a.heads, a.kv_heads);
+    TEO_CHECK_ARG(a.kv_len >= a.q_len || !a.causal, "teo_attention: causal needs kv_len >= q_len");
+    if (attn_mfma_ok(a, dtype)) {
+        dim3 grid(cdiv(a.q_len, 64), a.heads, a.batch);
+        const size_t lds = 64 * a.head_dim * 2 + a.head_dim * 128;
+        if (a.head_dim == 128) {
+            if (a.causal) attn_mfma_kernel<128, true><<<grid, 256, lds, st>>>(a);
+            else attn_mfma_kernel<128, false><<<grid, 256, lds, st>>>(a);
+        } else {
+            if (a.causal) attn_mfma_kernel<64, true><<<grid, 256, lds, st>>>(a);
+            else attn_mfma_kernel<64, false><<<grid, 256, lds, st>>>(a);
+        }
+        TEO_LAUNCH_CHECK("attn_mfma");
+        return TEO_OK;
+    }
+    TEO_CHECK_ARG(a.v != nullptr, "teo_attention: generic kernel needs row-major V");
+    const size_t lds = (size_t)(a.head_dim + a.kv_len) * sizeof(float);
+    if (lds > 64 * 1024) {
+        set_error("teo_attention: generic kernel supports kv_len + head_dim <= 16384 (got %d)", a.kv_len + a.head_dim);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    dim3 grid(a.q_len, a.heads, a.batch);
+    if (dtype == TEO_F32) attn_simple_kernel<float><<<grid, 64, lds, st>>>(a);
+    else attn_simple_kernel<bf16_t><<<grid, 64, lds, st>>>(a);
+    TEO_LAUNCH_CHECK("attn_simple");
+    return TEO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode: one query row, kv_len read from device memory (hipGraph replays the same launch each token)
+// ------------------------------------------------------------------------------------------------
+constexpr int DEC_CHUNK = 256;   // keys per workgroup
+
+// q: [heads*hd] (already rotated), K/V cache [kv_heads][S_max][hd]; partial: [heads][nsplit][hd + 2] fp32 (m, l, o[hd])
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                                  const T* __restrict__ vc, float* __restrict__ part,
+                                                                  const int* __restrict__ d_pos, int S_max, int heads,
+                                                                  int kv_heads, int hd, float scale, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qs = sm;                // [hd]
+    float* ps = sm + hd;           // [DEC_CHUNK]
+    float* red = ps + DEC_CHUNK;   // [4 + 2*hd] scratch
+    const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+    const int hk = h / (heads / kv_heads);
+    const int kv_len = *d_pos + 1;
+    const int c0 = sp * DEC_CHUNK, c1 = min(kv_len, c0 + DEC_CHUNK);
+    float* out = part + ((long long)h * nsplit + sp) * (hd + 2);
+    if (c0 >= kv_len) {            // nothing here: neutral partial
+        if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
+        for (int d = tid; d < hd; d += 256) out[2 + d] = 0.f;
+        return;
+    }
+    for (int d = tid; d < hd; d += 256) qs[d] = Elem<T>::ld(q + h * hd + d);
+    __syncthreads();
+    const T* kb = kc + (long long)hk * S_max * hd;
+    const T* vb = vc + (long long)hk * S_max * hd;
+    // scores: 16-byte vector loads, lanes of a (16/sizeof(T) * ...)-group share a key
+    constexpr int VE = 16 / sizeof(T);             // elements per 16-byte load
+    const int lpk = hd / VE;                        // lanes per key (hd = 128, bf16 -> 16)
+    const int kpp = 256 / lpk;                      // keys per pass
+    const int sub = tid % lpk, kslot = tid / lpk;
+    for (int j = c0 + kslot; j < c0 + DEC_CHUNK; j += kpp) {
+        float s = 0.f;
+        if (j < c1) {
+            const T* kr = kb + (long long)j * hd + sub * VE;
+            const uint4 raw = *reinterpret_cast<const uint4*>(kr);
+            const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+            for (int x = 0; x < VE; ++x) s = fmaf(qs[sub * VE + x], Elem<T>::ld(e + x), s);
+        }
+        for (int o = lpk >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (sub == 0) ps[j - c0] = (j < c1) ? s * scale : -INFINITY;
+    }
+    __syncthreads();
+    // block max / sum over the chunk
+    float v = ps[tid];
+    float mx = wave_max(v);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float p = expf(v - mx);                   // -inf -> 0
+    float sum = wave_sum(p);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    ps[tid] = Elem<T>::round(p);
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    // o[d] = sum_j p[j] V[j][d]: thread -> (d, key group)
+    const int ng = 256 / hd > 0 ? 256 / hd : 1;     // key groups (hd = 128 -> 2)
+    float acc = 0.f;
+    if (hd <= 256) {
+        const int d = tid % hd, g = tid / hd;
+        if (g < ng) {
+            for (int j = c0 + g; j < c1; j += ng) acc = fmaf(ps[j - c0], Elem<T>::ld(vb + (long long)j * hd + d), acc);
+        }
+        __syncthreads();
+        float* ob = red + 4;
+        if (g < ng) ob[g * hd + d] = acc;
+        __syncthreads();
+        if (tid < hd) {
+            float t = 0.f;
+            for (int g2 = 0; g2 < ng; ++g2) t += ob[g2 * hd + tid];
+            out[2 + tid] = t;
+        }
+    }
+    if (tid == 0) { out[0] = mx; out[1] = sum; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
+                                                                  int hd, int nsplit) {
+    const int h = blockIdx.x;
+    const float* pb = part + (long long)h * nsplit * (hd + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[s * (hd + 2)]);
+    float L = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float m = pb[s * (hd + 2)];
+        if (m != -INFINITY) L += pb[s * (hd + 2) + 1] * expf(m - M);
+    }
+    for (int d = threadIdx.x; d < hd; d += 128) {
+        float acc = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            const float m = pb[s * (hd + 2)];
+            if (m != -INFINITY) acc += pb[s * (hd + 2) + 2 + d] * expf(m - M);
+        }
+        Elem<T>::st(o + h * hd + d, acc / L);
+    }
+}
+
+size_t attn_decode_ws_bytes(int heads, int hd, int S_max) {
+    const int nsplit = cdiv(S_max, DEC_CHUNK);
+    return (size_t)heads * nsplit * (hd + 2) * sizeof(float);
+}
+
+int attn_decode(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos, int S_max,
+                int heads, int kv_heads, int hd, float scale, int dtype, hipStream_t st) {
+    const int nsplit = cdiv(S_max, DEC_CHUNK);
+    const int esz = dtype == TEO_F32 ? 4 : 2;
+    if (hd > 256 || (hd * esz) % 16 != 0 || 256 % (hd * esz / 16) != 0) {
+        set_error("attn_decode: unsupported head_dim %d", hd);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (size_t)(hd + DEC_CHUNK + 4 + 2 * 256) * sizeof(float);
+    dim3 grid(heads, nsplit);
+    if (dtype == TEO_F32) {
+        attn_decode_partial_kernel<float><<<grid, 256, lds, st>>>((const float*)q, (const float*)kc, (const float*)vc, part,
+                                                                  d_pos, S_max, heads, kv_heads, hd, scale, nsplit);
+        attn_decode_combine_kernel<float><<<heads, 128, 0, st>>>(part, (float*)o, hd, nsplit);
+    } else {
+        attn_decode_partial_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc,
+                                                                   part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit);
+        attn_decode_combine_kernel<bf16_t><<<heads, 128, 0, st>>>(part, (bf16_t*)o, hd, nsplit);
+    }
+    TEO_LAUNCH_CHECK("attn_decode");
+    return TEO_OK;
+}
+
+}  // namespace teo

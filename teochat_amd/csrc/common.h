@@ -1,0 +1,94 @@
+// Shared device/host helpers for libteo_hip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/teo_hip.h"
+
+namespace teo {
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define TEO_CHECK_ARG(cond, ...)                   \
+    do {                                           \
+        if (!(cond)) {                             \
+            teo::set_error(__VA_ARGS__);           \
+            return TEO_ERR_ARG;                    \
+        }                                          \
+    } while (0)
+
+#define TEO_LAUNCH_CHECK(name)                                   \
+    do {                                                         \
+        hipError_t e__ = hipGetLastError();                      \
+        if (e__ != hipSuccess) return teo::hip_fail(e__, name);  \
+    } while (0)
+
+// ---- bf16 <-> f32 -----------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kDtype = TEO_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kDtype = TEO_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
+};
+
+// ---- wave / block reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x == NT (multiple of 64); `red` has NT/64 floats of LDS
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// ---- activations -------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == TEO_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (act == TEO_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
+    return x;
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace teo

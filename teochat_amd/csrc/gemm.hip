@@ -1,0 +1,316 @@
+// C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual        (nn.Linear layout: both operands K-contiguous)
+//
+//  gemm_simple_kernel<T,TO> : shape-agnostic 64x64x16 VALU tile kernel, fp32 accumulate.  It is the fp32
+//                             parity path and the fallback for shapes the MFMA kernel does not take.
+//  gemm_mfma_bf16_kernel    : bf16 in, fp32 accumulate on v_mfma_f32_16x16x32_bf16.  128x128x64 workgroup tile,
+//                             4 waves (2x2) of 64x64, LDS double buffer (64 KiB), register-staged global loads
+//                             issued one K-tile ahead, 16-byte XOR-swizzled LDS rows (ds_read_b128 <= 2-way),
+//                             XCD-aware tile order (m fastest so one XCD's L2 keeps a W panel).
+//                             Operands are swapped (D^T = W . A^T) so a lane owns 4 consecutive N of one M row:
+//                             8-byte stores, vector bias/residual loads, and the gate/up pair of SwiGLU sits in
+//                             the same lane (W rows interleaved in blocks of 16 at load time).
+//
+// Roofline: MFMA bf16 dense (2.5 PFLOP/s); algorithmic FLOPs = 2*M*N*K.
+#include "common.h"
+
+namespace teo {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ------------------------------------------------------------------------------------------------
+// generic kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, bool SWIGLU>
+__global__ __launch_bounds__(256) void gemm_simple_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                          const T* __restrict__ bias, const T* __restrict__ res,
+                                                          TO* __restrict__ C, int M, int N, int K, int lda, int ldc,
+                                                          int act) {
+    __shared__ float As[16][65];
+    __shared__ float Ws[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = threadIdx.x + i * 256;
+            const int r = id >> 4, kk = id & 15;
+            const bool kin = (k0 + kk) < K;
+            As[kk][r] = (kin && (m0 + r) < M) ? Elem<T>::ld(A + (long long)(m0 + r) * lda + k0 + kk) : 0.f;
+            Ws[kk][r] = (kin && (n0 + r) < N) ? Elem<T>::ld(W + (long long)(n0 + r) * K + k0 + kk) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Ws[kk][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 16 * i;
+        if (m >= M) continue;
+        if (SWIGLU) {
+            // columns tx+16j: (j=0,1) and (j=2,3) are (gate, up) pairs of the interleaved-16 layout
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ng = n0 + tx + 32 * p;       // gate column
+                if (ng < N) {   // N % 32 == 0, so the whole (gate, up) block is in range
+                    const float g = acc[i][2 * p], u = acc[i][2 * p + 1];
+                    const int oc = (n0 >> 1) + 16 * p + tx;
+                    Elem<TO>::st(C + (long long)m * ldc + oc, silu(g) * u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + tx + 16 * j;
+                if (n >= N) continue;
+                float v = acc[i][j];
+                if (bias) v += Elem<T>::ld(bias + n);
+                v = act_apply(v, act);
+                if (res) v += Elem<T>::ld(res + (long long)m * ldc + n);
+                Elem<TO>::st(C + (long long)m * ldc + n, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous range of tiles (bijective form)
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(const bf16_t* __restrict__ A,
+                                                             const bf16_t* __restrict__ W,
+                                                             const bf16_t* __restrict__ bias,
+                                                             const bf16_t* __restrict__ res, void* __restrict__ Cv,
+                                                             int M, int N, int K, int lda, int ldc, int act,
+                                                             int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // staging: thread owns 4 chunks (16 B) of each operand tile: chunk id = tid + 256*i -> row id>>3, chunk id&7
+    const bf16_t* ag[4];
+    const bf16_t* wg[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id >> 3, c = id & 7;
+        const int gm = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);
+        ag[i] = A + (long long)gm * lda + c * 8;
+        wg[i] = W + (long long)gn * K + c * 8;
+        soff[i] = row * (BK * 2) + ((c ^ (row & 7)) << 4);
+    }
+    uint4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const uint4*>(ag[i] + kt * BK);
+            rb[i] = *reinterpret_cast<const uint4*>(wg[i] + kt * BK);
+        }
+    };
+    auto swrite = [&](int buf) {
+        unsigned char* sa = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(sa + soff[i]) = ra[i];
+            *reinterpret_cast<uint4*>(sa + TILE_BYTES + soff[i]) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = base + i*16 + (lane&15); logical chunk = ks*4 + (lane>>4)
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / BK;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const unsigned char* sA = smem + (kt & 1) * (2 * TILE_BYTES);
+        const unsigned char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra_ = wm * 64 + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * (BK * 2) + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
+                const int rw_ = wn * 64 + i * 16 + fr;
+                wf[i] = *reinterpret_cast<const bf16x8*>(sB + rw_ * (BK * 2) + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) swrite((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+        if (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int ng = nw + ni * 16 + fg * 4;              // gate rows; up rows are +16
+                if (ng >= N) continue;                               // N % 32 == 0: whole block in or out
+                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) =
+                        make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) =
+                        make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
+                if (n + 3 < N) {
+                    if (bias) {
+                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
+                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                    }
+                    if (act != TEO_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
+                    }
+                    if (res) {
+                        const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
+                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                    }
+                    if (OUT_F32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) =
+                            make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) =
+                            make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                    }
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) {
+                        float v = o[r];
+                        if (bias) v += bf2f(bias[n + r]);
+                        v = act_apply(v, act);
+                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned flags, const void* A, const void* W,
+                  const void* bias, const void* res, const void* C) {
+    if (dtype != TEO_BF16 || (flags & TEO_GEMM_FORCE_SIMPLE)) return false;
+    if (K % BK != 0 || lda % 8 != 0 || ldc % 4 != 0 || N % 4 != 0) return false;
+    if (M < 1 || N < 1) return false;
+    if ((flags & TEO_GEMM_SWIGLU16) && (N % 32 != 0)) return false;
+    auto al = [](const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; };
+    return al(A, 16) && al(W, 16) && al(bias, 8) && al(res, 8) && al(C, 16);
+}
+
+template <typename T, typename TO>
+static void launch_simple(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N,
+                          int K, int lda, int ldc, int act, bool swiglu, hipStream_t st) {
+    dim3 grid(cdiv(N, 64), cdiv(M, 64));
+    if (swiglu)
+        gemm_simple_kernel<T, TO, true><<<grid, 256, 0, st>>>((const T*)A, (const T*)W, (const T*)bias,
+                                                              (const T*)res, (TO*)C, M, N, K, lda, ldc, act);
+    else
+        gemm_simple_kernel<T, TO, false><<<grid, 256, 0, st>>>((const T*)A, (const T*)W, (const T*)bias,
+                                                               (const T*)res, (TO*)C, M, N, K, lda, ldc, act);
+}
+
+int gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
+         int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st) {
+    if (M == 0 || N == 0) return TEO_OK;
+    const bool swiglu = flags & TEO_GEMM_SWIGLU16;
+    if (swiglu && (bias || res || act != TEO_ACT_NONE || N % 32 != 0)) {
+        set_error("teo_gemm: SWIGLU16 needs N %% 32 == 0 and no bias/residual/act");
+        return TEO_ERR_ARG;
+    }
+    if (gemm_mfma_ok(M, N, K, lda, ldc, dtype, flags, A, W, bias, res, C)) {
+        const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+        const int nwg = tiles_m * tiles_n;
+        const size_t lds = 4 * TILE_BYTES;
+        const bool of32 = out_dtype == TEO_F32;
+#define TEO_GEMM_LAUNCH(SW, OF)                                                                                   \
+    gemm_mfma_bf16_kernel<SW, OF><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+                                                         (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m,  \
+                                                         tiles_n)
+        if (swiglu) { if (of32) TEO_GEMM_LAUNCH(true, true); else TEO_GEMM_LAUNCH(true, false); }
+        else        { if (of32) TEO_GEMM_LAUNCH(false, true); else TEO_GEMM_LAUNCH(false, false); }
+#undef TEO_GEMM_LAUNCH
+        TEO_LAUNCH_CHECK("gemm_mfma_bf16");
+        return TEO_OK;
+    }
+    if (dtype == TEO_F32) {
+        if (out_dtype != TEO_F32) { set_error("teo_gemm: f32 inputs need f32 output"); return TEO_ERR_UNSUPPORTED; }
+        launch_simple<float, float>(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, st);
+    } else if (dtype == TEO_BF16) {
+        if (out_dtype == TEO_F32) launch_simple<bf16_t, float>(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, st);
+        else launch_simple<bf16_t, bf16_t>(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, st);
+    } else {
+        set_error("teo_gemm: unknown dtype %d", dtype);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    TEO_LAUNCH_CHECK("gemm_simple");
+    return TEO_OK;
+}
+
+}  // namespace teo

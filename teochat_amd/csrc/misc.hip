@@ -1,0 +1,293 @@
+// Data-movement and small kernels: RoPE + KV append, V transposes, im2col, embedding splice, CLS drop, argmax,
+// decode bookkeeping.  All HBM/latency-bound; none is shaped into a GEMM.
+#include "common.h"
+
+namespace teo {
+
+// ------------------------------------------------------------------------------------------------
+// RoPE (rotate-half convention, tf llama apply_rotary_pos_emb) + KV append
+//   grid (S, heads + 2*kv_heads); block = hd/2 threads (>= 1 wave)
+//   d_past (optional) overrides `past` with a device-resident position (decode under hipGraph replay)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rope_kv_append_kernel(T* __restrict__ qkv, int ld, const int* __restrict__ positions,
+                                      const float* __restrict__ cs, const float* __restrict__ sn, T* __restrict__ kc,
+                                      T* __restrict__ vc, T* __restrict__ vtc, int past, const int* __restrict__ d_past,
+                                      int S_max, int heads, int kv_heads, int hd, int write_vt) {
+    const int s = blockIdx.x, hh = blockIdx.y, half = hd >> 1;
+    const int base_pos = d_past ? *d_past : past;
+    const int pos = positions ? positions[s] : base_pos + s;   // rotary position of this token
+    const int slot = base_pos + s;                             // cache slot
+    T* row = qkv + (long long)s * ld;
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        if (hh < heads + kv_heads) {
+            T* x = row + hh * hd;
+            const float c = cs[(long long)pos * half + i], sv = sn[(long long)pos * half + i];
+            const float x1 = Elem<T>::ld(x + i), x2 = Elem<T>::ld(x + i + half);
+            const float y1 = x1 * c - x2 * sv, y2 = x2 * c + x1 * sv;
+            if (hh < heads) {
+                Elem<T>::st(x + i, y1);
+                Elem<T>::st(x + i + half, y2);
+            } else {
+                T* dst = kc + ((long long)(hh - heads) * S_max + slot) * hd;
+                Elem<T>::st(dst + i, y1);
+                Elem<T>::st(dst + i + half, y2);
+            }
+        } else {
+            const int hk = hh - heads - kv_heads;
+            const T* x = row + (heads + kv_heads + hk) * hd;
+            T* dst = vc + ((long long)hk * S_max + slot) * hd;
+            const T a = x[i], b = x[i + half];
+            dst[i] = a;
+            dst[i + half] = b;
+            if (write_vt) {
+                vtc[((long long)hk * hd + i) * S_max + slot] = a;
+                vtc[((long long)hk * hd + i + half) * S_max + slot] = b;
+            }
+        }
+    }
+}
+
+// tiled V -> V^T append for long prefills: block = (64 positions, one kv head); 128-byte rows out
+template <typename T>
+__global__ __launch_bounds__(256) void vt_append_kernel(const T* __restrict__ qkv, int ld, T* __restrict__ vtc, int S,
+                                                        int past, int S_max, int v_off, int hd) {
+    __shared__ T tile[64][129];
+    const int s0 = blockIdx.x * 64, hk = blockIdx.y;
+    for (int d0 = 0; d0 < hd; d0 += 128) {
+        const int dw = min(128, hd - d0);
+        for (int id = threadIdx.x; id < 64 * dw; id += 256) {
+            const int r = id / dw, d = id % dw;
+            tile[r][d] = (s0 + r < S) ? qkv[(long long)(s0 + r) * ld + v_off + hk * hd + d0 + d] : (T)0;
+        }
+        __syncthreads();
+        for (int id = threadIdx.x; id < 64 * dw; id += 256) {
+            const int d = id / 64, r = id % 64;
+            if (s0 + r < S) vtc[((long long)hk * hd + d0 + d) * S_max + past + s0 + r] = tile[r][d];
+        }
+        __syncthreads();
+    }
+}
+
+int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
+                   void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,
+                   hipStream_t st) {
+    if (S == 0) return TEO_OK;
+    TEO_CHECK_ARG(hd % 2 == 0, "rope: odd head_dim %d", hd);
+    const int threads = ((hd / 2 + 63) / 64) * 64;
+    dim3 grid(S, heads + 2 * kv_heads);
+    const bool tiled_vt = vtc && S >= 16 && d_past == nullptr;
+    const int wvt = (vtc && !tiled_vt) ? 1 : 0;
+    if (dtype == TEO_F32) {
+        rope_kv_append_kernel<float><<<grid, threads, 0, st>>>((float*)qkv, ld, positions, cs, sn, (float*)kc, (float*)vc,
+                                                               (float*)vtc, past, d_past, S_max, heads, kv_heads, hd, wvt);
+        if (tiled_vt)
+            vt_append_kernel<float><<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const float*)qkv, ld, (float*)vtc, S, past,
+                                                                                 S_max, (heads + kv_heads) * hd, hd);
+    } else {
+        rope_kv_append_kernel<bf16_t><<<grid, threads, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
+                                                                (bf16_t*)vc, (bf16_t*)vtc, past, d_past, S_max, heads,
+                                                                kv_heads, hd, wvt);
+        if (tiled_vt)
+            vt_append_kernel<bf16_t><<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const bf16_t*)qkv, ld, (bf16_t*)vtc, S,
+                                                                                  past, S_max, (heads + kv_heads) * hd, hd);
+    }
+    TEO_LAUNCH_CHECK("rope_kv_append");
+    return TEO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ViT: V^T[t][h][d][j] = qkv[t*N + j][2*D + h*hd + d]; columns j in [N, ldv) are zero
+//   grid (ceil(ldv/64), heads, T)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void vit_vt_kernel(const T* __restrict__ qkv, T* __restrict__ vt, int N, int heads,
+                                                     int hd, int ldv) {
+    __shared__ T tile[64][65];
+    const int j0 = blockIdx.x * 64, h = blockIdx.y, t = blockIdx.z;
+    const int D = heads * hd;
+    for (int d0 = 0; d0 < hd; d0 += 64) {
+        const int dw = min(64, hd - d0);
+        for (int id = threadIdx.x; id < 64 * dw; id += 256) {
+            const int r = id / dw, d = id % dw;
+            tile[r][d] = (j0 + r < N) ? qkv[((long long)t * N + j0 + r) * (3 * D) + 2 * D + h * hd + d0 + d] : (T)0;
+        }
+        __syncthreads();
+        for (int id = threadIdx.x; id < 64 * dw; id += 256) {
+            const int d = id / 64, r = id % 64;
+            if (j0 + r < ldv) vt[(((long long)t * heads + h) * hd + d0 + d) * ldv + j0 + r] = tile[r][d];
+        }
+        __syncthreads();
+    }
+}
+
+int vit_value_transpose(const void* qkv, void* vt, int T_, int N, int heads, int hd, int ldv, int dtype, hipStream_t st) {
+    if (T_ == 0) return TEO_OK;
+    dim3 grid(cdiv(ldv, 64), heads, T_);
+    if (dtype == TEO_F32) vit_vt_kernel<float><<<grid, 256, 0, st>>>((const float*)qkv, (float*)vt, N, heads, hd, ldv);
+    else vit_vt_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)qkv, (bf16_t*)vt, N, heads, hd, ldv);
+    TEO_LAUNCH_CHECK("vit_value_transpose");
+    return TEO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col for the patch-embedding conv (kernel = stride = P): one thread per output element
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_kernel(const T* __restrict__ px, T* __restrict__ cols, int C, int img, int P, int ld,
+                              long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int col = (int)(idx % ld);
+    const long long row = idx / ld;
+    const int g = img / P;
+    const int K = C * P * P;
+    T v = (T)0;
+    if (col < K) {
+        const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+        const int t = (int)(row / (g * g)), py = (int)((row / g) % g), pxx = (int)(row % g);
+        v = px[(((long long)t * C + c) * img + py * P + ky) * img + pxx * P + kx];
+    }
+    cols[idx] = v;
+}
+
+int im2col_patches(const void* px, void* cols, int T_, int C, int img, int P, int ld, int dtype, hipStream_t st) {
+    const int g = img / P;
+    const long long total = (long long)T_ * g * g * ld;
+    if (total == 0) return TEO_OK;
+    TEO_CHECK_ARG(img % P == 0 && ld >= C * P * P, "im2col: image %d patch %d ld %d", img, P, ld);
+    const int blocks = cdiv(total, 256);
+    if (dtype == TEO_F32) im2col_kernel<float><<<blocks, 256, 0, st>>>((const float*)px, (float*)cols, C, img, P, ld, total);
+    else im2col_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)px, (bf16_t*)cols, C, img, P, ld, total);
+    TEO_LAUNCH_CHECK("im2col");
+    return TEO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding splice: pure gather/copy driven by the host-built int32 plan
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int* __restrict__ plan, const T* __restrict__ embed,
+                                                           const T* __restrict__ visual, T* __restrict__ out, int dim) {
+    const long long r = blockIdx.x;
+    const int p = plan[r];
+    T* dst = out + r * dim;
+    if (p == INT32_MIN) {
+        for (int i = threadIdx.x; i < dim; i += 256) dst[i] = (T)0;
+        return;
+    }
+    const T* src = (p >= 0) ? embed + (long long)p * dim : visual + (long long)(-(p + 1)) * dim;
+    constexpr int VE = 16 / sizeof(T);
+    if (dim % VE == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (int i = threadIdx.x; i < dim / VE; i += 256) d4[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < dim; i += 256) dst[i] = src[i];
+    }
+}
+
+int embed_splice(const int* plan, const void* embed, const void* visual, void* out, int rows, int dim, int dtype,
+                 hipStream_t st) {
+    if (rows == 0) return TEO_OK;
+    if (dtype == TEO_F32)
+        embed_splice_kernel<float><<<rows, 256, 0, st>>>(plan, (const float*)embed, (const float*)visual, (float*)out, dim);
+    else
+        embed_splice_kernel<bf16_t><<<rows, 256, 0, st>>>(plan, (const bf16_t*)embed, (const bf16_t*)visual, (bf16_t*)out, dim);
+    TEO_LAUNCH_CHECK("embed_splice");
+    return TEO_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void drop_cls_kernel(const T* __restrict__ in, T* __restrict__ out, int ntok, int dim) {
+    const int t = blockIdx.x / (ntok - 1), p = blockIdx.x % (ntok - 1);
+    const T* src = in + ((long long)t * ntok + 1 + p) * dim;
+    T* dst = out + (long long)blockIdx.x * dim;
+    for (int i = threadIdx.x; i < dim; i += 256) dst[i] = src[i];
+}
+
+int drop_cls(const void* in, void* out, int T_, int ntok, int dim, int dtype, hipStream_t st) {
+    const int rows = T_ * (ntok - 1);
+    if (rows <= 0) return TEO_OK;
+    if (dtype == TEO_F32) drop_cls_kernel<float><<<rows, 256, 0, st>>>((const float*)in, (float*)out, ntok, dim);
+    else drop_cls_kernel<bf16_t><<<rows, 256, 0, st>>>((const bf16_t*)in, (bf16_t*)out, ntok, dim);
+    TEO_LAUNCH_CHECK("drop_cls");
+    return TEO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// argmax (first index on ties) + greedy bookkeeping
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, long long* __restrict__ tok,
+                                                      int vocab) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const float* row = logits + (long long)blockIdx.x * vocab;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < vocab; i += 1024) {
+        const float v = row[i];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = i; }   // indices ascend per thread: strict > keeps the first
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        tok[blockIdx.x] = bi;
+    }
+}
+
+int argmax(const float* logits, long long* tok, int rows, int vocab, hipStream_t st) {
+    if (rows == 0) return TEO_OK;
+    argmax_kernel<<<rows, 1024, 0, st>>>(logits, tok, vocab);
+    TEO_LAUNCH_CHECK("argmax");
+    return TEO_OK;
+}
+
+// after argmax wrote the next token into st.d_token: append it, advance the position, check the stop suffix
+__global__ void decode_advance_kernel(teo_decode_state st) {
+    if (threadIdx.x != 0) return;
+    const int n = *st.d_out_count;
+    const long long t = *st.d_token;
+    st.d_out_tokens[n] = t;
+    *st.d_out_count = n + 1;
+    *st.d_pos = *st.d_pos + 1;
+    if (st.d_stop_ids && st.n_stop_ids > 0 && n + 1 >= st.n_stop_ids) {
+        bool eq = true;
+        for (int k = 0; k < st.n_stop_ids; ++k)
+            eq = eq && (st.d_out_tokens[n + 1 - st.n_stop_ids + k] == st.d_stop_ids[k]);
+        if (eq) *st.d_stop = 1;
+    }
+}
+
+int decode_advance(const teo_decode_state* s, hipStream_t st) {
+    decode_advance_kernel<<<1, 64, 0, st>>>(*s);
+    TEO_LAUNCH_CHECK("decode_advance");
+    return TEO_OK;
+}
+
+// h[:] = embed[token][:]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_token_kernel(const long long* __restrict__ tok, const T* __restrict__ embed,
+                                                          T* __restrict__ h, int dim) {
+    const long long t = *tok;
+    for (int i = threadIdx.x + blockIdx.x * 256; i < dim; i += 256 * gridDim.x) h[i] = embed[t * dim + i];
+}
+
+int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st) {
+    const int blocks = cdiv(dim, 256);
+    if (dtype == TEO_F32) embed_token_kernel<float><<<blocks, 256, 0, st>>>(tok, (const float*)embed, (float*)h, dim);
+    else embed_token_kernel<bf16_t><<<blocks, 256, 0, st>>>(tok, (const bf16_t*)embed, (bf16_t*)h, dim);
+    TEO_LAUNCH_CHECK("embed_token");
+    return TEO_OK;
+}
+
+}  // namespace teo

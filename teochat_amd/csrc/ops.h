@@ -1,0 +1,45 @@
+// Internal C++ entry points of the kernels (one per .hip file); the extern "C" surface is in abi.hip.
+#pragma once
+#include "common.h"
+
+struct teo_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+namespace teo {
+
+int layernorm(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, int dtype, hipStream_t st);
+int rmsnorm(const void* x, const void* w, void* y, int rows, int dim, float eps, int dtype, hipStream_t st);
+int vit_embed_ln(const void* patch, const void* cls, const void* pos, const void* w, const void* b, void* out, int T,
+                 int NP, int dim, float eps, int dtype, hipStream_t st);
+
+bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned flags, const void* A, const void* W,
+                  const void* bias, const void* res, const void* C);
+int gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
+         int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st);
+
+int attention(const teo_attn_args* a, int dtype, hipStream_t st);
+size_t attn_decode_ws_bytes(int heads, int hd, int S_max);
+int attn_decode(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos, int S_max,
+                int heads, int kv_heads, int hd, float scale, int dtype, hipStream_t st);
+
+int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
+                   void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,
+                   hipStream_t st);
+int vit_value_transpose(const void* qkv, void* vt, int T, int N, int heads, int hd, int ldv, int dtype, hipStream_t st);
+int im2col_patches(const void* px, void* cols, int T, int C, int img, int P, int ld, int dtype, hipStream_t st);
+int embed_splice(const int* plan, const void* embed, const void* visual, void* out, int rows, int dim, int dtype,
+                 hipStream_t st);
+int drop_cls(const void* in, void* out, int T, int ntok, int dim, int dtype, hipStream_t st);
+int argmax(const float* logits, long long* tok, int rows, int vocab, hipStream_t st);
+int decode_advance(const teo_decode_state* s, hipStream_t st);
+int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st);
+
+int gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
+         unsigned flags, int dtype, int out_dtype, hipStream_t st);
+
+inline size_t esize(int dtype) { return dtype == TEO_F32 ? 4 : 2; }
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace teo

@@ -1,0 +1,284 @@
+// Composed entry points: the ViT / projector / LLaMA layer loops and the greedy decode step live here, in C++,
+// so that one host call enqueues a whole phase on the caller's stream (no per-op Python round trips) and the
+// decode step can be captured into a hipGraph and replayed once per token.
+#include <vector>
+
+#include "ops.h"
+
+namespace teo {
+
+struct Carver {
+    unsigned char* base;
+    size_t off = 0, cap;
+    Carver(void* p, size_t c) : base((unsigned char*)p), cap(c) {}
+    void* take(size_t bytes) {
+        void* r = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+#define TEO_TRY(expr)                  \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__ != TEO_OK) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// ViT
+// ------------------------------------------------------------------------------------------------
+struct VitWs {
+    void *cols, *patch, *h, *ln, *qkv, *vt, *attn, *mlp;
+    int ldv;
+    size_t total;
+};
+
+static VitWs vit_carve(const teo_vit_desc* d, int T, void* ws, size_t cap) {
+    const size_t e = esize(d->dtype);
+    const int g = d->image / d->patch, NP = g * g, N = NP + 1, D = d->hidden;
+    VitWs w;
+    w.ldv = (N + 63) / 64 * 64;
+    Carver c(ws, cap);
+    w.cols = c.take((size_t)T * NP * d->k_pad * e);
+    w.patch = c.take((size_t)T * NP * D * e);
+    w.h = c.take((size_t)T * N * D * e);
+    w.ln = c.take((size_t)T * N * D * e);
+    w.qkv = c.take((size_t)T * N * 3 * D * e);
+    w.vt = c.take((size_t)T * D * w.ldv * e);
+    w.attn = c.take((size_t)T * N * D * e);
+    w.mlp = c.take((size_t)T * N * d->inter * e);
+    w.total = c.off;
+    return w;
+}
+
+size_t vit_workspace_bytes(const teo_vit_desc* d, int T) { return vit_carve(d, T, nullptr, 0).total; }
+
+int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features, void* ws, size_t ws_bytes,
+               hipStream_t st) {
+    if (T == 0) return TEO_OK;
+    const VitWs w = vit_carve(d, T, ws, ws_bytes);
+    if (w.total > ws_bytes) {
+        set_error("teo_vit_encode: workspace %zu < %zu", ws_bytes, w.total);
+        return TEO_ERR_WORKSPACE;
+    }
+    const int dt = d->dtype;
+    const int g = d->image / d->patch, NP = g * g, N = NP + 1, D = d->hidden, H = d->heads, hd = D / H;
+    const int rows = T * N;
+    TEO_TRY(im2col_patches(pixels, w.cols, T, d->channels, d->image, d->patch, d->k_pad, dt, st));
+    TEO_TRY(gemm(w.cols, d->patch_w, nullptr, nullptr, w.patch, T * NP, D, d->k_pad, d->k_pad, D, TEO_ACT_NONE, 0, dt, dt, st));
+    TEO_TRY(vit_embed_ln(w.patch, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, w.h, T, NP, D, d->eps, dt, st));
+    for (int l = 0; l < d->layers_run; ++l) {
+        TEO_TRY(layernorm(w.h, d->ln1_w[l], d->ln1_b[l], w.ln, rows, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.ln, d->qkv_w[l], d->qkv_b[l], nullptr, w.qkv, rows, 3 * D, D, D, 3 * D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(vit_value_transpose(w.qkv, w.vt, T, N, H, hd, w.ldv, dt, st));
+        teo_attn_args a;
+        memset(&a, 0, sizeof(a));
+        const size_t e = esize(dt);
+        a.q = w.qkv;
+        a.k = (const char*)w.qkv + (size_t)D * e;
+        a.v = (const char*)w.qkv + (size_t)2 * D * e;
+        a.vt = w.vt;
+        a.o = w.attn;
+        a.q_bs = a.k_bs = a.v_bs = (long long)N * 3 * D;
+        a.q_hs = a.k_hs = a.v_hs = hd;
+        a.q_rs = a.k_rs = a.v_rs = 3 * D;
+        a.vt_bs = (long long)D * w.ldv;
+        a.vt_hs = (long long)hd * w.ldv;
+        a.vt_rs = w.ldv;
+        a.o_bs = (long long)N * D;
+        a.o_rs = D;
+        a.batch = T; a.heads = H; a.kv_heads = H; a.head_dim = hd; a.q_len = N; a.kv_len = N;
+        a.causal = 0;
+        a.scale = 1.0f / sqrtf((float)hd);
+        TEO_TRY(attention(&a, dt, st));
+        TEO_TRY(gemm(w.attn, d->out_w[l], d->out_b[l], w.h, w.h, rows, D, D, D, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(layernorm(w.h, d->ln2_w[l], d->ln2_b[l], w.ln, rows, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.ln, d->fc1_w[l], d->fc1_b[l], nullptr, w.mlp, rows, d->inter, D, D, d->inter, d->act, 0, dt, dt, st));
+        TEO_TRY(gemm(w.mlp, d->fc2_w[l], d->fc2_b[l], w.h, w.h, rows, D, d->inter, d->inter, D, TEO_ACT_NONE, 0, dt, dt, st));
+    }
+    return drop_cls(w.h, features, T, N, D, dt, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// projector
+// ------------------------------------------------------------------------------------------------
+size_t projector_workspace_bytes(const teo_proj_desc* d, int rows) {
+    return d->depth > 1 ? 2 * align_up((size_t)rows * d->out_dim * esize(d->dtype)) : 0;
+}
+
+int projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (rows == 0) return TEO_OK;
+    TEO_CHECK_ARG(d->depth >= 1 && d->depth <= 4, "teo_projector: depth %d", d->depth);
+    if (ws_bytes < projector_workspace_bytes(d, rows)) {
+        set_error("teo_projector: workspace too small");
+        return TEO_ERR_WORKSPACE;
+    }
+    const int dt = d->dtype;
+    const size_t buf = align_up((size_t)rows * d->out_dim * esize(dt));
+    const void* in = x;
+    int in_dim = d->in_dim;
+    for (int j = 0; j < d->depth; ++j) {
+        const bool last = j == d->depth - 1;
+        void* out = last ? y : (unsigned char*)ws + (j & 1) * buf;
+        TEO_TRY(gemm(in, d->w[j], d->b[j], nullptr, out, rows, d->out_dim, in_dim, in_dim, d->out_dim,
+                     last ? TEO_ACT_NONE : TEO_ACT_GELU_ERF, 0, dt, dt, st));
+        in = out;
+        in_dim = d->out_dim;
+    }
+    return TEO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLaMA prefill
+// ------------------------------------------------------------------------------------------------
+struct PrefillWs {
+    void *h, *n, *qkv, *attn, *act;
+    size_t total;
+};
+
+static PrefillWs prefill_carve(const teo_llama_desc* d, int S, void* ws, size_t cap) {
+    const size_t e = esize(d->dtype);
+    const int QKV = (d->heads + 2 * d->kv_heads) * d->head_dim;
+    PrefillWs w;
+    Carver c(ws, cap);
+    w.h = c.take((size_t)S * d->hidden * e);
+    w.n = c.take((size_t)S * d->hidden * e);
+    w.qkv = c.take((size_t)S * QKV * e);
+    w.attn = c.take((size_t)S * d->heads * d->head_dim * e);
+    w.act = c.take((size_t)S * d->inter * e);
+    w.total = c.off;
+    return w;
+}
+
+size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S) { return prefill_carve(d, S, nullptr, 0).total; }
+
+int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
+                  float* logits, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (S == 0) return TEO_OK;
+    TEO_CHECK_ARG(past + S <= d->max_seq, "teo_llama_prefill: past %d + S %d exceeds max_seq %d", past, S, d->max_seq);
+    const PrefillWs w = prefill_carve(d, S, ws, ws_bytes);
+    if (w.total > ws_bytes) {
+        set_error("teo_llama_prefill: workspace %zu < %zu", ws_bytes, w.total);
+        return TEO_ERR_WORKSPACE;
+    }
+    const int dt = d->dtype;
+    const size_t e = esize(dt);
+    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
+    const int QKV = (H + 2 * Hk) * hd;
+    hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
+    if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
+    for (int l = 0; l < d->layers; ++l) {
+        TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(rope_kv_append(w.qkv, QKV, positions, d->rope_cos, d->rope_sin, d->k_cache[l], d->v_cache[l],
+                               d->vt_cache[l], S, past, nullptr, d->max_seq, H, Hk, hd, dt, st));
+        teo_attn_args a;
+        memset(&a, 0, sizeof(a));
+        a.q = w.qkv; a.k = d->k_cache[l]; a.v = d->v_cache[l]; a.vt = d->vt_cache[l]; a.o = w.attn;
+        a.q_bs = 0; a.q_hs = hd; a.q_rs = QKV;
+        a.k_bs = 0; a.k_hs = (long long)d->max_seq * hd; a.k_rs = hd;
+        a.v_bs = 0; a.v_hs = (long long)d->max_seq * hd; a.v_rs = hd;
+        a.vt_bs = 0; a.vt_hs = (long long)hd * d->max_seq; a.vt_rs = d->max_seq;
+        a.o_bs = 0; a.o_rs = (long long)H * hd;
+        a.batch = 1; a.heads = H; a.kv_heads = Hk; a.head_dim = hd; a.q_len = S; a.kv_len = past + S;
+        a.causal = 1;
+        a.scale = 1.0f / sqrtf((float)hd);
+        TEO_TRY(attention(&a, dt, st));
+        TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(rmsnorm(w.h, d->post_norm_w[l], w.n, S, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st));
+        TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st));
+    }
+    if (last_only) {
+        const void* hl = (const unsigned char*)w.h + (size_t)(S - 1) * D * e;
+        return gemv(hl, d->lm_head, d->final_norm_w, nullptr, logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st);
+    }
+    TEO_TRY(rmsnorm(w.h, d->final_norm_w, w.n, S, D, d->eps, dt, st));
+    return gemm(w.n, d->lm_head, nullptr, nullptr, logits, S, d->vocab, D, D, d->vocab, TEO_ACT_NONE, 0, dt, TEO_F32, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLaMA greedy decode step
+// ------------------------------------------------------------------------------------------------
+struct DecodeWs {
+    void *h, *qkv, *attn, *act;
+    float* part;
+    size_t total;
+};
+
+static DecodeWs decode_carve(const teo_llama_desc* d, void* ws, size_t cap) {
+    const size_t e = esize(d->dtype);
+    const int QKV = (d->heads + 2 * d->kv_heads) * d->head_dim;
+    DecodeWs w;
+    Carver c(ws, cap);
+    w.h = c.take((size_t)d->hidden * e);
+    w.qkv = c.take((size_t)QKV * e);
+    w.attn = c.take((size_t)d->heads * d->head_dim * e);
+    w.act = c.take((size_t)d->inter * e);
+    w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq));
+    w.total = c.off;
+    return w;
+}
+
+size_t llama_decode_workspace_bytes(const teo_llama_desc* d) { return decode_carve(d, nullptr, 0).total; }
+
+int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st) {
+    const DecodeWs w = decode_carve(d, ws, ws_bytes);
+    if (w.total > ws_bytes) {
+        set_error("teo_llama_decode_step: workspace %zu < %zu", ws_bytes, w.total);
+        return TEO_ERR_WORKSPACE;
+    }
+    const int dt = d->dtype;
+    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
+    const int QKV = (H + 2 * Hk) * hd;
+    TEO_TRY(embed_token(s->d_token, d->embed, w.h, D, dt, st));
+    for (int l = 0; l < d->layers; ++l) {
+        TEO_TRY(gemv(w.h, d->qkv_w[l], d->in_norm_w[l], nullptr, w.qkv, QKV, D, d->eps, 0, dt, dt, st));
+        TEO_TRY(rope_kv_append(w.qkv, QKV, s->d_pos, d->rope_cos, d->rope_sin, d->k_cache[l], d->v_cache[l],
+                               d->vt_cache[l], 1, 0, s->d_pos, d->max_seq, H, Hk, hd, dt, st));
+        TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], w.attn, w.part, s->d_pos, d->max_seq, H, Hk, hd,
+                            1.0f / sqrtf((float)hd), dt, st));
+        TEO_TRY(gemv(w.attn, d->o_w[l], nullptr, w.h, w.h, D, H * hd, d->eps, 0, dt, dt, st));
+        TEO_TRY(gemv(w.h, d->gateup_w[l], d->post_norm_w[l], nullptr, w.act, 2 * F, D, d->eps, TEO_GEMM_SWIGLU16, dt, dt, st));
+        TEO_TRY(gemv(w.act, d->down_w[l], nullptr, w.h, w.h, D, F, d->eps, 0, dt, dt, st));
+    }
+    TEO_TRY(gemv(w.h, d->lm_head, d->final_norm_w, nullptr, s->d_logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
+    TEO_TRY(argmax(s->d_logits, s->d_token, 1, d->vocab, st));
+    return decode_advance(s, st);
+}
+
+}  // namespace teo
+
+// ------------------------------------------------------------------------------------------------
+// hipGraph wrapper
+// ------------------------------------------------------------------------------------------------
+namespace teo {
+
+int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
+                        teo_graph** out) {
+    *out = nullptr;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
+    const int rc = llama_decode_step(d, s, ws, ws_bytes, st);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(st, &g);
+    if (rc != TEO_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return hip_fail(e, "hipGraphInstantiate");
+    }
+    teo_graph* tg = new teo_graph();
+    tg->graph = g;
+    tg->exec = ex;
+    *out = tg;
+    return TEO_OK;
+}
+
+}  // namespace teo

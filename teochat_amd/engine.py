@@ -1,0 +1,365 @@
+"""TeoEngine: device-resident weights + KV cache + workspaces, driving libteo_hip.so through the C ABI.
+
+PyTorch is used here only as a container: device allocation, host->device copies, dtype casts at load time and
+stream handles.  Every arithmetic step of the forward path is a teo_* call (include/teo_hip.h).
+
+Weights arrive keyed by the reference's state-dict names and are re-laid-out once:
+  * ViT q/k/v Linear weights+biases fused to one [3D, D] GEMM; patch conv weight flattened to [D, 3*P*P] and
+    zero-padded along K to a multiple of 64;
+  * LLaMA q/k/v fused to [(H + 2*Hkv)*hd, D]; gate/up fused to [2F, D] with rows interleaved in blocks of 16
+    (gate rows 16b..16b+15, then up rows 16b..16b+15) so the SwiGLU epilogue finds both operands in one lane;
+  * RoPE cos/sin tables [max_pos, hd/2] fp32, built on the host exactly as tf LlamaRotaryEmbedding computes them;
+  * KV cache per layer: K [Hkv][S_max][hd], V [Hkv][S_max][hd] (decode streams rows) and V^T [Hkv][hd][S_max]
+    (prefill MFMA attention wants key-contiguous values) -- 288 GB of HBM3E pays for the second V layout.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_ACT = {"quick_gelu": L.ACT_QUICK_GELU, "gelu": L.ACT_GELU_ERF}
+VIT_PREFIX = "model.image_tower.image_tower."
+
+
+def _dt(dtype):
+    if dtype == torch.float32:
+        return L.TEO_F32
+    if dtype == torch.bfloat16:
+        return L.TEO_BF16
+    raise ValueError(f"unsupported engine dtype {dtype}; use torch.float32 or torch.bfloat16")
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def interleave_gate_up(gate, up):
+    """[F, D], [F, D] -> [2F, D] with 16-row blocks alternating gate/up."""
+    F_, D = gate.shape
+    assert F_ % 16 == 0, "intermediate_size must be a multiple of 16"
+    return torch.stack((gate.view(F_ // 16, 16, D), up.view(F_ // 16, 16, D)), dim=1).reshape(2 * F_, D).contiguous()
+
+
+def rope_tables(head_dim, theta, max_pos):
+    """cos/sin [max_pos, hd/2] fp32; inv_freq and pos*inv_freq in fp32 on the host (tf LlamaRotaryEmbedding)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().contiguous(), fr.sin().contiguous()
+
+
+class TeoEngine:
+    def __init__(self, state_dict, config, dtype=torch.bfloat16, device="cuda:0", max_seq=None):
+        self.lib = L.load()                       # raises TeoLibraryError when the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("TeoEngine needs an MI355X (no CPU fallback exists for the product path)")
+        self.cfg = config
+        self.vcfg = config.vision_config
+        self.dtype = dtype
+        self.dt = _dt(dtype)
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.max_seq = int(math.ceil((max_seq or config.max_position_embeddings) / 64.0) * 64)
+        self._keep = []                           # host pointer arrays referenced by the descriptors
+        self._ws = {}
+        self._graph = None
+        self._load_vit(state_dict)
+        self._load_projector(state_dict)
+        self._load_llama(state_dict)
+        self._alloc_cache()
+        self._alloc_decode_state()
+
+    # ------------------------------------------------------------------ weights
+    def _dev(self, t):
+        return t.to(device=self.device, dtype=self.dtype).contiguous()
+
+    def _arr(self, tensors):
+        arr, pp = L.ptr_array([t.data_ptr() for t in tensors])
+        self._keep.append((arr, tensors))
+        return pp
+
+    def _load_vit(self, sd):
+        v = self.vcfg
+        n_states = v.num_hidden_layers + 1
+        sel = self.cfg.mm_vision_select_layer
+        idx = sel if sel >= 0 else n_states + sel
+        if not 0 <= idx <= v.num_hidden_layers:
+            raise ValueError(f"mm_vision_select_layer {sel} out of range")
+        self.vit_layers_run = idx                  # layers after the selected hidden state are dead code
+        if v.hidden_act not in _ACT:
+            raise ValueError(f"unsupported vision hidden_act {v.hidden_act}")
+        D, P = v.hidden_size, v.patch_size
+        K = v.num_channels * P * P
+        self.vit_kpad = (K + 63) // 64 * 64
+        pw = sd[VIT_PREFIX + "embeddings.patch_embedding.weight"].reshape(D, K)
+        pw_pad = torch.zeros(D, self.vit_kpad, dtype=pw.dtype, device=pw.device)
+        pw_pad[:, :K] = pw
+        w = {"patch_w": self._dev(pw_pad),
+             "cls": self._dev(sd[VIT_PREFIX + "embeddings.class_embedding"]),
+             "pos": self._dev(sd[VIT_PREFIX + "embeddings.position_embedding.weight"]),
+             "pre_w": self._dev(sd[VIT_PREFIX + "pre_layrnorm.weight"]),
+             "pre_b": self._dev(sd[VIT_PREFIX + "pre_layrnorm.bias"])}
+        per = {k: [] for k in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b",
+                               "fc2_w", "fc2_b")}
+        for i in range(self.vit_layers_run):
+            p = VIT_PREFIX + f"encoder.layers.{i}."
+            per["ln1_w"].append(self._dev(sd[p + "layer_norm1.weight"]))
+            per["ln1_b"].append(self._dev(sd[p + "layer_norm1.bias"]))
+            per["qkv_w"].append(self._dev(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], dim=0)))
+            per["qkv_b"].append(self._dev(torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], dim=0)))
+            per["out_w"].append(self._dev(sd[p + "self_attn.out_proj.weight"]))
+            per["out_b"].append(self._dev(sd[p + "self_attn.out_proj.bias"]))
+            per["ln2_w"].append(self._dev(sd[p + "layer_norm2.weight"]))
+            per["ln2_b"].append(self._dev(sd[p + "layer_norm2.bias"]))
+            per["fc1_w"].append(self._dev(sd[p + "mlp.fc1.weight"]))
+            per["fc1_b"].append(self._dev(sd[p + "mlp.fc1.bias"]))
+            per["fc2_w"].append(self._dev(sd[p + "mlp.fc2.weight"]))
+            per["fc2_b"].append(self._dev(sd[p + "mlp.fc2.bias"]))
+        self.vit_w = (w, per)
+        d = L.VitDesc()
+        d.hidden, d.heads, d.inter, d.layers_run = D, v.num_attention_heads, v.intermediate_size, self.vit_layers_run
+        d.image, d.patch, d.channels = v.image_size, v.patch_size, v.num_channels
+        d.act, d.eps, d.dtype, d.k_pad = _ACT[v.hidden_act], v.layer_norm_eps, self.dt, self.vit_kpad
+        d.patch_w, d.cls, d.pos = w["patch_w"].data_ptr(), w["cls"].data_ptr(), w["pos"].data_ptr()
+        d.pre_ln_w, d.pre_ln_b = w["pre_w"].data_ptr(), w["pre_b"].data_ptr()
+        for k in per:
+            setattr(d, k, self._arr(per[k]))
+        self.vit_desc = d
+
+    def _load_projector(self, sd):
+        import re
+        pt = getattr(self.cfg, "mm_projector_type", "linear")
+        pre = "model.mm_projector."
+        d = L.ProjDesc()
+        d.in_dim, d.out_dim, d.dtype = self.cfg.mm_hidden_size, self.cfg.hidden_size, self.dt
+        ws, bs = [], []
+        if pt == "linear":
+            ws.append(self._dev(sd[pre + "weight"])); bs.append(self._dev(sd[pre + "bias"]))
+        elif pt == "identity":
+            pass
+        else:
+            m = re.match(r"^mlp(\d+)x_gelu$", pt)
+            if not m:
+                raise ValueError(f"Unknown projector type: {pt}")
+            depth = int(m.group(1))
+            if depth > 4:
+                raise ValueError("projector depth > 4 not supported")
+            for j in range(depth):
+                ws.append(self._dev(sd[pre + f"{2 * j}.weight"])); bs.append(self._dev(sd[pre + f"{2 * j}.bias"]))
+        d.depth = len(ws)
+        for j, (w, b) in enumerate(zip(ws, bs)):
+            d.w[j], d.b[j] = w.data_ptr(), b.data_ptr()
+        self.proj_w = (ws, bs)
+        self.proj_desc = d
+
+    def _load_llama(self, sd):
+        c = self.cfg
+        H, Hk, hd = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        self.embed = self._dev(sd["model.embed_tokens.weight"])
+        self.final_norm = self._dev(sd["model.norm.weight"])
+        self.lm_head = self._dev(sd["lm_head.weight"])
+        self.max_pos = max(c.max_position_embeddings, self.max_seq)
+        cs, sn = rope_tables(hd, c.rope_theta, self.max_pos)
+        self.rope_cos, self.rope_sin = cs.to(self.device), sn.to(self.device)
+        per = {k: [] for k in ("in_norm", "qkv", "o", "post_norm", "gateup", "down")}
+        for i in range(c.num_hidden_layers):
+            p = f"model.layers.{i}."
+            per["in_norm"].append(self._dev(sd[p + "input_layernorm.weight"]))
+            per["qkv"].append(self._dev(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], dim=0)))
+            per["o"].append(self._dev(sd[p + "self_attn.o_proj.weight"]))
+            per["post_norm"].append(self._dev(sd[p + "post_attention_layernorm.weight"]))
+            per["gateup"].append(self._dev(interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"])))
+            per["down"].append(self._dev(sd[p + "mlp.down_proj.weight"]))
+        self.llama_w = per
+
+    def _alloc_cache(self):
+        c = self.cfg
+        Lr, Hk, hd, S = c.num_hidden_layers, c.num_key_value_heads, c.head_dim, self.max_seq
+        self.k_cache = torch.zeros(Lr, Hk, S, hd, dtype=self.dtype, device=self.device)
+        self.v_cache = torch.zeros(Lr, Hk, S, hd, dtype=self.dtype, device=self.device)
+        self.vt_cache = torch.zeros(Lr, Hk, hd, S, dtype=self.dtype, device=self.device)
+        self.cache_len = 0
+        d = L.LlamaDesc()
+        d.hidden, d.heads, d.kv_heads, d.head_dim = c.hidden_size, c.num_attention_heads, Hk, hd
+        d.inter, d.layers, d.vocab, d.eps = c.intermediate_size, Lr, c.vocab_size, c.rms_norm_eps
+        d.dtype, d.max_seq = self.dt, S
+        d.embed, d.final_norm_w, d.lm_head = self.embed.data_ptr(), self.final_norm.data_ptr(), self.lm_head.data_ptr()
+        d.rope_cos, d.rope_sin, d.max_pos = self.rope_cos.data_ptr(), self.rope_sin.data_ptr(), self.max_pos
+        d.in_norm_w = self._arr(self.llama_w["in_norm"])
+        d.qkv_w = self._arr(self.llama_w["qkv"])
+        d.o_w = self._arr(self.llama_w["o"])
+        d.post_norm_w = self._arr(self.llama_w["post_norm"])
+        d.gateup_w = self._arr(self.llama_w["gateup"])
+        d.down_w = self._arr(self.llama_w["down"])
+        d.k_cache = self._arr([self.k_cache[i] for i in range(Lr)])
+        d.v_cache = self._arr([self.v_cache[i] for i in range(Lr)])
+        d.vt_cache = self._arr([self.vt_cache[i] for i in range(Lr)])
+        self.llama_desc = d
+
+    def _alloc_decode_state(self, max_new=4096):
+        dev = self.device
+        self.d_token = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.d_pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_out = torch.zeros(max_new, dtype=torch.int64, device=dev)
+        self.d_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_stop = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_stop_ids = torch.zeros(16, dtype=torch.int64, device=dev)
+        self.d_logits = torch.zeros(self.cfg.vocab_size, dtype=torch.float32, device=dev)
+        self.max_new_cap = max_new
+        s = L.DecodeState()
+        s.d_token, s.d_pos, s.d_out_tokens = self.d_token.data_ptr(), self.d_pos.data_ptr(), self.d_out.data_ptr()
+        s.d_out_count, s.d_stop = self.d_count.data_ptr(), self.d_stop.data_ptr()
+        s.d_stop_ids, s.n_stop_ids, s.d_logits = self.d_stop_ids.data_ptr(), 0, self.d_logits.data_ptr()
+        self.decode_state = s
+
+    # ------------------------------------------------------------------ plumbing
+    def _workspace(self, key, nbytes):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+    class _Phase:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            cur = torch.cuda.current_stream(self.eng.device)
+            self.cur = cur
+            self.eng.stream.wait_stream(cur)
+            self.ctx = torch.cuda.stream(self.eng.stream)
+            self.ctx.__enter__()
+            return C.c_void_p(self.eng.stream.cuda_stream)
+
+        def __exit__(self, *a):
+            self.ctx.__exit__(*a)
+            self.cur.wait_stream(self.eng.stream)
+            return False
+
+    def phase(self):
+        return TeoEngine._Phase(self)
+
+    # ------------------------------------------------------------------ vision
+    def vit_features(self, pixels):
+        """[T,3,H,W] -> hidden_states[select_layer][:, 1:]  ([T, n_patches, Dv]); H7-H11."""
+        v = self.vcfg
+        if pixels.dim() != 4 or pixels.shape[1] != v.num_channels or pixels.shape[2] != v.image_size or pixels.shape[3] != v.image_size:
+            raise ValueError(f"Input image size ({tuple(pixels.shape)}) doesn't match model "
+                             f"({v.num_channels}x{v.image_size}x{v.image_size}).")
+        if self.cfg.mm_vision_select_feature not in ("patch",):
+            raise ValueError(f"Unexpected select feature: {self.cfg.mm_vision_select_feature}")
+        T = pixels.shape[0]
+        with self.phase() as st:
+            px = pixels.to(device=self.device, dtype=self.dtype).contiguous()
+            out = torch.empty(T, v.num_patches, v.hidden_size, dtype=self.dtype, device=self.device)
+            need = self.lib.teo_vit_workspace_bytes(C.byref(self.vit_desc), T)
+            ws = self._workspace("vit", need)
+            L.check(self.lib.teo_vit_encode(C.byref(self.vit_desc), _p(px), T, _p(out), _p(ws), ws.numel(), st), "teo_vit_encode")
+        return out
+
+    def project(self, feats):
+        """[..., Dv] -> [..., D] through the mm_projector (H12)."""
+        if self.proj_desc.depth == 0:
+            return feats
+        shape = feats.shape
+        rows = feats.numel() // shape[-1]
+        with self.phase() as st:
+            x = feats.to(device=self.device, dtype=self.dtype).contiguous()
+            y = torch.empty(rows, self.cfg.hidden_size, dtype=self.dtype, device=self.device)
+            need = self.lib.teo_projector_workspace_bytes(C.byref(self.proj_desc), rows)
+            ws = self._workspace("proj", need)
+            L.check(self.lib.teo_projector(C.byref(self.proj_desc), _p(x), rows, _p(y), _p(ws), ws.numel(), st), "teo_projector")
+        return y.view(*shape[:-1], self.cfg.hidden_size)
+
+    def encode_images(self, pixels):
+        return self.project(self.vit_features(pixels))
+
+    # ------------------------------------------------------------------ splice
+    def splice(self, plan, visual):
+        """plan int32 [rows] (host or device) -> embeds [rows, D] (H13 data movement)."""
+        with self.phase() as st:
+            plan_d = plan.to(device=self.device, dtype=torch.int32).contiguous()
+            rows = plan_d.numel()
+            out = torch.empty(rows, self.cfg.hidden_size, dtype=self.dtype, device=self.device)
+            vis = visual.to(device=self.device, dtype=self.dtype).contiguous() if visual is not None else None
+            L.check(self.lib.teo_embed_splice(_p(plan_d), _p(self.embed), _p(vis), _p(out), rows, self.cfg.hidden_size,
+                                              self.dt, st), "teo_embed_splice")
+        return out
+
+    # ------------------------------------------------------------------ LLaMA
+    def reset_cache(self):
+        self.cache_len = 0
+
+    def prefill(self, embeds, positions=None, last_only=False):
+        """embeds [S, D] appended to the cache; returns fp32 logits [S, V] (or [1, V])."""
+        S = embeds.shape[0]
+        past = self.cache_len
+        if past + S > self.max_seq:
+            raise ValueError(f"sequence length {past + S} exceeds the engine's max_seq {self.max_seq}")
+        with self.phase() as st:
+            e = embeds.to(device=self.device, dtype=self.dtype).contiguous()
+            if positions is None:
+                pos = torch.arange(past, past + S, dtype=torch.int32, device=self.device)
+            else:
+                pos = positions.to(device=self.device, dtype=torch.int32).contiguous()
+            rows = 1 if last_only else S
+            logits = torch.empty(rows, self.cfg.vocab_size, dtype=torch.float32, device=self.device)
+            need = self.lib.teo_llama_prefill_workspace_bytes(C.byref(self.llama_desc), S)
+            ws = self._workspace("prefill", need)
+            L.check(self.lib.teo_llama_prefill(C.byref(self.llama_desc), _p(e), _p(pos), S, past, 1 if last_only else 0,
+                                               _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill")
+        self.cache_len = past + S
+        return logits
+
+    def decode_begin(self, first_token, stop_ids=None):
+        """Arm the device-side greedy loop: first_token is the input of the next step, at position cache_len."""
+        with self.phase():
+            self.d_token.fill_(int(first_token))
+            self.d_pos.fill_(self.cache_len)
+            self.d_count.zero_()
+            self.d_stop.zero_()
+            n = 0
+            if stop_ids:
+                n = min(len(stop_ids), 16)
+                self.d_stop_ids[:n] = torch.tensor(list(stop_ids)[-n:], dtype=torch.int64, device=self.device)
+            if n != self.decode_state.n_stop_ids:
+                self.decode_state.n_stop_ids = n
+                self._drop_graph()
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            self.lib.teo_graph_destroy(self._graph)
+            self._graph = None
+
+    def decode_steps(self, n, use_graph=True):
+        """Run n greedy steps on the device (hipGraph replay by default).  The caller bounds n by max_seq."""
+        if self.cache_len + n > self.max_seq:
+            raise ValueError(f"decode would exceed max_seq {self.max_seq}")
+        ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
+        with self.phase() as st:
+            if use_graph:
+                if self._graph is None or self._graph_ws != ws.data_ptr():
+                    self._drop_graph()
+                    g = C.c_void_p()
+                    L.check(self.lib.teo_llama_decode_graph_create(C.byref(self.llama_desc), C.byref(self.decode_state),
+                                                                   _p(ws), ws.numel(), st, C.byref(g)),
+                            "teo_llama_decode_graph_create")
+                    self._graph, self._graph_ws = g, ws.data_ptr()
+                L.check(self.lib.teo_graph_launch(self._graph, n, st), "teo_graph_launch")
+            else:
+                for _ in range(n):
+                    L.check(self.lib.teo_llama_decode_step(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws),
+                                                           ws.numel(), st), "teo_llama_decode_step")
+        self.cache_len += n
+
+    def generated(self):
+        n = int(self.d_count.item())
+        return self.d_out[:n].clone()
+
+    def __del__(self):
+        try:
+            self._drop_graph()
+        except Exception:  # noqa: BLE001
+            pass

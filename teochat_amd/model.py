@@ -1,0 +1,450 @@
+"""LlavaLlamaForCausalLM for MI355X: the reference's model-level interface over TeoEngine.
+
+Mirrors (names, argument order, defaults, error behaviour):
+  language_model/llava_llama.py:40-108  LlavaLlamaForCausalLM.forward / prepare_inputs_for_generation / get_model
+  llava_arch.py:125-346                 get_image_tower / encode_images / prepare_inputs_labels_for_multimodal
+  generation: the greedy / sampled loop GenerationMixin.generate runs for eval/inference.py:64-72
+There is no nn.Module underneath: weights live in the engine's device buffers and all arithmetic is HIP kernels.
+The index logic of the embedding splice runs on the host on integers (bit-exact); the data movement is one
+teo_embed_splice launch driven by the resulting int32 plan.
+"""
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+from .engine import TeoEngine
+
+
+class CausalLMOutputWithPast(dict):
+    """Minimal stand-in for transformers.modeling_outputs.CausalLMOutputWithPast (attribute + key access)."""
+
+    def __init__(self, loss=None, logits=None, past_key_values=None, hidden_states=None, attentions=None):
+        super().__init__(loss=loss, logits=logits, past_key_values=past_key_values, hidden_states=hidden_states,
+                         attentions=attentions)
+        self.__dict__ = self
+
+    def to_tuple(self):
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values) if v is not None)
+
+
+class TeoKVCache:
+    """Handle to the engine's device KV cache (one sequence).  `[-1][-1].shape[-2]` reports the cached length so that
+    code written against the legacy tuple cache (llava_arch.py:156) keeps working."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def get_seq_length(self):
+        return self.engine.cache_len
+
+    def __len__(self):
+        return self.engine.cfg.num_hidden_layers
+
+    def __getitem__(self, i):
+        c = self.engine.cfg
+        shape = SimpleNamespace(shape=(1, c.num_key_value_heads, self.engine.cache_len, c.head_dim))
+        return (shape, shape)
+
+
+class TeoImageTower:
+    """The tower object `get_image_tower()` returns (LanguageBindImageTower surface, languagebind/__init__.py:94-173)."""
+
+    def __init__(self, engine, processor=None):
+        self._engine = engine
+        self.is_loaded = True
+        self.select_layer = engine.cfg.mm_vision_select_layer
+        self.select_feature = engine.cfg.mm_vision_select_feature
+        self.image_processor = processor
+        self.config = engine.vcfg
+
+    def load_model(self):
+        self.is_loaded = True
+
+    def __call__(self, images):
+        return self.forward(images)
+
+    @torch.no_grad()
+    def forward(self, images):
+        if type(images) is list:
+            return [self._engine.vit_features(im.unsqueeze(0)).to(im.dtype) for im in images]
+        return self._engine.vit_features(images).to(images.dtype)
+
+    @property
+    def dtype(self):
+        return self._engine.dtype
+
+    @property
+    def device(self):
+        return self._engine.device
+
+    @property
+    def hidden_size(self):
+        return self.config.hidden_size
+
+    @property
+    def num_patches(self):
+        return self.config.num_patches
+
+    @property
+    def dummy_feature(self):
+        return torch.zeros(1, self.hidden_size, device=self.device, dtype=self.dtype)
+
+
+class _Projector:
+    def __init__(self, engine):
+        self._engine = engine
+
+    def __call__(self, x):
+        return self._engine.project(x)
+
+
+class _Embedding:
+    def __init__(self, engine):
+        self._engine = engine
+
+    @property
+    def weight(self):
+        return self._engine.embed
+
+    def __call__(self, ids):
+        flat = ids.reshape(-1).to(torch.int32)
+        return self._engine.splice(flat, None).view(*ids.shape, -1)
+
+
+class LlavaLlamaModel:
+    """`model.model`: holds image_tower / video_tower / mm_projector / embed_tokens like LlavaMetaModel (llava_arch.py:27-49)."""
+
+    def __init__(self, engine, processor=None):
+        self.image_tower = TeoImageTower(engine, processor)
+        self.video_tower = None
+        self.mm_projector = _Projector(engine)
+        self.embed_tokens = _Embedding(engine)
+
+    def get_image_tower(self):
+        t = getattr(self, "image_tower", None)
+        return t[0] if type(t) is list else t
+
+    def get_video_tower(self):
+        t = getattr(self, "video_tower", None)
+        return t[0] if type(t) is list else t
+
+
+def build_splice_plan(input_ids, attention_mask, labels, n_feature_rows: List[int], max_length, padding_side):
+    """Integer half of prepare_inputs_labels_for_multimodal (llava_arch.py:248-329), on host numpy arrays.
+
+    input_ids [B,n] int64, attention_mask [B,n] bool, labels [B,n] int64, n_feature_rows[i] = rows of image feature i.
+    Returns plan [B,Lmax] int32 (>=0 vocab id, <0 -(global visual row)-1, INT32_MIN pad), labels [B,Lmax],
+    mask [B,Lmax] bool, position_ids [B,Lmax], lengths.
+    Raises IndexError when a sample needs more image features than were supplied (reference: llava_arch.py:284).
+    """
+    starts = np.concatenate(([0], np.cumsum(n_feature_rows))).astype(np.int64)
+    plans, labs = [], []
+    nxt = 0                                   # next unused image feature, consumed globally across the batch
+    for b in range(input_ids.shape[0]):
+        keep = attention_mask[b]
+        ids = input_ids[b][keep]
+        lab = labels[b][keep]
+        if not (ids == IMAGE_TOKEN_INDEX).any():
+            if nxt >= len(n_feature_rows):
+                raise IndexError("list index out of range")     # the reference indexes image_features[cur_image_idx]
+            nxt += 1                          # a text-only sample still consumes one (empty slice of a) feature
+            plans.append(ids.astype(np.int64))
+            labs.append(lab)
+            continue
+        p_parts, l_parts = [], []
+        cuts = np.flatnonzero(ids == IMAGE_TOKEN_INDEX)
+        lo = 0
+        for cpos in cuts:
+            p_parts.append(ids[lo:cpos].astype(np.int64))
+            l_parts.append(lab[lo:cpos])
+            if nxt >= len(n_feature_rows):
+                raise IndexError("list index out of range")
+            rows = np.arange(starts[nxt], starts[nxt + 1], dtype=np.int64)
+            p_parts.append(-(rows + 1))
+            l_parts.append(np.full(rows.shape[0], IGNORE_INDEX, dtype=lab.dtype))
+            nxt += 1
+            lo = cpos + 1
+        p_parts.append(ids[lo:].astype(np.int64))
+        l_parts.append(lab[lo:])
+        plans.append(np.concatenate(p_parts))
+        labs.append(np.concatenate(l_parts))
+    if max_length is not None:
+        plans = [p[:max_length] for p in plans]
+        labs = [l[:max_length] for l in labs]
+    lens = [p.shape[0] for p in plans]
+    Lmax = max(lens)
+    B = len(plans)
+    plan = np.full((B, Lmax), L.INT32_MIN, dtype=np.int64)
+    lab_out = np.full((B, Lmax), IGNORE_INDEX, dtype=np.int64)
+    mask = np.zeros((B, Lmax), dtype=bool)
+    pos = np.zeros((B, Lmax), dtype=np.int64)
+    for b, (p, l) in enumerate(zip(plans, labs)):
+        n = p.shape[0]
+        if n == 0:
+            continue
+        sl = slice(Lmax - n, Lmax) if padding_side == "left" else slice(0, n)
+        plan[b, sl] = p
+        lab_out[b, sl] = l
+        mask[b, sl] = True
+        pos[b, sl] = np.arange(n)
+    return plan.astype(np.int32), lab_out, mask, pos, lens
+
+
+class LlavaLlamaForCausalLM:
+    def __init__(self, config, engine: TeoEngine, processor=None):
+        self.config = config
+        self.engine = engine
+        self.model = LlavaLlamaModel(engine, processor)
+        self.vocab_size = config.vocab_size
+        self.pretraining_tp = getattr(config, "pretraining_tp", 1)
+        self.generation_config = SimpleNamespace(eos_token_id=getattr(config, "eos_token_id", None), top_k=50,
+                                                 top_p=1.0, temperature=1.0)
+        self.training = False
+
+    # --- nn.Module-ish surface the harness touches
+    @property
+    def device(self):
+        return self.engine.device
+
+    @property
+    def dtype(self):
+        return self.engine.dtype
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def get_model(self):
+        return self.model
+
+    def get_image_tower(self):
+        return self.get_model().get_image_tower()
+
+    def get_video_tower(self):
+        return self.get_model().get_video_tower()
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    # --- H12
+    def encode_images(self, images):
+        feats = self.get_model().get_image_tower()(images)
+        return self.get_model().mm_projector(feats)
+
+    # --- H13
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images):
+        image_tower, video_tower = self.get_image_tower(), self.get_video_tower()
+        if (image_tower is None and video_tower is None) or images is None or input_ids.shape[1] == 1:
+            if (past_key_values is not None and (image_tower is not None or video_tower is not None)
+                    and images is not None and input_ids.shape[1] == 1):
+                target = past_key_values[-1][-1].shape[-2] + 1
+                pad = torch.ones((attention_mask.shape[0], target - attention_mask.shape[1]),
+                                 dtype=attention_mask.dtype, device=attention_mask.device)
+                attention_mask = torch.cat((attention_mask, pad), dim=1)
+                position_ids = torch.sum(attention_mask, dim=1).unsqueeze(-1) - 1
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels
+
+        if any(im.ndim == 4 for im in images):
+            raise ValueError("4-D (video) items need a video tower; load_model removes it (eval/eval.py:31)")
+        if any(im.ndim != 3 for im in images):
+            raise ValueError("images must be a flat list of [3,H,W] tensors")
+        if getattr(self.config, "tune_mm_mlp_adapter", False) and getattr(self.config, "mm_use_im_start_end", False):
+            raise NotImplementedError
+
+        feats = self.encode_images(torch.stack(list(images)))           # [n_img, NV, D], one batched tower call
+        n_img, NV, D = feats.shape
+        dev = input_ids.device
+        ids_h = input_ids.detach().cpu().numpy()
+        mask_h = (np.ones_like(ids_h, dtype=bool) if attention_mask is None
+                  else attention_mask.detach().cpu().numpy().astype(bool))
+        lab_h = (np.full_like(ids_h, IGNORE_INDEX) if labels is None else labels.detach().cpu().numpy())
+        plan, lab_out, mask, pos, _ = build_splice_plan(
+            ids_h, mask_h, lab_h, [NV] * n_img, getattr(self.config, "tokenizer_model_max_length", None),
+            getattr(self.config, "tokenizer_padding_side", "right"))
+        B, Lmax = plan.shape
+        embeds = self.engine.splice(torch.from_numpy(plan.reshape(-1)), feats.reshape(n_img * NV, D)).view(B, Lmax, D)
+        new_labels = None if labels is None else torch.from_numpy(lab_out).to(dev)
+        if attention_mask is None:
+            new_mask = None
+        else:
+            new_mask = torch.from_numpy(mask).to(device=dev, dtype=attention_mask.dtype)
+        new_pos = None if position_ids is None else torch.from_numpy(pos).to(device=dev, dtype=position_ids.dtype)
+        return None, new_pos, new_mask, past_key_values, embeds, new_labels
+
+    # --- H14 + H15
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                return_dict=None):
+        if inputs_embeds is None:
+            (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = \
+                self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
+                                                          labels, images)
+        if inputs_embeds is None:
+            inputs_embeds = self.get_model().embed_tokens(input_ids)
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        eng = self.engine
+        B, S, _ = inputs_embeds.shape
+        if past_key_values is None:
+            eng.reset_cache()
+        elif not isinstance(past_key_values, TeoKVCache) or past_key_values.engine is not eng:
+            raise ValueError("past_key_values must be the TeoKVCache returned by this model")
+        if B > 1 and past_key_values is not None:
+            raise ValueError("the device KV cache holds one sequence; batched continuation is not supported")
+        past = eng.cache_len
+        logits = torch.zeros(B, S, self.config.vocab_size, dtype=torch.float32, device=eng.device)
+        for b in range(B):
+            if B > 1:
+                eng.reset_cache()
+            if attention_mask is not None:
+                m = attention_mask[b].to(torch.bool)
+                m_new = m[-S:] if m.shape[0] >= S else m
+                idx = torch.nonzero(m_new, as_tuple=False).flatten()
+                if idx.numel() and int(idx[-1] - idx[0]) + 1 != idx.numel():
+                    raise ValueError("attention_mask with holes inside the sequence is not supported")
+                if m.shape[0] > S and not bool(m[:-S].all()):
+                    raise ValueError("masked positions inside the cached prefix are not supported")
+            else:
+                idx = torch.arange(S, device=inputs_embeds.device)
+            if idx.numel() == 0:
+                continue
+            lo, hi = int(idx[0]), int(idx[-1]) + 1
+            pos = None
+            if position_ids is not None:
+                pr = position_ids[b] if position_ids.dim() == 2 else position_ids
+                pos = pr[lo:hi] if pr.shape[-1] == S else pr
+            out = eng.prefill(inputs_embeds[b, lo:hi], positions=pos, last_only=False)
+            logits[b, lo:hi] = out
+        loss = None
+        if labels is not None:
+            # N4 ("next" row): training-shape loss; plain torch on the fp32 logits, not part of the inference path
+            shift_logits = logits[:, :-1, :].reshape(-1, self.config.vocab_size)
+            shift_labels = labels[:, 1:].reshape(-1).to(shift_logits.device)
+            loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX)
+        pkv = TeoKVCache(eng) if (use_cache is None or use_cache) and B == 1 else None
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv)
+        if return_dict is False:
+            return out.to_tuple()
+        return out
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
+        images = kwargs.pop("images", None)
+        if past_key_values is not None:
+            input_ids = input_ids[:, -1:]
+        inputs = {"input_ids": input_ids, "past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"),
+                  "attention_mask": kwargs.get("attention_mask")}
+        if inputs_embeds is not None and past_key_values is None:
+            inputs = {"inputs_embeds": inputs_embeds, **{k: v for k, v in inputs.items() if k != "input_ids"}}
+        if images is not None:
+            inputs["images"] = images
+        return inputs
+
+    # --- H16
+    @torch.no_grad()
+    def generate(self, input_ids=None, images=None, do_sample=False, temperature=1.0, top_k=None, top_p=None,
+                 max_new_tokens=20, use_cache=True, stopping_criteria=None, eos_token_id="config", attention_mask=None,
+                 generator=None, chunk=16, **kwargs):
+        """Greedy (device-resident loop, hipGraph replay) or sampled decoding of ONE sequence.
+
+        Returns int64 [1, n_prompt + n_generated]; the prompt part still contains the -200 sentinels, as with the
+        reference (eval/inference.py:75 slices at input_ids.shape[1]).  `eos_token_id=None` disables EOS stopping.
+        """
+        if input_ids.shape[0] != 1:
+            raise ValueError("generate() decodes one conversation at a time (the reference's eval path is batch 1)")
+        eng = self.engine
+        if eos_token_id == "config":
+            eos_token_id = getattr(self.config, "eos_token_id", None)
+        crits = list(stopping_criteria or [])
+        if max_new_tokens <= 0:
+            return input_ids
+        # ---- prefill
+        (_, pos, mask, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None,
+                                                                               None, images)
+        if embeds is None:
+            embeds = self.get_model().embed_tokens(input_ids)
+        eng.reset_cache()
+        if embeds.shape[1] + max_new_tokens > eng.max_seq:
+            raise ValueError(f"prompt ({embeds.shape[1]}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
+        logits = eng.prefill(embeds[0], last_only=True)
+        first = self._pick(logits[0], do_sample, temperature, top_k, top_p, generator)
+        new_tokens = [first]
+
+        def done(tokens):
+            if eos_token_id is not None and tokens[-1] == eos_token_id:
+                return True
+            if crits:
+                row = torch.cat([input_ids[0].cpu(), torch.tensor(tokens, dtype=torch.long)]).unsqueeze(0)
+                return any(bool(c(row, None)) for c in crits)
+            return False
+
+        if done(new_tokens) or max_new_tokens == 1:
+            return self._finish(input_ids, new_tokens)
+        # ---- decode
+        stop_ids = None
+        if not do_sample:
+            cands = [ids for c in crits for ids in getattr(c, "keyword_id_lists", []) if ids]
+            if eos_token_id is not None:
+                cands.append([int(eos_token_id)])
+            if len(cands) == 1:
+                stop_ids = cands[0]
+        eng.decode_begin(first, stop_ids)
+        remaining = max_new_tokens - 1
+        while remaining > 0:
+            if do_sample:
+                eng.decode_steps(1, use_graph=True)
+                tok = self._pick(eng.d_logits, True, temperature, top_k, top_p, generator)
+                n = int(eng.d_count.item())
+                eng.d_out[n - 1] = tok           # replace the greedy choice by the sampled one
+                eng.d_token.fill_(tok)
+                new_tokens.append(tok)
+                remaining -= 1
+                if done(new_tokens):
+                    break
+                continue
+            n = min(chunk, remaining)
+            eng.decode_steps(n, use_graph=True)
+            got = eng.generated().tolist()
+            fresh = got[len(new_tokens) - 1:]
+            stop_here = False
+            for t in fresh:
+                new_tokens.append(int(t))
+                remaining -= 1
+                if done(new_tokens):
+                    stop_here = True
+                    break
+            if stop_here:
+                break
+        return self._finish(input_ids, new_tokens)
+
+    def _finish(self, input_ids, new_tokens):
+        tail = torch.tensor([new_tokens], dtype=input_ids.dtype, device=input_ids.device)
+        return torch.cat([input_ids, tail], dim=1)
+
+    def _pick(self, logits, do_sample, temperature, top_k, top_p, generator):
+        if not do_sample:
+            tok = torch.empty(1, dtype=torch.int64, device=self.engine.device)
+            with self.engine.phase() as st:
+                lg = logits.contiguous()
+                L.check(self.engine.lib.teo_argmax(lg.data_ptr(), tok.data_ptr(), 1, lg.numel(), st), "teo_argmax")
+            return int(tok.item())
+        # N1 ("next" row): temperature / top-k / top-p / multinomial, interim torch implementation on the fp32 logits
+        x = logits.float() / max(float(temperature), 1e-6)
+        k = self.generation_config.top_k if top_k is None else top_k
+        if k and k > 0:
+            kth = torch.topk(x, min(int(k), x.numel())).values[-1]
+            x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
+        p = top_p if top_p is not None else self.generation_config.top_p
+        if p is not None and p < 1.0:
+            sx, si = torch.sort(x, descending=True)
+            cp = torch.softmax(sx, dim=-1).cumsum(-1)
+            drop = cp - torch.softmax(sx, dim=-1) > p
+            sx = sx.masked_fill(drop, float("-inf"))
+            x = torch.full_like(x, float("-inf")).scatter(0, si, sx)
+        probs = torch.softmax(x, dim=-1)
+        return int(torch.multinomial(probs, 1, generator=generator).item())

@@ -1,0 +1,185 @@
+"""CPU tests of the host-side mirror (teochat_amd) against the golden vectors the reference produced, and of the
+C-ABI library's export table.  No GPU needed, no compute calls into the library."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from teochat_amd import _lib as L
+from teochat_amd import constants, conversation, inference, mm_utils
+from teochat_amd.model import build_splice_plan
+from teochat_amd.tokenizer_stub import ByteTokenizer
+from tests import _tiny as TY
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_constants():
+    assert constants.IMAGE_TOKEN_INDEX == -200 and constants.IGNORE_INDEX == -100
+    assert constants.DEFAULT_IMAGE_TOKEN == "<image>" and constants.DEFAULT_VIDEO_TOKEN == "<video>"
+    assert constants.MAX_IMAGE_LENGTH == 16
+
+
+def test_run_inference_single_plumbing_matches_reference():
+    """Same fake model/processor as the golden generator: the ids handed to generate() and the decoded text must be
+    identical to what the reference's run_inference_single produced."""
+    g = TY.load_json("host")
+    reply = ByteTokenizer(add_bos=False)("Two new buildings.</s>").input_ids
+
+    class FakeModel:
+        device = torch.device("cpu")
+        dtype = torch.float16
+
+        def generate(self, input_ids=None, images=None, **kw):
+            self.seen = (input_ids.clone(), len(images), kw)
+            return torch.cat([input_ids, torch.tensor([reply])], dim=1)
+
+    class FakeProc:
+        def preprocess(self, p, return_tensors=None):
+            return {"pixel_values": [torch.zeros(3, 2, 2)]}
+
+    for c in g["run_inference_single"]:
+        fm = FakeModel()
+        paths = ["frame_%d.png" % i for i in range(c["T"])]
+        text = inference.run_inference_single(fm, FakeProc(), ByteTokenizer(), c["inp"], paths, conv_mode="v1",
+                                              timestamps=list(c["timestamps"]), prompt_strategy=c["strategy"],
+                                              chronological_prefix=c["chrono"], temperature=0.2, max_new_tokens=16)
+        assert fm.seen[0][0].tolist() == c["input_ids"], c
+        assert fm.seen[1] == c["n_images"]
+        assert text == c["output_text"]
+        kw = fm.seen[2]
+        for k, v in c["generate_kwargs"].items():
+            assert kw[k] == v, (k, kw[k], v)
+        assert len(kw["stopping_criteria"]) == 1
+
+
+def test_tokenizer_image_token_edge_cases():
+    g = TY.load_json("host")
+    for c in g["tokenizer_image_token"]:
+        ids = mm_utils.tokenizer_image_token(c["prompt"], ByteTokenizer(add_bos=c["add_bos"]), -200)
+        assert ids == c["ids"], c
+    t = mm_utils.tokenizer_image_token("a<image>b", ByteTokenizer(), -200, return_tensors="pt")
+    assert t.dtype == torch.long
+    with pytest.raises(ValueError):
+        mm_utils.tokenizer_image_token("a", ByteTokenizer(), -200, return_tensors="np")
+
+
+def test_replace_video_token_errors():
+    with pytest.raises(ValueError):
+        inference.replace_video_token("<video>", [1], "bogus")
+    assert inference.replace_video_token("x <video> y", [1, 2], None) == "x <image><image> y"
+
+
+def test_stopping_criteria_truth_table():
+    g = TY.load_json("host")
+    tok = ByteTokenizer()
+    for c in g["stopping"]:
+        crit = mm_utils.KeywordsStoppingCriteria(c["keywords"], tok, torch.zeros(1, c["prompt_len"], dtype=torch.long))
+        assert bool(crit(torch.tensor([c["row"]]), None)) == c["stop"], c
+    b = g["stopping_batch"]
+    crit = mm_utils.KeywordsStoppingCriteria(b["keywords"], tok, torch.zeros(1, b["prompt_len"], dtype=torch.long))
+    assert bool(crit(torch.tensor(b["rows"]), None)) == b["stop"]
+
+
+def _decode_plan(plan_row, NV):
+    out = []
+    for p in plan_row:
+        if p == L.INT32_MIN:
+            out.append(0)                       # zero pad row: the coded embedding of a pad is 0
+        elif p >= 0:
+            out.append(int(p))
+        else:
+            g = -(int(p) + 1)
+            out.append(-(1000 * (g // NV) + (g % NV) + 1))
+    return out
+
+
+def test_splice_plan_bit_exact():
+    g = TY.load_json("splice")
+    NV = g["NV"]
+    for name, c in g.items():
+        if not isinstance(c, dict) or "plan" not in c:
+            continue
+        ids = np.array(c["ids"], dtype=np.int64)
+        mask = np.array(c["mask"], dtype=bool) if "mask" in c else np.ones_like(ids, dtype=bool)
+        labels = np.array(c["labels"], dtype=np.int64) if "labels" in c else np.full_like(ids, -100)
+        plan, lab, m, pos, _ = build_splice_plan(ids, mask, labels, [NV] * c["n_images"], c.get("max_len"),
+                                                 c.get("padding_side", "right"))
+        assert [_decode_plan(r, NV) for r in plan.tolist()] == c["plan"], name
+        # zero rows in the reference output: the pad rows, plus rows gathered from vocab id 0 (coded value 0)
+        zero_ref = np.array(c["embeds_is_zero_row"])
+        assert ((plan == L.INT32_MIN) | (plan == 0)).tolist() == zero_ref.tolist(), name
+        if c["position_ids"] is not None:
+            assert pos.tolist() == c["position_ids"], name
+        if c["attention_mask"] is not None:
+            assert m.astype(np.int64).tolist() == c["attention_mask"], name
+        if c["labels_out"] is not None:
+            assert lab.tolist() == c["labels_out"], name
+    with pytest.raises(IndexError):
+        ids = np.array([[1, -200, -200]])
+        build_splice_plan(ids, np.ones_like(ids, dtype=bool), np.full_like(ids, -100), [NV], None, "right")
+
+
+def test_conversation_v1():
+    c = conversation.conv_templates["v1"].copy()
+    c.append_message(c.roles[0], "hi")
+    c.append_message(c.roles[1], None)
+    assert c.get_prompt().endswith("USER: hi ASSISTANT:")
+    assert c.sep_style == conversation.SeparatorStyle.TWO and c.sep2 == "</s>"
+    assert conversation.conv_templates["v1"].messages == []          # copy() did not alias the template
+
+
+def test_processor_identity_at_224():
+    from oracle import teo_oracle as O
+    from teochat_amd.processor import TeoImageProcessor
+    g = torch.Generator().manual_seed(3)
+    raw = torch.randint(0, 256, (224, 224, 3), generator=g, dtype=torch.uint8)
+    p = TeoImageProcessor()
+    out = p.preprocess(raw.numpy(), return_tensors="pt")["pixel_values"][0]
+    assert torch.equal(out, O.preprocess_uint8(raw))
+    big = torch.randint(0, 256, (300, 448, 3), generator=g, dtype=torch.uint8)
+    assert p.preprocess(big, return_tensors="pt")["pixel_values"].shape == (1, 3, 224, 224)
+    assert p.image_mean[0] == pytest.approx(0.48145466) and p.crop_size == {"height": 224, "width": 224}
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/teo_hip.h declares must be exported by the built .so and bound in _lib.py."""
+    hdr = open(os.path.join(ROOT, "include", "teo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(teo_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"teo_graph"}
+    assert declared, "no declarations parsed"
+    assert os.path.exists(L.LIB_PATH), "libteo_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} not exported"
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    assert L.load().teo_version() == 1
+
+
+def test_gate_up_interleave_layout():
+    from teochat_amd.engine import interleave_gate_up, rope_tables
+    F_, D = 48, 4
+    gate = torch.arange(F_ * D, dtype=torch.float32).view(F_, D)
+    up = -gate
+    gu = interleave_gate_up(gate, up)
+    for j in range(F_):
+        r = (j // 16) * 32 + (j % 16)
+        assert torch.equal(gu[r], gate[j]) and torch.equal(gu[r + 16], up[j])
+    from oracle import teo_oracle as O
+    cs, sn = rope_tables(16, 10000.0, 600)
+    c2, s2 = O.rope_cos_sin(torch.arange(600), 16, 10000.0, torch.float32)
+    assert torch.equal(cs, c2[:, :8]) and torch.equal(sn, s2[:, :8])
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the oracle (or the reference)."""
+    pkg = os.path.join(ROOT, "teochat_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), fn
+            assert "/root/reference" not in src, fn

@@ -1,0 +1,385 @@
+"""GPU parity tests of the HIP primitives, called through the C ABI, against the CPU oracle (oracle/teo_oracle.py)
+and plain torch-CPU fp32 references on the same seeded inputs.
+
+Tolerances (stated per test):
+  fp32 kernels : absolute 1e-5 on O(1) values (accumulation order is the only difference)
+  bf16 kernels : the oracle is evaluated in fp32 on the SAME bf16-rounded inputs and rounded to bf16 at the same
+                 boundary; kernels must agree within 1 bf16 ulp (2^-8 relative) plus an absolute 1e-3 floor.
+  integer / data-movement kernels : bit-exact.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import teo_oracle as O
+from teochat_amd import _lib as L
+from tests import _gpu as G
+
+pytestmark = pytest.mark.gpu
+
+FP32_ATOL = 1e-5
+
+
+def close_bf16(got, ref, ulps=1.0, floor=1e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = ulps * (2.0 ** -8) * ref.abs() + floor
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} outside tolerance; max abs diff {float((got - ref).abs().max()):.3e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,dim", [(1, 64), (5, 1024), (3, 4096), (2, 100)])
+def test_layernorm_rmsnorm_fp32(rows, dim):
+    x, w, b = rnd(rows, dim, seed=1), 1 + 0.1 * rnd(dim, seed=2), rnd(dim, seed=3, scale=0.1)
+    y = G.layernorm(G.dev(x), G.dev(w), G.dev(b), 1e-5).cpu()
+    torch.testing.assert_close(y, F.layer_norm(x, (dim,), w, b, 1e-5), atol=FP32_ATOL, rtol=1e-5)
+    y = G.rmsnorm(G.dev(x), G.dev(w), 1e-5).cpu()
+    torch.testing.assert_close(y, O.rmsnorm(x, w, 1e-5), atol=FP32_ATOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("rows,dim", [(4, 1024), (3, 4096)])
+def test_layernorm_rmsnorm_bf16(rows, dim):
+    bf = torch.bfloat16
+    x, w, b = G.bf16_round(rnd(rows, dim, seed=1)), G.bf16_round(1 + 0.1 * rnd(dim, seed=2)), G.bf16_round(rnd(dim, seed=3, scale=0.1))
+    y = G.layernorm(G.dev(x, bf), G.dev(w, bf), G.dev(b, bf), 1e-5)
+    close_bf16(y, G.bf16_round(F.layer_norm(x, (dim,), w, b, 1e-5)))
+    y = G.rmsnorm(G.dev(x, bf), G.dev(w, bf), 1e-5)
+    close_bf16(y, G.bf16_round(O.rmsnorm(x, w, 1e-5)))
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def _gemm_ref(A, W, bias, res, act):
+    y = A @ W.t()
+    if bias is not None:
+        y = y + bias
+    if act == L.ACT_GELU_ERF:
+        y = F.gelu(y)
+    elif act == L.ACT_QUICK_GELU:
+        y = y * torch.sigmoid(1.702 * y)
+    if res is not None:
+        y = y + res
+    return y
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 13, 5), (65, 130, 33), (257, 64, 588), (64, 300, 64)])
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_GELU_ERF, L.ACT_QUICK_GELU])
+def test_gemm_generic_fp32(M, N, K, act):
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    y = G.gemm(G.dev(A), G.dev(W), G.dev(bias), G.dev(res), act=act).cpu()
+    torch.testing.assert_close(y, _gemm_ref(A, W, bias, res, act), atol=2e-5, rtol=1e-5)
+    y = G.gemm(G.dev(A), G.dev(W)).cpu()
+    torch.testing.assert_close(y, A @ W.t(), atol=2e-5, rtol=1e-5)
+
+
+def _swiglu_ref(A, gate, up):
+    return F.silu(A @ gate.t()) * (A @ up.t())
+
+
+def test_gemm_swiglu_fp32_and_layout():
+    from teochat_amd.engine import interleave_gate_up
+    M, K, Fd = 37, 48, 96
+    A, gate, up = rnd(M, K, seed=1), rnd(Fd, K, seed=2, scale=0.3), rnd(Fd, K, seed=3, scale=0.3)
+    gu = interleave_gate_up(gate, up)
+    y = G.gemm(G.dev(A), G.dev(gu), flags=L.GEMM_SWIGLU16).cpu()
+    torch.testing.assert_close(y, _swiglu_ref(A, gate, up), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (514, 256, 640), (1, 128, 64), (129, 132, 192)])
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_GELU_ERF])
+def test_gemm_mfma_bf16(M, N, K, act):
+    bf = torch.bfloat16
+    assert G.lib().teo_gemm_uses_mfma(M, N, K, L.TEO_BF16, 0) == 1
+    A, W = G.bf16_round(rnd(M, K, seed=1)), G.bf16_round(rnd(N, K, seed=2, scale=0.2))
+    bias, res = G.bf16_round(rnd(N, seed=3)), G.bf16_round(rnd(M, N, seed=4))
+    ref = _gemm_ref(A, W, bias, res, act)
+    y = G.gemm(G.dev(A, bf), G.dev(W, bf), G.dev(bias, bf), G.dev(res, bf), act=act)
+    close_bf16(y, G.bf16_round(ref))
+    # fp32 output (logits form) must match the exact product tightly: no output rounding
+    y32 = G.gemm(G.dev(A, bf), G.dev(W, bf), out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(y32, A @ W.t(), atol=1e-3, rtol=1e-4)
+    # and the generic kernel on the same inputs (on-GPU cross-check used at full size below)
+    ys = G.gemm(G.dev(A, bf), G.dev(W, bf), out_dtype=torch.float32, flags=L.GEMM_FORCE_SIMPLE).cpu()
+    torch.testing.assert_close(y32, ys, atol=1e-3, rtol=1e-4)
+
+
+def test_gemm_mfma_swiglu_bf16():
+    from teochat_amd.engine import interleave_gate_up
+    bf = torch.bfloat16
+    M, K, Fd = 150, 128, 256
+    A = G.bf16_round(rnd(M, K, seed=1))
+    gate, up = G.bf16_round(rnd(Fd, K, seed=2, scale=0.2)), G.bf16_round(rnd(Fd, K, seed=3, scale=0.2))
+    gu = interleave_gate_up(gate, up)
+    assert G.lib().teo_gemm_uses_mfma(M, 2 * Fd, K, L.TEO_BF16, L.GEMM_SWIGLU16) == 1
+    y = G.gemm(G.dev(A, bf), G.dev(gu, bf), flags=L.GEMM_SWIGLU16)
+    close_bf16(y, G.bf16_round(_swiglu_ref(A, gate, up)))
+
+
+def test_gemm_mfma_identity_asymmetric():
+    """A = I against an asymmetric W catches transposed fragment/epilogue mappings exactly."""
+    bf = torch.bfloat16
+    n = 256
+    A = torch.eye(n)
+    W = (torch.arange(n * n, dtype=torch.float32).view(n, n) % 251) - 125.0     # exactly representable in bf16
+    y = G.gemm(G.dev(A, bf), G.dev(W, bf), out_dtype=torch.float32).cpu()
+    assert torch.equal(y, W.t())
+
+
+def test_gemm_full_size_7b_shapes_mfma_vs_generic():
+    """BASELINE shapes (prefill rows of config C3, one LLaMA layer's FFN): MFMA kernel vs the generic kernel on the
+    GPU for all outputs, and vs the CPU fp32 product on a sample of rows/cols."""
+    bf = torch.bfloat16
+    M, K, N = 2168, 4096, 11008
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.randn(M, K, generator=g, device="cuda").to(bf)
+    W = (torch.randn(N, K, generator=g, device="cuda") * 0.02).to(bf)
+    y = G.gemm(A, W, out_dtype=torch.float32)
+    ys = G.gemm(A, W, out_dtype=torch.float32, flags=L.GEMM_FORCE_SIMPLE)
+    torch.testing.assert_close(y, ys, atol=2e-3, rtol=1e-3)
+    rows = torch.tensor([0, 1, 127, 128, 1000, 2047, 2048, 2167])
+    cols = torch.tensor([0, 5, 127, 128, 5000, 11007])
+    ref = A[rows].float().cpu() @ W[cols].float().cpu().t()
+    torch.testing.assert_close(y[rows][:, cols].cpu(), ref, atol=2e-3, rtol=1e-3)
+    # linearity (size-independent property): f(2A) == 2 f(A) exactly in fp32 output (powers of two are exact)
+    y2 = G.gemm((A.float() * 2).to(bf), W, out_dtype=torch.float32)
+    assert torch.equal(y2, 2 * y)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, causal, scale, round_p=False):
+    B, H, Sq, d = q.shape
+    Hk, Sk = k.shape[1], k.shape[2]
+    if Hk != H:
+        k = k.repeat_interleave(H // Hk, dim=1)
+        v = v.repeat_interleave(H // Hk, dim=1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    if causal:
+        qpos = torch.arange(Sq).view(Sq, 1) + (Sk - Sq)
+        s = s.masked_fill(torch.arange(Sk).view(1, Sk) > qpos, float("-inf"))
+    m = s.max(-1, keepdim=True).values
+    p = torch.exp(s - m)
+    pn = G.bf16_round(p) if round_p else p
+    o = (pn @ v) / p.sum(-1, keepdim=True)
+    return o.transpose(1, 2).reshape(B, Sq, H * d)
+
+
+@pytest.mark.parametrize("B,H,Hk,Sq,Sk,d,causal", [(2, 4, 4, 257, 257, 16, False), (1, 4, 2, 70, 70, 16, True),
+                                                   (1, 2, 2, 5, 133, 128, True), (1, 3, 1, 1, 300, 64, True)])
+def test_attention_generic_fp32(B, H, Hk, Sq, Sk, d, causal):
+    q, k, v = rnd(B, H, Sq, d, seed=1), rnd(B, Hk, Sk, d, seed=2), rnd(B, Hk, Sk, d, seed=3)
+    sc = d ** -0.5
+    o = G.attention(G.dev(q), G.dev(k), G.dev(v), causal, sc).cpu()
+    torch.testing.assert_close(o, _attn_ref(q, k, v, causal, sc), atol=FP32_ATOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,Hk,Sq,Sk,d,causal", [(2, 2, 2, 257, 257, 64, False),     # ViT shape (N = 257)
+                                                   (1, 2, 2, 300, 300, 128, True),      # LLaMA prefill
+                                                   (1, 4, 2, 100, 420, 128, True),      # continuation with a past, GQA
+                                                   (1, 2, 2, 64, 64, 64, True),
+                                                   (1, 1, 1, 1, 65, 128, True)])
+def test_attention_mfma_bf16(B, H, Hk, Sq, Sk, d, causal):
+    bf = torch.bfloat16
+    q, k, v = (G.bf16_round(rnd(B, H, Sq, d, seed=1)), G.bf16_round(rnd(B, Hk, Sk, d, seed=2)),
+               G.bf16_round(rnd(B, Hk, Sk, d, seed=3)))
+    sc = d ** -0.5
+    qd, kd, vd = G.dev(q, bf), G.dev(k, bf), G.dev(v, bf)
+    vt = G.make_vt(vd)
+    vt[..., Sk:] = float("nan")          # padding beyond kv_len must never reach the output
+    o = G.attention(qd, kd, vd, causal, sc, vt=vt)
+    ref = _attn_ref(q, k, v, causal, sc, round_p=True)
+    assert torch.isfinite(o.float()).all()
+    torch.testing.assert_close(o.float().cpu(), ref, atol=1.5e-2, rtol=1.5e-2)
+    os_ = G.attention(qd, kd, vd, causal, sc, force_simple=True)
+    torch.testing.assert_close(o.float(), os_.float(), atol=1.5e-2, rtol=1.5e-2)
+
+
+def test_attention_mfma_online_softmax_rescale_branch():
+    """Force the running max to jump late in the key sequence (spike one key against one query)."""
+    bf = torch.bfloat16
+    B, H, S, d = 1, 1, 256, 128
+    q, k, v = rnd(B, H, S, d, seed=1, scale=0.3), rnd(B, H, S, d, seed=2, scale=0.3), rnd(B, H, S, d, seed=3)
+    k[0, 0, 200] = q[0, 0, 230] * 40.0       # key 200 dominates query 230 (third KV tile)
+    q, k, v = G.bf16_round(q), G.bf16_round(k), G.bf16_round(v)
+    sc = d ** -0.5
+    vd = G.dev(v, bf)
+    o = G.attention(G.dev(q, bf), G.dev(k, bf), vd, True, sc, vt=G.make_vt(vd)).float().cpu()
+    ref = _attn_ref(q.double(), k.double(), v.double(), True, sc).float()
+    torch.testing.assert_close(o, ref, atol=1.5e-2, rtol=1.5e-2)
+
+
+def test_attention_mfma_full_size_properties():
+    """Config C3 prefill shape (L = 2168, 32 heads, d = 128): V = ones gives ones (softmax rows sum to 1);
+    a sample of rows matches the generic kernel; two runs are bit-identical."""
+    bf = torch.bfloat16
+    H, S, d = 32, 2168, 128
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q = torch.randn(1, H, S, d, generator=g, device="cuda").to(bf)
+    k = torch.randn(1, H, S, d, generator=g, device="cuda").to(bf)
+    v = torch.randn(1, H, S, d, generator=g, device="cuda").to(bf)
+    sc = d ** -0.5
+    ones = torch.ones_like(v)
+    o1 = G.attention(q, k, ones, True, sc, vt=G.make_vt(ones)).float()
+    torch.testing.assert_close(o1, torch.ones_like(o1), atol=8e-3, rtol=0)
+    vt = G.make_vt(v)
+    o = G.attention(q, k, v, True, sc, vt=vt)
+    o2 = G.attention(q, k, v, True, sc, vt=vt)
+    assert torch.equal(o, o2)
+    rows = [0, 1, 63, 64, 1000, 2167]
+    for r in rows:
+        osr = G.attention(q[:, :, r:r + 1].contiguous(), k[:, :, :r + 1].contiguous(), v[:, :, :r + 1].contiguous(), True, sc,
+                          force_simple=True)
+        torch.testing.assert_close(o[:, r:r + 1].float(), osr.float(), atol=1.5e-2, rtol=1.5e-2)
+
+
+# ---------------------------------------------------------------------------------------------- RoPE + KV append
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("S,past", [(37, 0), (1, 12), (70, 5)])
+def test_rope_kv_append(dtype, S, past):
+    from teochat_amd.engine import rope_tables
+    H, Hk, hd, S_max = 4, 2, 32, 128
+    ld = (H + 2 * Hk) * hd
+    qkv = rnd(S, ld, seed=1)
+    if dtype == torch.bfloat16:
+        qkv = G.bf16_round(qkv)
+    pos = torch.arange(past, past + S)
+    cs, sn = rope_tables(hd, 10000.0, 256)
+    d_qkv = G.dev(qkv, dtype)
+    kc = torch.zeros(Hk, S_max, hd, dtype=dtype, device="cuda")
+    vc, vtc = torch.zeros_like(kc), torch.zeros(Hk, hd, S_max, dtype=dtype, device="cuda")
+    L.check(G.lib().teo_rope_kv_append(G.p(d_qkv), ld, G.p(pos.to(torch.int32).cuda()), G.p(cs.cuda()), G.p(sn.cuda()),
+                                       G.p(kc), G.p(vc), G.p(vtc), S, past, S_max, H, Hk, hd, G.DT[dtype], G.stream()), "rope")
+    c, s = O.rope_cos_sin(pos, hd, 10000.0, torch.float32)
+    q = qkv[:, :H * hd].view(S, H, hd)
+    k = qkv[:, H * hd:(H + Hk) * hd].view(S, Hk, hd)
+    v = qkv[:, (H + Hk) * hd:].view(S, Hk, hd)
+    qr = q * c[:, None] + O.rotate_half(q) * s[:, None]
+    kr = k * c[:, None] + O.rotate_half(k) * s[:, None]
+    got_q = d_qkv[:, :H * hd].float().cpu().view(S, H, hd)
+    got_k = kc[:, past:past + S].float().cpu().transpose(0, 1)
+    if dtype == torch.float32:
+        torch.testing.assert_close(got_q, qr, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(got_k, kr, atol=1e-6, rtol=1e-6)
+    else:
+        close_bf16(got_q, G.bf16_round(qr))
+        close_bf16(got_k, G.bf16_round(kr))
+    assert torch.equal(vc[:, past:past + S].float().cpu().transpose(0, 1), v)            # V is a bit-exact copy
+    assert torch.equal(vtc[:, :, past:past + S].float().cpu().permute(2, 0, 1), v)       # and so is V^T
+    assert float(kc[:, :past].abs().sum()) == 0 and float(kc[:, past + S:].abs().sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------- data movement
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_splice_bit_exact(dtype):
+    V, D, NV = 50, 72, 6
+    emb, vis = rnd(V, D, seed=1).to(dtype), rnd(2 * NV, D, seed=2).to(dtype)
+    plan = torch.tensor([1, 7, -1, -2, -12, L.INT32_MIN, 49, 0, -6], dtype=torch.int32)
+    out = torch.empty(plan.numel(), D, dtype=dtype, device="cuda")
+    L.check(G.lib().teo_embed_splice(G.p(plan.cuda()), G.p(emb.cuda()), G.p(vis.cuda()), G.p(out), plan.numel(), D,
+                                     G.DT[dtype], G.stream()), "splice")
+    for r, pl in enumerate(plan.tolist()):
+        exp = torch.zeros(D, dtype=dtype) if pl == L.INT32_MIN else (emb[pl] if pl >= 0 else vis[-pl - 1])
+        assert torch.equal(out[r].cpu(), exp), r
+
+
+def test_im2col_vt_dropcls_bit_exact():
+    T, Cc, img, P = 2, 3, 28, 14
+    px = rnd(T, Cc, img, img, seed=1)
+    ld = 640
+    cols = torch.empty(T * 4, ld, device="cuda")
+    L.check(G.lib().teo_im2col_patches(G.p(px.cuda()), G.p(cols), T, Cc, img, P, ld, L.TEO_F32, G.stream()), "im2col")
+    ref = F.unfold(px, kernel_size=P, stride=P).transpose(1, 2).reshape(T * 4, Cc * P * P)
+    assert torch.equal(cols[:, :Cc * P * P].cpu(), ref) and float(cols[:, Cc * P * P:].abs().sum()) == 0
+    # ViT value transpose
+    N, H, hd = 37, 2, 64
+    D = H * hd
+    qkv = rnd(T * N, 3 * D, seed=2)
+    ldv = 64
+    vt = torch.full((T, H, hd, ldv), 7.0, device="cuda")
+    L.check(G.lib().teo_vit_value_transpose(G.p(qkv.cuda()), G.p(vt), T, N, H, hd, ldv, L.TEO_F32, G.stream()), "vt")
+    v = qkv.view(T, N, 3, H, hd)[:, :, 2]                       # [T,N,H,hd]
+    assert torch.equal(vt[..., :N].cpu(), v.permute(0, 2, 3, 1)) and float(vt[..., N:].abs().sum()) == 0
+    # drop CLS
+    h = rnd(T, N, D, seed=3)
+    out = torch.empty(T, N - 1, D, device="cuda")
+    L.check(G.lib().teo_drop_cls(G.p(h.cuda()), G.p(out), T, N, D, L.TEO_F32, G.stream()), "drop_cls")
+    assert torch.equal(out.cpu(), h[:, 1:])
+
+
+def test_vit_embed_ln_fp32():
+    T, NP, D = 2, 16, 64
+    patch, cls, pos = rnd(T * NP, D, seed=1), rnd(D, seed=2), rnd(NP + 1, D, seed=3)
+    w, b = 1 + 0.1 * rnd(D, seed=4), rnd(D, seed=5, scale=0.1)
+    out = torch.empty(T, NP + 1, D, device="cuda")
+    L.check(G.lib().teo_vit_embed_ln(G.p(patch.cuda()), G.p(cls.cuda()), G.p(pos.cuda()), G.p(w.cuda()), G.p(b.cuda()),
+                                     G.p(out), T, NP, D, 1e-5, L.TEO_F32, G.stream()), "embed_ln")
+    emb = torch.cat([cls.view(1, 1, D).expand(T, 1, D), patch.view(T, NP, D)], dim=1) + pos
+    torch.testing.assert_close(out.cpu(), F.layer_norm(emb, (D,), w, b, 1e-5), atol=FP32_ATOL, rtol=1e-5)
+
+
+def test_argmax_first_index_on_ties():
+    x = torch.zeros(3, 32000)
+    x[0, 31999] = 5.0
+    x[1, 77] = 2.0; x[1, 20000] = 2.0
+    x[2] = -1.0
+    tok = torch.empty(3, dtype=torch.int64, device="cuda")
+    L.check(G.lib().teo_argmax(G.p(x.cuda()), G.p(tok), 3, 32000, G.stream()), "argmax")
+    assert tok.tolist() == [31999, 77, 0]
+    y = rnd(1, 32000, seed=9)
+    L.check(G.lib().teo_argmax(G.p(y.cuda()), G.p(tok), 1, 32000, G.stream()), "argmax")
+    assert int(tok[0]) == int(y.argmax())
+
+
+# ---------------------------------------------------------------------------------------------- GEMV
+@pytest.mark.parametrize("N,K", [(64, 64), (300, 1376), (4096, 4096), (130, 520)])
+def test_gemv_fp32(N, K):
+    x, W, res, nw = rnd(K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), 1 + 0.1 * rnd(K, seed=4)
+    y = G.gemv(G.dev(x), G.dev(W)).cpu()
+    torch.testing.assert_close(y, W @ x, atol=3e-5, rtol=1e-5)
+    y = G.gemv(G.dev(x), G.dev(W), norm_w=G.dev(nw), res=G.dev(res)).cpu()
+    torch.testing.assert_close(y, W @ O.rmsnorm(x, nw, 1e-5) + res, atol=3e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,K", [(256, 256), (12288, 4096), (4096, 11008), (32000, 4096)])
+def test_gemv_bf16_real_shapes(N, K):
+    bf = torch.bfloat16
+    x, W, res = G.bf16_round(rnd(K, seed=1)), G.bf16_round(rnd(N, K, seed=2, scale=0.02)), G.bf16_round(rnd(N, seed=3))
+    nw = G.bf16_round(1 + 0.1 * rnd(K, seed=4))
+    y = G.gemv(G.dev(x, bf), G.dev(W, bf), res=G.dev(res, bf))
+    close_bf16(y, G.bf16_round(W @ x + res))
+    y32 = G.gemv(G.dev(x, bf), G.dev(W, bf), norm_w=G.dev(nw, bf), out_dtype=torch.float32).cpu()
+    xn = G.bf16_round(O.rmsnorm(x, nw, 1e-5))
+    torch.testing.assert_close(y32, W @ xn, atol=2e-4, rtol=1e-4)
+
+
+def test_gemv_swiglu_bf16_and_matches_gemm_row():
+    from teochat_amd.engine import interleave_gate_up
+    bf = torch.bfloat16
+    K, Fd = 4096, 11008
+    x = G.bf16_round(rnd(K, seed=1))
+    gate, up = G.bf16_round(rnd(Fd, K, seed=2, scale=0.02)), G.bf16_round(rnd(Fd, K, seed=3, scale=0.02))
+    nw = G.bf16_round(1 + 0.1 * rnd(K, seed=4))
+    gu = G.dev(interleave_gate_up(gate, up), bf)
+    y = G.gemv(G.dev(x, bf), gu, norm_w=G.dev(nw, bf), flags=L.GEMM_SWIGLU16)
+    xn = G.bf16_round(O.rmsnorm(x, nw, 1e-5))
+    close_bf16(y, G.bf16_round(F.silu(gate @ xn) * (up @ xn)))
+    # the prefill GEMM on a 1-row batch of the same (already normalised) activations agrees
+    yg = G.gemm(G.dev(xn.view(1, K), bf), gu, flags=L.GEMM_SWIGLU16)
+    close_bf16(y, yg[0].float(), ulps=2.0)
+
+
+def test_abi_error_convention():
+    lib = G.lib()
+    rc = lib.teo_gemm(None, None, None, None, None, 4, 4, 4, 4, 4, 0, 0, 7, 0, None)
+    assert rc == -1 and b"dtype" in lib.teo_last_error()
+    x = torch.zeros(8, device="cuda")
+    rc = lib.teo_gemv(G.p(x), G.p(x), None, None, G.p(x), 2, 3, 1e-5, 0, L.TEO_F32, L.TEO_F32, G.stream())
+    assert rc == -1 and b"multiple" in lib.teo_last_error()
+    assert lib.teo_layernorm(None, None, None, None, 0, 8, 1e-5, L.TEO_F32, None) == 0      # empty input is fine
