@@ -46,6 +46,8 @@ typedef enum {
 
 int teo_version(void);
 const char* teo_last_error(void);
+/* Performance tuning knobs (never change results): "gemv_variant" (-1 = default), "gemv_nt", "gemv_max_blocks". */
+int teo_tune_set(const char* key, int value);
 /* 1 when the MFMA (fast) kernel would be used for this GEMM, 0 when the generic kernel would. */
 int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags);
 

@@ -73,6 +73,7 @@ class DecodeState(C.Structure):
 _SIGS = {
     "teo_version": (C.c_int, []),
     "teo_last_error": (C.c_char_p, []),
+    "teo_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
     "teo_gemm_uses_mfma": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "teo_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "teo_rmsnorm": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
@@ -112,6 +113,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (libamdhip64.so); it must be loaded first so that this library binds to the
+    # SAME runtime instance (streams and device pointers are shared with torch).  Loading /opt/rocm's copy first
+    # leaves two runtimes in the process and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TeoLibraryError(
             f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). Build it with "

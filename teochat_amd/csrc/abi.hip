@@ -40,11 +40,20 @@ using namespace teo;
 #define ST(s) ((hipStream_t)(s))
 #define NEED(p, name) TEO_CHECK_ARG((p) != nullptr, "%s: null %s", __func__, name)
 #define NEED_DT(dt) TEO_CHECK_ARG(dtype_ok(dt), "%s: bad dtype %d", __func__, dt)
+// hipGetLastError is sticky per thread: drop whatever an earlier, unrelated runtime call left behind so that our
+// post-launch checks only ever report our own failures.
+#define ENTER() (void)hipGetLastError()
 
 extern "C" {
 
 int teo_version(void) { return TEO_ABI_VERSION; }
 const char* teo_last_error(void) { return g_err; }
+
+int teo_tune_set(const char* key, int value) {
+    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0)) return TEO_OK;
+    set_error("teo_tune_set: unknown key");
+    return TEO_ERR_ARG;
+}
 
 int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags) {
     return gemm_mfma_ok(M, N, K, K, (flags & TEO_GEMM_SWIGLU16) ? N / 2 : N, dtype, flags, nullptr, nullptr, nullptr,
@@ -53,12 +62,14 @@ int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags) {
 
 int teo_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int dim, float eps, int dtype,
                   teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); TEO_CHECK_ARG(rows >= 0 && dim > 0, "teo_layernorm: rows %d dim %d", rows, dim);
     if (rows) { NEED(x, "x"); NEED(w, "w"); NEED(b, "b"); NEED(y, "y"); }
     return layernorm(x, w, b, y, rows, dim, eps, dtype, ST(s));
 }
 
 int teo_rmsnorm(const void* x, const void* w, void* y, int rows, int dim, float eps, int dtype, teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); TEO_CHECK_ARG(rows >= 0 && dim > 0, "teo_rmsnorm: rows %d dim %d", rows, dim);
     if (rows) { NEED(x, "x"); NEED(w, "w"); NEED(y, "y"); }
     return rmsnorm(x, w, y, rows, dim, eps, dtype, ST(s));
@@ -66,6 +77,7 @@ int teo_rmsnorm(const void* x, const void* w, void* y, int rows, int dim, float 
 
 int teo_gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
              int ldc, int act, unsigned flags, int dtype, int out_dtype, teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); NEED_DT(out_dtype);
     TEO_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && lda >= K, "teo_gemm: M %d N %d K %d lda %d", M, N, K, lda);
     TEO_CHECK_ARG(ldc >= ((flags & TEO_GEMM_SWIGLU16) ? N / 2 : N), "teo_gemm: ldc %d too small", ldc);
@@ -76,6 +88,7 @@ int teo_gemm(const void* A, const void* W, const void* bias, const void* res, vo
 
 int teo_im2col_patches(const void* px, void* cols, int T, int channels, int image, int patch, int ldcols, int dtype,
                        teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); TEO_CHECK_ARG(T >= 0 && patch > 0 && image > 0, "teo_im2col_patches: bad sizes");
     if (T) { NEED(px, "pixels"); NEED(cols, "cols"); }
     return im2col_patches(px, cols, T, channels, image, patch, ldcols, dtype, ST(s));
@@ -83,6 +96,7 @@ int teo_im2col_patches(const void* px, void* cols, int T, int channels, int imag
 
 int teo_vit_embed_ln(const void* patch, const void* cls, const void* pos, const void* w, const void* b, void* out, int T,
                      int n_patches, int dim, float eps, int dtype, teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype);
     TEO_CHECK_ARG(T >= 0 && n_patches > 0 && dim > 0 && dim <= 16384, "teo_vit_embed_ln: bad sizes");
     if (T) { NEED(patch, "patch"); NEED(cls, "cls"); NEED(pos, "pos"); NEED(w, "w"); NEED(b, "b"); NEED(out, "out"); }
@@ -90,6 +104,7 @@ int teo_vit_embed_ln(const void* patch, const void* cls, const void* pos, const 
 }
 
 int teo_attention(const teo_attn_args* a, int dtype, teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); NEED(a, "args");
     TEO_CHECK_ARG(a->batch >= 0 && a->heads > 0 && a->kv_heads > 0 && a->head_dim > 0 && a->q_len >= 0 && a->kv_len >= 0,
                   "teo_attention: bad sizes");
@@ -99,6 +114,7 @@ int teo_attention(const teo_attn_args* a, int dtype, teo_stream_t s) {
 
 int teo_vit_value_transpose(const void* qkv, void* vt, int T, int N, int heads, int head_dim, int ldv, int dtype,
                             teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); TEO_CHECK_ARG(T >= 0 && N > 0 && ldv >= N, "teo_vit_value_transpose: bad sizes");
     if (T) { NEED(qkv, "qkv"); NEED(vt, "vt"); }
     return vit_value_transpose(qkv, vt, T, N, heads, head_dim, ldv, dtype, ST(s));
@@ -107,6 +123,7 @@ int teo_vit_value_transpose(const void* qkv, void* vt, int T, int N, int heads, 
 int teo_rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                        void* vtc, int S, int past, int S_max, int heads, int kv_heads, int head_dim, int dtype,
                        teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype);
     TEO_CHECK_ARG(S >= 0 && past >= 0 && past + S <= S_max, "teo_rope_kv_append: S %d past %d S_max %d", S, past, S_max);
     if (S) { NEED(qkv, "qkv"); NEED(cs, "cos"); NEED(sn, "sin"); NEED(kc, "k_cache"); NEED(vc, "v_cache"); }
@@ -116,18 +133,21 @@ int teo_rope_kv_append(void* qkv, int ld, const int* positions, const float* cs,
 
 int teo_embed_splice(const int* plan, const void* embed, const void* visual, void* out, int rows, int dim, int dtype,
                      teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); TEO_CHECK_ARG(rows >= 0 && dim > 0, "teo_embed_splice: bad sizes");
     if (rows) { NEED(plan, "plan"); NEED(embed, "embed"); NEED(out, "out"); }
     return embed_splice(plan, embed, visual, out, rows, dim, dtype, ST(s));
 }
 
 int teo_drop_cls(const void* in, void* out, int T, int n_tokens, int dim, int dtype, teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); TEO_CHECK_ARG(T >= 0 && n_tokens >= 1 && dim > 0, "teo_drop_cls: bad sizes");
     if (T && n_tokens > 1) { NEED(in, "in"); NEED(out, "out"); }
     return drop_cls(in, out, T, n_tokens, dim, dtype, ST(s));
 }
 
 int teo_argmax(const float* logits, long long* tok, int rows, int vocab, teo_stream_t s) {
+    ENTER();
     TEO_CHECK_ARG(rows >= 0 && vocab > 0, "teo_argmax: bad sizes");
     if (rows) { NEED(logits, "logits"); NEED(tok, "token"); }
     return argmax(logits, tok, rows, vocab, ST(s));
@@ -135,6 +155,7 @@ int teo_argmax(const float* logits, long long* tok, int rows, int vocab, teo_str
 
 int teo_gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
              unsigned flags, int dtype, int out_dtype, teo_stream_t s) {
+    ENTER();
     NEED_DT(dtype); NEED_DT(out_dtype); TEO_CHECK_ARG(N >= 0 && K > 0, "teo_gemv: N %d K %d", N, K);
     if (N) { NEED(x, "x"); NEED(W, "W"); NEED(y, "y"); }
     return gemv(x, W, norm_w, res, y, N, K, eps, flags, dtype, out_dtype, ST(s));
@@ -142,6 +163,7 @@ int teo_gemv(const void* x, const void* W, const void* norm_w, const void* res, 
 
 size_t teo_vit_workspace_bytes(const teo_vit_desc* d, int T) { return d ? vit_workspace_bytes(d, T) : 0; }
 int teo_vit_encode(const teo_vit_desc* d, const void* px, int T, void* feat, void* ws, size_t wsb, teo_stream_t s) {
+    ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype);
     TEO_CHECK_ARG(T >= 0 && d->hidden % d->heads == 0 && d->image % d->patch == 0, "teo_vit_encode: bad config");
     if (T) { NEED(px, "pixels"); NEED(feat, "features"); NEED(ws, "workspace"); }
@@ -150,6 +172,7 @@ int teo_vit_encode(const teo_vit_desc* d, const void* px, int T, void* feat, voi
 
 size_t teo_projector_workspace_bytes(const teo_proj_desc* d, int rows) { return d ? projector_workspace_bytes(d, rows) : 0; }
 int teo_projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws, size_t wsb, teo_stream_t s) {
+    ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype);
     if (rows) { NEED(x, "x"); NEED(y, "y"); }
     return projector(d, x, rows, y, ws, wsb, ST(s));
@@ -158,6 +181,7 @@ int teo_projector(const teo_proj_desc* d, const void* x, int rows, void* y, void
 size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S) { return d ? llama_prefill_workspace_bytes(d, S) : 0; }
 int teo_llama_prefill(const teo_llama_desc* d, const void* emb, const int* pos, int S, int past, int last_only,
                       float* logits, void* ws, size_t wsb, teo_stream_t s) {
+    ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype);
     TEO_CHECK_ARG(S >= 0 && past >= 0, "teo_llama_prefill: S %d past %d", S, past);
     if (S) { NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace"); }
@@ -166,6 +190,7 @@ int teo_llama_prefill(const teo_llama_desc* d, const void* emb, const int* pos, 
 
 size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d) { return d ? llama_decode_workspace_bytes(d) : 0; }
 int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, teo_stream_t s) {
+    ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
     NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
     NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
@@ -174,12 +199,14 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
 
 int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb,
                                   teo_stream_t s, teo_graph** out) {
+    ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED(out, "out"); NEED_DT(d->dtype);
     TEO_CHECK_ARG(s != nullptr, "teo_llama_decode_graph_create: needs a non-default stream to capture on");
     return decode_graph_create(d, st, ws, wsb, ST(s), out);
 }
 
 int teo_graph_launch(teo_graph* g, int n_times, teo_stream_t s) {
+    ENTER();
     NEED(g, "graph");
     for (int i = 0; i < n_times; ++i) {
         hipError_t e = hipGraphLaunch(g->exec, ST(s));
@@ -198,6 +225,7 @@ int teo_graph_destroy(teo_graph* g) {
 
 int teo_time_gemv_chain(const void* x, const void* const* Ws, int n, const void* norm_w, void* y, int N, int K,
                         float eps, unsigned flags, int dtype, int reps, float* avg_ms_out, teo_stream_t s) {
+    ENTER();
     NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
     TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_gemv_chain: n %d reps %d", n, reps);
     hipEvent_t e0, e1;

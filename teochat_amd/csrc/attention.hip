@@ -265,104 +265,164 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------
 // decode: one query row, kv_len read from device memory (hipGraph replays the same launch each token)
+//
+// grid (heads, nsplit), 256 threads; a workgroup owns DEC_CHUNK keys, each wave a quarter of them.  Rows of K and V
+// are streamed with 16-byte loads, LPR = head_dim*sizeof(T)/16 lanes per row; ALL loads of the chunk (K and V) are
+// issued before the first use so one lane has 2*DEC_CHUNK/4/(64/LPR) loads in flight (16 for bf16, d=128).
+// scores: per-row partial dot + xor-shuffle over the LPR lanes; PV: each lane accumulates its 16-byte column slice
+// over its keys, lanes of different rows are summed with two xor-shuffles at the end.  No MFMA: 1 query row.
 // ------------------------------------------------------------------------------------------------
-constexpr int DEC_CHUNK = 256;   // keys per workgroup
+constexpr int DEC_CHUNK = 128;   // keys per workgroup
+
+template <typename T> struct Cvt16;
+template <> struct Cvt16<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+};
+template <> struct Cvt16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
+        f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+    }
+};
 
 // q: [heads*hd] (already rotated), K/V cache [kv_heads][S_max][hd]; partial: [heads][nsplit][hd + 2] fp32 (m, l, o[hd])
-template <typename T>
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                                   const T* __restrict__ vc, float* __restrict__ part,
                                                                   const int* __restrict__ d_pos, int S_max, int heads,
-                                                                  int kv_heads, int hd, float scale, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* qs = sm;                // [hd]
-    float* ps = sm + hd;           // [DEC_CHUNK]
-    float* red = ps + DEC_CHUNK;   // [4 + 2*hd] scratch
-    const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+                                                                  int kv_heads, float scale, int nsplit) {
+    constexpr int VE = Cvt16<T>::N;
+    constexpr int HD = LPR * VE;
+    constexpr int RPI = 64 / LPR;                       // rows (keys) per wave-wide load instruction
+    constexpr int KPW = DEC_CHUNK / 4;                  // keys per wave
+    constexpr int NI = KPW / RPI;                       // load instructions per wave per operand
+    __shared__ float sc[DEC_CHUNK];
+    __shared__ float red[8];
+    __shared__ float obuf[4][HD];
+    const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hk = h / (heads / kv_heads);
     const int kv_len = *d_pos + 1;
-    const int c0 = sp * DEC_CHUNK, c1 = min(kv_len, c0 + DEC_CHUNK);
-    float* out = part + ((long long)h * nsplit + sp) * (hd + 2);
-    if (c0 >= kv_len) {            // nothing here: neutral partial
+    const int c0 = sp * DEC_CHUNK;
+    float* out = part + ((long long)h * nsplit + sp) * (HD + 2);
+    if (c0 >= kv_len) {                                 // nothing here: neutral partial
         if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
-        for (int d = tid; d < hd; d += 256) out[2 + d] = 0.f;
+        for (int d = tid; d < HD; d += 256) out[2 + d] = 0.f;
         return;
     }
-    for (int d = tid; d < hd; d += 256) qs[d] = Elem<T>::ld(q + h * hd + d);
-    __syncthreads();
-    const T* kb = kc + (long long)hk * S_max * hd;
-    const T* vb = vc + (long long)hk * S_max * hd;
-    // scores: 16-byte vector loads, lanes of a (16/sizeof(T) * ...)-group share a key
-    constexpr int VE = 16 / sizeof(T);             // elements per 16-byte load
-    const int lpk = hd / VE;                        // lanes per key (hd = 128, bf16 -> 16)
-    const int kpp = 256 / lpk;                      // keys per pass
-    const int sub = tid % lpk, kslot = tid / lpk;
-    for (int j = c0 + kslot; j < c0 + DEC_CHUNK; j += kpp) {
-        float s = 0.f;
-        if (j < c1) {
-            const T* kr = kb + (long long)j * hd + sub * VE;
-            const uint4 raw = *reinterpret_cast<const uint4*>(kr);
-            const T* e = reinterpret_cast<const T*>(&raw);
+    const int sub = lane % LPR, grp = lane / LPR;
+    const T* kb = kc + (long long)hk * S_max * HD + sub * VE;
+    const T* vb = vc + (long long)hk * S_max * HD + sub * VE;
+    const int kw0 = c0 + wid * KPW;                     // first key of this wave
+    uint4 kr[NI], vr[NI];
 #pragma unroll
-            for (int x = 0; x < VE; ++x) s = fmaf(qs[sub * VE + x], Elem<T>::ld(e + x), s);
-        }
-        for (int o = lpk >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (sub == 0) ps[j - c0] = (j < c1) ? s * scale : -INFINITY;
+    for (int i = 0; i < NI; ++i) {
+        const int j = min(kw0 + i * RPI + grp, kv_len - 1);
+        kr[i] = *reinterpret_cast<const uint4*>(kb + (long long)j * HD);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = min(kw0 + i * RPI + grp, kv_len - 1);
+        vr[i] = *reinterpret_cast<const uint4*>(vb + (long long)j * HD);
+    }
+    float qf[VE];
+    {
+        const uint4 qraw = *reinterpret_cast<const uint4*>(q + h * HD + sub * VE);
+        Cvt16<T>::cvt(qraw, qf);
+    }
+    // ---- scores
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float kf[VE];
+        Cvt16<T>::cvt(kr[i], kf);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s = fmaf(qf[e], kf[e], s);
+#pragma unroll
+        for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const int j = kw0 + i * RPI + grp;
+        if (sub == 0) sc[j - c0] = (j < kv_len) ? s * scale : -INFINITY;
     }
     __syncthreads();
-    // block max / sum over the chunk
-    float v = ps[tid];
-    float mx = wave_max(v);
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    // ---- chunk max / exp / sum (every wave redundantly over the 128 scores: 2 per lane)
+    const float s0 = sc[lane], s1 = sc[lane + 64];
+    const float mx = wave_max(fmaxf(s0, s1));
+    const float p0 = expf(s0 - mx), p1 = expf(s1 - mx);          // -inf -> 0
+    const float sum = wave_sum(p0 + p1);
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float p = expf(v - mx);                   // -inf -> 0
-    float sum = wave_sum(p);
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = sum;
-    ps[tid] = Elem<T>::round(p);
-    __syncthreads();
-    sum = red[0] + red[1] + red[2] + red[3];
-    // o[d] = sum_j p[j] V[j][d]: thread -> (d, key group)
-    const int ng = 256 / hd > 0 ? 256 / hd : 1;     // key groups (hd = 128 -> 2)
-    float acc = 0.f;
-    if (hd <= 256) {
-        const int d = tid % hd, g = tid / hd;
-        if (g < ng) {
-            for (int j = c0 + g; j < c1; j += ng) acc = fmaf(ps[j - c0], Elem<T>::ld(vb + (long long)j * hd + d), acc);
-        }
-        __syncthreads();
-        float* ob = red + 4;
-        if (g < ng) ob[g * hd + d] = acc;
-        __syncthreads();
-        if (tid < hd) {
-            float t = 0.f;
-            for (int g2 = 0; g2 < ng; ++g2) t += ob[g2 * hd + tid];
-            out[2 + tid] = t;
-        }
+    if (wid == 0) {
+        sc[lane] = Elem<T>::round(p0);
+        sc[lane + 64] = Elem<T>::round(p1);
     }
+    __syncthreads();
+    // ---- PV on this wave's keys
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const float p = sc[wid * KPW + i * RPI + grp];           // 0 for keys >= kv_len
+        float vf[VE];
+        Cvt16<T>::cvt(vr[i], vf);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) obuf[wid][sub * VE + e] = acc[e];
+    }
+    __syncthreads();
+    for (int d = tid; d < HD; d += 256) out[2 + d] = obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d];
     if (tid == 0) { out[0] = mx; out[1] = sum; }
 }
 
+// one workgroup per head: split weights are computed by one thread per split (parallel loads), then each thread
+// owns one output column and sums the active splits with independent loads (no dependent-latency chain).
 template <typename T>
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
-                                                                  int hd, int nsplit) {
-    const int h = blockIdx.x;
-    const float* pb = part + (long long)h * nsplit * (hd + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[s * (hd + 2)]);
-    float L = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float m = pb[s * (hd + 2)];
-        if (m != -INFINITY) L += pb[s * (hd + 2) + 1] * expf(m - M);
-    }
-    for (int d = threadIdx.x; d < hd; d += 128) {
-        float acc = 0.f;
-        for (int s = 0; s < nsplit; ++s) {
-            const float m = pb[s * (hd + 2)];
-            if (m != -INFINITY) acc += pb[s * (hd + 2) + 2 + d] * expf(m - M);
+                                                                  const int* __restrict__ d_pos, int hd, int nsplit) {
+    __shared__ float w[256];
+    __shared__ float red[4];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int stride = hd + 2;
+    const float* pb = part + (long long)h * nsplit * stride;
+    const int nact = min(nsplit, (*d_pos + 1 + DEC_CHUNK - 1) / DEC_CHUNK);       // splits that hold keys
+    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
+    if (tid + 128 < nact) { m1 = pb[(tid + 128) * stride]; l1 = pb[(tid + 128) * stride + 1]; }
+    float M = wave_max(fmaxf(m0, m1));
+    if (lane == 0) red[wid] = M;
+    __syncthreads();
+    M = fmaxf(red[0], red[1]);
+    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M), w1 = (m1 == -INFINITY) ? 0.f : expf(m1 - M);
+    if (tid < nact) w[tid] = w0;
+    if (tid + 128 < nact) w[tid + 128] = w1;
+    float L = wave_sum(l0 * w0 + l1 * w1);
+    __syncthreads();
+    if (lane == 0) red[2 + wid] = L;
+    __syncthreads();
+    const float inv = 1.0f / (red[2] + red[3]);
+    for (int d = tid; d < hd; d += 128) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s_ = 0;
+        for (; s_ + 4 <= nact; s_ += 4) {
+            const float v0 = pb[s_ * stride + 2 + d], v1 = pb[(s_ + 1) * stride + 2 + d];
+            const float v2 = pb[(s_ + 2) * stride + 2 + d], v3 = pb[(s_ + 3) * stride + 2 + d];
+            a0 = fmaf(v0, w[s_], a0); a1 = fmaf(v1, w[s_ + 1], a1);
+            a2 = fmaf(v2, w[s_ + 2], a2); a3 = fmaf(v3, w[s_ + 3], a3);
         }
-        Elem<T>::st(o + h * hd + d, acc / L);
+        for (; s_ < nact; ++s_) a0 = fmaf(pb[s_ * stride + 2 + d], w[s_], a0);
+        Elem<T>::st(o + h * hd + d, ((a0 + a1) + (a2 + a3)) * inv);
     }
 }
 
@@ -371,25 +431,33 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max) {
     return (size_t)heads * nsplit * (hd + 2) * sizeof(float);
 }
 
+template <typename T, int LPR>
+static void attn_decode_launch(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos,
+                               int S_max, int heads, int kv_heads, int hd, float scale, int nsplit, hipStream_t st) {
+    dim3 grid(heads, nsplit);
+    attn_decode_partial_kernel<T, LPR><<<grid, 256, 0, st>>>((const T*)q, (const T*)kc, (const T*)vc, part, d_pos, S_max,
+                                                             heads, kv_heads, scale, nsplit);
+    attn_decode_combine_kernel<T><<<heads, 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit);
+}
+
 int attn_decode(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos, int S_max,
                 int heads, int kv_heads, int hd, float scale, int dtype, hipStream_t st) {
     const int nsplit = cdiv(S_max, DEC_CHUNK);
     const int esz = dtype == TEO_F32 ? 4 : 2;
-    if (hd > 256 || (hd * esz) % 16 != 0 || 256 % (hd * esz / 16) != 0) {
-        set_error("attn_decode: unsupported head_dim %d", hd);
+    const int lpr = hd * esz / 16;
+    if (nsplit > 256 || (hd * esz) % 16 != 0 || (lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16 && lpr != 32)) {
+        set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
         return TEO_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)(hd + DEC_CHUNK + 4 + 2 * 256) * sizeof(float);
-    dim3 grid(heads, nsplit);
+#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, st)
     if (dtype == TEO_F32) {
-        attn_decode_partial_kernel<float><<<grid, 256, lds, st>>>((const float*)q, (const float*)kc, (const float*)vc, part,
-                                                                  d_pos, S_max, heads, kv_heads, hd, scale, nsplit);
-        attn_decode_combine_kernel<float><<<heads, 128, 0, st>>>(part, (float*)o, hd, nsplit);
+        switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
+                       case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }
     } else {
-        attn_decode_partial_kernel<bf16_t><<<grid, 256, lds, st>>>((const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc,
-                                                                   part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit);
-        attn_decode_combine_kernel<bf16_t><<<heads, 128, 0, st>>>(part, (bf16_t*)o, hd, nsplit);
+        switch (lpr) { case 2: TEO_DEC(bf16_t, 2); break; case 4: TEO_DEC(bf16_t, 4); break; case 8: TEO_DEC(bf16_t, 8); break;
+                       case 16: TEO_DEC(bf16_t, 16); break; default: TEO_DEC(bf16_t, 32); }
     }
+#undef TEO_DEC
     TEO_LAUNCH_CHECK("attn_decode");
     return TEO_OK;
 }

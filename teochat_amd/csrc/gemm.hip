@@ -17,6 +17,7 @@ namespace teo {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // ------------------------------------------------------------------------------------------------
 // generic kernel
@@ -103,8 +104,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <bool SWIGLU, bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(const bf16_t* __restrict__ A,
+template <bool SWIGLU, bool OUT_F32, int DEPTH>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __restrict__ A,
                                                              const bf16_t* __restrict__ W,
                                                              const bf16_t* __restrict__ bias,
                                                              const bf16_t* __restrict__ res, void* __restrict__ Cv,
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(const bf16_t* __res
     const int tm = tile % tiles_m, tn = tile / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // staging: thread owns 4 chunks (16 B) of each operand tile: chunk id = tid + 256*i -> row id>>3, chunk id&7
+    // staging: thread owns 4 chunks (16 B) of each operand tile: chunk id = tid + 256*i -> row id>>3, chunk id&7.
+    // NOTE: plain arrays + fully unrolled loops only -- lambdas capturing these arrays made hipcc spill them to scratch.
     const bf16_t* ag[4];
     const bf16_t* wg[4];
     int soff[4];
@@ -130,22 +132,21 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(const bf16_t* __res
         wg[i] = W + (long long)gn * K + c * 8;
         soff[i] = row * (BK * 2) + ((c ^ (row & 7)) << 4);
     }
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const uint4*>(ag[i] + kt * BK);
-            rb[i] = *reinterpret_cast<const uint4*>(wg[i] + kt * BK);
-        }
-    };
-    auto swrite = [&](int buf) {
-        unsigned char* sa = smem + buf * (2 * TILE_BYTES);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(sa + soff[i]) = ra[i];
-            *reinterpret_cast<uint4*>(sa + TILE_BYTES + soff[i]) = rb[i];
-        }
-    };
+    u32x4 ra0[4], rb0[4], ra1[4], rb1[4];     // two register stages: tiles kt+1 and kt+2 are in flight during compute(kt)
+
+#define TEO_GLOAD(RA, RB, KT)                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
+        RA[i] = *reinterpret_cast<const u32x4*>(ag[i] + (long long)(KT) * BK);  \
+        RB[i] = *reinterpret_cast<const u32x4*>(wg[i] + (long long)(KT) * BK);  \
+    }
+#define TEO_SWRITE(RA, RB, BUF)                                                 \
+    {                                                                           \
+        unsigned char* sa_ = smem + (BUF) * (2 * TILE_BYTES);                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                         \
+            *reinterpret_cast<u32x4*>(sa_ + soff[i]) = RA[i];                   \
+            *reinterpret_cast<u32x4*>(sa_ + TILE_BYTES + soff[i]) = RB[i];      \
+        }                                                                       \
+    }
 
     f32x4 acc[4][4];   // [ni][mi]
 #pragma unroll
@@ -156,32 +157,59 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(const bf16_t* __res
     // fragment read offsets: row = base + i*16 + (lane&15); logical chunk = ks*4 + (lane>>4)
     const int fr = lane & 15, fg = lane >> 4;
     const int nk = K / BK;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
-        const unsigned char* sA = smem + (kt & 1) * (2 * TILE_BYTES);
-        const unsigned char* sB = sA + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra_ = wm * 64 + i * 16 + fr;
-                af[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * (BK * 2) + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
-                const int rw_ = wn * 64 + i * 16 + fr;
-                wf[i] = *reinterpret_cast<const bf16x8*>(sB + rw_ * (BK * 2) + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
-        if (kt + 1 < nk) swrite((kt + 1) & 1);
-        __syncthreads();
+
+#define TEO_COMPUTE(BUF)                                                                                             \
+    {                                                                                                                \
+        const unsigned char* sA = smem + (BUF) * (2 * TILE_BYTES);                                                   \
+        const unsigned char* sB = sA + TILE_BYTES;                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+            bf16x8 af[4], wf[4];                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+                const int ra_ = wm * 64 + i * 16 + fr;                                                               \
+                af[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * (BK * 2) + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));  \
+                const int rw_ = wn * 64 + i * 16 + fr;                                                               \
+                wf[i] = *reinterpret_cast<const bf16x8*>(sB + rw_ * (BK * 2) + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));  \
+            }                                                                                                        \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                         \
+                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                     \
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);     \
+        }                                                                                                            \
     }
+
+    if (DEPTH == 2) {
+        TEO_GLOAD(ra0, rb0, 0);
+        if (nk > 1) TEO_GLOAD(ra1, rb1, 1);
+        TEO_SWRITE(ra0, rb0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even step: tile kt in LDS buffer 0, tile kt+1 in flight in set 1
+            if (kt + 2 < nk) TEO_GLOAD(ra0, rb0, kt + 2);
+            TEO_COMPUTE(0);
+            if (kt + 1 < nk) TEO_SWRITE(ra1, rb1, 1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // odd step: tile kt+1 in LDS buffer 1, tile kt+2 in flight in set 0
+            if (kt + 3 < nk) TEO_GLOAD(ra1, rb1, kt + 3);
+            TEO_COMPUTE(1);
+            if (kt + 2 < nk) TEO_SWRITE(ra0, rb0, 0);
+            __syncthreads();
+        }
+    } else {
+        TEO_GLOAD(ra0, rb0, 0);
+        TEO_SWRITE(ra0, rb0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) TEO_GLOAD(ra0, rb0, kt + 1);
+            if (kt & 1) { TEO_COMPUTE(1); } else { TEO_COMPUTE(0); }
+            if (kt + 1 < nk) {
+                if (kt & 1) { TEO_SWRITE(ra0, rb0, 0); } else { TEO_SWRITE(ra0, rb0, 1); }
+            }
+            __syncthreads();
+        }
+    }
+#undef TEO_GLOAD
+#undef TEO_SWRITE
+#undef TEO_COMPUTE
 
     // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
@@ -254,6 +282,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_bf16_kernel(const bf16_t* __res
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
+static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
+int gemm_tune_set(const char* key, int value) {
+    if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
+    return -1;
+}
+
 bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned flags, const void* A, const void* W,
                   const void* bias, const void* res, const void* C) {
     if (dtype != TEO_BF16 || (flags & TEO_GEMM_FORCE_SIMPLE)) return false;
@@ -289,12 +323,17 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
-#define TEO_GEMM_LAUNCH(SW, OF)                                                                                   \
-    gemm_mfma_bf16_kernel<SW, OF><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
-                                                         (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m,  \
-                                                         tiles_n)
-        if (swiglu) { if (of32) TEO_GEMM_LAUNCH(true, true); else TEO_GEMM_LAUNCH(true, false); }
-        else        { if (of32) TEO_GEMM_LAUNCH(false, true); else TEO_GEMM_LAUNCH(false, false); }
+#define TEO_GEMM_LAUNCH(SW, OF)                                                                                      \
+    if ((g_gemm_depth == 0 && !(SW)) || g_gemm_depth == 2)                                                            \
+        gemm_mfma_bf16_kernel<SW, OF, 2><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
+                                                                tiles_n);                                            \
+    else                                                                                                             \
+        gemm_mfma_bf16_kernel<SW, OF, 1><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
+                                                                tiles_n)
+        if (swiglu) { if (of32) { TEO_GEMM_LAUNCH(true, true); } else { TEO_GEMM_LAUNCH(true, false); } }
+        else        { if (of32) { TEO_GEMM_LAUNCH(false, true); } else { TEO_GEMM_LAUNCH(false, false); } }
 #undef TEO_GEMM_LAUNCH
         TEO_LAUNCH_CHECK("gemm_mfma_bf16");
         return TEO_OK;

@@ -38,82 +38,131 @@ __device__ __forceinline__ uint4 ld_nt16(const void* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// R rows per wave per pass.  SWIGLU: rows come in (gate, up) pairs 16 apart inside 32-row blocks.
-template <typename T, typename TO, int R, bool SWIGLU>
+// Tunables (teo_tune_set): which <R,U,DB,PF> instantiation runs, non-temporal loads on/off, workgroup cap.
+struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; };
+static GemvTune g_tune;
+int gemv_tune_set(const char* key, int value) {
+    if (!strcmp(key, "gemv_variant")) g_tune.variant = value;
+    else if (!strcmp(key, "gemv_nt")) g_tune.nt = value;
+    else if (!strcmp(key, "gemv_max_blocks")) g_tune.max_blocks = value;
+    else return -1;
+    return 0;
+}
+
+// R rows per wave per pass, U 16-byte chunks per lane per row per K-iteration (R*U loads issued back to back).
+//   DB: the next iteration's R*U loads are issued before the current ones are consumed (register double buffer);
+//   PF: the first R*U loads are issued before the x staging / RMSNorm prologue (the weight stream does not depend on x);
+//   NT: non-temporal weight loads.
+// SWIGLU: rows come in (gate, up) pairs 16 apart inside 32-row blocks.
+template <typename T, typename TO, int R, int U, bool DB, bool PF, bool NT, bool SWIGLU>
 __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ x, const T* __restrict__ W,
                                                           const T* __restrict__ norm_w, const T* __restrict__ res,
                                                           TO* __restrict__ y, int N, int K, float eps) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];     // [K] fp32 (+4 floats of reduction scratch)
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [K] fp32 (+8 floats of reduction scratch)
     constexpr int VE = Vec16<T>::N;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    float* red = xs + K;
-    // ---- stage f(x) in LDS
-    if (norm_w) {
-        float ss = 0.f;
-        for (int i = tid; i < K; i += GV_THREADS) {
-            const float v = Elem<T>::ld(x + i);
-            xs[i] = v;
-            ss += v * v;
+    const int nchunk = K / VE;                    // 16-byte chunks per row
+    const int kpad = (K + 3) & ~3;
+    float* red = xs + kpad;
+    const int wave_global = blockIdx.x * GV_WAVES + wid;
+    const int nwaves = gridDim.x * GV_WAVES;
+    const int ngroups = SWIGLU ? (N / 2 + (R / 2) - 1) / (R / 2) : (N + R - 1) / R;
+
+    auto row_of = [&](int grp, int r) -> long long {
+        if (SWIGLU) {
+            const int j = min(grp * (R / 2) + (r >> 1), N / 2 - 1);     // output column
+            return (long long)((j >> 4) * 32 + (j & 15) + ((r & 1) ? 16 : 0));
         }
-        const float r = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
-        for (int i = tid; i < K; i += GV_THREADS) xs[i] = Elem<T>::round(xs[i] * r * Elem<T>::ld(norm_w + i));
-    } else {
-        for (int i = tid; i < K; i += GV_THREADS) xs[i] = Elem<T>::ld(x + i);
+        return (long long)min(grp * R + r, N - 1);
+    };
+    auto issue = [&](uint4 (&w)[U][R], int grp, int c0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const T* p = W + row_of(grp, r) * K + (long long)c * VE;
+                w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+
+    uint4 wa[U][R];
+    int grp = wave_global;
+    if (PF && grp < ngroups) issue(wa, grp, 0);
+
+    // ---- stage f(x) in LDS (fp32), 16-byte loads
+    float ss = 0.f;
+    for (int c = tid; c < nchunk; c += GV_THREADS) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
+        float f[VE];
+        Vec16<T>::cvt(raw, f);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            xs[c * VE + e] = f[e];
+            ss = fmaf(f[e], f[e], ss);
+        }
+    }
+    if (norm_w) {
+        const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+        for (int c = tid; c < nchunk; c += GV_THREADS) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE);
+            float f[VE];
+            Vec16<T>::cvt(raw, f);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(xs[c * VE + e] * rr * f[e]);
+        }
     }
     __syncthreads();
 
-    const int nchunk = K / VE;                    // 16-byte chunks per row
-    const int wave_global = blockIdx.x * GV_WAVES + wid;
-    const int nwaves = gridDim.x * GV_WAVES;
-    // row groups: plain -> R consecutive rows; swiglu -> R/2 (gate, up) pairs
-    const int ngroups = SWIGLU ? (N / 2 + (R / 2) - 1) / (R / 2) : (N + R - 1) / R;
-    for (int grp = wave_global; grp < ngroups; grp += nwaves) {
-        int rows[R];
+    auto consume = [&](const uint4 (&w)[U][R], int c0, float (&acc)[R]) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (SWIGLU) {
-                const int j = grp * (R / 2) + (r >> 1);                 // output column
-                const int jr = min(j, N / 2 - 1);
-                rows[r] = (jr >> 4) * 32 + (jr & 15) + ((r & 1) ? 16 : 0);
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            float xv[VE];
+            if (c < nchunk) {
+#pragma unroll
+                for (int e = 0; e < VE; e += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
+                    xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
+                }
             } else {
-                rows[r] = min(grp * R + r, N - 1);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) xv[e] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float f[VE];
+                Vec16<T>::cvt(w[u][r], f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
             }
         }
+    };
+
+    constexpr int STEP = 64 * U;
+    bool have = PF;                              // wa already holds block 0 of the first group
+    for (; grp < ngroups; grp += nwaves) {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        for (int c = lane; c < nchunk; c += 128) {
-            // two chunks per lane per iteration -> 2R loads in flight
-            const int c2 = c + 64;
-            const bool has2 = c2 < nchunk;
-            uint4 w0[R], w1[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T* wr = W + (long long)rows[r] * K;
-                w0[r] = ld_nt16(wr + (long long)c * VE);
-                w1[r] = has2 ? ld_nt16(wr + (long long)c2 * VE) : make_uint4(0, 0, 0, 0);
+        if (DB) {
+            uint4 wb[U][R];
+            if (!have) issue(wa, grp, 0);
+            for (int c0 = 0; c0 < nchunk; c0 += 2 * STEP) {
+                const int c1 = c0 + STEP, c2 = c0 + 2 * STEP;
+                if (c1 < nchunk) issue(wb, grp, c1);
+                consume(wa, c0, acc);
+                if (c2 < nchunk) issue(wa, grp, c2);
+                if (c1 < nchunk) consume(wb, c1, acc);
             }
-            float xa[VE], xb[VE];
-#pragma unroll
-            for (int e = 0; e < VE; e += 4) {
-                const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
-                xa[e] = t.x; xa[e + 1] = t.y; xa[e + 2] = t.z; xa[e + 3] = t.w;
-                if (has2) {
-                    const float4 u = *reinterpret_cast<const float4*>(xs + c2 * VE + e);
-                    xb[e] = u.x; xb[e + 1] = u.y; xb[e + 2] = u.z; xb[e + 3] = u.w;
-                } else {
-                    xb[e] = xb[e + 1] = xb[e + 2] = xb[e + 3] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float f[VE], g[VE];
-                Vec16<T>::cvt(w0[r], f);
-                Vec16<T>::cvt(w1[r], g);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xa[e], acc[r]);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) acc[r] = fmaf(g[e], xb[e], acc[r]);
+            have = false;
+        } else {
+            int c0 = 0;
+            if (have) { consume(wa, 0, acc); c0 = STEP; have = false; }
+            for (; c0 < nchunk; c0 += STEP) {
+                issue(wa, grp, c0);
+                consume(wa, c0, acc);
             }
         }
 #pragma unroll
@@ -140,21 +189,206 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     }
 }
 
+template <typename T, typename TO, int R, int U, bool DB, bool PF>
+static int gemv_launch_ru(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K,
+                          float eps, bool swiglu, hipStream_t st) {
+    const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
+    int blocks = cdiv(ngroups, GV_WAVES);
+    if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
+    const size_t lds = (size_t)(((K + 3) & ~3) + 8) * sizeof(float);
+#define TEO_GV(NTV, SW)                                                                                              \
+    gemv_kernel<T, TO, R, U, DB, PF, NTV, SW><<<blocks, GV_THREADS, lds, st>>>((const T*)x, (const T*)W, (const T*)norm_w, \
+                                                                                (const T*)res, (TO*)y, N, K, eps)
+    if (g_tune.nt) { if (swiglu) TEO_GV(true, true); else TEO_GV(true, false); }
+    else           { if (swiglu) TEO_GV(false, true); else TEO_GV(false, false); }
+#undef TEO_GV
+    TEO_LAUNCH_CHECK("gemv");
+    return TEO_OK;
+}
+
 template <typename T, typename TO>
 static int gemv_launch(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
                        bool swiglu, hipStream_t st) {
-    constexpr int R = 4;
-    const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
+    return gemv_launch_ru<T, TO, 4, 2, false, false>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
+}
+
+// tuning sweep: bf16 -> bf16 only
+static int gemv_launch_variant(int v, const void* x, const void* W, const void* norm_w, const void* res, void* y, int N,
+                               int K, float eps, bool swiglu, hipStream_t st) {
+#define TEO_V(id, R, U, DB, PF) \
+    case id: return gemv_launch_ru<bf16_t, bf16_t, R, U, DB, PF>(x, W, norm_w, res, y, N, K, eps, swiglu, st)
+    switch (v) {
+        TEO_V(0, 4, 2, false, false);
+        TEO_V(1, 4, 2, false, true);
+        TEO_V(2, 4, 2, true, true);
+        TEO_V(3, 2, 2, false, true);
+        TEO_V(4, 2, 4, false, true);
+        TEO_V(5, 4, 1, false, true);
+        TEO_V(6, 8, 1, false, true);
+        TEO_V(7, 4, 4, false, true);
+        TEO_V(8, 2, 2, true, true);
+        TEO_V(9, 8, 2, false, true);
+        TEO_V(10, 2, 1, false, true);
+        TEO_V(11, 2, 8, false, true);
+        default: break;
+    }
+#undef TEO_V
+    set_error("gemv: unknown variant %d", v);
+    return TEO_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decode QKV projection with the RoPE rotation and the KV-cache append fused into the epilogue.
+//   rows of Wqkv: [q: H*hd | k: Hk*hd | v: Hk*hd].  A wave owns two rotation pairs (i, i + hd/2) of one q/k head
+//   (4 rows), or 4 consecutive v rows.  q is written rotated to qout[H*hd]; k rotated to K cache[hk][pos][:];
+//   v to V cache[hk][pos][:] and V^T cache[hk][:][pos].  pos (= cache slot = rotary position) is read from device
+//   memory so the launch can be replayed from a hipGraph.  Rounding points are those of the unfused path:
+//   round(linear) -> rotate in fp32 -> round.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool NT>
+__global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __restrict__ x, const T* __restrict__ W,
+                                                                   const T* __restrict__ norm_w, T* __restrict__ qout,
+                                                                   const float* __restrict__ cs, const float* __restrict__ sn,
+                                                                   const int* __restrict__ d_pos, T* __restrict__ kc,
+                                                                   T* __restrict__ vc, T* __restrict__ vtc, int S_max, int H,
+                                                                   int Hk, int hd, int K, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    constexpr int VE = Vec16<T>::N;
+    constexpr int R = 4, U = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nchunk = K / VE, kpad = (K + 3) & ~3;
+    float* red = xs + kpad;
+    const int half = hd >> 1;
+    const int qk_pairs = (H + Hk) * half;               // rotation pairs
+    const int qk_groups = qk_pairs / 2;                 // 2 pairs per wave
+    const int v_groups = (Hk * hd) / 4;
+    const int ngroups = qk_groups + v_groups;
+    const int nwaves = gridDim.x * GV_WAVES;
+
+    float ss = 0.f;
+    for (int c = tid; c < nchunk; c += GV_THREADS) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
+        float f[VE];
+        Vec16<T>::cvt(raw, f);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { xs[c * VE + e] = f[e]; ss = fmaf(f[e], f[e], ss); }
+    }
+    {
+        const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+        for (int c = tid; c < nchunk; c += GV_THREADS) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE);
+            float f[VE];
+            Vec16<T>::cvt(raw, f);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(xs[c * VE + e] * rr * f[e]);
+        }
+    }
+    __syncthreads();
+    const int pos = *d_pos;
+
+    for (int grp = blockIdx.x * GV_WAVES + wid; grp < ngroups; grp += nwaves) {
+        long long rows[R];
+        int head = 0, i0 = 0;
+        const bool is_qk = grp < qk_groups;
+        if (is_qk) {
+            const int p0 = grp * 2;                      // pairs p0, p0+1 (same head: half is even)
+            head = p0 / half;
+            i0 = p0 % half;
+            rows[0] = (long long)head * hd + i0;         rows[1] = rows[0] + half;
+            rows[2] = rows[0] + 1;                       rows[3] = rows[2] + half;
+        } else {
+            const int r0 = (H + Hk) * hd + (grp - qk_groups) * 4;
+#pragma unroll
+            for (int r = 0; r < R; ++r) rows[r] = r0 + r;
+        }
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        for (int c0 = 0; c0 < nchunk; c0 += 64 * U) {
+            uint4 w[U][R];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T* p = W + rows[r] * K + (long long)c * VE;
+                    w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                float xv[VE];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) xv[e] = 0.f;
+                if (c < nchunk) {
+#pragma unroll
+                    for (int e = 0; e < VE; e += 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
+                        xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float f[VE];
+                    Vec16<T>::cvt(w[u][r], f);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+        if (lane == 0) {
+            if (is_qk) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int i = i0 + pr;
+                    const float x1 = Elem<T>::round(acc[2 * pr]), x2 = Elem<T>::round(acc[2 * pr + 1]);
+                    const float c = cs[(long long)pos * half + i], sv = sn[(long long)pos * half + i];
+                    const float y1 = x1 * c - x2 * sv, y2 = x2 * c + x1 * sv;
+                    if (head < H) {
+                        Elem<T>::st(qout + head * hd + i, y1);
+                        Elem<T>::st(qout + head * hd + i + half, y2);
+                    } else {
+                        T* dst = kc + ((long long)(head - H) * S_max + pos) * hd;
+                        Elem<T>::st(dst + i, y1);
+                        Elem<T>::st(dst + i + half, y2);
+                    }
+                }
+            } else {
+                const int v0 = (grp - qk_groups) * 4;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int hk = (v0 + r) / hd, d = (v0 + r) % hd;
+                    T val;
+                    Elem<T>::st(&val, acc[r]);
+                    vc[((long long)hk * S_max + pos) * hd + d] = val;
+                    if (vtc) vtc[((long long)hk * hd + d) * S_max + pos] = val;
+                }
+            }
+        }
+    }
+}
+
+int gemv_qkv_rope(const void* x, const void* W, const void* norm_w, void* qout, const float* cs, const float* sn,
+                  const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk, int hd, int K, float eps,
+                  int dtype, hipStream_t st) {
+    const int ve = dtype == TEO_F32 ? 4 : 8;
+    TEO_CHECK_ARG(K % ve == 0 && hd % 4 == 0, "gemv_qkv_rope: K=%d hd=%d", K, hd);
+    TEO_CHECK_ARG((size_t)(K + 16) * 4 <= 64 * 1024, "gemv_qkv_rope: K=%d too large for LDS staging", K);
+    const int ngroups = (H + Hk) * (hd / 2) / 2 + Hk * hd / 4;
     int blocks = cdiv(ngroups, GV_WAVES);
-    if (blocks > 2048) blocks = 2048;
-    const size_t lds = (size_t)(K + 4) * sizeof(float);
-    if (swiglu)
-        gemv_kernel<T, TO, R, true><<<blocks, GV_THREADS, lds, st>>>((const T*)x, (const T*)W, (const T*)norm_w,
-                                                                     (const T*)res, (TO*)y, N, K, eps);
-    else
-        gemv_kernel<T, TO, R, false><<<blocks, GV_THREADS, lds, st>>>((const T*)x, (const T*)W, (const T*)norm_w,
-                                                                      (const T*)res, (TO*)y, N, K, eps);
-    TEO_LAUNCH_CHECK("gemv");
+    if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
+    const size_t lds = (size_t)(((K + 3) & ~3) + 8) * sizeof(float);
+#define TEO_QR(TT, NTV)                                                                                              \
+    gemv_qkv_rope_kernel<TT, NTV><<<blocks, GV_THREADS, lds, st>>>((const TT*)x, (const TT*)W, (const TT*)norm_w,     \
+                                                                   (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
+                                                                   S_max, H, Hk, hd, K, eps)
+    if (dtype == TEO_F32) { if (g_tune.nt) TEO_QR(float, true); else TEO_QR(float, false); }
+    else                  { if (g_tune.nt) TEO_QR(bf16_t, true); else TEO_QR(bf16_t, false); }
+#undef TEO_QR
+    TEO_LAUNCH_CHECK("gemv_qkv_rope");
     return TEO_OK;
 }
 
@@ -165,7 +399,8 @@ int gemv(const void* x, const void* W, const void* norm_w, const void* res, void
     const int ve = dtype == TEO_F32 ? 4 : 8;
     TEO_CHECK_ARG(K % ve == 0, "teo_gemv: K=%d must be a multiple of %d", K, ve);
     TEO_CHECK_ARG((reinterpret_cast<uintptr_t>(W) & 15) == 0, "teo_gemv: W must be 16-byte aligned");
-    TEO_CHECK_ARG((size_t)(K + 4) * 4 <= 160 * 1024, "teo_gemv: K=%d too large for LDS staging", K);
+    TEO_CHECK_ARG((size_t)(K + 16) * 4 <= 64 * 1024, "teo_gemv: K=%d too large for LDS staging", K);
+    TEO_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (norm_w == nullptr || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0), "teo_gemv: x / norm_w must be 16-byte aligned");
     if (swiglu) TEO_CHECK_ARG(N % 32 == 0 && !res, "teo_gemv: SWIGLU16 needs N %% 32 == 0 and no residual");
     if (dtype == TEO_F32) {
         TEO_CHECK_ARG(out_dtype == TEO_F32, "teo_gemv: f32 inputs need f32 output");
@@ -173,6 +408,7 @@ int gemv(const void* x, const void* W, const void* norm_w, const void* res, void
     }
     if (dtype == TEO_BF16) {
         if (out_dtype == TEO_F32) return gemv_launch<bf16_t, float>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
+        if (g_tune.variant >= 0) return gemv_launch_variant(g_tune.variant, x, W, norm_w, res, y, N, K, eps, swiglu, st);
         return gemv_launch<bf16_t, bf16_t>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
     }
     set_error("teo_gemv: unknown dtype %d", dtype);

@@ -234,9 +234,9 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     const int QKV = (H + 2 * Hk) * hd;
     TEO_TRY(embed_token(s->d_token, d->embed, w.h, D, dt, st));
     for (int l = 0; l < d->layers; ++l) {
-        TEO_TRY(gemv(w.h, d->qkv_w[l], d->in_norm_w[l], nullptr, w.qkv, QKV, D, d->eps, 0, dt, dt, st));
-        TEO_TRY(rope_kv_append(w.qkv, QKV, s->d_pos, d->rope_cos, d->rope_sin, d->k_cache[l], d->v_cache[l],
-                               d->vt_cache[l], 1, 0, s->d_pos, d->max_seq, H, Hk, hd, dt, st));
+        // rmsnorm -> QKV projection -> RoPE -> KV append, one launch (position read from s->d_pos on the device)
+        TEO_TRY(gemv_qkv_rope(w.h, d->qkv_w[l], d->in_norm_w[l], w.qkv, d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l],
+                              d->v_cache[l], d->vt_cache[l], d->max_seq, H, Hk, hd, D, d->eps, dt, st));
         TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], w.attn, w.part, s->d_pos, d->max_seq, H, Hk, hd,
                             1.0f / sqrtf((float)hd), dt, st));
         TEO_TRY(gemv(w.attn, d->o_w[l], nullptr, w.h, w.h, D, H * hd, d->eps, 0, dt, dt, st));

@@ -4,7 +4,7 @@ and plain torch-CPU fp32 references on the same seeded inputs.
 Tolerances (stated per test):
   fp32 kernels : absolute 1e-5 on O(1) values (accumulation order is the only difference)
   bf16 kernels : the oracle is evaluated in fp32 on the SAME bf16-rounded inputs and rounded to bf16 at the same
-                 boundary; kernels must agree within 1 bf16 ulp (2^-8 relative) plus an absolute 1e-3 floor.
+                 boundary; kernels must agree within 1 bf16 ulp (up to 2^-7 relative) plus an absolute 1e-3 floor.
   integer / data-movement kernels : bit-exact.
 """
 import ctypes as C
@@ -25,7 +25,7 @@ FP32_ATOL = 1e-5
 
 def close_bf16(got, ref, ulps=1.0, floor=1e-3):
     got, ref = got.float().cpu(), ref.float().cpu()
-    tol = ulps * (2.0 ** -8) * ref.abs() + floor
+    tol = ulps * (2.0 ** -7) * ref.abs() + floor
     bad = (got - ref).abs() > tol
     assert not bad.any(), f"{int(bad.sum())} / {bad.numel()} outside tolerance; max abs diff {float((got - ref).abs().max()):.3e}"
 
@@ -254,7 +254,8 @@ def test_rope_kv_append(dtype, S, past):
     d_qkv = G.dev(qkv, dtype)
     kc = torch.zeros(Hk, S_max, hd, dtype=dtype, device="cuda")
     vc, vtc = torch.zeros_like(kc), torch.zeros(Hk, hd, S_max, dtype=dtype, device="cuda")
-    L.check(G.lib().teo_rope_kv_append(G.p(d_qkv), ld, G.p(pos.to(torch.int32).cuda()), G.p(cs.cuda()), G.p(sn.cuda()),
+    d_pos, d_cs, d_sn = pos.to(torch.int32).cuda(), cs.cuda(), sn.cuda()      # keep device buffers alive across the call
+    L.check(G.lib().teo_rope_kv_append(G.p(d_qkv), ld, G.p(d_pos), G.p(d_cs), G.p(d_sn),
                                        G.p(kc), G.p(vc), G.p(vtc), S, past, S_max, H, Hk, hd, G.DT[dtype], G.stream()), "rope")
     c, s = O.rope_cos_sin(pos, hd, 10000.0, torch.float32)
     q = qkv[:, :H * hd].view(S, H, hd)
@@ -282,7 +283,8 @@ def test_embed_splice_bit_exact(dtype):
     emb, vis = rnd(V, D, seed=1).to(dtype), rnd(2 * NV, D, seed=2).to(dtype)
     plan = torch.tensor([1, 7, -1, -2, -12, L.INT32_MIN, 49, 0, -6], dtype=torch.int32)
     out = torch.empty(plan.numel(), D, dtype=dtype, device="cuda")
-    L.check(G.lib().teo_embed_splice(G.p(plan.cuda()), G.p(emb.cuda()), G.p(vis.cuda()), G.p(out), plan.numel(), D,
+    d_plan, d_emb, d_vis = plan.cuda(), emb.cuda(), vis.cuda()
+    L.check(G.lib().teo_embed_splice(G.p(d_plan), G.p(d_emb), G.p(d_vis), G.p(out), plan.numel(), D,
                                      G.DT[dtype], G.stream()), "splice")
     for r, pl in enumerate(plan.tolist()):
         exp = torch.zeros(D, dtype=dtype) if pl == L.INT32_MIN else (emb[pl] if pl >= 0 else vis[-pl - 1])
@@ -294,7 +296,8 @@ def test_im2col_vt_dropcls_bit_exact():
     px = rnd(T, Cc, img, img, seed=1)
     ld = 640
     cols = torch.empty(T * 4, ld, device="cuda")
-    L.check(G.lib().teo_im2col_patches(G.p(px.cuda()), G.p(cols), T, Cc, img, P, ld, L.TEO_F32, G.stream()), "im2col")
+    d_px = px.cuda()
+    L.check(G.lib().teo_im2col_patches(G.p(d_px), G.p(cols), T, Cc, img, P, ld, L.TEO_F32, G.stream()), "im2col")
     ref = F.unfold(px, kernel_size=P, stride=P).transpose(1, 2).reshape(T * 4, Cc * P * P)
     assert torch.equal(cols[:, :Cc * P * P].cpu(), ref) and float(cols[:, Cc * P * P:].abs().sum()) == 0
     # ViT value transpose
@@ -303,13 +306,15 @@ def test_im2col_vt_dropcls_bit_exact():
     qkv = rnd(T * N, 3 * D, seed=2)
     ldv = 64
     vt = torch.full((T, H, hd, ldv), 7.0, device="cuda")
-    L.check(G.lib().teo_vit_value_transpose(G.p(qkv.cuda()), G.p(vt), T, N, H, hd, ldv, L.TEO_F32, G.stream()), "vt")
+    d_qkv = qkv.cuda()
+    L.check(G.lib().teo_vit_value_transpose(G.p(d_qkv), G.p(vt), T, N, H, hd, ldv, L.TEO_F32, G.stream()), "vt")
     v = qkv.view(T, N, 3, H, hd)[:, :, 2]                       # [T,N,H,hd]
     assert torch.equal(vt[..., :N].cpu(), v.permute(0, 2, 3, 1)) and float(vt[..., N:].abs().sum()) == 0
     # drop CLS
     h = rnd(T, N, D, seed=3)
     out = torch.empty(T, N - 1, D, device="cuda")
-    L.check(G.lib().teo_drop_cls(G.p(h.cuda()), G.p(out), T, N, D, L.TEO_F32, G.stream()), "drop_cls")
+    d_h = h.cuda()
+    L.check(G.lib().teo_drop_cls(G.p(d_h), G.p(out), T, N, D, L.TEO_F32, G.stream()), "drop_cls")
     assert torch.equal(out.cpu(), h[:, 1:])
 
 
@@ -318,7 +323,8 @@ def test_vit_embed_ln_fp32():
     patch, cls, pos = rnd(T * NP, D, seed=1), rnd(D, seed=2), rnd(NP + 1, D, seed=3)
     w, b = 1 + 0.1 * rnd(D, seed=4), rnd(D, seed=5, scale=0.1)
     out = torch.empty(T, NP + 1, D, device="cuda")
-    L.check(G.lib().teo_vit_embed_ln(G.p(patch.cuda()), G.p(cls.cuda()), G.p(pos.cuda()), G.p(w.cuda()), G.p(b.cuda()),
+    dv = [t.cuda() for t in (patch, cls, pos, w, b)]
+    L.check(G.lib().teo_vit_embed_ln(G.p(dv[0]), G.p(dv[1]), G.p(dv[2]), G.p(dv[3]), G.p(dv[4]),
                                      G.p(out), T, NP, D, 1e-5, L.TEO_F32, G.stream()), "embed_ln")
     emb = torch.cat([cls.view(1, 1, D).expand(T, 1, D), patch.view(T, NP, D)], dim=1) + pos
     torch.testing.assert_close(out.cpu(), F.layer_norm(emb, (D,), w, b, 1e-5), atol=FP32_ATOL, rtol=1e-5)
@@ -330,10 +336,12 @@ def test_argmax_first_index_on_ties():
     x[1, 77] = 2.0; x[1, 20000] = 2.0
     x[2] = -1.0
     tok = torch.empty(3, dtype=torch.int64, device="cuda")
-    L.check(G.lib().teo_argmax(G.p(x.cuda()), G.p(tok), 3, 32000, G.stream()), "argmax")
+    d_x = x.cuda()
+    L.check(G.lib().teo_argmax(G.p(d_x), G.p(tok), 3, 32000, G.stream()), "argmax")
     assert tok.tolist() == [31999, 77, 0]
     y = rnd(1, 32000, seed=9)
-    L.check(G.lib().teo_argmax(G.p(y.cuda()), G.p(tok), 1, 32000, G.stream()), "argmax")
+    d_y = y.cuda()
+    L.check(G.lib().teo_argmax(G.p(d_y), G.p(tok), 1, 32000, G.stream()), "argmax")
     assert int(tok[0]) == int(y.argmax())
 
 

@@ -18,7 +18,7 @@ from tests import _tiny as TY
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-4      # absolute, logits O(1..10); north_star asks 1e-5 on fp32: measured values are printed
-BF16_REL = 1e-2
+BF16_REL = 2e-2
 
 
 def build(name, dtype, **cfg_over):

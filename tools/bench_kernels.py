@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Kernel microbenchmarks at LLaMA-2-7B / ViT-L shapes (GPU box).  Prints one line per kernel: time, GB/s or TFLOP/s.
+Usage: python tools/bench_kernels.py [gemv] [attn_decode] [gemm] [attn_prefill] [norm]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from teochat_amd import _lib as L  # noqa: E402
+from tests import _gpu as G  # noqa: E402
+
+bf = torch.bfloat16
+lib = L.load()
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def bench_gemv():
+    shapes = [("qkv", 12288, 4096, True, 0), ("o", 4096, 4096, False, 0), ("gateup", 22016, 4096, True, L.GEMM_SWIGLU16),
+              ("down", 4096, 11008, False, 0), ("lm_head", 32000, 4096, True, 0)]
+    for name, N, K, norm, flags in shapes:
+        n = max(2, int(600e6 // (N * K * 2)))          # > 256 MB L3 in rotation
+        Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
+        x = torch.randn(K, device="cuda").to(bf)
+        nw = torch.ones(K, device="cuda").to(bf) if norm else None
+        y = torch.empty(N, dtype=bf, device="cuda")
+        arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
+        avg = C.c_float(0)
+        L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
+                                        flags, L.TEO_BF16, 10, C.byref(avg), G.stream()), "chain")
+        us = avg.value * 1e3
+        print(f"gemv {name:8s} N={N:6d} K={K:6d}: {us:7.2f} us  {N * K * 2 / us / 1e3:7.1f} GB/s", flush=True)
+        del Ws
+
+
+def bench_gemv_sweep():
+    shapes = [("qkv", 12288, 4096, True, 0), ("o", 4096, 4096, False, 0), ("gateup", 22016, 4096, True, L.GEMM_SWIGLU16),
+              ("down", 4096, 11008, False, 0)]
+    bufs = {}
+    for name, N, K, norm, flags in shapes:
+        n = max(2, int(600e6 // (N * K * 2)))
+        bufs[name] = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
+    for maxb in (1024, 2048, 4096):
+        for nt in (1, 0):
+            for v in range(12):
+                lib.teo_tune_set(b"gemv_variant", v)
+                lib.teo_tune_set(b"gemv_nt", nt)
+                lib.teo_tune_set(b"gemv_max_blocks", maxb)
+                line = f"variant {v:2d} nt={nt} maxb={maxb}:"
+                tot = 0.0
+                for name, N, K, norm, flags in shapes:
+                    Ws = bufs[name]
+                    x = torch.randn(K, device="cuda").to(bf)
+                    nw = torch.ones(K, device="cuda").to(bf) if norm else None
+                    y = torch.empty(N, dtype=bf, device="cuda")
+                    arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
+                    avg = C.c_float(0)
+                    L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, len(Ws), nw.data_ptr() if norm else None, y.data_ptr(),
+                                                    N, K, 1e-5, flags, L.TEO_BF16, 5, C.byref(avg), G.stream()), "chain")
+                    us = avg.value * 1e3
+                    tot += us
+                    line += f"  {name} {us:6.1f}us {N * K * 2 / us / 1e3:6.0f}GB/s"
+                print(line + f"  | layer {tot:6.1f}us", flush=True)
+    lib.teo_tune_set(b"gemv_variant", -1)
+
+
+def bench_gemm():
+    shapes = [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
+              ("down", 2168, 4096, 11008, 0), ("vit_qkv", 2056, 3072, 1024, 0), ("vit_fc1", 2056, 4096, 1024, 0),
+              ("vit_fc2", 2056, 1024, 4096, 0), ("sq4096", 4096, 4096, 4096, 0)]
+    for name, M, N, K, flags in shapes:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+        us = timeit(lambda: G.gemm(A, W, flags=flags))
+        print(f"gemm {name:8s} M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+def bench_attn_prefill():
+    for (H, S, d, causal) in [(32, 2168, 128, True), (128, 257, 64, False)]:
+        q = torch.randn(1, H, S, d, device="cuda").to(bf)
+        k = torch.randn(1, H, S, d, device="cuda").to(bf)
+        v = torch.randn(1, H, S, d, device="cuda").to(bf)
+        vt = G.make_vt(v)
+        us = timeit(lambda: G.attention(q, k, v, causal, d ** -0.5, vt=vt))
+        fl = 4.0 * H * S * S * d * (0.5 if causal else 1.0)
+        print(f"attn prefill H={H} S={S} d={d} causal={causal}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+def bench_norm():
+    for rows, dim in [(2168, 4096), (2056, 1024)]:
+        x = torch.randn(rows, dim, device="cuda").to(bf)
+        w = torch.ones(dim, device="cuda").to(bf)
+        us = timeit(lambda: G.rmsnorm(x, w, 1e-5))
+        print(f"rmsnorm {rows}x{dim}: {us:7.2f} us  {rows * dim * 4 / us / 1e3:7.1f} GB/s", flush=True)
+        us = timeit(lambda: G.layernorm(x, w, w, 1e-5))
+        print(f"layernorm {rows}x{dim}: {us:7.2f} us  {rows * dim * 4 / us / 1e3:7.1f} GB/s", flush=True)
+
+
+
+
+def bench_gemm_depth():
+    for depth in (1, 2):
+        lib.teo_tune_set(b"gemm_depth", depth)
+        print("gemm_depth", depth, flush=True)
+        bench_gemm()
+    lib.teo_tune_set(b"gemm_depth", 0)
+
+
+def bench_gemm_stride():
+    """Does the power-of-two row stride (K=4096 -> 8 KB) hurt?  Same M,N with K = 4096 vs 4160 (= 65 * 64)."""
+    for (M, N, K) in [(2168, 4096, 4096), (2168, 4096, 4160), (2168, 12288, 4096), (2168, 12288, 4160), (4096, 4096, 4096),
+                      (4096, 4096, 4160), (2168, 4096, 11008), (2168, 4096, 11072)]:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+        us = timeit(lambda: G.gemm(A, W))
+        print(f"gemm M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
+    for w in which:
+        {"gemv": bench_gemv, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+
