@@ -211,7 +211,7 @@ def main():
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "gemv_kernel<bf16,bf16,4,SWIGLU> (decode gate/up, N=22016 K=4096)",
+    roofline = {"bound": "hbm", "kernel": "gemv_kernel<bf16,bf16,R=2,U=4,NT,SWIGLU> (decode rmsnorm + gate/up + SwiGLU, N=22016 K=4096)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": gemv_bytes, "avg_launch_ms": round(avg.value, 5)}

@@ -229,7 +229,12 @@ typedef struct {
 } teo_decode_state;
 
 size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d);
-/* One greedy decode step (embedding lookup -> 32 layers -> lm_head -> argmax -> append), all on device.
+/* Arm a generation: workspace.h <- embed[*d_token] (call once after filling d_token/d_pos; every step's tail then
+ * prepares the next step's embedding itself). */
+int teo_llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace,
+                           size_t workspace_bytes, teo_stream_t stream);
+
+/* One greedy decode step (32 layers -> lm_head -> argmax -> append -> next embedding), all on device.
  * Replaces one iteration of GenerationMixin's loop around LlavaLlamaForCausalLM.forward with
  * input_ids [1,1] (llava_arch.py:154-163 decode branch; position = past length). */
 int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace,

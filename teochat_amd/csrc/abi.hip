@@ -28,6 +28,7 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
                   float* logits, void* ws, size_t ws_bytes, hipStream_t st);
 size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
 int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
+int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
                         teo_graph** out);
 
@@ -195,6 +196,12 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
     NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
     NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
     return llama_decode_step(d, st, ws, wsb, ST(s));
+}
+
+int teo_llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, teo_stream_t s) {
+    ENTER();
+    NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype); NEED(st->d_token, "d_token");
+    return llama_decode_begin(d, st, ws, wsb, ST(s));
 }
 
 int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb,

@@ -87,30 +87,83 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
         }
     };
 
+    // ---- x first (the weight stream does not depend on it, but vmcnt retires in order: loads issued after the
+    // weights would have to wait for them), then the first weight block, then the prologue under the weight latency
+    constexpr int XPT = 6;                        // 16-byte x chunks a thread can hold: K <= 6*256*VE (12288 for bf16)
+    uint4 xr[XPT], nr[XPT];
+    const bool x_in_regs = nchunk <= XPT * GV_THREADS;
+    if (x_in_regs) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + i * GV_THREADS;
+            xr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(x + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+        }
+        if (norm_w) {                             // same round trip as x: no second dependent global-load phase
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int c = tid + i * GV_THREADS;
+                nr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
     uint4 wa[U][R];
     int grp = wave_global;
     if (PF && grp < ngroups) issue(wa, grp, 0);
 
-    // ---- stage f(x) in LDS (fp32), 16-byte loads
     float ss = 0.f;
-    for (int c = tid; c < nchunk; c += GV_THREADS) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
-        float f[VE];
-        Vec16<T>::cvt(raw, f);
+    if (x_in_regs) {
 #pragma unroll
-        for (int e = 0; e < VE; ++e) {
-            xs[c * VE + e] = f[e];
-            ss = fmaf(f[e], f[e], ss);
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + i * GV_THREADS;
+            if (c < nchunk) {
+                float f[VE];
+                Vec16<T>::cvt(xr[i], f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) ss = fmaf(f[e], f[e], ss);
+            }
         }
-    }
-    if (norm_w) {
-        const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+        if (norm_w) {
+            const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int c = tid + i * GV_THREADS;
+                if (c < nchunk) {
+                    float f[VE], g[VE];
+                    Vec16<T>::cvt(xr[i], f);
+                    Vec16<T>::cvt(nr[i], g);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(f[e] * rr * g[e]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int c = tid + i * GV_THREADS;
+                if (c < nchunk) {
+                    float f[VE];
+                    Vec16<T>::cvt(xr[i], f);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) xs[c * VE + e] = f[e];
+                }
+            }
+        }
+    } else {
         for (int c = tid; c < nchunk; c += GV_THREADS) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE);
+            const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
             float f[VE];
             Vec16<T>::cvt(raw, f);
 #pragma unroll
-            for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(xs[c * VE + e] * rr * f[e]);
+            for (int e = 0; e < VE; ++e) { xs[c * VE + e] = f[e]; ss = fmaf(f[e], f[e], ss); }
+        }
+        if (norm_w) {
+            const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+            for (int c = tid; c < nchunk; c += GV_THREADS) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE);
+                float f[VE];
+                Vec16<T>::cvt(raw, f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(xs[c * VE + e] * rr * f[e]);
+            }
         }
     }
     __syncthreads();
@@ -189,6 +242,82 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-K form for few, long rows (o / down projections: N = 4096): a workgroup owns R rows and its 4 waves take
+// interleaved 1-KiB chunks of every row, so 4x more waves stream than with one wave per row group; partial sums meet
+// in LDS.  x is read by each wave for its own chunks only (no norm on these layers -> no full-vector prologue).
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, int R, int U, bool NT>
+__global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __restrict__ x, const T* __restrict__ W,
+                                                                 const T* __restrict__ res, TO* __restrict__ y, int N,
+                                                                 int K) {
+    constexpr int VE = Vec16<T>::N;
+    __shared__ float part[GV_WAVES][R];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nchunk = K / VE;
+    const int row0 = blockIdx.x * R;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    // chunk index for (iteration it, unroll u): c = (it*U + u) * 256 + wid*64 + lane
+    for (int cb = 0; cb < nchunk; cb += 256 * U) {
+        uint4 xr[U];
+        uint4 w[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = cb + u * 256 + wid * 64 + lane;
+            xr[u] = (c < nchunk) ? *reinterpret_cast<const uint4*>(x + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = cb + u * 256 + wid * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const T* p = W + (long long)min(row0 + r, N - 1) * K + (long long)c * VE;
+                w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float xv[VE];
+            Vec16<T>::cvt(xr[u], xv);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float f[VE];
+                Vec16<T>::cvt(w[u][r], f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) part[wid][r] = acc[r];
+    }
+    __syncthreads();
+    if (tid < R) {
+        const int n = row0 + tid;
+        if (n < N) {
+            float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            if (res) v += Elem<T>::ld(res + n);
+            Elem<TO>::st(y + n, v);
+        }
+    }
+}
+
+template <typename T, typename TO, int R, int U>
+static int gemv_launch_splitk(const void* x, const void* W, const void* res, void* y, int N, int K, hipStream_t st) {
+    const int blocks = cdiv(N, R);
+    if (g_tune.nt)
+        gemv_splitk_kernel<T, TO, R, U, true><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const T*)W, (const T*)res, (TO*)y, N, K);
+    else
+        gemv_splitk_kernel<T, TO, R, U, false><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const T*)W, (const T*)res, (TO*)y, N, K);
+    TEO_LAUNCH_CHECK("gemv_splitk");
+    return TEO_OK;
+}
+
 template <typename T, typename TO, int R, int U, bool DB, bool PF>
 static int gemv_launch_ru(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K,
                           float eps, bool swiglu, hipStream_t st) {
@@ -209,7 +338,10 @@ static int gemv_launch_ru(const void* x, const void* W, const void* norm_w, cons
 template <typename T, typename TO>
 static int gemv_launch(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
                        bool swiglu, hipStream_t st) {
-    return gemv_launch_ru<T, TO, 4, 2, false, false>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
+    // few long rows without a fused norm (o / down projections): split-K workgroups, 2 rows each (measured best)
+    if (!swiglu && norm_w == nullptr && N <= 8192) return gemv_launch_splitk<T, TO, 2, 2>(x, W, res, y, N, K, st);
+    // >= 4 KiB contiguous per row per step streams ~7 % faster than 2 KiB (tools/stream_probe.py, profiles/r01_gemv_variant_sweep.txt)
+    return gemv_launch_ru<T, TO, 2, 4, false, false>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
 }
 
 // tuning sweep: bf16 -> bf16 only
@@ -230,9 +362,24 @@ static int gemv_launch_variant(int v, const void* x, const void* W, const void* 
         TEO_V(9, 8, 2, false, true);
         TEO_V(10, 2, 1, false, true);
         TEO_V(11, 2, 8, false, true);
+        TEO_V(18, 2, 4, false, false);
+        TEO_V(19, 4, 4, false, false);
+        TEO_V(20, 2, 8, false, false);
+        TEO_V(21, 2, 2, false, false);
         default: break;
     }
 #undef TEO_V
+    if (v >= 12 && v <= 17 && !swiglu && norm_w == nullptr) {
+        switch (v) {
+            case 12: return gemv_launch_splitk<bf16_t, bf16_t, 4, 1>(x, W, res, y, N, K, st);
+            case 13: return gemv_launch_splitk<bf16_t, bf16_t, 4, 2>(x, W, res, y, N, K, st);
+            case 14: return gemv_launch_splitk<bf16_t, bf16_t, 2, 2>(x, W, res, y, N, K, st);
+            case 15: return gemv_launch_splitk<bf16_t, bf16_t, 2, 4>(x, W, res, y, N, K, st);
+            case 16: return gemv_launch_splitk<bf16_t, bf16_t, 8, 1>(x, W, res, y, N, K, st);
+            case 17: return gemv_launch_splitk<bf16_t, bf16_t, 1, 4>(x, W, res, y, N, K, st);
+        }
+    }
+    if (v >= 12 && v <= 17) return gemv_launch_ru<bf16_t, bf16_t, 4, 2, false, false>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
     set_error("gemv: unknown variant %d", v);
     return TEO_ERR_ARG;
 }
@@ -254,26 +401,58 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
                                                                    int Hk, int hd, int K, float eps) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     constexpr int VE = Vec16<T>::N;
-    constexpr int R = 4, U = 2;
+    constexpr int R = 2, U = 4;                         // one rotation pair (rows i, i + hd/2) or two v rows per wave
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nchunk = K / VE, kpad = (K + 3) & ~3;
     float* red = xs + kpad;
     const int half = hd >> 1;
-    const int qk_pairs = (H + Hk) * half;               // rotation pairs
-    const int qk_groups = qk_pairs / 2;                 // 2 pairs per wave
-    const int v_groups = (Hk * hd) / 4;
+    const int qk_groups = (H + Hk) * half;              // rotation pairs
+    const int v_groups = (Hk * hd) / 2;
     const int ngroups = qk_groups + v_groups;
     const int nwaves = gridDim.x * GV_WAVES;
 
+    // x and norm_w in one round trip, then the normalised row (rounded to T) in LDS as fp32
+    constexpr int XPT = 6;
     float ss = 0.f;
-    for (int c = tid; c < nchunk; c += GV_THREADS) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
-        float f[VE];
-        Vec16<T>::cvt(raw, f);
+    if (nchunk <= XPT * GV_THREADS) {
+        uint4 xr[XPT], nr[XPT];
 #pragma unroll
-        for (int e = 0; e < VE; ++e) { xs[c * VE + e] = f[e]; ss = fmaf(f[e], f[e], ss); }
-    }
-    {
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + i * GV_THREADS;
+            xr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(x + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + i * GV_THREADS;
+            nr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            float f[VE];
+            Vec16<T>::cvt(xr[i], f);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) ss = fmaf(f[e], f[e], ss);
+        }
+        const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + i * GV_THREADS;
+            if (c < nchunk) {
+                float f[VE], g[VE];
+                Vec16<T>::cvt(xr[i], f);
+                Vec16<T>::cvt(nr[i], g);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(f[e] * rr * g[e]);
+            }
+        }
+    } else {
+        for (int c = tid; c < nchunk; c += GV_THREADS) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
+            float f[VE];
+            Vec16<T>::cvt(raw, f);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { xs[c * VE + e] = f[e]; ss = fmaf(f[e], f[e], ss); }
+        }
         const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
         for (int c = tid; c < nchunk; c += GV_THREADS) {
             const uint4 raw = *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE);
@@ -291,15 +470,13 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
         int head = 0, i0 = 0;
         const bool is_qk = grp < qk_groups;
         if (is_qk) {
-            const int p0 = grp * 2;                      // pairs p0, p0+1 (same head: half is even)
-            head = p0 / half;
-            i0 = p0 % half;
-            rows[0] = (long long)head * hd + i0;         rows[1] = rows[0] + half;
-            rows[2] = rows[0] + 1;                       rows[3] = rows[2] + half;
+            head = grp / half;
+            i0 = grp % half;
+            rows[0] = (long long)head * hd + i0;
+            rows[1] = rows[0] + half;
         } else {
-            const int r0 = (H + Hk) * hd + (grp - qk_groups) * 4;
-#pragma unroll
-            for (int r = 0; r < R; ++r) rows[r] = r0 + r;
+            rows[0] = (long long)(H + Hk) * hd + (grp - qk_groups) * 2;
+            rows[1] = rows[0] + 1;
         }
         float acc[R];
 #pragma unroll
@@ -341,23 +518,19 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
             if (is_qk) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int i = i0 + pr;
-                    const float x1 = Elem<T>::round(acc[2 * pr]), x2 = Elem<T>::round(acc[2 * pr + 1]);
-                    const float c = cs[(long long)pos * half + i], sv = sn[(long long)pos * half + i];
-                    const float y1 = x1 * c - x2 * sv, y2 = x2 * c + x1 * sv;
-                    if (head < H) {
-                        Elem<T>::st(qout + head * hd + i, y1);
-                        Elem<T>::st(qout + head * hd + i + half, y2);
-                    } else {
-                        T* dst = kc + ((long long)(head - H) * S_max + pos) * hd;
-                        Elem<T>::st(dst + i, y1);
-                        Elem<T>::st(dst + i + half, y2);
-                    }
+                const float x1 = Elem<T>::round(acc[0]), x2 = Elem<T>::round(acc[1]);
+                const float c = cs[(long long)pos * half + i0], sv = sn[(long long)pos * half + i0];
+                const float y1 = x1 * c - x2 * sv, y2 = x2 * c + x1 * sv;
+                if (head < H) {
+                    Elem<T>::st(qout + head * hd + i0, y1);
+                    Elem<T>::st(qout + head * hd + i0 + half, y2);
+                } else {
+                    T* dst = kc + ((long long)(head - H) * S_max + pos) * hd;
+                    Elem<T>::st(dst + i0, y1);
+                    Elem<T>::st(dst + i0 + half, y2);
                 }
             } else {
-                const int v0 = (grp - qk_groups) * 4;
+                const int v0 = (grp - qk_groups) * 2;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int hk = (v0 + r) / hd, d = (v0 + r) % hd;
@@ -375,9 +548,9 @@ int gemv_qkv_rope(const void* x, const void* W, const void* norm_w, void* qout, 
                   const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk, int hd, int K, float eps,
                   int dtype, hipStream_t st) {
     const int ve = dtype == TEO_F32 ? 4 : 8;
-    TEO_CHECK_ARG(K % ve == 0 && hd % 4 == 0, "gemv_qkv_rope: K=%d hd=%d", K, hd);
+    TEO_CHECK_ARG(K % ve == 0 && hd % 2 == 0, "gemv_qkv_rope: K=%d hd=%d", K, hd);
     TEO_CHECK_ARG((size_t)(K + 16) * 4 <= 64 * 1024, "gemv_qkv_rope: K=%d too large for LDS staging", K);
-    const int ngroups = (H + Hk) * (hd / 2) / 2 + Hk * hd / 4;
+    const int ngroups = (H + Hk) * (hd / 2) + Hk * hd / 2;
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
     const size_t lds = (size_t)(((K + 3) & ~3) + 8) * sizeof(float);

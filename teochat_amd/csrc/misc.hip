@@ -245,6 +245,71 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     }
 }
 
+// Decode tail in one launch: argmax over the fp32 logits (float4 loads), then thread 0 appends the token, advances the
+// position and runs the id-suffix stop test, then the whole workgroup copies the next token's embedding row into h.
+// (embed_next: the NEXT step's embedding lookup is hoisted here; the first step of a generation runs embed_token.)
+template <typename T>
+__global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restrict__ logits, teo_decode_state st,
+                                                           const T* __restrict__ embed, T* __restrict__ h, int vocab,
+                                                           int dim) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ long long s_tok;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    const int nv4 = vocab >> 2;
+    const float4* l4 = reinterpret_cast<const float4*>(logits);
+    for (int i = threadIdx.x; i < nv4; i += 1024) {
+        const float4 v = l4[i];
+        const int b = i << 2;
+        if (v.x > best || bi == 0x7fffffff) { best = v.x; bi = b; }
+        if (v.y > best) { best = v.y; bi = b + 1; }
+        if (v.z > best) { best = v.z; bi = b + 2; }
+        if (v.w > best) { best = v.w; bi = b + 3; }
+    }
+    for (int i = (nv4 << 2) + threadIdx.x; i < vocab; i += 1024) {
+        const float v = logits[i];
+        if (v > best || bi == 0x7fffffff) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        const long long t = bi;
+        *st.d_token = t;
+        const int n = *st.d_out_count;
+        st.d_out_tokens[n] = t;
+        *st.d_out_count = n + 1;
+        *st.d_pos = *st.d_pos + 1;
+        if (st.d_stop_ids && st.n_stop_ids > 0 && n + 1 >= st.n_stop_ids) {
+            bool eq = true;
+            for (int k = 0; k < st.n_stop_ids; ++k)
+                eq = eq && (st.d_out_tokens[n + 1 - st.n_stop_ids + k] == st.d_stop_ids[k]);
+            if (eq) *st.d_stop = 1;
+        }
+        s_tok = t;
+    }
+    __syncthreads();
+    const long long t = s_tok;
+    for (int i = threadIdx.x; i < dim; i += 1024) h[i] = embed[t * dim + i];
+}
+
+int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
+                hipStream_t st) {
+    if (dtype == TEO_F32) decode_tail_kernel<float><<<1, 1024, 0, st>>>(logits, *s, (const float*)embed, (float*)h, vocab, dim);
+    else decode_tail_kernel<bf16_t><<<1, 1024, 0, st>>>(logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim);
+    TEO_LAUNCH_CHECK("decode_tail");
+    return TEO_OK;
+}
+
 int argmax(const float* logits, long long* tok, int rows, int vocab, hipStream_t st) {
     if (rows == 0) return TEO_OK;
     argmax_kernel<<<rows, 1024, 0, st>>>(logits, tok, vocab);

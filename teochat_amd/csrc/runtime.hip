@@ -232,7 +232,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     const int dt = d->dtype;
     const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
     const int QKV = (H + 2 * Hk) * hd;
-    TEO_TRY(embed_token(s->d_token, d->embed, w.h, D, dt, st));
+    // w.h holds the embedding of *s->d_token: written by the previous step's tail (or by teo_llama_decode_begin)
     for (int l = 0; l < d->layers; ++l) {
         // rmsnorm -> QKV projection -> RoPE -> KV append, one launch (position read from s->d_pos on the device)
         TEO_TRY(gemv_qkv_rope(w.h, d->qkv_w[l], d->in_norm_w[l], w.qkv, d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l],
@@ -244,8 +244,8 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
         TEO_TRY(gemv(w.act, d->down_w[l], nullptr, w.h, w.h, D, F, d->eps, 0, dt, dt, st));
     }
     TEO_TRY(gemv(w.h, d->lm_head, d->final_norm_w, nullptr, s->d_logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
-    TEO_TRY(argmax(s->d_logits, s->d_token, 1, d->vocab, st));
-    return decode_advance(s, st);
+    // argmax -> append/advance/stop test -> embedding row of the next token into w.h, one launch
+    return decode_tail(s->d_logits, s, d->embed, w.h, d->vocab, D, dt, st);
 }
 
 }  // namespace teo
@@ -254,6 +254,16 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
 // hipGraph wrapper
 // ------------------------------------------------------------------------------------------------
 namespace teo {
+
+// h <- embed[*d_token]: arms the first step of a generation (later steps get it from the previous step's tail)
+int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st) {
+    const DecodeWs w = decode_carve(d, ws, ws_bytes);
+    if (w.total > ws_bytes) {
+        set_error("teo_llama_decode_begin: workspace %zu < %zu", ws_bytes, w.total);
+        return TEO_ERR_WORKSPACE;
+    }
+    return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st);
+}
 
 int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
                         teo_graph** out) {

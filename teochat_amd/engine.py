@@ -327,6 +327,20 @@ class TeoEngine:
             if n != self.decode_state.n_stop_ids:
                 self.decode_state.n_stop_ids = n
                 self._drop_graph()
+        ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
+        with self.phase() as st:
+            L.check(self.lib.teo_llama_decode_begin(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(),
+                                                    st), "teo_llama_decode_begin")
+
+    def override_last_token(self, tok):
+        """Sampling: replace the token the device tail chose (greedy) by `tok` and re-arm the next step's embedding."""
+        ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
+        with self.phase() as st:
+            n = int(self.d_count.item())
+            self.d_out[n - 1] = int(tok)
+            self.d_token.fill_(int(tok))
+            L.check(self.lib.teo_llama_decode_begin(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(),
+                                                    st), "teo_llama_decode_begin")
 
     def _drop_graph(self):
         if self._graph is not None:

@@ -399,9 +399,7 @@ class LlavaLlamaForCausalLM:
             if do_sample:
                 eng.decode_steps(1, use_graph=True)
                 tok = self._pick(eng.d_logits, True, temperature, top_k, top_p, generator)
-                n = int(eng.d_count.item())
-                eng.d_out[n - 1] = tok           # replace the greedy choice by the sampled one
-                eng.d_token.fill_(tok)
+                eng.override_last_token(tok)     # replace the greedy choice by the sampled one
                 new_tokens.append(tok)
                 remaining -= 1
                 if done(new_tokens):

@@ -54,9 +54,9 @@ def bench_gemv_sweep():
     for name, N, K, norm, flags in shapes:
         n = max(2, int(600e6 // (N * K * 2)))
         bufs[name] = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
-    for maxb in (1024, 2048, 4096):
-        for nt in (1, 0):
-            for v in range(12):
+    for maxb in (1024,):
+        for nt in (1,):
+            for v in (0, 1, 21, 3, 18, 4, 19, 7, 20, 11):
                 lib.teo_tune_set(b"gemv_variant", v)
                 lib.teo_tune_set(b"gemv_nt", nt)
                 lib.teo_tune_set(b"gemv_max_blocks", maxb)
