@@ -201,6 +201,77 @@ def preprocess_uint8(img_hwc_u8: torch.Tensor) -> torch.Tensor:
     return (x - mean) / std
 
 
+
+# --------------------------------------------------------------------------------------
+# attention core shared by the ViT and LLaMA restatements
+# --------------------------------------------------------------------------------------
+LOG2E = 1.44269504088896340736
+
+
+def attention_core(q, k, v, visible, scale, R, mode="exact"):
+    """softmax(scale * q k^T restricted to `visible`) v   with q [B,H,Sq,d], k/v [B,H,Sk,d], visible bool [B,1,Sq,Sk] or None.
+
+    mode "exact"    : global row max, P rounded by R for the PV product, normaliser from unrounded P (the reference's
+                      eager attention when R is the identity; also what the generic HIP kernel does).
+    mode "flash64"  : arithmetic of the MFMA flash kernel (csrc/attention.hip attn_mfma_kernel): 64-key tiles from key
+                      0, running max, P = exp2(s*scale*log2e - m_run) rounded by R per tile, fp32 rescale.
+    mode "split128" : arithmetic of the decode kernel: independent 128-key chunks (chunk max, rounded P), fp32 combine.
+    The bf16 parity tests use the emulating modes so that P is rounded at exactly the kernels' points.
+    """
+    B, H, Sq, d = q.shape
+    Sk = k.shape[2]
+    neg = float("-inf")
+    if mode == "exact":
+        s = (q @ k.transpose(-1, -2)) * scale
+        if visible is not None:
+            s = s.masked_fill(~visible, neg)
+        m = s.max(dim=-1, keepdim=True).values
+        p = torch.exp(s - m)
+        return (R(p) @ v) / p.sum(dim=-1, keepdim=True)
+    if mode == "flash64":
+        sl2 = (torch.tensor(scale, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32)).to(q.dtype)
+        m = torch.full((B, H, Sq, 1), neg, dtype=q.dtype)
+        l = torch.zeros((B, H, Sq, 1), dtype=q.dtype)
+        acc = torch.zeros((B, H, Sq, d), dtype=q.dtype)
+        for j0 in range(0, Sk, 64):
+            j1 = min(Sk, j0 + 64)
+            s = (q @ k[:, :, j0:j1].transpose(-1, -2)) * sl2
+            if visible is not None:
+                s = s.masked_fill(~visible[..., j0:j1], neg)
+            m_new = torch.maximum(m, s.max(dim=-1, keepdim=True).values)
+            m_use = torch.where(torch.isinf(m_new), torch.zeros_like(m_new), m_new)
+            alpha = torch.exp2(m - m_use)
+            p = torch.exp2(s - m_use)
+            l = l * alpha + p.sum(dim=-1, keepdim=True)
+            acc = acc * alpha + R(p) @ v[:, :, j0:j1]
+            m = m_new
+        return acc / l
+    if mode == "split128":
+        ms, ls, os_ = [], [], []
+        for j0 in range(0, Sk, 128):
+            j1 = min(Sk, j0 + 128)
+            s = (q @ k[:, :, j0:j1].transpose(-1, -2)) * scale
+            if visible is not None:
+                s = s.masked_fill(~visible[..., j0:j1], neg)
+            mc = s.max(dim=-1, keepdim=True).values
+            p = torch.exp(s - torch.where(torch.isinf(mc), torch.zeros_like(mc), mc))
+            ms.append(mc); ls.append(p.sum(dim=-1, keepdim=True)); os_.append(R(p) @ v[:, :, j0:j1])
+        M = torch.stack(ms).max(dim=0).values
+        L = sum(l_ * torch.exp(m_ - M) for m_, l_ in zip(ms, ls))
+        O = sum(o_ * torch.exp(m_ - M) for m_, o_ in zip(ms, os_))
+        return O / L
+    raise ValueError(f"unknown attention mode {mode}")
+
+
+def kernel_attention_mode(rounding, head_dim, q_len, decode_kernel=False):
+    """Which arithmetic the HIP path uses for this call (bf16 path only; fp32 always runs the exact generic kernel)."""
+    if rounding is None:
+        return "exact"
+    if decode_kernel and q_len == 1:
+        return "split128"
+    return "flash64" if head_dim in (64, 128) else "exact"
+
+
 # --------------------------------------------------------------------------------------
 # H9-H11, H7/H8: CLIP ViT
 # --------------------------------------------------------------------------------------
@@ -232,7 +303,7 @@ def _layernorm(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w.to(x.dtype), b.to(x.dtype), eps)
 
 
-def vit_attention(x, sd, pre, cfg: VitCfg, R):
+def vit_attention(x, sd, pre, cfg: VitCfg, R, mode="exact"):
     """tf CLIPAttention (constructed at modeling_image.py:69): q/k/v/out Linear with bias,
     heads x head_dim, softmax(q k^T * d^-1/2) v, no mask on the vision path."""
     B, N, D = x.shape
@@ -245,19 +316,16 @@ def vit_attention(x, sd, pre, cfg: VitCfg, R):
     q = lin("self_attn.q_proj").view(B, N, H, d).transpose(1, 2)
     k = lin("self_attn.k_proj").view(B, N, H, d).transpose(1, 2)
     v = lin("self_attn.v_proj").view(B, N, H, d).transpose(1, 2)
-    s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
-    m = s.max(dim=-1, keepdim=True).values
-    p = torch.exp(s - m)
-    o = (R(p) @ v) / p.sum(dim=-1, keepdim=True)
+    o = attention_core(q, k, v, None, d ** -0.5, R, mode)
     return R(o.transpose(1, 2).reshape(B, N, D))
 
 
-def vit_layer(h, sd, i, cfg: VitCfg, R):
+def vit_layer(h, sd, i, cfg: VitCfg, R, mode="exact"):
     """modeling_image.py:136-151 (spatial branch; add_time_attn is False for the image tower):
     h += Attn(LN1(h)); h += MLP(LN2(h))."""
     pre = VIT_PREFIX + f"encoder.layers.{i}."
     a = R(_layernorm(h, sd[pre + "layer_norm1.weight"], sd[pre + "layer_norm1.bias"], cfg.layer_norm_eps))
-    a = vit_attention(a, sd, pre, cfg, R)
+    a = vit_attention(a, sd, pre, cfg, R, mode)
     h = R(h + a @ sd[pre + "self_attn.out_proj.weight"].to(h.dtype).t() + sd[pre + "self_attn.out_proj.bias"].to(h.dtype))
     m = R(_layernorm(h, sd[pre + "layer_norm2.weight"], sd[pre + "layer_norm2.bias"], cfg.layer_norm_eps))
     m = R(_act(cfg.hidden_act)(m @ sd[pre + "mlp.fc1.weight"].to(h.dtype).t() + sd[pre + "mlp.fc1.bias"].to(h.dtype)))
@@ -274,8 +342,9 @@ def vit_hidden_states(pixels, sd, cfg: VitCfg, rounding=None, n_layers=None):
     h = R(_layernorm(h, sd[VIT_PREFIX + "pre_layrnorm.weight"], sd[VIT_PREFIX + "pre_layrnorm.bias"], cfg.layer_norm_eps))
     states = [h]
     L = cfg.num_hidden_layers if n_layers is None else n_layers
+    mode = kernel_attention_mode(rounding, cfg.hidden_size // cfg.num_attention_heads, cfg.num_positions)
     for i in range(L):
-        h = vit_layer(h, sd, i, cfg, R)
+        h = vit_layer(h, sd, i, cfg, R, mode)
         states.append(h)
     return states
 
@@ -444,7 +513,7 @@ class KVCache:
         return 0 if not self.k else self.k[0].shape[2]
 
 
-def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, bias, cache: KVCache, R):
+def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, mode="exact"):
     """tf LlamaDecoderLayer/LlamaAttention/LlamaMLP (called from llava_llama.py:88-99)."""
     B, S, D = h.shape
     H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -467,10 +536,7 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, bias, cache: KVCache, R):
         rep = H // Hk
         kk = kk[:, :, None].expand(B, Hk, rep, kk.shape[2], d).reshape(B, H, -1, d)
         vv = vv[:, :, None].expand(B, Hk, rep, vv.shape[2], d).reshape(B, H, -1, d)
-    sc = (q @ kk.transpose(2, 3)) * (1.0 / math.sqrt(d)) + bias
-    m = sc.max(dim=-1, keepdim=True).values
-    p = torch.exp(sc - m)
-    o = (R(p) @ vv) / p.sum(dim=-1, keepdim=True)
+    o = attention_core(q, kk, vv, visible, 1.0 / math.sqrt(d), R, mode)
     o = R(o.transpose(1, 2).reshape(B, S, D))
     h = R(h + o @ sd[pre + "self_attn.o_proj.weight"].to(h.dtype).t())
     n2 = R(rmsnorm(h, sd[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
@@ -482,7 +548,7 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, bias, cache: KVCache, R):
 
 
 def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[KVCache], sd, cfg: LlamaCfg,
-                  rounding=None, last_only=False, return_hidden=False):
+                  rounding=None, last_only=False, return_hidden=False, decode_kernel=False):
     """LlamaModel + lm_head.  inputs_embeds [B,S,D]; position_ids [B,S] or None (-> past..past+S);
     attention_mask [B, past+S] of 0/1 or None.  Returns fp logits [B,S,V] (or [B,1,V])."""
     R = _rounder(rounding)
@@ -495,15 +561,14 @@ def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[K
     h = R(inputs_embeds)
     cos, sin = rope_cos_sin(position_ids, cfg.head_dim, cfg.rope_theta, h.dtype)
     T = past + S
-    neg = torch.finfo(h.dtype).min
     qpos = torch.arange(past, T).view(S, 1)
     kpos = torch.arange(0, T).view(1, T)
-    bias = torch.zeros((B, 1, S, T), dtype=h.dtype)
-    bias.masked_fill_((kpos > qpos).view(1, 1, S, T), neg)
+    visible = (kpos <= qpos).view(1, 1, S, T).expand(B, 1, S, T)
     if attention_mask is not None:
-        bias = bias.masked_fill((attention_mask[:, None, None, :T] == 0), neg)
+        visible = visible & (attention_mask[:, None, None, :T] != 0)
+    mode = kernel_attention_mode(rounding, cfg.head_dim, S, decode_kernel)
     for i in range(cfg.num_hidden_layers):
-        h = llama_layer(h, i, sd, cfg, cos, sin, bias, cache, R)
+        h = llama_layer(h, i, sd, cfg, cos, sin, visible, cache, R, mode)
     if last_only:
         h = h[:, -1:, :]
     hn = R(rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps))
@@ -543,7 +608,7 @@ def greedy_generate(input_ids, images, sd, vcfg, lcfg, mm, max_new_tokens, round
         if eos_token_id is not None and nxt == eos_token_id:
             break
         e = emb_w[torch.tensor([[nxt]])]
-        logits, cache = llama_forward(e, None, None, cache, sd, lcfg, rounding)
+        logits, cache = llama_forward(e, None, None, cache, sd, lcfg, rounding, decode_kernel=True)
         nxt = int(torch.argmax(logits[0, -1]))
         step_logits.append(logits[0, -1].clone())
         out.append(nxt)
