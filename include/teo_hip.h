@@ -139,6 +139,12 @@ int teo_drop_cls(const void* d_in, void* d_out, int T, int n_tokens, int dim, in
  * Replaces the greedy branch of GenerationMixin (call at eval/inference.py:64-72 with do_sample=False). */
 int teo_argmax(const float* d_logits, long long* d_token, int rows, int vocab, teo_stream_t stream);
 
+/* token = multinomial(softmax(top_k(logits / temperature))) with u = uniform(seed, draw).  Same filter order as HF's
+ * TemperatureLogitsWarper -> TopKLogitsWarper -> softmax -> multinomial (the sampled branch the reference uses,
+ * eval/inference.py:64-72 with do_sample=True).  top_k <= 0 or >= vocab disables the filter (capped at 1024). */
+int teo_sample_topk(const float* d_logits, long long* d_token, int vocab, float temperature, int top_k,
+                    unsigned long long seed, unsigned long long draw, teo_stream_t stream);
+
 /* Decode GEMV: y[N] = W[N,K] . f(x) (+ residual), x one row.
  *   norm_w != NULL : f(x) = rmsnorm(x) * norm_w (rounded to dtype), else f(x) = x
  *   flags & TEO_GEMM_SWIGLU16 : W is gate/up interleaved-16; y[N/2] = silu(g)*u
@@ -226,6 +232,10 @@ typedef struct {
     int* d_stop;             /* [1] set to 1 when the generated tail equals d_stop_ids (id-suffix match) */
     const long long* d_stop_ids; int n_stop_ids; /* may be NULL/0 */
     float* d_logits;         /* [vocab] fp32 logits of the last step */
+    /* sampling (N1): do_sample = 0 -> argmax.  Otherwise logits/temperature -> top-k -> softmax -> multinomial with a
+     * counter-based generator: draw i of a generation uses (seed, i).  d_rng = {seed, draws so far} on the device. */
+    int do_sample; int top_k; float temperature;
+    unsigned long long* d_rng; /* [2] */
 } teo_decode_state;
 
 size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d);

@@ -154,6 +154,14 @@ int teo_argmax(const float* logits, long long* tok, int rows, int vocab, teo_str
     return argmax(logits, tok, rows, vocab, ST(s));
 }
 
+int teo_sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, unsigned long long seed,
+                    unsigned long long draw, teo_stream_t s) {
+    ENTER();
+    TEO_CHECK_ARG(vocab > 0 && temperature > 0.f, "teo_sample_topk: vocab %d temperature %g", vocab, temperature);
+    NEED(logits, "logits"); NEED(tok, "token");
+    return sample_topk(logits, tok, vocab, temperature, top_k, seed, draw, ST(s));
+}
+
 int teo_gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
              unsigned flags, int dtype, int out_dtype, teo_stream_t s) {
     ENTER();
@@ -195,6 +203,7 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
     NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
     NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
+    if (st->do_sample) { NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "teo_llama_decode_step: temperature %g", st->temperature); }
     return llama_decode_step(d, st, ws, wsb, ST(s));
 }
 

@@ -245,6 +245,129 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sampler: temperature -> top-k -> softmax -> multinomial, one 1024-thread workgroup, logits stay in L2.
+//   k-th largest value by a 4-pass radix select on the order-preserving uint image of the floats (LDS histogram),
+//   survivors (>= threshold, at most TOPK_CAP) gathered in index order, softmax over them in fp32, inverse-CDF draw.
+//   RNG: splitmix64(seed, draw) -> 24-bit uniform in [0,1): counter based, so a hipGraph replay only needs the draw
+//   counter in device memory.
+// ------------------------------------------------------------------------------------------------
+constexpr int TOPK_CAP = 1024;
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long draw) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (draw + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// returns the sampled index to every thread; smem: caller provides the shared arrays
+__device__ int sample_topk_block(const float* __restrict__ logits, int vocab, float temperature, int top_k, float u,
+                                 unsigned* hist, int* sel_idx, float* sel_val, int* s_misc) {
+    const int tid = threadIdx.x;
+    int k = top_k;
+    if (k <= 0 || k > vocab) k = vocab;
+    if (k > TOPK_CAP) k = TOPK_CAP;
+    // ---- radix select of the k-th largest key
+    unsigned prefix = 0, mask = 0;
+    int want = k;                                   // rank (1 = largest) still to find inside the current prefix class
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < vocab; i += 1024) {
+            const unsigned key = f2ord(logits[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0, b = 255;
+            for (; b > 0; --b) {
+                if (acc + (int)hist[b] >= want) break;
+                acc += (int)hist[b];
+            }
+            s_misc[0] = b;
+            s_misc[1] = want - acc;
+        }
+        __syncthreads();
+        prefix |= ((unsigned)s_misc[0]) << shift;
+        mask |= 255u << shift;
+        want = s_misc[1];
+        __syncthreads();
+    }
+    const unsigned thr = prefix;                    // key of the k-th largest logit; ties at thr are all kept (as torch.topk
+                                                    // keeps an arbitrary subset, the distribution only differs on exact ties)
+    // ---- gather survivors in index order (deterministic): ordered compaction by 1024-element strips
+    if (tid == 0) s_misc[2] = 0;
+    __syncthreads();
+    for (int base = 0; base < vocab; base += 1024) {
+        const int i = base + tid;
+        const bool keep = i < vocab && f2ord(logits[i]) >= thr;
+        const unsigned long long bal = __ballot(keep);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) hist[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        int off = s_misc[2];
+        for (int ww = 0; ww < w; ++ww) off += (int)hist[ww];
+        const int my = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && my < TOPK_CAP) { sel_idx[my] = i; sel_val[my] = logits[i]; }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int ww = 0; ww < 16; ++ww) t += (int)hist[ww]; s_misc[2] += t; }
+        __syncthreads();
+    }
+    const int n = min(s_misc[2], TOPK_CAP);
+    // ---- softmax over the survivors at the given temperature, inverse CDF in index order
+    const float invt = 1.0f / fmaxf(temperature, 1e-6f);
+    float mx = -INFINITY;
+    for (int j = tid; j < n; j += 1024) mx = fmaxf(mx, sel_val[j] * invt);
+    mx = wave_max(mx);
+    __shared__ float redf[16];
+    if ((tid & 63) == 0) redf[tid >> 6] = mx;
+    __syncthreads();
+    mx = redf[0];
+    for (int ww = 1; ww < 16; ++ww) mx = fmaxf(mx, redf[ww]);
+    __syncthreads();
+    for (int j = tid; j < n; j += 1024) sel_val[j] = expf(sel_val[j] * invt - mx);
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int j = 0; j < n; ++j) tot += sel_val[j];
+        const float target = u * tot;
+        float run = 0.f;
+        int pick = sel_idx[n - 1];
+        for (int j = 0; j < n; ++j) {
+            run += sel_val[j];
+            if (run > target) { pick = sel_idx[j]; break; }
+        }
+        s_misc[3] = pick;
+    }
+    __syncthreads();
+    return s_misc[3];
+}
+
+__global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restrict__ logits, long long* __restrict__ tok,
+                                                           int vocab, float temperature, int top_k,
+                                                           unsigned long long seed, unsigned long long draw) {
+    __shared__ unsigned hist[256];
+    __shared__ int sel_idx[TOPK_CAP];
+    __shared__ float sel_val[TOPK_CAP];
+    __shared__ int s_misc[4];
+    const int pick = sample_topk_block(logits, vocab, temperature, top_k, uniform01(seed, draw), hist, sel_idx, sel_val, s_misc);
+    if (threadIdx.x == 0) *tok = pick;
+}
+
+int sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, unsigned long long seed,
+                unsigned long long draw, hipStream_t st) {
+    sample_topk_kernel<<<1, 1024, 0, st>>>(logits, tok, vocab, temperature, top_k, seed, draw);
+    TEO_LAUNCH_CHECK("sample_topk");
+    return TEO_OK;
+}
+
 // Decode tail in one launch: argmax over the fp32 logits (float4 loads), then thread 0 appends the token, advances the
 // position and runs the id-suffix stop test, then the whole workgroup copies the next token's embedding row into h.
 // (embed_next: the NEXT step's embedding lookup is hoisted here; the first step of a generation runs embed_token.)
@@ -255,6 +378,17 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ long long s_tok;
+    __shared__ unsigned hist[256];
+    __shared__ int sel_idx[TOPK_CAP];
+    __shared__ float sel_val[TOPK_CAP];
+    __shared__ int s_misc[4];
+    int sampled = -1;
+    if (st.do_sample) {
+        const unsigned long long draw = st.d_rng[1];
+        sampled = sample_topk_block(logits, vocab, st.temperature, st.top_k, uniform01(st.d_rng[0], draw), hist, sel_idx,
+                                    sel_val, s_misc);
+        if (threadIdx.x == 0) st.d_rng[1] = draw + 1;
+    }
     float best = -INFINITY;
     int bi = 0x7fffffff;
     const int nv4 = vocab >> 2;
@@ -283,7 +417,7 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
     if (threadIdx.x == 0) {
         for (int k = 1; k < 16; ++k)
             if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
-        const long long t = bi;
+        const long long t = st.do_sample ? sampled : bi;
         *st.d_token = t;
         const int n = *st.d_out_count;
         st.d_out_tokens[n] = t;

@@ -206,11 +206,13 @@ class TeoEngine:
         self.d_stop = torch.zeros(1, dtype=torch.int32, device=dev)
         self.d_stop_ids = torch.zeros(16, dtype=torch.int64, device=dev)
         self.d_logits = torch.zeros(self.cfg.vocab_size, dtype=torch.float32, device=dev)
+        self.d_rng = torch.zeros(2, dtype=torch.int64, device=dev)       # {seed, draws so far} of the device sampler
         self.max_new_cap = max_new
         s = L.DecodeState()
         s.d_token, s.d_pos, s.d_out_tokens = self.d_token.data_ptr(), self.d_pos.data_ptr(), self.d_out.data_ptr()
         s.d_out_count, s.d_stop = self.d_count.data_ptr(), self.d_stop.data_ptr()
         s.d_stop_ids, s.n_stop_ids, s.d_logits = self.d_stop_ids.data_ptr(), 0, self.d_logits.data_ptr()
+        s.do_sample, s.top_k, s.temperature, s.d_rng = 0, 0, 1.0, self.d_rng.data_ptr()
         self.decode_state = s
 
     # ------------------------------------------------------------------ plumbing
@@ -313,32 +315,36 @@ class TeoEngine:
         self.cache_len = past + S
         return logits
 
-    def decode_begin(self, first_token, stop_ids=None):
-        """Arm the device-side greedy loop: first_token is the input of the next step, at position cache_len."""
+    def sample(self, logits, temperature, top_k, seed, draw):
+        """One draw of the device sampler (temperature -> top-k -> softmax -> multinomial) from fp32 logits [V]."""
+        tok = torch.empty(1, dtype=torch.int64, device=self.device)
+        with self.phase() as st:
+            lg = logits.to(device=self.device, dtype=torch.float32).contiguous()
+            L.check(self.lib.teo_sample_topk(_p(lg), _p(tok), lg.numel(), float(temperature), int(top_k or 0),
+                                             int(seed) & (2 ** 64 - 1), int(draw), st), "teo_sample_topk")
+        return int(tok.item())
+
+    def decode_begin(self, first_token, stop_ids=None, do_sample=False, temperature=1.0, top_k=0, seed=0, draws_done=0):
+        """Arm the device-side decode loop: first_token is the input of the next step, at position cache_len.
+        With do_sample the steps draw from the device sampler (counter-based RNG: draw index = draws so far)."""
         with self.phase():
             self.d_token.fill_(int(first_token))
             self.d_pos.fill_(self.cache_len)
             self.d_count.zero_()
             self.d_stop.zero_()
+            self.d_rng[0] = int(seed) & (2 ** 63 - 1)
+            self.d_rng[1] = int(draws_done)
             n = 0
             if stop_ids:
                 n = min(len(stop_ids), 16)
                 self.d_stop_ids[:n] = torch.tensor(list(stop_ids)[-n:], dtype=torch.int64, device=self.device)
-            if n != self.decode_state.n_stop_ids:
-                self.decode_state.n_stop_ids = n
+            s = self.decode_state
+            key = (n, int(bool(do_sample)), int(top_k or 0), C.c_float(float(temperature)).value)
+            if key != (s.n_stop_ids, s.do_sample, s.top_k, float(s.temperature)):
+                s.n_stop_ids, s.do_sample, s.top_k, s.temperature = key     # baked into the captured launch: re-capture
                 self._drop_graph()
         ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
         with self.phase() as st:
-            L.check(self.lib.teo_llama_decode_begin(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(),
-                                                    st), "teo_llama_decode_begin")
-
-    def override_last_token(self, tok):
-        """Sampling: replace the token the device tail chose (greedy) by `tok` and re-arm the next step's embedding."""
-        ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
-        with self.phase() as st:
-            n = int(self.d_count.item())
-            self.d_out[n - 1] = int(tok)
-            self.d_token.fill_(int(tok))
             L.check(self.lib.teo_llama_decode_begin(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(),
                                                     st), "teo_llama_decode_begin")
 

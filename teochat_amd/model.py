@@ -350,7 +350,8 @@ class LlavaLlamaForCausalLM:
     def generate(self, input_ids=None, images=None, do_sample=False, temperature=1.0, top_k=None, top_p=None,
                  max_new_tokens=20, use_cache=True, stopping_criteria=None, eos_token_id="config", attention_mask=None,
                  generator=None, chunk=16, **kwargs):
-        """Greedy (device-resident loop, hipGraph replay) or sampled decoding of ONE sequence.
+        """Greedy or sampled (temperature / top-k, device sampler) decoding of ONE sequence; the loop is device-resident
+        and replayed from a hipGraph.
 
         Returns int64 [1, n_prompt + n_generated]; the prompt part still contains the -200 sentinels, as with the
         reference (eval/inference.py:75 slices at input_ids.shape[1]).  `eos_token_id=None` disables EOS stopping.
@@ -372,7 +373,15 @@ class LlavaLlamaForCausalLM:
         if embeds.shape[1] + max_new_tokens > eng.max_seq:
             raise ValueError(f"prompt ({embeds.shape[1]}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
         logits = eng.prefill(embeds[0], last_only=True)
-        first = self._pick(logits[0], do_sample, temperature, top_k, top_p, generator)
+        if do_sample:
+            if top_p is not None and top_p < 1.0:
+                raise NotImplementedError("top_p < 1 is not implemented by the device sampler (HF default is 1.0)")
+            k = self.generation_config.top_k if top_k is None else top_k
+            seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            first = eng.sample(logits[0], temperature, k, seed, 0)
+        else:
+            k, seed = 0, 0
+            first = self._argmax(logits[0])
         new_tokens = [first]
 
         def done(tokens):
@@ -385,26 +394,15 @@ class LlavaLlamaForCausalLM:
 
         if done(new_tokens) or max_new_tokens == 1:
             return self._finish(input_ids, new_tokens)
-        # ---- decode
-        stop_ids = None
-        if not do_sample:
-            cands = [ids for c in crits for ids in getattr(c, "keyword_id_lists", []) if ids]
-            if eos_token_id is not None:
-                cands.append([int(eos_token_id)])
-            if len(cands) == 1:
-                stop_ids = cands[0]
-        eng.decode_begin(first, stop_ids)
+        # ---- decode: the whole loop (incl. the sampler) runs on the device, replayed from a hipGraph in chunks;
+        # the host only looks at the tokens once per chunk to apply EOS / stopping criteria at the exact token.
+        cands = [ids for c in crits for ids in getattr(c, "keyword_id_lists", []) if ids]
+        if eos_token_id is not None:
+            cands.append([int(eos_token_id)])
+        stop_ids = cands[0] if len(cands) == 1 else None
+        eng.decode_begin(first, stop_ids, do_sample=do_sample, temperature=temperature, top_k=k, seed=seed, draws_done=1)
         remaining = max_new_tokens - 1
         while remaining > 0:
-            if do_sample:
-                eng.decode_steps(1, use_graph=True)
-                tok = self._pick(eng.d_logits, True, temperature, top_k, top_p, generator)
-                eng.override_last_token(tok)     # replace the greedy choice by the sampled one
-                new_tokens.append(tok)
-                remaining -= 1
-                if done(new_tokens):
-                    break
-                continue
             n = min(chunk, remaining)
             eng.decode_steps(n, use_graph=True)
             got = eng.generated().tolist()
@@ -424,25 +422,9 @@ class LlavaLlamaForCausalLM:
         tail = torch.tensor([new_tokens], dtype=input_ids.dtype, device=input_ids.device)
         return torch.cat([input_ids, tail], dim=1)
 
-    def _pick(self, logits, do_sample, temperature, top_k, top_p, generator):
-        if not do_sample:
-            tok = torch.empty(1, dtype=torch.int64, device=self.engine.device)
-            with self.engine.phase() as st:
-                lg = logits.contiguous()
-                L.check(self.engine.lib.teo_argmax(lg.data_ptr(), tok.data_ptr(), 1, lg.numel(), st), "teo_argmax")
-            return int(tok.item())
-        # N1 ("next" row): temperature / top-k / top-p / multinomial, interim torch implementation on the fp32 logits
-        x = logits.float() / max(float(temperature), 1e-6)
-        k = self.generation_config.top_k if top_k is None else top_k
-        if k and k > 0:
-            kth = torch.topk(x, min(int(k), x.numel())).values[-1]
-            x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
-        p = top_p if top_p is not None else self.generation_config.top_p
-        if p is not None and p < 1.0:
-            sx, si = torch.sort(x, descending=True)
-            cp = torch.softmax(sx, dim=-1).cumsum(-1)
-            drop = cp - torch.softmax(sx, dim=-1) > p
-            sx = sx.masked_fill(drop, float("-inf"))
-            x = torch.full_like(x, float("-inf")).scatter(0, si, sx)
-        probs = torch.softmax(x, dim=-1)
-        return int(torch.multinomial(probs, 1, generator=generator).item())
+    def _argmax(self, logits):
+        tok = torch.empty(1, dtype=torch.int64, device=self.engine.device)
+        with self.engine.phase() as st:
+            lg = logits.contiguous()
+            L.check(self.engine.lib.teo_argmax(lg.data_ptr(), tok.data_ptr(), 1, lg.numel(), st), "teo_argmax")
+        return int(tok.item())

@@ -396,3 +396,46 @@ def test_abi_error_convention():
     rc = lib.teo_gemv(G.p(x), G.p(x), None, None, G.p(x), 2, 3, 1e-5, 0, L.TEO_F32, L.TEO_F32, G.stream())
     assert rc == -1 and b"multiple" in lib.teo_last_error()
     assert lib.teo_layernorm(None, None, None, None, 0, 8, 1e-5, L.TEO_F32, None) == 0      # empty input is fine
+
+
+# ---------------------------------------------------------------------------------------------- sampler (N1)
+def _sample(lg, temperature, top_k, seed, draw):
+    tok = torch.empty(1, dtype=torch.int64, device="cuda")
+    L.check(G.lib().teo_sample_topk(G.p(lg), G.p(tok), lg.numel(), temperature, top_k, seed, draw, G.stream()), "sample")
+    return int(tok.item())
+
+
+def test_sampler_limits_and_determinism():
+    lg = rnd(32000, seed=5, scale=3.0).cuda()
+    am = int(lg.argmax())
+    assert _sample(lg, 1e-4, 50, 1, 0) == am                 # temperature -> 0 is greedy
+    assert all(_sample(lg, 1.0, 1, s, d) == am for s in (1, 2) for d in (0, 7))     # top-1 is greedy
+    a = [_sample(lg, 0.8, 50, 1234, d) for d in range(64)]
+    b = [_sample(lg, 0.8, 50, 1234, d) for d in range(64)]
+    c = [_sample(lg, 0.8, 50, 999, d) for d in range(64)]
+    assert a == b and a != c                                   # counter-based: (seed, draw) fixes the token
+    top50 = set(lg.topk(50).indices.tolist())
+    assert set(a) <= top50 and set(c) <= top50
+
+
+def test_sampler_distribution_matches_softmax_of_topk():
+    g = torch.Generator().manual_seed(11)
+    lg = torch.randn(1000, generator=g) * 2.0
+    k, temp, n = 8, 0.7, 4000
+    d_lg = lg.cuda()
+    draws = torch.tensor([_sample(d_lg, temp, k, 42, d) for d in range(n)])
+    top = lg.topk(k)
+    p = torch.softmax(top.values / temp, dim=0)
+    counts = torch.stack([(draws == i).sum() for i in top.indices]).float()
+    assert int(counts.sum()) == n                              # never outside the top-k
+    # each frequency within 5 sigma of the binomial expectation
+    sigma = torch.sqrt(n * p * (1 - p)).clamp_min(1.0)
+    assert bool(((counts - n * p).abs() < 5 * sigma).all()), (counts, n * p)
+
+
+def test_sampler_ties_and_small_vocab():
+    lg = torch.zeros(300).cuda()                               # all tied: every index may be drawn, never out of range
+    s = {_sample(lg, 1.0, 50, 3, d) for d in range(200)}
+    assert min(s) >= 0 and max(s) < 300 and len(s) > 20
+    lg2 = torch.tensor([0.0, 5.0, -1.0]).cuda()
+    assert _sample(lg2, 0.05, 0, 1, 0) == 1                    # top_k = 0 disables the filter

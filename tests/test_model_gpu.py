@@ -208,8 +208,20 @@ def test_run_inference_single_end_to_end_synthetic_tiny():
     text2 = run_inference_single(model, processor, tokenizer, "<video>\nWhat changed?", imgs, max_new_tokens=8,
                                  do_sample=False)
     assert text == text2                                    # deterministic
-    sampled = run_inference_single(model, processor, tokenizer, "<video>\nWhat changed?", imgs, max_new_tokens=4)
-    assert isinstance(sampled, str)
+    # the reference's default path: do_sample=True, temperature=0.2 -> device sampler inside the hipGraph decode step
+    torch.manual_seed(7)
+    s1 = run_inference_single(model, processor, tokenizer, "<video>\nWhat changed?", imgs, max_new_tokens=12)
+    torch.manual_seed(7)
+    s2 = run_inference_single(model, processor, tokenizer, "<video>\nWhat changed?", imgs, max_new_tokens=12)
+    assert isinstance(s1, str) and s1 == s2                 # reproducible under torch.manual_seed
+    ids = torch.tensor([[1, 5, -200, 9, 10, -200, 11]], device=model.device)
+    fr = [processor.preprocess(i, return_tensors="pt")["pixel_values"][0].to(model.device) for i in imgs]
+    hot = [model.generate(input_ids=ids, images=fr, do_sample=True, temperature=5.0, top_k=50, max_new_tokens=16,
+                          eos_token_id=None, generator=torch.Generator().manual_seed(s))[0, ids.shape[1]:].tolist() for s in (1, 2)]
+    assert hot[0] != hot[1]                                 # different seeds, hot temperature: different streams
+    cold = model.generate(input_ids=ids, images=fr, do_sample=True, temperature=1e-4, max_new_tokens=16, eos_token_id=None)
+    greedy = model.generate(input_ids=ids, images=fr, do_sample=False, max_new_tokens=16, eos_token_id=None)
+    assert torch.equal(cold, greedy)                        # temperature -> 0 == greedy
 
 
 def test_causality_and_determinism_property():
