@@ -111,8 +111,10 @@ class _Embedding:
         return self._engine.embed
 
     def __call__(self, ids):
-        flat = ids.reshape(-1).to(torch.int32)
-        return self._engine.splice(flat, None).view(*ids.shape, -1)
+        flat = ids.reshape(-1)
+        if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= self._engine.cfg.vocab_size):
+            raise IndexError("index out of range in self")        # what nn.Embedding raises (e.g. a stray -200 sentinel)
+        return self._engine.splice(flat.to(torch.int32), None).view(*ids.shape, -1)
 
 
 class LlavaLlamaModel:

@@ -1,0 +1,174 @@
+"""Checkpoint loading (N2), loud failure without a GPU, and edge cases of the drop-in surface."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import teo_oracle as O
+from tests import _tiny as TY
+
+
+def _write_checkpoint(tmp_path, name="tinyA"):
+    from safetensors.torch import save_file
+    from teochat_amd.config import LlavaConfig, VisionConfig
+    t = TY.TINY[name]
+    cfg = LlavaConfig(**t["llm"], mm_hidden_size=t["vit"]["hidden_size"], max_position_embeddings=1024,
+                      vision_config=VisionConfig(**t["vit"]))
+    sd = TY.state_dict(name)
+    d = tmp_path / "llava-tiny"
+    d.mkdir()
+    keys = sorted(sd)
+    half = len(keys) // 2                      # two shards, like an HF sharded checkpoint
+    save_file({k: sd[k].contiguous() for k in keys[:half]}, str(d / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[half:]}, str(d / "model-00002-of-00002.safetensors"))
+    json.dump(cfg.to_dict(), open(d / "config.json", "w"))
+    return str(d), cfg, sd
+
+
+def test_config_and_lazy_safetensors_roundtrip(tmp_path):
+    from teochat_amd.builder import LazySafetensors
+    from teochat_amd.config import LlavaConfig
+    path, cfg, sd = _write_checkpoint(tmp_path)
+    c2 = LlavaConfig.from_pretrained(path)
+    for k in ("hidden_size", "num_key_value_heads", "mm_projector_type", "mm_vision_select_layer", "rms_norm_eps"):
+        assert getattr(c2, k) == getattr(cfg, k)
+    assert c2.vision_config.hidden_act == cfg.vision_config.hidden_act and c2.head_dim == cfg.head_dim
+    lz = LazySafetensors(path, "cpu")
+    assert set(lz.keys()) == set(sd)
+    for k in ("model.embed_tokens.weight", "model.mm_projector.2.bias", O.VIT_PREFIX + "pre_layrnorm.weight"):
+        assert torch.equal(lz[k], sd[k])
+    with pytest.raises(KeyError):
+        lz["nope"]
+
+
+def test_product_fails_loudly_without_gpu_or_library(tmp_path, monkeypatch):
+    from teochat_amd import _lib as L
+    from teochat_amd.builder import load_pretrained_model
+    path, _, _ = _write_checkpoint(tmp_path)
+    with pytest.raises(NotImplementedError):                       # LoRA checkpoints must be merged first
+        load_pretrained_model(path, "base", "llava-lora-tiny")
+    with pytest.raises(ValueError):                                # not a llava/teochat checkpoint name (builder.py:33)
+        load_pretrained_model(path, None, "vicuna-7b")
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="MI355X"):          # no CPU fallback
+            load_pretrained_model(path, None, "llava-tiny")
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.raises(L.TeoLibraryError):
+        L.load()
+
+
+@pytest.mark.gpu
+def test_load_model_from_safetensors_equals_direct_engine(tmp_path):
+    from teochat_amd.eval import load_model
+    from tests.test_model_gpu import build
+    path, cfg, sd = _write_checkpoint(tmp_path)
+    tok, model, proc = load_model(path, None, device="cuda:0", dtype=torch.float32, max_seq=1024)
+    ref_model, _ = build("tinyA", torch.float32)
+    frames = O.synthetic_frames(2, 224, seed=0)
+    ids = O.synthetic_prompt_ids(24, 2, cfg.vocab_size, seed=1).unsqueeze(0).cuda()
+    a = model(input_ids=ids, images=[f.cuda() for f in frames]).logits
+    b = ref_model(input_ids=ids, images=[f.cuda() for f in frames]).logits
+    assert torch.equal(a, b)
+    assert model.model.video_tower is None and proc.crop_size == {"height": 224, "width": 224}
+
+
+@pytest.mark.gpu
+def test_edge_cases_generate_and_forward():
+    from teochat_amd.mm_utils import KeywordsStoppingCriteria
+    from teochat_amd.tokenizer_stub import ByteTokenizer
+    from tests.test_model_gpu import build
+    model, sd = build("tinyA", torch.float32)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs("tinyA")
+    frames = [f.to(dev) for f in O.synthetic_frames(1, 224, seed=3)]
+    ids = torch.tensor([[1, 20, -200, 21, 22]], device=dev)
+    # T = 1, max_new_tokens = 1 and 0
+    g1 = model.generate(input_ids=ids, images=frames, max_new_tokens=1, eos_token_id=None)
+    assert g1.shape == (1, 6)
+    assert model.generate(input_ids=ids, images=frames, max_new_tokens=0).shape == (1, 5)
+    ref, _, _ = O.greedy_generate(ids.cpu(), [f.cpu() for f in frames], sd, vcfg, lcfg, mm, max_new_tokens=6)
+    g6 = model.generate(input_ids=ids, images=frames, max_new_tokens=6, eos_token_id=None)[0, 5:].tolist()
+    assert g6 == ref
+    # EOS: stop exactly at the token (inclusive), as HF does
+    g_eos = model.generate(input_ids=ids, images=frames, max_new_tokens=6, eos_token_id=ref[2])[0, 5:].tolist()
+    assert g_eos == ref[:ref.index(ref[2]) + 1]
+    # keyword stopping criterion on ids (device-side suffix test + host check per chunk)
+    class Tok(ByteTokenizer):
+        def __call__(self, text, **kw):
+            r = super().__call__(text, **kw)
+            return r
+    crit = KeywordsStoppingCriteria(["</s>"], ByteTokenizer(), ids)
+    assert crit.keyword_id_lists == [[2]]
+    out = model.generate(input_ids=ids, images=frames, max_new_tokens=6, eos_token_id=None, stopping_criteria=[crit], chunk=4)
+    assert out[0, 5:].tolist() == ref          # "</s>" (id 2) never generated -> runs to max_new_tokens
+    # text-only prompt (images=None) and a prompt made only of an image
+    t_ids = torch.tensor([[1, 5, 6, 7]], device=dev)
+    lo, _ = O.llama_forward(sd["model.embed_tokens.weight"][t_ids.cpu()], None, None, None, sd, lcfg)
+    torch.testing.assert_close(model(input_ids=t_ids, images=None).logits.cpu(), lo, atol=1e-4, rtol=1e-4)
+    only = model(input_ids=torch.tensor([[-200, 5]], device=dev), images=frames).logits
+    assert only.shape == (1, 257, lcfg.vocab_size)
+    # a 1-token input takes the decode-branch early-out (llava_arch.py:154) even if it is a sentinel: the embedding
+    # lookup then rejects -200 exactly like nn.Embedding does in the reference
+    with pytest.raises(IndexError):
+        model(input_ids=torch.tensor([[-200]], device=dev), images=frames)
+    # errors: wrong image size, too many sentinels, sequence beyond max_seq, 4-D (video) item, unknown strategy
+    with pytest.raises(ValueError):
+        model(input_ids=ids, images=[torch.zeros(3, 112, 112, device=dev)])
+    with pytest.raises(IndexError):
+        model(input_ids=torch.tensor([[1, -200, -200]], device=dev), images=frames)
+    with pytest.raises(ValueError):
+        model.generate(input_ids=ids, images=frames, max_new_tokens=5000)
+    with pytest.raises(ValueError):
+        model(input_ids=ids, images=[torch.zeros(2, 3, 224, 224, device=dev)])
+    with pytest.raises(NotImplementedError):
+        model(input_ids=ids, images=frames, output_attentions=True)
+
+
+@pytest.mark.gpu
+def test_truncation_and_loss_shapes():
+    from tests.test_model_gpu import build
+    model, sd = build("tinyA", torch.float32, tokenizer_model_max_length=200)
+    dev = model.device
+    vcfg, lcfg, _ = TY.cfgs("tinyA")
+    mm = O.MMCfg(mm_hidden_size=vcfg.hidden_size, tokenizer_model_max_length=200)
+    frames = O.synthetic_frames(1, 224, seed=3)
+    ids = torch.tensor([[1, 20, -200, 21, 22]])
+    labels = torch.tensor([[-100, -100, -100, 21, 22]])
+    out = model(input_ids=ids.to(dev), labels=labels.to(dev), images=[f.to(dev) for f in frames])
+    lo, _, emb = O.mm_forward(ids, frames, sd, vcfg, lcfg, mm)
+    assert out.logits.shape[1] == 200 == lo.shape[1]              # truncated (llava_arch.py:295-299): the text tail is cut
+    torch.testing.assert_close(out.logits.cpu(), lo, atol=1e-4, rtol=1e-4)
+    assert out.loss is not None and bool(torch.isnan(out.loss))    # every label was truncated away -> nan, as torch gives
+
+
+@pytest.mark.gpu
+def test_real_width_two_layer_model_bf16_vs_oracle():
+    """LLaMA-2-7B / ViT-L widths (4096/11008/32 heads, 1024/4096/16 heads, vocab 32000) with 2 layers each: the MFMA,
+    flash-attention, GEMV and decode kernels at their production tile shapes against the CPU oracle."""
+    from teochat_amd.config import LlavaConfig, VisionConfig
+    from teochat_amd.engine import TeoEngine
+    from teochat_amd.model import LlavaLlamaForCausalLM
+    vit = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=3, hidden_act="gelu")
+    llm = dict(hidden_size=4096, num_attention_heads=32, num_key_value_heads=32, intermediate_size=11008, num_hidden_layers=2,
+               vocab_size=32000)
+    vcfg, lcfg, mm = O.VitCfg(**vit), O.LlamaCfg(**llm), O.MMCfg()
+    sd = O.make_state_dict(vcfg, lcfg, mm, seed=2, std=0.02)
+    sd16 = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    cfg = LlavaConfig(**llm, max_position_embeddings=1024, vision_config=VisionConfig(**vit))
+    eng = TeoEngine(sd, cfg, dtype=torch.bfloat16, device="cuda:0", max_seq=1024)
+    model = LlavaLlamaForCausalLM(cfg, eng)
+    frames = O.synthetic_frames(2, 224, seed=0)
+    ids = O.synthetic_prompt_ids(32, 2, 32000, seed=1).unsqueeze(0)
+    imgs = [f.to("cuda:0", dtype=torch.bfloat16) for f in frames]
+    got = model(input_ids=ids.cuda(), images=imgs).logits[0].cpu()
+    ref, _, _ = O.mm_forward(ids, frames, sd16, vcfg, lcfg, mm, rounding="bf16")
+    rel = float((got - ref[0]).abs().max()) / float(ref.abs().max())
+    print(f"real-width 2-layer bf16 logits rel-to-max diff vs boundary oracle: {rel:.2e}")
+    assert rel < 2e-2
+    assert (got.argmax(-1) == ref[0].argmax(-1)).float().mean() > 0.9
+    toks, _, _ = O.greedy_generate(ids, frames, sd16, vcfg, lcfg, mm, max_new_tokens=4, rounding="bf16")
+    gen = model.generate(input_ids=ids.cuda(), images=imgs, do_sample=False, max_new_tokens=4, eos_token_id=None)
+    assert gen.shape[1] == ids.shape[1] + 4
+    print("greedy", gen[0, ids.shape[1]:].tolist(), "oracle", toks)
