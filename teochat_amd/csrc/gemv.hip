@@ -75,14 +75,26 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
         }
         return (long long)min(grp * R + r, N - 1);
     };
-    auto issue = [&](uint4 (&w)[U][R], int grp, int c0) {
+    // full = every lane's chunk is in range (no per-load exec masking in the steady-state loop)
+    auto issue = [&](uint4 (&w)[U][R], int grp, int c0, bool full) {
+        if (full) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = c0 + u * 64 + lane;
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T* p = W + row_of(grp, r) * K + (long long)c * VE;
-                w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
+                for (int r = 0; r < R; ++r) {
+                    const T* p = W + row_of(grp, r) * K + (long long)(c0 + u * 64 + lane) * VE;
+                    w[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T* p = W + row_of(grp, r) * K + (long long)c * VE;
+                    w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
+                }
             }
         }
     };
@@ -108,7 +120,9 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     }
     uint4 wa[U][R];
     int grp = wave_global;
-    if (PF && grp < ngroups) issue(wa, grp, 0);
+    constexpr int STEP0 = 64 * U;
+    const bool pf = PF && grp < ngroups && nchunk >= STEP0;   // unconditional loads only: masked ones get drained at once
+    if (pf) issue(wa, grp, 0, true);
 
     float ss = 0.f;
     if (x_in_regs) {
@@ -168,12 +182,12 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     }
     __syncthreads();
 
-    auto consume = [&](const uint4 (&w)[U][R], int c0, float (&acc)[R]) {
+    auto consume = [&](const uint4 (&w)[U][R], int c0, float (&acc)[R], bool full) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = c0 + u * 64 + lane;
             float xv[VE];
-            if (c < nchunk) {
+            if (full || c < nchunk) {
 #pragma unroll
                 for (int e = 0; e < VE; e += 4) {
                     const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
@@ -194,28 +208,33 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     };
 
     constexpr int STEP = 64 * U;
-    bool have = PF;                              // wa already holds block 0 of the first group
+    bool have = pf;                              // wa already holds block 0 of the first group
     for (; grp < ngroups; grp += nwaves) {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
         if (DB) {
             uint4 wb[U][R];
-            if (!have) issue(wa, grp, 0);
+            if (!have) issue(wa, grp, 0, false);
             for (int c0 = 0; c0 < nchunk; c0 += 2 * STEP) {
                 const int c1 = c0 + STEP, c2 = c0 + 2 * STEP;
-                if (c1 < nchunk) issue(wb, grp, c1);
-                consume(wa, c0, acc);
-                if (c2 < nchunk) issue(wa, grp, c2);
-                if (c1 < nchunk) consume(wb, c1, acc);
+                if (c1 < nchunk) issue(wb, grp, c1, false);
+                consume(wa, c0, acc, false);
+                if (c2 < nchunk) issue(wa, grp, c2, false);
+                if (c1 < nchunk) consume(wb, c1, acc, false);
             }
             have = false;
         } else {
             int c0 = 0;
-            if (have) { consume(wa, 0, acc); c0 = STEP; have = false; }
-            for (; c0 < nchunk; c0 += STEP) {
-                issue(wa, grp, c0);
-                consume(wa, c0, acc);
+            if (have) { consume(wa, 0, acc, true); c0 = STEP; have = false; }
+            const int cfull = (nchunk / STEP) * STEP;          // steady state: no bounds checks, no exec masking
+            for (; c0 < cfull; c0 += STEP) {
+                issue(wa, grp, c0, true);
+                consume(wa, c0, acc, true);
+            }
+            if (c0 < nchunk) {
+                issue(wa, grp, c0, false);
+                consume(wa, c0, acc, false);
             }
         }
 #pragma unroll
@@ -260,7 +279,38 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
     // chunk index for (iteration it, unroll u): c = (it*U + u) * 256 + wid*64 + lane
-    for (int cb = 0; cb < nchunk; cb += 256 * U) {
+    const T* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = W + (long long)min(row0 + r, N - 1) * K;
+    const int cfull = (nchunk / (256 * U)) * (256 * U);       // steady state: every lane in range, no exec masking
+    int cb = 0;
+    for (; cb < cfull; cb += 256 * U) {
+        uint4 xr[U];
+        uint4 w[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xr[u] = *reinterpret_cast<const uint4*>(x + (long long)(cb + u * 256 + wid * 64 + lane) * VE);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const T* p = wrow[r] + (long long)(cb + u * 256 + wid * 64 + lane) * VE;
+                w[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float xv[VE];
+            Vec16<T>::cvt(xr[u], xv);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float f[VE];
+                Vec16<T>::cvt(w[u][r], f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
+            }
+        }
+    }
+    for (; cb < nchunk; cb += 256 * U) {
         uint4 xr[U];
         uint4 w[U][R];
 #pragma unroll
@@ -273,7 +323,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
             const int c = cb + u * 256 + wid * 64 + lane;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const T* p = W + (long long)min(row0 + r, N - 1) * K + (long long)c * VE;
+                const T* p = wrow[r] + (long long)c * VE;
                 w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
             }
         }
@@ -341,7 +391,8 @@ static int gemv_launch(const void* x, const void* W, const void* norm_w, const v
     // few long rows without a fused norm (o / down projections): split-K workgroups, 2 rows each (measured best)
     if (!swiglu && norm_w == nullptr && N <= 8192) return gemv_launch_splitk<T, TO, 2, 2>(x, W, res, y, N, K, st);
     // >= 4 KiB contiguous per row per step streams ~7 % faster than 2 KiB (tools/stream_probe.py, profiles/r01_gemv_variant_sweep.txt)
-    return gemv_launch_ru<T, TO, 2, 4, false, false>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
+    // and the first weight block is issued (unconditionally) before the RMSNorm prologue so that it hides under the latency
+    return gemv_launch_ru<T, TO, 2, 4, false, true>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
 }
 
 // tuning sweep: bf16 -> bf16 only
@@ -411,9 +462,26 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
     const int ngroups = qk_groups + v_groups;
     const int nwaves = gridDim.x * GV_WAVES;
 
-    // x and norm_w in one round trip, then the normalised row (rounded to T) in LDS as fp32
+    auto rows_of = [&](int grp, long long (&rows)[R], int& head, int& i0) -> bool {
+        const bool qk = grp < qk_groups;
+        if (qk) {
+            head = grp / half;
+            i0 = grp % half;
+            rows[0] = (long long)head * hd + i0;
+            rows[1] = rows[0] + half;
+        } else {
+            rows[0] = (long long)(H + Hk) * hd + (grp - qk_groups) * 2;
+            rows[1] = rows[0] + 1;
+        }
+        return qk;
+    };
+    // x and norm_w in one round trip, the wave's first weight block right behind them (it hides under the prologue),
+    // then the normalised row (rounded to T) in LDS as fp32
     constexpr int XPT = 6;
     float ss = 0.f;
+    uint4 wpre[U][R];
+    const int grp0 = blockIdx.x * GV_WAVES + wid;
+    bool have = false;
     if (nchunk <= XPT * GV_THREADS) {
         uint4 xr[XPT], nr[XPT];
 #pragma unroll
@@ -425,6 +493,19 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
         for (int i = 0; i < XPT; ++i) {
             const int c = tid + i * GV_THREADS;
             nr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+        }
+        if (grp0 < ngroups && nchunk >= 64 * U) {
+            long long rows[R];
+            int head, i0;
+            rows_of(grp0, rows, head, i0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T* p = W + rows[r] * K + (long long)(u * 64 + lane) * VE;
+                    wpre[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
+                }
+            have = true;
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
@@ -465,23 +546,65 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
     __syncthreads();
     const int pos = *d_pos;
 
-    for (int grp = blockIdx.x * GV_WAVES + wid; grp < ngroups; grp += nwaves) {
+    for (int grp = grp0; grp < ngroups; grp += nwaves) {
         long long rows[R];
         int head = 0, i0 = 0;
-        const bool is_qk = grp < qk_groups;
-        if (is_qk) {
-            head = grp / half;
-            i0 = grp % half;
-            rows[0] = (long long)head * hd + i0;
-            rows[1] = rows[0] + half;
-        } else {
-            rows[0] = (long long)(H + Hk) * hd + (grp - qk_groups) * 2;
-            rows[1] = rows[0] + 1;
-        }
+        const bool is_qk = rows_of(grp, rows, head, i0);
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        for (int c0 = 0; c0 < nchunk; c0 += 64 * U) {
+        const int cfull = (nchunk / (64 * U)) * (64 * U);
+        int c0 = 0;
+        if (have) {                                           // block 0 of the first group was prefetched
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = u * 64 + lane;
+                float xv[VE];
+#pragma unroll
+                for (int e = 0; e < VE; e += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
+                    xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float f[VE];
+                    Vec16<T>::cvt(wpre[u][r], f);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
+                }
+            }
+            c0 = 64 * U;
+            have = false;
+        }
+        for (; c0 < cfull; c0 += 64 * U) {                   // steady state: no bounds checks
+            uint4 w[U][R];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T* p = W + rows[r] * K + (long long)(c0 + u * 64 + lane) * VE;
+                    w[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u * 64 + lane;
+                float xv[VE];
+#pragma unroll
+                for (int e = 0; e < VE; e += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
+                    xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float f[VE];
+                    Vec16<T>::cvt(w[u][r], f);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
+                }
+            }
+        }
+        for (; c0 < nchunk; c0 += 64 * U) {
             uint4 w[U][R];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
