@@ -272,7 +272,11 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // scores: per-row partial dot + xor-shuffle over the LPR lanes; PV: each lane accumulates its 16-byte column slice
 // over its keys, lanes of different rows are summed with two xor-shuffles at the end.  No MFMA: 1 query row.
 // ------------------------------------------------------------------------------------------------
-constexpr int DEC_CHUNK = 128;   // keys per workgroup
+static int g_dec_chunk = 128;     // keys per workgroup (tunable: 64 / 128 / 256)
+int attn_tune_set(const char* key, int value) {
+    if (!strcmp(key, "attn_chunk") && (value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
+    return -1;
+}
 
 template <typename T> struct Cvt16;
 template <> struct Cvt16<bf16_t> {
@@ -292,7 +296,7 @@ template <> struct Cvt16<float> {
 };
 
 // q: [heads*hd] (already rotated), K/V cache [kv_heads][S_max][hd]; partial: [heads][nsplit][hd + 2] fp32 (m, l, o[hd])
-template <typename T, int LPR>
+template <typename T, int LPR, int DEC_CHUNK>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                                   const T* __restrict__ vc, float* __restrict__ part,
                                                                   const int* __restrict__ d_pos, int S_max, int heads,
@@ -349,15 +353,21 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
         if (sub == 0) sc[j - c0] = (j < kv_len) ? s * scale : -INFINITY;
     }
     __syncthreads();
-    // ---- chunk max / exp / sum (every wave redundantly over the 128 scores: 2 per lane)
-    const float s0 = sc[lane], s1 = sc[lane + 64];
-    const float mx = wave_max(fmaxf(s0, s1));
-    const float p0 = expf(s0 - mx), p1 = expf(s1 - mx);          // -inf -> 0
-    const float sum = wave_sum(p0 + p1);
+    // ---- chunk max / exp / sum (every wave redundantly over the chunk's scores: DEC_CHUNK/64 per lane)
+    constexpr int SPL = DEC_CHUNK / 64;
+    float sv[SPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) { sv[i] = sc[lane + 64 * i]; mx = fmaxf(mx, sv[i]); }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) { sv[i] = expf(sv[i] - mx); sum += sv[i]; }      // -inf -> 0
+    sum = wave_sum(sum);
     __syncthreads();
     if (wid == 0) {
-        sc[lane] = Elem<T>::round(p0);
-        sc[lane + 64] = Elem<T>::round(p1);
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) sc[lane + 64 * i] = Elem<T>::round(sv[i]);
     }
     __syncthreads();
     // ---- PV on this wave's keys
@@ -390,13 +400,13 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
 // owns one output column and sums the active splits with independent loads (no dependent-latency chain).
 template <typename T>
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
-                                                                  const int* __restrict__ d_pos, int hd, int nsplit) {
+                                                                  const int* __restrict__ d_pos, int hd, int nsplit, int chunk) {
     __shared__ float w[256];
     __shared__ float red[4];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int stride = hd + 2;
     const float* pb = part + (long long)h * nsplit * stride;
-    const int nact = min(nsplit, (*d_pos + 1 + DEC_CHUNK - 1) / DEC_CHUNK);       // splits that hold keys
+    const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys
     float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
     if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
     if (tid + 128 < nact) { m1 = pb[(tid + 128) * stride]; l1 = pb[(tid + 128) * stride + 1]; }
@@ -427,29 +437,40 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 }
 
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max) {
-    const int nsplit = cdiv(S_max, DEC_CHUNK);
+    const int nsplit = cdiv(S_max, 64);      // sized for the smallest chunk
     return (size_t)heads * nsplit * (hd + 2) * sizeof(float);
 }
 
 template <typename T, int LPR>
 static void attn_decode_launch(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos,
-                               int S_max, int heads, int kv_heads, int hd, float scale, int nsplit, hipStream_t st) {
+                               int S_max, int heads, int kv_heads, int hd, float scale, int nsplit, int chunk, hipStream_t st) {
     dim3 grid(heads, nsplit);
-    attn_decode_partial_kernel<T, LPR><<<grid, 256, 0, st>>>((const T*)q, (const T*)kc, (const T*)vc, part, d_pos, S_max,
-                                                             heads, kv_heads, scale, nsplit);
-    attn_decode_combine_kernel<T><<<heads, 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit);
+#define TEO_PART(CH)                                                                                                  \
+    attn_decode_partial_kernel<T, LPR, CH><<<grid, 256, 0, st>>>((const T*)q, (const T*)kc, (const T*)vc, part, d_pos, S_max, \
+                                                                 heads, kv_heads, scale, nsplit)
+    if constexpr (64 / 4 >= 64 / LPR) {
+        if (chunk == 64) { TEO_PART(64); } else if (chunk == 256) { TEO_PART(256); } else { TEO_PART(128); }
+    } else {
+        if (chunk == 256) { TEO_PART(256); } else { TEO_PART(128); }
+    }
+#undef TEO_PART
+    attn_decode_combine_kernel<T><<<heads, 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk);
 }
 
 int attn_decode(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos, int S_max,
                 int heads, int kv_heads, int hd, float scale, int dtype, hipStream_t st) {
-    const int nsplit = cdiv(S_max, DEC_CHUNK);
+    int chunk = g_dec_chunk;
     const int esz = dtype == TEO_F32 ? 4 : 2;
     const int lpr = hd * esz / 16;
+    if (chunk / 4 < 64 / lpr) chunk = 4 * (64 / lpr);          // every wave needs at least one load instruction of keys
+    if (chunk != 64 && chunk != 128 && chunk != 256) chunk = 128;
+    if (cdiv(S_max, chunk) > 256) chunk = 256;
+    const int nsplit = cdiv(S_max, chunk);
     if (nsplit > 256 || (hd * esz) % 16 != 0 || (lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16 && lpr != 32)) {
         set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
         return TEO_ERR_UNSUPPORTED;
     }
-#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, st)
+#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, st)
     if (dtype == TEO_F32) {
         switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
                        case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }

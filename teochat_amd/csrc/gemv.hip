@@ -462,6 +462,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
     const int ngroups = qk_groups + v_groups;
     const int nwaves = gridDim.x * GV_WAVES;
 
+    const int pos = *d_pos;                              // issued first: everything that depends on it is far downstream
     auto rows_of = [&](int grp, long long (&rows)[R], int& head, int& i0) -> bool {
         const bool qk = grp < qk_groups;
         if (qk) {
@@ -544,12 +545,14 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
         }
     }
     __syncthreads();
-    const int pos = *d_pos;
 
     for (int grp = grp0; grp < ngroups; grp += nwaves) {
         long long rows[R];
         int head = 0, i0 = 0;
         const bool is_qk = rows_of(grp, rows, head, i0);
+        // rotation coefficients of this pair: loaded before the weight stream so the epilogue never waits on memory
+        float rc = 1.f, rs = 0.f;
+        if (is_qk) { rc = cs[(long long)pos * half + i0]; rs = sn[(long long)pos * half + i0]; }
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
@@ -642,8 +645,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
         if (lane == 0) {
             if (is_qk) {
                 const float x1 = Elem<T>::round(acc[0]), x2 = Elem<T>::round(acc[1]);
-                const float c = cs[(long long)pos * half + i0], sv = sn[(long long)pos * half + i0];
-                const float y1 = x1 * c - x2 * sv, y2 = x2 * c + x1 * sv;
+                const float y1 = x1 * rc - x2 * rs, y2 = x2 * rc + x1 * rs;
                 if (head < H) {
                     Elem<T>::st(qout + head * hd + i0, y1);
                     Elem<T>::st(qout + head * hd + i0 + half, y2);

@@ -45,6 +45,7 @@ int gemv(const void* x, const void* W, const void* norm_w, const void* res, void
 
 int gemv_tune_set(const char* key, int value);
 int gemm_tune_set(const char* key, int value);
+int attn_tune_set(const char* key, int value);
 int gemv_qkv_rope(const void* x, const void* W, const void* norm_w, void* qout, const float* cs, const float* sn,
                   const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk, int hd, int K, float eps,
                   int dtype, hipStream_t st);
