@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--shard-frames", action="store_true", help="C4 mode: one conversation, ViT frames sharded over ranks + all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8 = config C5 weight path (decode streams fp8-e4m3 weights); the headline is bf16")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo for plumbing tests")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to teo_tune_set (perf knobs only)")
@@ -141,7 +142,7 @@ def main():
     max_seq = (Lseq + n_out + 255) // 256 * 256
     dtype = torch.bfloat16
     tok, model, _, _ = load_pretrained_model("synthetic:teochat-7b", None, "synthetic:teochat-7b", device=device,
-                                             dtype=dtype, max_seq=max_seq)
+                                             dtype=dtype, max_seq=max_seq, weight_format=("fp8" if args.weights == "fp8" else None))
     eng = model.engine
     for kv in args.tune:
         k_, v_ = kv.split("=")
@@ -210,7 +211,7 @@ def main():
     y = torch.empty(cfg.intermediate_size, dtype=dtype, device=device)
     avg = C.c_float(0)
     with eng.phase() as st:
-        L.check(eng.lib.teo_time_gemv_chain(x.data_ptr(), pp, len(Ws), eng.llama_w["post_norm"][0].data_ptr(), y.data_ptr(),
+        L.check(eng.lib.teo_time_gemv_chain(x.data_ptr(), pp, None, len(Ws), eng.llama_w["post_norm"][0].data_ptr(), y.data_ptr(),
                                             2 * cfg.intermediate_size, cfg.hidden_size, cfg.rms_norm_eps,
                                             L.GEMM_SWIGLU16, L.TEO_BF16, 5, C.byref(avg), st), "teo_time_gemv_chain")
     gemv_bytes = 2 * cfg.intermediate_size * cfg.hidden_size * 2
@@ -235,7 +236,7 @@ def main():
         "metric": "end-to-end tokens/sec (prefill+decode), T=8 frames, LLaMA-2-7B",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
         "config": {"workload": f"{'C4' if args.shard_frames else ('C3' if T == 8 else 'C2-like')}: T={T} frames 224x224 -> CLIP-ViT-L/14 (23 layers) -> mlp2x_gelu -> splice of a "
                                f"{n_text}-token prompt (L={Lseq}) -> LLaMA-2-7B prefill -> {n_out} forced greedy tokens; "
                                f"value = generated tokens / total time",

@@ -153,6 +153,10 @@ int teo_sample_topk(const float* d_logits, long long* d_token, int vocab, float 
 int teo_gemv(const void* d_x, const void* d_W, const void* d_norm_w, const void* d_residual, void* d_y, int N, int K,
              float eps, unsigned flags, int dtype, int out_dtype, teo_stream_t stream);
 
+/* teo_gemv with fp8 e4m3 weights: W8 [N,K] bytes, w_scale [N] fp32 (y = scale * (W8 . f(x))); bf16 activations only. */
+int teo_gemv_w8(const void* d_x, const void* d_W8, const float* d_w_scale, const void* d_norm_w, const void* d_residual,
+                void* d_y, int N, int K, float eps, unsigned flags, int out_dtype, teo_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Composed runtime entry points (the layer loops live in C++, not Python)
  * ------------------------------------------------------------------------------------------- */
@@ -212,6 +216,14 @@ typedef struct {
     void* const* k_cache;  /* [kv_heads][max_seq][head_dim] */
     void* const* v_cache;  /* [kv_heads][max_seq][head_dim] */
     void* const* vt_cache; /* [kv_heads][head_dim][max_seq] */
+    /* Optional fp8 (OCP e4m3fn) copies of the Linear weights for the DECODE path (config C5): same row layouts as
+     * above, one fp32 scale per output row (W = fp8 * scale; power-of-two scales make the bf16 weights above, used by
+     * prefill, exactly equal to the dequantised fp8 weights).  All NULL -> decode streams the bf16/f32 weights. */
+    const void* const* qkv_w8;    const float* const* qkv_s;
+    const void* const* o_w8;      const float* const* o_s;
+    const void* const* gateup_w8; const float* const* gateup_s;
+    const void* const* down_w8;   const float* const* down_s;
+    const void* lm_head8;         const float* lm_head_s;
 } teo_llama_desc;
 
 size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
@@ -259,9 +271,9 @@ int teo_graph_destroy(teo_graph* g);
 
 /* Bench helper: run the decode gate/up GEMV (the dominant kernel by bytes) over n weight matrices
  * back to back between two HIP events on `stream`; returns the average milliseconds per launch. */
-int teo_time_gemv_chain(const void* d_x, const void* const* d_Ws, int n, const void* d_norm_w, void* d_y, int N,
-                        int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out,
-                        teo_stream_t stream);
+int teo_time_gemv_chain(const void* d_x, const void* const* d_Ws, const float* const* d_scales, int n, const void* d_norm_w,
+                        void* d_y, int N, int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out,
+                        teo_stream_t stream);   /* d_scales != NULL: the matrices are fp8-e4m3 with per-row scales */
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,9 @@ class LlamaDesc(C.Structure):
                 ("embed", C.c_void_p), ("final_norm_w", C.c_void_p), ("lm_head", C.c_void_p),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("max_pos", C.c_int),
                 ("in_norm_w", PP), ("qkv_w", PP), ("o_w", PP), ("post_norm_w", PP), ("gateup_w", PP),
-                ("down_w", PP), ("k_cache", PP), ("v_cache", PP), ("vt_cache", PP)]
+                ("down_w", PP), ("k_cache", PP), ("v_cache", PP), ("vt_cache", PP),
+                ("qkv_w8", PP), ("qkv_s", PP), ("o_w8", PP), ("o_s", PP), ("gateup_w8", PP), ("gateup_s", PP),
+                ("down_w8", PP), ("down_s", PP), ("lm_head8", C.c_void_p), ("lm_head_s", C.c_void_p)]
 
 
 class DecodeState(C.Structure):
@@ -89,6 +91,7 @@ _SIGS = {
     "teo_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "teo_sample_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
     "teo_gemv": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_uint, C.c_int, C.c_int, C.c_void_p]),
+    "teo_gemv_w8": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.c_uint, C.c_int, C.c_void_p]),
     "teo_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitDesc), C.c_int]),
     "teo_vit_encode": (C.c_int, [C.POINTER(VitDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_projector_workspace_bytes": (C.c_size_t, [C.POINTER(ProjDesc), C.c_int]),
@@ -103,7 +106,7 @@ _SIGS = {
                                                 C.c_void_p, C.POINTER(C.c_void_p)]),
     "teo_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "teo_graph_destroy": (C.c_int, [C.c_void_p]),
-    "teo_time_gemv_chain": (C.c_int, [C.c_void_p, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+    "teo_time_gemv_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                       C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }
 

@@ -59,7 +59,7 @@ class LazySafetensors:
 
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
-                          device="cuda", cache_dir=None, dtype=torch.bfloat16, max_seq=None, seed=2):
+                          device="cuda", cache_dir=None, dtype=torch.bfloat16, max_seq=None, seed=2, weight_format=None):
     if device in (None, "cuda"):
         device = "cuda:0"
     if load_8bit or load_4bit:
@@ -89,7 +89,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
             tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
         else:
             tokenizer = ByteTokenizer()
-    engine = TeoEngine(sd, cfg, dtype=dtype, device=device, max_seq=max_seq)
+    engine = TeoEngine(sd, cfg, dtype=dtype, device=device, max_seq=max_seq, weight_format=weight_format)
     del sd
     image_processor = TeoImageProcessor(size=cfg.vision_config.image_size)
     model = LlavaLlamaForCausalLM(cfg, engine, image_processor)

@@ -170,6 +170,14 @@ int teo_gemv(const void* x, const void* W, const void* norm_w, const void* res, 
     return gemv(x, W, norm_w, res, y, N, K, eps, flags, dtype, out_dtype, ST(s));
 }
 
+int teo_gemv_w8(const void* x, const void* W8, const float* ws, const void* norm_w, const void* res, void* y, int N, int K,
+                float eps, unsigned flags, int out_dtype, teo_stream_t s) {
+    ENTER();
+    NEED_DT(out_dtype); TEO_CHECK_ARG(N >= 0 && K > 0, "teo_gemv_w8: N %d K %d", N, K);
+    if (N) { NEED(x, "x"); NEED(W8, "W8"); NEED(ws, "w_scale"); NEED(y, "y"); }
+    return gemv_w(x, W8, ws, 1, norm_w, res, y, N, K, eps, flags, TEO_BF16, out_dtype, ST(s));
+}
+
 size_t teo_vit_workspace_bytes(const teo_vit_desc* d, int T) { return d ? vit_workspace_bytes(d, T) : 0; }
 int teo_vit_encode(const teo_vit_desc* d, const void* px, int T, void* feat, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
@@ -239,8 +247,8 @@ int teo_graph_destroy(teo_graph* g) {
     return TEO_OK;
 }
 
-int teo_time_gemv_chain(const void* x, const void* const* Ws, int n, const void* norm_w, void* y, int N, int K,
-                        float eps, unsigned flags, int dtype, int reps, float* avg_ms_out, teo_stream_t s) {
+int teo_time_gemv_chain(const void* x, const void* const* Ws, const float* const* scales, int n, const void* norm_w, void* y,
+                        int N, int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out, teo_stream_t s) {
     ENTER();
     NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
     TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_gemv_chain: n %d reps %d", n, reps);
@@ -251,11 +259,11 @@ int teo_time_gemv_chain(const void* x, const void* const* Ws, int n, const void*
     if (e != hipSuccess) { (void)hipEventDestroy(e0); return hip_fail(e, "hipEventCreate"); }
     int rc = TEO_OK;
     for (int i = 0; i < n && rc == TEO_OK; ++i)   // warm-up pass (not timed)
-        rc = gemv(x, Ws[i], norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
+        rc = gemv_w(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
     (void)hipEventRecord(e0, ST(s));
     for (int r = 0; r < reps && rc == TEO_OK; ++r)
         for (int i = 0; i < n && rc == TEO_OK; ++i)
-            rc = gemv(x, Ws[i], norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
+            rc = gemv_w(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
     (void)hipEventRecord(e1, ST(s));
     e = hipEventSynchronize(e1);
     float ms = 0.f;

@@ -1,19 +1,26 @@
 // Decode GEMV: y[N] = W[N,K] . f(x) for ONE activation row (q_len == 1 decode step).
 //
-// HBM-bound: every weight byte is read exactly once per token, so the kernel is a pure weight stream:
-//   - no MFMA, no LDS staging of W (each byte is used once; an LDS round trip would be pure overhead);
-//   - 16-byte non-temporal loads (the stream must not evict x / the KV cache from L2), R rows per wave in
-//     flight at once, K loop unrolled so >= 8 loads per lane are outstanding before the first use;
-//   - x (after the optional fused RMSNorm) is staged once per workgroup in LDS as fp32 and re-read with
-//     conflict-free ds_read_b128;
-//   - epilogues fused: residual add, SwiGLU on the interleaved-16 gate/up layout, fp32 logits.
-// Roofline: HBM (8 TB/s spec); algorithmic bytes per launch = N*K*sizeof(T) (+ K + N elements, negligible).
+// HBM-bound: every weight byte is read exactly once per token, so the kernels are pure weight streams:
+//   - no MFMA, no LDS staging of W (each byte is used once; an LDS round trip would be pure overhead, and LDS-DMA
+//     streaming measured no faster than non-temporal loads to VGPRs: tools/stream_probe.py);
+//   - 16-byte non-temporal loads, 2 rows x 4 KiB contiguous per wave per step (8 loads in flight per lane);
+//   - x (and the RMSNorm weight) are loaded in ONE round trip, the wave's first weight block is issued right behind
+//     them UNCONDITIONALLY (exec-masked loads make hipcc wait vmcnt(0) immediately) so it hides under the prologue;
+//     f(x) is staged once per workgroup in LDS as fp32 and re-read with conflict-free ds_read_b128;
+//   - few-long-rows layers (o / down, N = 4096) use split-K workgroups: 4 waves share 2 rows;
+//   - epilogues fused: residual add, SwiGLU on the interleaved-16 gate/up layout, fp32 logits, RoPE + KV append;
+//   - weights may be bf16/f32 (same type as x) or fp8 e4m3 (OCP) with one fp32 scale per output row.
+// Roofline: HBM (8 TB/s spec); algorithmic bytes per launch = N*K*sizeof(WT) (+ K + N elements, negligible).
+#include <type_traits>
+
 #include "common.h"
 
 namespace teo {
 
 constexpr int GV_WAVES = 4;           // waves per workgroup
 constexpr int GV_THREADS = GV_WAVES * 64;
+typedef unsigned char fp8_t;          // OCP e4m3fn bits
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T> struct Vec16;   // 16 bytes of T -> floats
 template <> struct Vec16<bf16_t> {
@@ -31,14 +38,52 @@ template <> struct Vec16<float> {
         f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
     }
 };
+template <> struct Vec16<fp8_t> {
+    static constexpr int N = 16;
+    __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false);   // bytes 0,1
+            const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);    // bytes 2,3
+            f[4 * i] = lo.x; f[4 * i + 1] = lo.y; f[4 * i + 2] = hi.x; f[4 * i + 3] = hi.y;
+        }
+    }
+};
 
-__device__ __forceinline__ uint4 ld_nt16(const void* p) {
+// acc += <16 bytes of weights> . xv  -- fp8 is consumed word by word so only 4 converted values are live at a time
+template <typename WT>
+__device__ __forceinline__ float dot16(const uint4& w, const float* xv, float acc) {
+    constexpr int VE = Vec16<WT>::N;
+    float f[VE];
+    Vec16<WT>::cvt(w, f);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc = fmaf(f[e], xv[e], acc);
+    return acc;
+}
+template <>
+__device__ __forceinline__ float dot16<fp8_t>(const uint4& w, const float* xv, float acc) {
+    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(ww[i], false);
+        const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8(ww[i], true);
+        acc = fmaf(lo.x, xv[4 * i], acc);
+        acc = fmaf(lo.y, xv[4 * i + 1], acc);
+        acc = fmaf(hi.x, xv[4 * i + 2], acc);
+        acc = fmaf(hi.y, xv[4 * i + 3], acc);
+    }
+    return acc;
+}
+
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const void* p) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+    const v4u v = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p)) : *reinterpret_cast<const v4u*>(p);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// Tunables (teo_tune_set): which <R,U,DB,PF> instantiation runs, non-temporal loads on/off, workgroup cap.
+// Tunables (teo_tune_set): non-temporal loads on/off, workgroup cap, variant of the row-group kernel.
 struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; };
 static GemvTune g_tune;
 int gemv_tune_set(const char* key, int value) {
@@ -49,22 +94,154 @@ int gemv_tune_set(const char* key, int value) {
     return 0;
 }
 
-// R rows per wave per pass, U 16-byte chunks per lane per row per K-iteration (R*U loads issued back to back).
-//   DB: the next iteration's R*U loads are issued before the current ones are consumed (register double buffer);
-//   PF: the first R*U loads are issued before the x staging / RMSNorm prologue (the weight stream does not depend on x);
-//   NT: non-temporal weight loads.
-// SWIGLU: rows come in (gate, up) pairs 16 apart inside 32-row blocks.
-template <typename T, typename TO, int R, int U, bool DB, bool PF, bool NT, bool SWIGLU>
-__global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ x, const T* __restrict__ W,
-                                                          const T* __restrict__ norm_w, const T* __restrict__ res,
-                                                          TO* __restrict__ y, int N, int K, float eps) {
+// LDS image of f(x) for weight chunks of VE elements: the lanes of a wave read chunk (cb*64 + lane), so the image is
+// lane-linear per 4-float group -- [cb][g = e/4][lane][4 floats] -- and every ds_read_b128 of a wave is one contiguous
+// KiB (conflict-free).  (A plain xs[k] image makes lanes stride by VE*4 bytes: 2-way conflicts for bf16 chunks, 4-way
+// for fp8 chunks.)  k must be a multiple of 4.
+template <int VE>
+__device__ __forceinline__ int xs_off(int k) {
+    const int c = k / VE, g = (k % VE) >> 2;
+    return (((c >> 6) * (VE / 4) + g) << 8) + ((c & 63) << 2);
+}
+template <int VE>
+static size_t xs_lds_bytes(int K) { return ((size_t)((K / VE + 63) / 64) * 64 * VE + 8) * sizeof(float); }
+
+// ------------------------------------------------------------------------------------------------
+// prologue shared by the row-group kernels: xs (fp32, LDS, xs_off layout) = f(x), f = identity or rmsnorm(x)*norm_w rounded to T.
+// `after_loads()` runs once the x / norm_w loads are in flight (the caller issues its weight prefetch there).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VE, typename F>
+__device__ __forceinline__ void stage_x(const T* __restrict__ x, const T* __restrict__ norm_w, float* xs, float* red, int K,
+                                        float eps, F after_loads) {
+    constexpr int VX = Vec16<T>::N;
+    constexpr int XPT = 6;                        // 16-byte x chunks a thread can hold: K <= 6*256*VX (12288 for bf16)
+    const int tid = threadIdx.x;
+    const int nx = K / VX;
+    float ss = 0.f;
+    if (nx <= XPT * GV_THREADS) {
+        uint4 xr[XPT], nr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + i * GV_THREADS;
+            xr[i] = (c < nx) ? *reinterpret_cast<const uint4*>(x + (long long)c * VX) : make_uint4(0, 0, 0, 0);
+        }
+        if (norm_w) {                             // same round trip as x: no second dependent global-load phase
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int c = tid + i * GV_THREADS;
+                nr[i] = (c < nx) ? *reinterpret_cast<const uint4*>(norm_w + (long long)c * VX) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        after_loads();
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            float f[VX];
+            Vec16<T>::cvt(xr[i], f);
+#pragma unroll
+            for (int e = 0; e < VX; ++e) ss = fmaf(f[e], f[e], ss);
+        }
+        float rr = 1.f;
+        if (norm_w) rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int c = tid + i * GV_THREADS;
+            if (c < nx) {
+                float f[VX], g[VX];
+                Vec16<T>::cvt(xr[i], f);
+                if (norm_w) {
+                    Vec16<T>::cvt(nr[i], g);
+#pragma unroll
+                    for (int e = 0; e < VX; ++e) f[e] = Elem<T>::round(f[e] * rr * g[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < VX; e += 4)
+                    *reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e)) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+            }
+        }
+    } else {
+        after_loads();
+        for (int c = tid; c < nx; c += GV_THREADS) {
+            float f[VX];
+            Vec16<T>::cvt(*reinterpret_cast<const uint4*>(x + (long long)c * VX), f);
+#pragma unroll
+            for (int e = 0; e < VX; ++e) ss = fmaf(f[e], f[e], ss);
+#pragma unroll
+            for (int e = 0; e < VX; e += 4)
+                *reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e)) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+        }
+        if (norm_w) {
+            const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
+            for (int c = tid; c < nx; c += GV_THREADS) {
+                float f[VX];
+                Vec16<T>::cvt(*reinterpret_cast<const uint4*>(norm_w + (long long)c * VX), f);
+#pragma unroll
+                for (int e = 0; e < VX; e += 4) {
+                    float4* p4 = reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e));
+                    float4 v = *p4;
+                    v.x = Elem<T>::round(v.x * rr * f[e]); v.y = Elem<T>::round(v.y * rr * f[e + 1]);
+                    v.z = Elem<T>::round(v.z * rr * f[e + 2]); v.w = Elem<T>::round(v.w * rr * f[e + 3]);
+                    *p4 = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// one block of R rows x U chunks: loads and the dot-product update
+template <typename WT, int R, int U, bool NT, bool FULL>
+__device__ __forceinline__ void issue_block(uint4 (&w)[U][R], const WT* const (&rowp)[R], int c0, int lane, int nchunk) {
+    constexpr int VE = Vec16<WT>::N;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (FULL) w[u][r] = ld16<NT>(rowp[r] + (long long)c * VE);
+            else w[u][r] = (c < nchunk) ? ld16<NT>(rowp[r] + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+template <typename WT, int R, int U, bool FULL>
+__device__ __forceinline__ void consume_block(const uint4 (&w)[U][R], const float* xs, int c0, int lane, int nchunk,
+                                              float (&acc)[R]) {
+    constexpr int VE = Vec16<WT>::N;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = c0 + u * 64 + lane;
+        float xv[VE];
+        if (FULL || c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < VE; e += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xs + xs_off<VE>(c * VE + e));
+                xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) xv[e] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = dot16<WT>(w[u][r], xv, acc[r]);
+        // 16-element chunks (fp8): keep the scheduler from hoisting every chunk's LDS reads and conversions to the top
+        // of the step (that costs 170-250 VGPRs and the occupancy with it)
+        if (VE > 8) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-group kernel: a wave owns R rows (SWIGLU: R/2 (gate, up) pairs 16 apart inside 32-row blocks).
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, typename WT, int R, int U, bool PF, bool NT, bool SWIGLU>
+__global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ x, const WT* __restrict__ W,
+                                                          const float* __restrict__ wscale, const T* __restrict__ norm_w,
+                                                          const T* __restrict__ res, TO* __restrict__ y, int N, int K,
+                                                          float eps) {
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [K] fp32 (+8 floats of reduction scratch)
-    constexpr int VE = Vec16<T>::N;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nchunk = K / VE;                    // 16-byte chunks per row
-    const int kpad = (K + 3) & ~3;
-    float* red = xs + kpad;
-    const int wave_global = blockIdx.x * GV_WAVES + wid;
+    constexpr int VE = Vec16<WT>::N;
+    constexpr int STEP = 64 * U;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nchunk = K / VE;                    // 16-byte weight chunks per row
+    float* red = xs + ((nchunk + 63) / 64) * 64 * VE;
     const int nwaves = gridDim.x * GV_WAVES;
     const int ngroups = SWIGLU ? (N / 2 + (R / 2) - 1) / (R / 2) : (N + R - 1) / R;
 
@@ -75,171 +252,49 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
         }
         return (long long)min(grp * R + r, N - 1);
     };
-    // full = every lane's chunk is in range (no per-load exec masking in the steady-state loop)
-    auto issue = [&](uint4 (&w)[U][R], int grp, int c0, bool full) {
-        if (full) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const T* p = W + row_of(grp, r) * K + (long long)(c0 + u * 64 + lane) * VE;
-                    w[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * 64 + lane;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const T* p = W + row_of(grp, r) * K + (long long)c * VE;
-                    w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
-                }
-            }
-        }
-    };
 
-    // ---- x first (the weight stream does not depend on it, but vmcnt retires in order: loads issued after the
-    // weights would have to wait for them), then the first weight block, then the prologue under the weight latency
-    constexpr int XPT = 6;                        // 16-byte x chunks a thread can hold: K <= 6*256*VE (12288 for bf16)
-    uint4 xr[XPT], nr[XPT];
-    const bool x_in_regs = nchunk <= XPT * GV_THREADS;
-    if (x_in_regs) {
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int c = tid + i * GV_THREADS;
-            xr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(x + (long long)c * VE) : make_uint4(0, 0, 0, 0);
-        }
-        if (norm_w) {                             // same round trip as x: no second dependent global-load phase
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int c = tid + i * GV_THREADS;
-                nr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE) : make_uint4(0, 0, 0, 0);
-            }
-        }
-    }
     uint4 wa[U][R];
-    int grp = wave_global;
-    constexpr int STEP0 = 64 * U;
-    const bool pf = PF && grp < ngroups && nchunk >= STEP0;   // unconditional loads only: masked ones get drained at once
-    if (pf) issue(wa, grp, 0, true);
+    int grp = blockIdx.x * GV_WAVES + wid;
+    // PF (host guarantees nchunk >= STEP): NO branch around the prefetch -- at a control-flow merge hipcc waits vmcnt(0),
+    // which would drain the weights before the prologue.  Waves past the last group prefetch a clamped (valid) row.
+    stage_x<T, VE>(x, norm_w, xs, red, K, eps, [&]() {
+        if (PF) {
+            const int gp = min(grp, ngroups - 1);
+            const WT* rowp[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) rowp[r] = W + row_of(gp, r) * K;
+            issue_block<WT, R, U, NT, true>(wa, rowp, 0, lane, nchunk);
+        }
+    });
 
-    float ss = 0.f;
-    if (x_in_regs) {
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int c = tid + i * GV_THREADS;
-            if (c < nchunk) {
-                float f[VE];
-                Vec16<T>::cvt(xr[i], f);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) ss = fmaf(f[e], f[e], ss);
-            }
-        }
-        if (norm_w) {
-            const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int c = tid + i * GV_THREADS;
-                if (c < nchunk) {
-                    float f[VE], g[VE];
-                    Vec16<T>::cvt(xr[i], f);
-                    Vec16<T>::cvt(nr[i], g);
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(f[e] * rr * g[e]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int c = tid + i * GV_THREADS;
-                if (c < nchunk) {
-                    float f[VE];
-                    Vec16<T>::cvt(xr[i], f);
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) xs[c * VE + e] = f[e];
-                }
-            }
-        }
-    } else {
-        for (int c = tid; c < nchunk; c += GV_THREADS) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
-            float f[VE];
-            Vec16<T>::cvt(raw, f);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) { xs[c * VE + e] = f[e]; ss = fmaf(f[e], f[e], ss); }
-        }
-        if (norm_w) {
-            const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
-            for (int c = tid; c < nchunk; c += GV_THREADS) {
-                const uint4 raw = *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE);
-                float f[VE];
-                Vec16<T>::cvt(raw, f);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(xs[c * VE + e] * rr * f[e]);
-            }
-        }
-    }
-    __syncthreads();
-
-    auto consume = [&](const uint4 (&w)[U][R], int c0, float (&acc)[R], bool full) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = c0 + u * 64 + lane;
-            float xv[VE];
-            if (full || c < nchunk) {
-#pragma unroll
-                for (int e = 0; e < VE; e += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
-                    xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VE; ++e) xv[e] = 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float f[VE];
-                Vec16<T>::cvt(w[u][r], f);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
-            }
-        }
-    };
-
-    constexpr int STEP = 64 * U;
-    bool have = pf;                              // wa already holds block 0 of the first group
+    bool have = PF;
     for (; grp < ngroups; grp += nwaves) {
+        const WT* rowp[R];
+        long long rows[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { rows[r] = row_of(grp, r); rowp[r] = W + rows[r] * K; }
+        float sc[R];                                 // row scales: loaded ahead of the weight stream, never waited on later
+#pragma unroll
+        for (int r = 0; r < R; ++r) sc[r] = wscale ? wscale[rows[r]] : 1.f;
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        if (DB) {
-            uint4 wb[U][R];
-            if (!have) issue(wa, grp, 0, false);
-            for (int c0 = 0; c0 < nchunk; c0 += 2 * STEP) {
-                const int c1 = c0 + STEP, c2 = c0 + 2 * STEP;
-                if (c1 < nchunk) issue(wb, grp, c1, false);
-                consume(wa, c0, acc, false);
-                if (c2 < nchunk) issue(wa, grp, c2, false);
-                if (c1 < nchunk) consume(wb, c1, acc, false);
-            }
-            have = false;
-        } else {
-            int c0 = 0;
-            if (have) { consume(wa, 0, acc, true); c0 = STEP; have = false; }
-            const int cfull = (nchunk / STEP) * STEP;          // steady state: no bounds checks, no exec masking
-            for (; c0 < cfull; c0 += STEP) {
-                issue(wa, grp, c0, true);
-                consume(wa, c0, acc, true);
-            }
-            if (c0 < nchunk) {
-                issue(wa, grp, c0, false);
-                consume(wa, c0, acc, false);
-            }
+        int c0 = 0;
+        if (have) { consume_block<WT, R, U, true>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
+        const int cfull = (nchunk / STEP) * STEP;          // steady state: no bounds checks, no exec masking
+        for (; c0 < cfull; c0 += STEP) {
+            issue_block<WT, R, U, NT, true>(wa, rowp, c0, lane, nchunk);
+            consume_block<WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
+        }
+        if (c0 < nchunk) {
+            issue_block<WT, R, U, NT, false>(wa, rowp, c0, lane, nchunk);
+            consume_block<WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] *= sc[r];
             if (SWIGLU) {
 #pragma unroll
                 for (int p = 0; p < R / 2; ++p) {
@@ -263,83 +318,58 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // Split-K form for few, long rows (o / down projections: N = 4096): a workgroup owns R rows and its 4 waves take
-// interleaved 1-KiB chunks of every row, so 4x more waves stream than with one wave per row group; partial sums meet
-// in LDS.  x is read by each wave for its own chunks only (no norm on these layers -> no full-vector prologue).
+// interleaved chunks of every row, so 4x more waves stream than with one wave per row group; partial sums meet in LDS.
+// x is read by each wave for its own chunks only (no norm on these layers -> no full-vector prologue).
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TO, int R, int U, bool NT>
-__global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __restrict__ x, const T* __restrict__ W,
-                                                                 const T* __restrict__ res, TO* __restrict__ y, int N,
-                                                                 int K) {
-    constexpr int VE = Vec16<T>::N;
+template <typename T, typename TO, typename WT, int R, int U, bool NT>
+__global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __restrict__ x, const WT* __restrict__ W,
+                                                                 const float* __restrict__ wscale, const T* __restrict__ res,
+                                                                 TO* __restrict__ y, int N, int K) {
+    constexpr int VE = Vec16<WT>::N, VX = Vec16<T>::N;
+    constexpr int XL = VE / VX;                           // 16-byte x loads per weight chunk (1, or 2 for fp8 weights)
     __shared__ float part[GV_WAVES][R];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nchunk = K / VE;
     const int row0 = blockIdx.x * R;
+    const float my_scale = (wscale && tid < R && row0 + tid < N) ? wscale[row0 + tid] : 1.f;   // ahead of the stream
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
-    // chunk index for (iteration it, unroll u): c = (it*U + u) * 256 + wid*64 + lane
-    const T* wrow[R];
+    const WT* wrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wrow[r] = W + (long long)min(row0 + r, N - 1) * K;
+    // chunk index for (iteration, unroll u): c = cb + u*256 + wid*64 + lane
+    auto step = [&](int cb, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        uint4 xr[U][XL];
+        uint4 w[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = cb + u * 256 + wid * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < XL; ++j)
+                xr[u][j] = (FULL || c < nchunk) ? *reinterpret_cast<const uint4*>(x + (long long)c * VE + j * VX) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = cb + u * 256 + wid * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                w[u][r] = (FULL || c < nchunk) ? ld16<NT>(wrow[r] + (long long)c * VE) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float xv[VE];
+#pragma unroll
+            for (int j = 0; j < XL; ++j) Vec16<T>::cvt(xr[u][j], xv + j * VX);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = dot16<WT>(w[u][r], xv, acc[r]);
+        }
+    };
     const int cfull = (nchunk / (256 * U)) * (256 * U);       // steady state: every lane in range, no exec masking
     int cb = 0;
-    for (; cb < cfull; cb += 256 * U) {
-        uint4 xr[U];
-        uint4 w[U][R];
-#pragma unroll
-        for (int u = 0; u < U; ++u) xr[u] = *reinterpret_cast<const uint4*>(x + (long long)(cb + u * 256 + wid * 64 + lane) * VE);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T* p = wrow[r] + (long long)(cb + u * 256 + wid * 64 + lane) * VE;
-                w[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float xv[VE];
-            Vec16<T>::cvt(xr[u], xv);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float f[VE];
-                Vec16<T>::cvt(w[u][r], f);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
-            }
-        }
-    }
-    for (; cb < nchunk; cb += 256 * U) {
-        uint4 xr[U];
-        uint4 w[U][R];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = cb + u * 256 + wid * 64 + lane;
-            xr[u] = (c < nchunk) ? *reinterpret_cast<const uint4*>(x + (long long)c * VE) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = cb + u * 256 + wid * 64 + lane;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const T* p = wrow[r] + (long long)c * VE;
-                w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float xv[VE];
-            Vec16<T>::cvt(xr[u], xv);
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float f[VE];
-                Vec16<T>::cvt(w[u][r], f);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
-            }
-        }
-    }
+    for (; cb < cfull; cb += 256 * U) step(cb, std::true_type{});
+    for (; cb < nchunk; cb += 256 * U) step(cb, std::false_type{});
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
     if (lane == 0) {
@@ -351,118 +381,40 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
         const int n = row0 + tid;
         if (n < N) {
             float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            v *= my_scale;
             if (res) v += Elem<T>::ld(res + n);
             Elem<TO>::st(y + n, v);
         }
     }
 }
 
-template <typename T, typename TO, int R, int U>
-static int gemv_launch_splitk(const void* x, const void* W, const void* res, void* y, int N, int K, hipStream_t st) {
-    const int blocks = cdiv(N, R);
-    if (g_tune.nt)
-        gemv_splitk_kernel<T, TO, R, U, true><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const T*)W, (const T*)res, (TO*)y, N, K);
-    else
-        gemv_splitk_kernel<T, TO, R, U, false><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const T*)W, (const T*)res, (TO*)y, N, K);
-    TEO_LAUNCH_CHECK("gemv_splitk");
-    return TEO_OK;
-}
-
-template <typename T, typename TO, int R, int U, bool DB, bool PF>
-static int gemv_launch_ru(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K,
-                          float eps, bool swiglu, hipStream_t st) {
-    const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
-    int blocks = cdiv(ngroups, GV_WAVES);
-    if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
-    const size_t lds = (size_t)(((K + 3) & ~3) + 8) * sizeof(float);
-#define TEO_GV(NTV, SW)                                                                                              \
-    gemv_kernel<T, TO, R, U, DB, PF, NTV, SW><<<blocks, GV_THREADS, lds, st>>>((const T*)x, (const T*)W, (const T*)norm_w, \
-                                                                                (const T*)res, (TO*)y, N, K, eps)
-    if (g_tune.nt) { if (swiglu) TEO_GV(true, true); else TEO_GV(true, false); }
-    else           { if (swiglu) TEO_GV(false, true); else TEO_GV(false, false); }
-#undef TEO_GV
-    TEO_LAUNCH_CHECK("gemv");
-    return TEO_OK;
-}
-
-template <typename T, typename TO>
-static int gemv_launch(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
-                       bool swiglu, hipStream_t st) {
-    // few long rows without a fused norm (o / down projections): split-K workgroups, 2 rows each (measured best)
-    if (!swiglu && norm_w == nullptr && N <= 8192) return gemv_launch_splitk<T, TO, 2, 2>(x, W, res, y, N, K, st);
-    // >= 4 KiB contiguous per row per step streams ~7 % faster than 2 KiB (tools/stream_probe.py, profiles/r01_gemv_variant_sweep.txt)
-    // and the first weight block is issued (unconditionally) before the RMSNorm prologue so that it hides under the latency
-    return gemv_launch_ru<T, TO, 2, 4, false, true>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
-}
-
-// tuning sweep: bf16 -> bf16 only
-static int gemv_launch_variant(int v, const void* x, const void* W, const void* norm_w, const void* res, void* y, int N,
-                               int K, float eps, bool swiglu, hipStream_t st) {
-#define TEO_V(id, R, U, DB, PF) \
-    case id: return gemv_launch_ru<bf16_t, bf16_t, R, U, DB, PF>(x, W, norm_w, res, y, N, K, eps, swiglu, st)
-    switch (v) {
-        TEO_V(0, 4, 2, false, false);
-        TEO_V(1, 4, 2, false, true);
-        TEO_V(2, 4, 2, true, true);
-        TEO_V(3, 2, 2, false, true);
-        TEO_V(4, 2, 4, false, true);
-        TEO_V(5, 4, 1, false, true);
-        TEO_V(6, 8, 1, false, true);
-        TEO_V(7, 4, 4, false, true);
-        TEO_V(8, 2, 2, true, true);
-        TEO_V(9, 8, 2, false, true);
-        TEO_V(10, 2, 1, false, true);
-        TEO_V(11, 2, 8, false, true);
-        TEO_V(18, 2, 4, false, false);
-        TEO_V(19, 4, 4, false, false);
-        TEO_V(20, 2, 8, false, false);
-        TEO_V(21, 2, 2, false, false);
-        default: break;
-    }
-#undef TEO_V
-    if (v >= 12 && v <= 17 && !swiglu && norm_w == nullptr) {
-        switch (v) {
-            case 12: return gemv_launch_splitk<bf16_t, bf16_t, 4, 1>(x, W, res, y, N, K, st);
-            case 13: return gemv_launch_splitk<bf16_t, bf16_t, 4, 2>(x, W, res, y, N, K, st);
-            case 14: return gemv_launch_splitk<bf16_t, bf16_t, 2, 2>(x, W, res, y, N, K, st);
-            case 15: return gemv_launch_splitk<bf16_t, bf16_t, 2, 4>(x, W, res, y, N, K, st);
-            case 16: return gemv_launch_splitk<bf16_t, bf16_t, 8, 1>(x, W, res, y, N, K, st);
-            case 17: return gemv_launch_splitk<bf16_t, bf16_t, 1, 4>(x, W, res, y, N, K, st);
-        }
-    }
-    if (v >= 12 && v <= 17) return gemv_launch_ru<bf16_t, bf16_t, 4, 2, false, false>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
-    set_error("gemv: unknown variant %d", v);
-    return TEO_ERR_ARG;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Decode QKV projection with the RoPE rotation and the KV-cache append fused into the epilogue.
-//   rows of Wqkv: [q: H*hd | k: Hk*hd | v: Hk*hd].  A wave owns two rotation pairs (i, i + hd/2) of one q/k head
-//   (4 rows), or 4 consecutive v rows.  q is written rotated to qout[H*hd]; k rotated to K cache[hk][pos][:];
-//   v to V cache[hk][pos][:] and V^T cache[hk][:][pos].  pos (= cache slot = rotary position) is read from device
-//   memory so the launch can be replayed from a hipGraph.  Rounding points are those of the unfused path:
-//   round(linear) -> rotate in fp32 -> round.
+//   rows of Wqkv: [q: H*hd | k: Hk*hd | v: Hk*hd].  A wave owns one rotation pair (i, i + hd/2) of a q/k head, or 2
+//   consecutive v rows.  q is written rotated to qout[H*hd]; k rotated to K cache[hk][pos][:]; v to V cache[hk][pos][:]
+//   and V^T cache[hk][:][pos].  pos (= cache slot = rotary position) is read from device memory so the launch can be
+//   replayed from a hipGraph.  Rounding points are those of the unfused path: round(linear) -> rotate in fp32 -> round.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool NT>
-__global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __restrict__ x, const T* __restrict__ W,
+template <typename T, typename WT, bool NT, bool PF, int U>
+__global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __restrict__ x, const WT* __restrict__ W,
+                                                                   const float* __restrict__ wscale,
                                                                    const T* __restrict__ norm_w, T* __restrict__ qout,
                                                                    const float* __restrict__ cs, const float* __restrict__ sn,
                                                                    const int* __restrict__ d_pos, T* __restrict__ kc,
                                                                    T* __restrict__ vc, T* __restrict__ vtc, int S_max, int H,
                                                                    int Hk, int hd, int K, float eps) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    constexpr int VE = Vec16<T>::N;
-    constexpr int R = 2, U = 4;                         // one rotation pair (rows i, i + hd/2) or two v rows per wave
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nchunk = K / VE, kpad = (K + 3) & ~3;
-    float* red = xs + kpad;
+    constexpr int VE = Vec16<WT>::N;
+    constexpr int R = 2, STEP = 64 * U;                  // U chunks per row per step (4 for 2-byte weights, 2 for fp8)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nchunk = K / VE;
+    float* red = xs + ((nchunk + 63) / 64) * 64 * VE;
     const int half = hd >> 1;
     const int qk_groups = (H + Hk) * half;              // rotation pairs
-    const int v_groups = (Hk * hd) / 2;
-    const int ngroups = qk_groups + v_groups;
+    const int ngroups = qk_groups + (Hk * hd) / 2;
     const int nwaves = gridDim.x * GV_WAVES;
-
     const int pos = *d_pos;                              // issued first: everything that depends on it is far downstream
+
     auto rows_of = [&](int grp, long long (&rows)[R], int& head, int& i0) -> bool {
         const bool qk = grp < qk_groups;
         if (qk) {
@@ -476,173 +428,45 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
         }
         return qk;
     };
-    // x and norm_w in one round trip, the wave's first weight block right behind them (it hides under the prologue),
-    // then the normalised row (rounded to T) in LDS as fp32
-    constexpr int XPT = 6;
-    float ss = 0.f;
-    uint4 wpre[U][R];
+
+    uint4 wa[U][R];
     const int grp0 = blockIdx.x * GV_WAVES + wid;
-    bool have = false;
-    if (nchunk <= XPT * GV_THREADS) {
-        uint4 xr[XPT], nr[XPT];
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int c = tid + i * GV_THREADS;
-            xr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(x + (long long)c * VE) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int c = tid + i * GV_THREADS;
-            nr[i] = (c < nchunk) ? *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE) : make_uint4(0, 0, 0, 0);
-        }
-        if (grp0 < ngroups && nchunk >= 64 * U) {
+    stage_x<T, VE>(x, norm_w, xs, red, K, eps, [&]() {
+        if (PF) {                                         // branch-free (see gemv_kernel)
             long long rows[R];
             int head, i0;
-            rows_of(grp0, rows, head, i0);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const T* p = W + rows[r] * K + (long long)(u * 64 + lane) * VE;
-                    wpre[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
-                }
-            have = true;
+            rows_of(min(grp0, ngroups - 1), rows, head, i0);
+            const WT* rowp[R] = {W + rows[0] * K, W + rows[1] * K};
+            issue_block<WT, R, U, NT, true>(wa, rowp, 0, lane, nchunk);
         }
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            float f[VE];
-            Vec16<T>::cvt(xr[i], f);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) ss = fmaf(f[e], f[e], ss);
-        }
-        const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int c = tid + i * GV_THREADS;
-            if (c < nchunk) {
-                float f[VE], g[VE];
-                Vec16<T>::cvt(xr[i], f);
-                Vec16<T>::cvt(nr[i], g);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(f[e] * rr * g[e]);
-            }
-        }
-    } else {
-        for (int c = tid; c < nchunk; c += GV_THREADS) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VE);
-            float f[VE];
-            Vec16<T>::cvt(raw, f);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) { xs[c * VE + e] = f[e]; ss = fmaf(f[e], f[e], ss); }
-        }
-        const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
-        for (int c = tid; c < nchunk; c += GV_THREADS) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(norm_w + (long long)c * VE);
-            float f[VE];
-            Vec16<T>::cvt(raw, f);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) xs[c * VE + e] = Elem<T>::round(xs[c * VE + e] * rr * f[e]);
-        }
-    }
-    __syncthreads();
+    });
 
+    bool have = PF;
     for (int grp = grp0; grp < ngroups; grp += nwaves) {
         long long rows[R];
         int head = 0, i0 = 0;
         const bool is_qk = rows_of(grp, rows, head, i0);
+        const WT* rowp[R] = {W + rows[0] * K, W + rows[1] * K};
         // rotation coefficients of this pair: loaded before the weight stream so the epilogue never waits on memory
         float rc = 1.f, rs = 0.f;
         if (is_qk) { rc = cs[(long long)pos * half + i0]; rs = sn[(long long)pos * half + i0]; }
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        const int cfull = (nchunk / (64 * U)) * (64 * U);
+        const float sc0 = wscale ? wscale[rows[0]] : 1.f, sc1 = wscale ? wscale[rows[1]] : 1.f;
+        float acc[R] = {0.f, 0.f};
         int c0 = 0;
-        if (have) {                                           // block 0 of the first group was prefetched
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = u * 64 + lane;
-                float xv[VE];
-#pragma unroll
-                for (int e = 0; e < VE; e += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
-                    xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float f[VE];
-                    Vec16<T>::cvt(wpre[u][r], f);
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
-                }
-            }
-            c0 = 64 * U;
-            have = false;
+        if (have) { consume_block<WT, R, U, true>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
+        const int cfull = (nchunk / STEP) * STEP;
+        for (; c0 < cfull; c0 += STEP) {
+            issue_block<WT, R, U, NT, true>(wa, rowp, c0, lane, nchunk);
+            consume_block<WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
         }
-        for (; c0 < cfull; c0 += 64 * U) {                   // steady state: no bounds checks
-            uint4 w[U][R];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const T* p = W + rows[r] * K + (long long)(c0 + u * 64 + lane) * VE;
-                    w[u][r] = NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * 64 + lane;
-                float xv[VE];
-#pragma unroll
-                for (int e = 0; e < VE; e += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
-                    xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float f[VE];
-                    Vec16<T>::cvt(w[u][r], f);
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
-                }
-            }
-        }
-        for (; c0 < nchunk; c0 += 64 * U) {
-            uint4 w[U][R];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * 64 + lane;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const T* p = W + rows[r] * K + (long long)c * VE;
-                    w[u][r] = (c < nchunk) ? (NT ? ld_nt16(p) : *reinterpret_cast<const uint4*>(p)) : make_uint4(0, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u * 64 + lane;
-                float xv[VE];
-#pragma unroll
-                for (int e = 0; e < VE; ++e) xv[e] = 0.f;
-                if (c < nchunk) {
-#pragma unroll
-                    for (int e = 0; e < VE; e += 4) {
-                        const float4 t = *reinterpret_cast<const float4*>(xs + c * VE + e);
-                        xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float f[VE];
-                    Vec16<T>::cvt(w[u][r], f);
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) acc[r] = fmaf(f[e], xv[e], acc[r]);
-                }
-            }
+        if (c0 < nchunk) {
+            issue_block<WT, R, U, NT, false>(wa, rowp, c0, lane, nchunk);
+            consume_block<WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
         if (lane == 0) {
+            acc[0] *= sc0; acc[1] *= sc1;
             if (is_qk) {
                 const float x1 = Elem<T>::round(acc[0]), x2 = Elem<T>::round(acc[1]);
                 const float y1 = x1 * rc - x2 * rs, y2 = x2 * rc + x1 * rs;
@@ -669,48 +493,129 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
     }
 }
 
-int gemv_qkv_rope(const void* x, const void* W, const void* norm_w, void* qout, const float* cs, const float* sn,
-                  const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk, int hd, int K, float eps,
-                  int dtype, hipStream_t st) {
-    const int ve = dtype == TEO_F32 ? 4 : 8;
-    TEO_CHECK_ARG(K % ve == 0 && hd % 2 == 0, "gemv_qkv_rope: K=%d hd=%d", K, hd);
-    TEO_CHECK_ARG((size_t)(K + 16) * 4 <= 64 * 1024, "gemv_qkv_rope: K=%d too large for LDS staging", K);
-    const int ngroups = (H + Hk) * (hd / 2) + Hk * hd / 2;
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, typename WT, int R, int U, bool PF>
+static int launch_rows(const void* x, const void* W, const float* ws, const void* norm_w, const void* res, void* y, int N,
+                       int K, float eps, bool swiglu, hipStream_t st) {
+    if (PF && K / Vec16<WT>::N < 64 * U)          // the unconditional prefetch needs one full step per row
+        return launch_rows<T, TO, WT, R, U, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+    const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
-    const size_t lds = (size_t)(((K + 3) & ~3) + 8) * sizeof(float);
-#define TEO_QR(TT, NTV)                                                                                              \
-    gemv_qkv_rope_kernel<TT, NTV><<<blocks, GV_THREADS, lds, st>>>((const TT*)x, (const TT*)W, (const TT*)norm_w,     \
-                                                                   (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
-                                                                   S_max, H, Hk, hd, K, eps)
-    if (dtype == TEO_F32) { if (g_tune.nt) TEO_QR(float, true); else TEO_QR(float, false); }
-    else                  { if (g_tune.nt) TEO_QR(bf16_t, true); else TEO_QR(bf16_t, false); }
-#undef TEO_QR
-    TEO_LAUNCH_CHECK("gemv_qkv_rope");
+    const size_t lds = xs_lds_bytes<Vec16<WT>::N>(K);
+#define TEO_GV(NTV, SW)                                                                                              \
+    gemv_kernel<T, TO, WT, R, U, PF, NTV, SW><<<blocks, GV_THREADS, lds, st>>>((const T*)x, (const WT*)W, ws, (const T*)norm_w, \
+                                                                               (const T*)res, (TO*)y, N, K, eps)
+    if (g_tune.nt) { if (swiglu) TEO_GV(true, true); else TEO_GV(true, false); }
+    else           { if (swiglu) TEO_GV(false, true); else TEO_GV(false, false); }
+#undef TEO_GV
+    TEO_LAUNCH_CHECK("gemv");
     return TEO_OK;
+}
+
+template <typename T, typename TO, typename WT, int R, int U>
+static int launch_splitk(const void* x, const void* W, const float* ws, const void* res, void* y, int N, int K, hipStream_t st) {
+    const int blocks = cdiv(N, R);
+    if (g_tune.nt)
+        gemv_splitk_kernel<T, TO, WT, R, U, true><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
+    else
+        gemv_splitk_kernel<T, TO, WT, R, U, false><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
+    TEO_LAUNCH_CHECK("gemv_splitk");
+    return TEO_OK;
+}
+
+template <typename T, typename TO, typename WT>
+static int gemv_launch(const void* x, const void* W, const float* ws, const void* norm_w, const void* res, void* y, int N, int K,
+                       float eps, bool swiglu, hipStream_t st) {
+    // few long rows without a fused norm (o / down projections): split-K workgroups, 2 rows each (measured best)
+    if (!swiglu && norm_w == nullptr && N <= 8192 && g_tune.variant < 0) {
+        if (sizeof(WT) == 1) return launch_splitk<T, TO, WT, 2, 2>(x, W, ws, res, y, N, K, st);
+        return launch_splitk<T, TO, WT, 2, 2>(x, W, ws, res, y, N, K, st);
+    }
+    switch (g_tune.variant) {          // tuning sweep (tools/bench_kernels.py): R rows x U chunks, prefetch on/off
+        case 0: return launch_rows<T, TO, WT, 4, 2, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+        case 1: return launch_rows<T, TO, WT, 2, 4, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+        case 2: return launch_rows<T, TO, WT, 2, 8, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+        default: break;
+    }
+    // >= 4 KiB contiguous per row per step streams ~7 % faster than 2 KiB; first block prefetched under the prologue.
+    // fp8 rows are half as long: 4 rows per wave keep the same bytes in flight per lane
+    if (sizeof(WT) == 1) {
+        switch (g_tune.variant) {
+            case 10: return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+            case 11: return launch_rows<T, TO, WT, 4, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+            case 12: return launch_rows<T, TO, WT, 2, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+            case 13: return launch_rows<T, TO, WT, 4, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+            default: break;
+        }
+        // fp8: occupancy wins (the 16-wide chunks cost registers): 2 rows x 2 chunks = 122 VGPRs, 4 waves/SIMD
+        return launch_rows<T, TO, WT, 2, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+    }
+    return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+}
+
+// w_dtype: -1 = same as dtype, 2 = fp8 e4m3 with per-row fp32 scales (bf16 activations only)
+int gemv_w(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, const void* res, void* y, int N,
+           int K, float eps, unsigned flags, int dtype, int out_dtype, hipStream_t st) {
+    if (N == 0) return TEO_OK;
+    const bool swiglu = flags & TEO_GEMM_SWIGLU16;
+    const int ve = w_fp8 ? 16 : (dtype == TEO_F32 ? 4 : 8);
+    TEO_CHECK_ARG(K % ve == 0, "teo_gemv: K=%d must be a multiple of %d", K, ve);
+    TEO_CHECK_ARG((reinterpret_cast<uintptr_t>(W) & 15) == 0, "teo_gemv: W must be 16-byte aligned");
+    TEO_CHECK_ARG((size_t)(K + 1040) * 4 <= 64 * 1024, "teo_gemv: K=%d too large for LDS staging", K);
+    TEO_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (norm_w == nullptr || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0),
+                  "teo_gemv: x / norm_w must be 16-byte aligned");
+    if (swiglu) TEO_CHECK_ARG(N % 32 == 0 && !res, "teo_gemv: SWIGLU16 needs N %% 32 == 0 and no residual");
+    if (w_fp8) {
+        TEO_CHECK_ARG(dtype == TEO_BF16 && wscale != nullptr, "teo_gemv: fp8 weights need bf16 activations and per-row scales");
+        if (out_dtype == TEO_F32) return gemv_launch<bf16_t, float, fp8_t>(x, W, wscale, norm_w, res, y, N, K, eps, swiglu, st);
+        return gemv_launch<bf16_t, bf16_t, fp8_t>(x, W, wscale, norm_w, res, y, N, K, eps, swiglu, st);
+    }
+    if (dtype == TEO_F32) {
+        TEO_CHECK_ARG(out_dtype == TEO_F32, "teo_gemv: f32 inputs need f32 output");
+        return gemv_launch<float, float, float>(x, W, nullptr, norm_w, res, y, N, K, eps, swiglu, st);
+    }
+    if (dtype == TEO_BF16) {
+        if (out_dtype == TEO_F32) return gemv_launch<bf16_t, float, bf16_t>(x, W, nullptr, norm_w, res, y, N, K, eps, swiglu, st);
+        return gemv_launch<bf16_t, bf16_t, bf16_t>(x, W, nullptr, norm_w, res, y, N, K, eps, swiglu, st);
+    }
+    set_error("teo_gemv: unknown dtype %d", dtype);
+    return TEO_ERR_UNSUPPORTED;
 }
 
 int gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
          unsigned flags, int dtype, int out_dtype, hipStream_t st) {
-    if (N == 0) return TEO_OK;
-    const bool swiglu = flags & TEO_GEMM_SWIGLU16;
-    const int ve = dtype == TEO_F32 ? 4 : 8;
-    TEO_CHECK_ARG(K % ve == 0, "teo_gemv: K=%d must be a multiple of %d", K, ve);
-    TEO_CHECK_ARG((reinterpret_cast<uintptr_t>(W) & 15) == 0, "teo_gemv: W must be 16-byte aligned");
-    TEO_CHECK_ARG((size_t)(K + 16) * 4 <= 64 * 1024, "teo_gemv: K=%d too large for LDS staging", K);
-    TEO_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (norm_w == nullptr || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0), "teo_gemv: x / norm_w must be 16-byte aligned");
-    if (swiglu) TEO_CHECK_ARG(N % 32 == 0 && !res, "teo_gemv: SWIGLU16 needs N %% 32 == 0 and no residual");
-    if (dtype == TEO_F32) {
-        TEO_CHECK_ARG(out_dtype == TEO_F32, "teo_gemv: f32 inputs need f32 output");
-        return gemv_launch<float, float>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
-    }
-    if (dtype == TEO_BF16) {
-        if (out_dtype == TEO_F32) return gemv_launch<bf16_t, float>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
-        if (g_tune.variant >= 0) return gemv_launch_variant(g_tune.variant, x, W, norm_w, res, y, N, K, eps, swiglu, st);
-        return gemv_launch<bf16_t, bf16_t>(x, W, norm_w, res, y, N, K, eps, swiglu, st);
-    }
-    set_error("teo_gemv: unknown dtype %d", dtype);
-    return TEO_ERR_UNSUPPORTED;
+    return gemv_w(x, W, nullptr, 0, norm_w, res, y, N, K, eps, flags, dtype, out_dtype, st);
+}
+
+int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,
+                  const float* cs, const float* sn, const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk,
+                  int hd, int K, float eps, int dtype, hipStream_t st) {
+    const int ve = w_fp8 ? 16 : (dtype == TEO_F32 ? 4 : 8);
+    TEO_CHECK_ARG(K % ve == 0 && hd % 2 == 0, "gemv_qkv_rope: K=%d hd=%d", K, hd);
+    TEO_CHECK_ARG((size_t)(K + 1040) * 4 <= 64 * 1024, "gemv_qkv_rope: K=%d too large for LDS staging", K);
+    TEO_CHECK_ARG(!w_fp8 || (dtype == TEO_BF16 && wscale), "gemv_qkv_rope: fp8 weights need bf16 activations and scales");
+    const int ngroups = (H + Hk) * (hd / 2) + Hk * hd / 2;
+    int blocks = cdiv(ngroups, GV_WAVES);
+    if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
+    const size_t lds = w_fp8 ? xs_lds_bytes<16>(K) : (dtype == TEO_F32 ? xs_lds_bytes<4>(K) : xs_lds_bytes<8>(K));
+    const int uu = w_fp8 ? 2 : 4;
+    const bool pf = K / ve >= 64 * uu;
+#define TEO_QR(TT, WW, NTV)                                                                                             \
+    if (pf) gemv_qkv_rope_kernel<TT, WW, NTV, true, (sizeof(WW) == 1 ? 2 : 4)><<<blocks, GV_THREADS, lds, st>>>((const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+                                                                       (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
+                                                                       S_max, H, Hk, hd, K, eps);                            \
+    else gemv_qkv_rope_kernel<TT, WW, NTV, false, (sizeof(WW) == 1 ? 2 : 4)><<<blocks, GV_THREADS, lds, st>>>((const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+                                                                       (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
+                                                                       S_max, H, Hk, hd, K, eps)
+    if (w_fp8)                 { if (g_tune.nt) { TEO_QR(bf16_t, fp8_t, true); } else { TEO_QR(bf16_t, fp8_t, false); } }
+    else if (dtype == TEO_F32) { if (g_tune.nt) { TEO_QR(float, float, true); } else { TEO_QR(float, float, false); } }
+    else                       { if (g_tune.nt) { TEO_QR(bf16_t, bf16_t, true); } else { TEO_QR(bf16_t, bf16_t, false); } }
+#undef TEO_QR
+    TEO_LAUNCH_CHECK("gemv_qkv_rope");
+    return TEO_OK;
 }
 
 }  // namespace teo

@@ -46,9 +46,11 @@ int gemv(const void* x, const void* W, const void* norm_w, const void* res, void
 int gemv_tune_set(const char* key, int value);
 int gemm_tune_set(const char* key, int value);
 int attn_tune_set(const char* key, int value);
-int gemv_qkv_rope(const void* x, const void* W, const void* norm_w, void* qout, const float* cs, const float* sn,
-                  const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk, int hd, int K, float eps,
-                  int dtype, hipStream_t st);
+int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,
+                  const float* cs, const float* sn, const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk,
+                  int hd, int K, float eps, int dtype, hipStream_t st);
+int gemv_w(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, const void* res, void* y, int N,
+           int K, float eps, unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
 inline size_t esize(int dtype) { return dtype == TEO_F32 ? 4 : 2; }
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }

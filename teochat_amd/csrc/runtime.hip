@@ -233,17 +233,26 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
     const int QKV = (H + 2 * Hk) * hd;
     // w.h holds the embedding of *s->d_token: written by the previous step's tail (or by teo_llama_decode_begin)
+    const bool w8 = d->qkv_w8 != nullptr;              // decode streams the fp8 copies when they are present
     for (int l = 0; l < d->layers; ++l) {
         // rmsnorm -> QKV projection -> RoPE -> KV append, one launch (position read from s->d_pos on the device)
-        TEO_TRY(gemv_qkv_rope(w.h, d->qkv_w[l], d->in_norm_w[l], w.qkv, d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l],
-                              d->v_cache[l], d->vt_cache[l], d->max_seq, H, Hk, hd, D, d->eps, dt, st));
+        TEO_TRY(gemv_qkv_rope(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.qkv,
+                              d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->max_seq, H,
+                              Hk, hd, D, d->eps, dt, st));
         TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], w.attn, w.part, s->d_pos, d->max_seq, H, Hk, hd,
                             1.0f / sqrtf((float)hd), dt, st));
-        TEO_TRY(gemv(w.attn, d->o_w[l], nullptr, w.h, w.h, D, H * hd, d->eps, 0, dt, dt, st));
-        TEO_TRY(gemv(w.h, d->gateup_w[l], d->post_norm_w[l], nullptr, w.act, 2 * F, D, d->eps, TEO_GEMM_SWIGLU16, dt, dt, st));
-        TEO_TRY(gemv(w.act, d->down_w[l], nullptr, w.h, w.h, D, F, d->eps, 0, dt, dt, st));
+        TEO_TRY(gemv_w(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps,
+                       0, dt, dt, st));
+        TEO_TRY(gemv_w(w.h, w8 ? d->gateup_w8[l] : d->gateup_w[l], w8 ? d->gateup_s[l] : nullptr, w8, d->post_norm_w[l], nullptr,
+                       w.act, 2 * F, D, d->eps, TEO_GEMM_SWIGLU16, dt, dt, st));
+        TEO_TRY(gemv_w(w.act, w8 ? d->down_w8[l] : d->down_w[l], w8 ? d->down_s[l] : nullptr, w8, nullptr, w.h, w.h, D, F, d->eps,
+                       0, dt, dt, st));
     }
-    TEO_TRY(gemv(w.h, d->lm_head, d->final_norm_w, nullptr, s->d_logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
+    {
+        const bool h8 = d->lm_head8 != nullptr;
+        TEO_TRY(gemv_w(w.h, h8 ? d->lm_head8 : d->lm_head, h8 ? d->lm_head_s : nullptr, h8, d->final_norm_w, nullptr,
+                       s->d_logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
+    }
     // argmax -> append/advance/stop test -> embedding row of the next token into w.h, one launch
     return decode_tail(s->d_logits, s, d->embed, w.h, d->vocab, D, dt, st);
 }

@@ -42,6 +42,19 @@ def interleave_gate_up(gate, up):
     return torch.stack((gate.view(F_ // 16, 16, D), up.view(F_ // 16, 16, D)), dim=1).reshape(2 * F_, D).contiguous()
 
 
+def quantize_fp8_rows(w):
+    """Per-output-row fp8 (OCP e4m3fn) quantisation with POWER-OF-TWO scales: W ~= q * s[:, None].
+
+    Returns (q uint8 [N,K], s fp32 [N], dq = q*s in w's dtype).  With power-of-two scales q*s is exactly representable
+    in bf16 (e4m3 has 3 mantissa bits), so a bf16 GEMM on dq and an fp8 GEMV on (q, s) see the same weights."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-30)
+    s = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+    q = (wf / s[:, None]).to(torch.float8_e4m3fn)
+    dq = (q.float() * s[:, None]).to(w.dtype)
+    return q.view(torch.uint8).contiguous(), s.contiguous(), dq.contiguous()
+
+
 def rope_tables(head_dim, theta, max_pos):
     """cos/sin [max_pos, hd/2] fp32; inv_freq and pos*inv_freq in fp32 on the host (tf LlamaRotaryEmbedding)."""
     inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
@@ -50,7 +63,7 @@ def rope_tables(head_dim, theta, max_pos):
 
 
 class TeoEngine:
-    def __init__(self, state_dict, config, dtype=torch.bfloat16, device="cuda:0", max_seq=None):
+    def __init__(self, state_dict, config, dtype=torch.bfloat16, device="cuda:0", max_seq=None, weight_format=None):
         self.lib = L.load()                       # raises TeoLibraryError when the HIP library is missing
         if not torch.cuda.is_available():
             raise RuntimeError("TeoEngine needs an MI355X (no CPU fallback exists for the product path)")
@@ -61,6 +74,11 @@ class TeoEngine:
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.max_seq = int(math.ceil((max_seq or config.max_position_embeddings) / 64.0) * 64)
+        self.weight_format = weight_format or "native"          # "fp8": decode streams fp8-e4m3 copies (config C5)
+        if self.weight_format not in ("native", "fp8"):
+            raise ValueError(f"unknown weight_format {weight_format!r}")
+        if self.weight_format == "fp8" and dtype != torch.bfloat16:
+            raise ValueError("weight_format='fp8' needs dtype=torch.bfloat16")
         self._keep = []                           # host pointer arrays referenced by the descriptors
         self._ws = {}
         self._graph = None
@@ -172,6 +190,21 @@ class TeoEngine:
             per["gateup"].append(self._dev(interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"])))
             per["down"].append(self._dev(sd[p + "mlp.down_proj.weight"]))
         self.llama_w = per
+        self.llama_w8 = None
+        if self.weight_format == "fp8":
+            # quantise the (already fused / interleaved) Linear weights row-wise; prefill keeps using the bf16 tensors,
+            # which are replaced by the exactly-dequantised values so both paths see identical weights
+            w8 = {k: [] for k in ("qkv", "o", "gateup", "down")}
+            s8 = {k: [] for k in ("qkv", "o", "gateup", "down")}
+            for k in w8:
+                for i in range(c.num_hidden_layers):
+                    q, s, dq = quantize_fp8_rows(per[k][i])
+                    per[k][i] = dq
+                    w8[k].append(q)
+                    s8[k].append(s)
+            q, s, dq = quantize_fp8_rows(self.lm_head)
+            self.lm_head, self.lm_head8, self.lm_head_s = dq, q, s
+            self.llama_w8 = (w8, s8)
 
     def _alloc_cache(self):
         c = self.cfg
@@ -195,6 +228,13 @@ class TeoEngine:
         d.k_cache = self._arr([self.k_cache[i] for i in range(Lr)])
         d.v_cache = self._arr([self.v_cache[i] for i in range(Lr)])
         d.vt_cache = self._arr([self.vt_cache[i] for i in range(Lr)])
+        if self.llama_w8 is not None:
+            w8, s8 = self.llama_w8
+            d.qkv_w8, d.qkv_s = self._arr(w8["qkv"]), self._arr(s8["qkv"])
+            d.o_w8, d.o_s = self._arr(w8["o"]), self._arr(s8["o"])
+            d.gateup_w8, d.gateup_s = self._arr(w8["gateup"]), self._arr(s8["gateup"])
+            d.down_w8, d.down_s = self._arr(w8["down"]), self._arr(s8["down"])
+            d.lm_head8, d.lm_head_s = self.lm_head8.data_ptr(), self.lm_head_s.data_ptr()
         self.llama_desc = d
 
     def _alloc_decode_state(self, max_new=4096):

@@ -439,3 +439,38 @@ def test_sampler_ties_and_small_vocab():
     assert min(s) >= 0 and max(s) < 300 and len(s) > 20
     lg2 = torch.tensor([0.0, 5.0, -1.0]).cuda()
     assert _sample(lg2, 0.05, 0, 1, 0) == 1                    # top_k = 0 disables the filter
+
+
+# ---------------------------------------------------------------------------------------------- fp8 weights (config C5)
+@pytest.mark.parametrize("N,K,norm,swiglu", [(12288, 4096, True, False), (4096, 11008, False, False), (22016, 4096, True, True),
+                                             (4096, 4096, False, False), (32000, 4096, True, False), (64, 48, False, False)])
+def test_gemv_fp8_weights(N, K, norm, swiglu):
+    """fp8-e4m3 weights with power-of-two row scales: the GEMV must equal the bf16 GEMV on the dequantised weights
+    (which are exactly representable in bf16) up to fp32 summation order."""
+    from teochat_amd.engine import quantize_fp8_rows
+    bf = torch.bfloat16
+    W = G.bf16_round(rnd(N, K, seed=2, scale=0.02))
+    q, s, dq = quantize_fp8_rows(W.to(bf))
+    assert torch.equal(dq.float(), q.view(torch.float8_e4m3fn).float() * s[:, None])          # exact in bf16
+    assert float((dq.float() - W).abs().max()) <= 0.07 * float(W.abs().max())                # e4m3: 3 mantissa bits
+    x = G.bf16_round(rnd(K, seed=1))
+    nw = G.bf16_round(1 + 0.1 * rnd(K, seed=4)) if norm else None
+    res = None if (swiglu or norm) else G.bf16_round(rnd(N, seed=3))
+    flags = L.GEMM_SWIGLU16 if swiglu else 0
+    dx, dq_d, q_d, s_d = G.dev(x, bf), dq.cuda(), q.cuda(), s.cuda()
+    dn = G.dev(nw, bf) if norm else None
+    dr = G.dev(res, bf) if res is not None else None
+    Ny = N // 2 if swiglu else N
+    y8 = torch.empty(Ny, dtype=torch.float32, device="cuda")
+    L.check(G.lib().teo_gemv_w8(G.p(dx), G.p(q_d), G.p(s_d), G.p(dn), G.p(dr), G.p(y8), N, K, 1e-5, flags, L.TEO_F32, G.stream()), "gemv_w8")
+    y16 = G.gemv(dx, dq_d, norm_w=dn, res=dr, flags=flags, out_dtype=torch.float32)
+    torch.testing.assert_close(y8, y16, atol=2e-4, rtol=1e-4)
+    xn = G.bf16_round(O.rmsnorm(x, nw, 1e-5)) if norm else x
+    ref = dq.float() @ xn
+    if swiglu:
+        idx = torch.arange(N // 2)
+        g_rows = (idx // 16) * 32 + idx % 16
+        ref = F.silu(ref[g_rows]) * ref[g_rows + 16]
+    if res is not None:
+        ref = ref + res
+    torch.testing.assert_close(y8.cpu(), ref, atol=3e-4, rtol=2e-4)

@@ -238,3 +238,40 @@ def test_causality_and_determinism_property():
     ids2[0, -1] = 17
     c = model(input_ids=ids2.to(dev), images=imgs).logits
     assert torch.equal(a[0, :-1], c[0, :-1]) and not torch.equal(a[0, -1], c[0, -1])
+
+
+def test_fp8_weight_path_matches_oracle_on_dequantised_weights():
+    """Config C5 weight path: decode streams fp8 weights, prefill the exactly-dequantised bf16 copies.  The oracle runs on
+    the same dequantised weights; greedy tokens must agree and the decode-step logits must be close."""
+    from teochat_amd.config import LlavaConfig, VisionConfig
+    from teochat_amd.engine import TeoEngine, quantize_fp8_rows
+    from teochat_amd.model import LlavaLlamaForCausalLM
+    name = "tinyB"
+    g = TY.load_npz(name)
+    t = TY.TINY[name]
+    cfg = LlavaConfig(**t["llm"], mm_hidden_size=t["vit"]["hidden_size"], max_position_embeddings=1024,
+                      vision_config=VisionConfig(**t["vit"]))
+    sd = TY.state_dict(name)
+    eng = TeoEngine(sd, cfg, dtype=torch.bfloat16, device="cuda:0", max_seq=1024, weight_format="fp8")
+    model = LlavaLlamaForCausalLM(cfg, eng)
+    # the oracle's weights: bf16-rounded everywhere, LLaMA Linear weights + lm_head replaced by their fp8 dequantisation
+    sd16 = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    for k in list(sd16):
+        if k == "lm_head.weight" or (k.startswith("model.layers.") and k.endswith("_proj.weight")):
+            sd16[k] = quantize_fp8_rows(sd16[k].to(torch.bfloat16))[2].float()
+    frames, ids = inputs(name, g)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    imgs = [f.to("cuda:0", dtype=torch.bfloat16) for f in frames]
+    toks, step_logits, _ = O.greedy_generate(ids, frames, sd16, vcfg, lcfg, mm, max_new_tokens=6, rounding="bf16")
+    gen = model.generate(input_ids=ids.cuda(), images=imgs, do_sample=False, max_new_tokens=6, eos_token_id=None)
+    mine = gen[0, ids.shape[1]:].tolist()
+    scale = float(step_logits.abs().max())
+    rel = float((eng.d_logits.cpu() - step_logits[-1]).abs().max()) / scale if mine == toks else None
+    print(f"fp8 path greedy {mine} oracle {toks} last-step logits rel diff {rel}")
+    for i, (a, b) in enumerate(zip(mine, toks)):
+        if a != b:
+            top2 = step_logits[i].topk(2).values
+            assert float(top2[0] - top2[1]) < 4e-2 * scale, (i, mine, toks)
+            break
+    if rel is not None:
+        assert rel < 3e-2

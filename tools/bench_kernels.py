@@ -40,10 +40,38 @@ def bench_gemv():
         y = torch.empty(N, dtype=bf, device="cuda")
         arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
         avg = C.c_float(0)
-        L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
+        L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, None, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
                                         flags, L.TEO_BF16, 10, C.byref(avg), G.stream()), "chain")
         us = avg.value * 1e3
         print(f"gemv {name:8s} N={N:6d} K={K:6d}: {us:7.2f} us  {N * K * 2 / us / 1e3:7.1f} GB/s", flush=True)
+        del Ws
+
+
+def bench_gemv_fp8_sweep():
+    for v in (10, 11, 12, 13):
+        lib.teo_tune_set(b"gemv_variant", v)
+        print("fp8 variant", v, flush=True)
+        bench_gemv_fp8()
+    lib.teo_tune_set(b"gemv_variant", -1)
+
+
+def bench_gemv_fp8():
+    shapes = [("qkv", 12288, 4096, True, 0), ("o", 4096, 4096, False, 0), ("gateup", 22016, 4096, True, L.GEMM_SWIGLU16),
+              ("down", 4096, 11008, False, 0), ("lm_head", 32000, 4096, True, 0)]
+    for name, N, K, norm, flags in shapes:
+        n = max(2, int(600e6 // (N * K)))
+        Ws = [torch.randint(0, 120, (N, K), dtype=torch.uint8, device="cuda") for _ in range(n)]
+        Ss = [torch.full((N,), 2.0 ** -9, device="cuda") for _ in range(n)]
+        x = torch.randn(K, device="cuda").to(bf)
+        nw = torch.ones(K, device="cuda").to(bf) if norm else None
+        y = torch.empty(N, dtype=bf, device="cuda")
+        arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
+        arr2, pp2 = L.ptr_array([s_.data_ptr() for s_ in Ss])
+        avg = C.c_float(0)
+        L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, pp2, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
+                                        flags, L.TEO_BF16, 10, C.byref(avg), G.stream()), "chain")
+        us = avg.value * 1e3
+        print(f"gemv fp8 {name:8s} N={N:6d} K={K:6d}: {us:7.2f} us  {N * K / us / 1e3:7.1f} GB/s", flush=True)
         del Ws
 
 
@@ -69,7 +97,7 @@ def bench_gemv_sweep():
                     y = torch.empty(N, dtype=bf, device="cuda")
                     arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
                     avg = C.c_float(0)
-                    L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, len(Ws), nw.data_ptr() if norm else None, y.data_ptr(),
+                    L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, None, len(Ws), nw.data_ptr() if norm else None, y.data_ptr(),
                                                     N, K, 1e-5, flags, L.TEO_BF16, 5, C.byref(avg), G.stream()), "chain")
                     us = avg.value * 1e3
                     tot += us
@@ -133,5 +161,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
