@@ -273,8 +273,12 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // over its keys, lanes of different rows are summed with two xor-shuffles at the end.  No MFMA: 1 query row.
 // ------------------------------------------------------------------------------------------------
 static int g_dec_chunk = 128;     // keys per workgroup (tunable: 64 / 128 / 256)
+int g_rope_in_attn = -1;          // decode RoPE + KV append: 0 = in the QKV GEMV epilogue, 1 = inside the attention kernel,
+                                   // -1 = auto (measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0,
+                                   // fp8 weights 2.216 vs 2.234 in favour of 1)
 int attn_tune_set(const char* key, int value) {
     if (!strcmp(key, "attn_chunk") && (value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
+    if (!strcmp(key, "rope_in_attn") && (value >= -1 && value <= 1)) { g_rope_in_attn = value; return 0; }
     return -1;
 }
 
@@ -287,20 +291,30 @@ template <> struct Cvt16<bf16_t> {
         f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
         f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
     }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+    }
 };
 template <> struct Cvt16<float> {
     static constexpr int N = 4;
     __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
         f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
     }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
 };
 
 // q: [heads*hd] (already rotated), K/V cache [kv_heads][S_max][hd]; partial: [heads][nsplit][hd + 2] fp32 (m, l, o[hd])
-template <typename T, int LPR, int DEC_CHUNK>
-__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, const T* __restrict__ kc,
-                                                                  const T* __restrict__ vc, float* __restrict__ part,
-                                                                  const int* __restrict__ d_pos, int S_max, int heads,
-                                                                  int kv_heads, float scale, int nsplit) {
+// ROPE: `q` is the raw [q | k | v] row of the new token (GEMV output, not yet rotated).  The kernel rotates q on load,
+// and the one lane group that owns key `pos` rotates the new k, takes the new v, appends both to the caches (K, V, V^T)
+// and uses them directly -- RoPE + KV append cost no launch and no pass of their own.
+template <typename T, int LPR, int DEC_CHUNK, bool ROPE>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, T* __restrict__ kc,
+                                                                  T* __restrict__ vc, T* __restrict__ vtc,
+                                                                  const float* __restrict__ cs, const float* __restrict__ sn,
+                                                                  float* __restrict__ part, const int* __restrict__ d_pos,
+                                                                  int S_max, int heads, int kv_heads, float scale, int nsplit) {
     constexpr int VE = Cvt16<T>::N;
     constexpr int HD = LPR * VE;
     constexpr int RPI = 64 / LPR;                       // rows (keys) per wave-wide load instruction
@@ -335,7 +349,34 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
         vr[i] = *reinterpret_cast<const uint4*>(vb + (long long)j * HD);
     }
     float qf[VE];
-    {
+    float knew[VE], vnew[VE];
+    const int pos = kv_len - 1;
+    if (ROPE) {
+        // rotate-half RoPE on 16-byte chunks: this lane owns elements sub*VE..+VE of the head, its partner (sub ^ LPR/2)
+        // the matching elements of the other half; coefficient index = element index mod hd/2
+        constexpr int HL = LPR / 2;
+        const int psub = sub ^ HL, ci = (sub % HL) * VE;
+        const float sgn = (sub < HL) ? -1.f : 1.f;
+        float cf[VE], sf[VE];
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) {
+            const float4 c4 = *reinterpret_cast<const float4*>(cs + (long long)pos * (HD / 2) + ci + e);
+            const float4 s4 = *reinterpret_cast<const float4*>(sn + (long long)pos * (HD / 2) + ci + e);
+            cf[e] = c4.x; cf[e + 1] = c4.y; cf[e + 2] = c4.z; cf[e + 3] = c4.w;
+            sf[e] = s4.x; sf[e + 1] = s4.y; sf[e + 2] = s4.z; sf[e + 3] = s4.w;
+        }
+        float own[VE], oth[VE];
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(q + h * HD + sub * VE), own);
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(q + h * HD + psub * VE), oth);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) qf[e] = Elem<T>::round(own[e] * cf[e] + sgn * oth[e] * sf[e]);
+        const T* kraw = q + (long long)(heads + hk) * HD;
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(kraw + sub * VE), own);
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(kraw + psub * VE), oth);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) knew[e] = Elem<T>::round(own[e] * cf[e] + sgn * oth[e] * sf[e]);
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(q + (long long)(heads + kv_heads + hk) * HD + sub * VE), vnew);
+    } else {
         const uint4 qraw = *reinterpret_cast<const uint4*>(q + h * HD + sub * VE);
         Cvt16<T>::cvt(qraw, qf);
     }
@@ -344,12 +385,26 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     for (int i = 0; i < NI; ++i) {
         float kf[VE];
         Cvt16<T>::cvt(kr[i], kf);
+        const int j = kw0 + i * RPI + grp;
+        if (ROPE && j == pos) {                         // the new token's key: not in the cache yet
+#pragma unroll
+            for (int e = 0; e < VE; ++e) kf[e] = knew[e];
+            if (h % (heads / kv_heads) == 0) {          // one q head per kv head appends
+                *reinterpret_cast<uint4*>(kc + ((long long)hk * S_max + pos) * HD + sub * VE) = Cvt16<T>::pack(knew);
+                *reinterpret_cast<uint4*>(vc + ((long long)hk * S_max + pos) * HD + sub * VE) = Cvt16<T>::pack(vnew);
+                if (vtc) {
+                    const uint4 pv = Cvt16<T>::pack(vnew);
+                    const T* pe = reinterpret_cast<const T*>(&pv);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) vtc[((long long)hk * HD + sub * VE + e) * S_max + pos] = pe[e];
+                }
+            }
+        }
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < VE; ++e) s = fmaf(qf[e], kf[e], s);
 #pragma unroll
         for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const int j = kw0 + i * RPI + grp;
         if (sub == 0) sc[j - c0] = (j < kv_len) ? s * scale : -INFINITY;
     }
     __syncthreads();
@@ -379,6 +434,10 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
         const float p = sc[wid * KPW + i * RPI + grp];           // 0 for keys >= kv_len
         float vf[VE];
         Cvt16<T>::cvt(vr[i], vf);
+        if (ROPE && kw0 + i * RPI + grp == pos) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) vf[e] = vnew[e];
+        }
 #pragma unroll
         for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
     }
@@ -442,23 +501,29 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max) {
 }
 
 template <typename T, int LPR>
-static void attn_decode_launch(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos,
-                               int S_max, int heads, int kv_heads, int hd, float scale, int nsplit, int chunk, hipStream_t st) {
+static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o,
+                               float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale,
+                               int nsplit, int chunk, bool rope, hipStream_t st) {
     dim3 grid(heads, nsplit);
-#define TEO_PART(CH)                                                                                                  \
-    attn_decode_partial_kernel<T, LPR, CH><<<grid, 256, 0, st>>>((const T*)q, (const T*)kc, (const T*)vc, part, d_pos, S_max, \
-                                                                 heads, kv_heads, scale, nsplit)
+#define TEO_PART(CH, RP)                                                                                              \
+    attn_decode_partial_kernel<T, LPR, CH, RP><<<grid, 256, 0, st>>>((const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
+                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit)
+#define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
     if constexpr (64 / 4 >= 64 / LPR) {
-        if (chunk == 64) { TEO_PART(64); } else if (chunk == 256) { TEO_PART(256); } else { TEO_PART(128); }
+        if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
     } else {
-        if (chunk == 256) { TEO_PART(256); } else { TEO_PART(128); }
+        if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
     }
+#undef TEO_PART_R
 #undef TEO_PART
     attn_decode_combine_kernel<T><<<heads, 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk);
 }
 
-int attn_decode(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos, int S_max,
-                int heads, int kv_heads, int hd, float scale, int dtype, hipStream_t st) {
+// rope_cos != NULL: q is the raw qkv row; RoPE and the KV append of the new token happen inside the kernel
+int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
+                float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
+                hipStream_t st) {
+    const bool rope = rope_cos != nullptr;
     int chunk = g_dec_chunk;
     const int esz = dtype == TEO_F32 ? 4 : 2;
     const int lpr = hd * esz / 16;
@@ -470,7 +535,7 @@ int attn_decode(const void* q, const void* kc, const void* vc, void* o, float* p
         set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
         return TEO_ERR_UNSUPPORTED;
     }
-#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, st)
+#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, st)
     if (dtype == TEO_F32) {
         switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
                        case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }

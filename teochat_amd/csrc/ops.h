@@ -21,8 +21,9 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
 
 int attention(const teo_attn_args* a, int dtype, hipStream_t st);
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max);
-int attn_decode(const void* q, const void* kc, const void* vc, void* o, float* part, const int* d_pos, int S_max,
-                int heads, int kv_heads, int hd, float scale, int dtype, hipStream_t st);
+int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
+                float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
+                hipStream_t st);
 
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                    void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,

@@ -6,6 +6,7 @@
 #include "ops.h"
 
 namespace teo {
+extern int g_rope_in_attn;
 
 struct Carver {
     unsigned char* base;
@@ -235,12 +236,21 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     // w.h holds the embedding of *s->d_token: written by the previous step's tail (or by teo_llama_decode_begin)
     const bool w8 = d->qkv_w8 != nullptr;              // decode streams the fp8 copies when they are present
     for (int l = 0; l < d->layers; ++l) {
-        // rmsnorm -> QKV projection -> RoPE -> KV append, one launch (position read from s->d_pos on the device)
-        TEO_TRY(gemv_qkv_rope(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.qkv,
-                              d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->max_seq, H,
-                              Hk, hd, D, d->eps, dt, st));
-        TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], w.attn, w.part, s->d_pos, d->max_seq, H, Hk, hd,
-                            1.0f / sqrtf((float)hd), dt, st));
+        if (g_rope_in_attn < 0 ? w8 : g_rope_in_attn != 0) {
+            // rmsnorm + QKV projection (plain weight stream); RoPE + KV append ride inside the attention kernel
+            // (position read from s->d_pos on the device)
+            TEO_TRY(gemv_w(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], nullptr,
+                           w.qkv, QKV, D, d->eps, 0, dt, dt, st));
+            TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
+                                s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
+        } else {
+            // rmsnorm -> QKV projection -> RoPE -> KV append in the GEMV epilogue
+            TEO_TRY(gemv_qkv_rope(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.qkv,
+                                  d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->max_seq,
+                                  H, Hk, hd, D, d->eps, dt, st));
+            TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], nullptr, nullptr, nullptr, w.attn, w.part, s->d_pos,
+                                d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
+        }
         TEO_TRY(gemv_w(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps,
                        0, dt, dt, st));
         TEO_TRY(gemv_w(w.h, w8 ? d->gateup_w8[l] : d->gateup_w[l], w8 ? d->gateup_s[l] : nullptr, w8, d->post_norm_w[l], nullptr,

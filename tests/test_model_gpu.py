@@ -95,6 +95,51 @@ def test_fp32_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+@pytest.mark.parametrize("placement", [0, 1])
+def test_decode_rope_placements_match_reference_golden(name, placement):
+    """Both decode RoPE/KV-append placements (QKV-GEMV epilogue, decode-attention kernel) reproduce the reference's
+    greedy tokens, KV snapshots and last-step logits (fp32), eager and through the hipGraph."""
+    from teochat_amd import _lib as L
+    lib = L.load()
+    g = TY.load_npz(name)
+    model, _ = build(name, torch.float32)
+    frames, ids = inputs(name, g)
+    dev = model.device
+    imgs = [f.to(dev) for f in frames]
+    assert lib.teo_tune_set(b"rope_in_attn", placement) == 0
+    try:
+        n_new = len(g["greedy_tokens"])
+        gen = model.generate(input_ids=ids.to(dev), images=imgs, do_sample=False, max_new_tokens=n_new, eos_token_id=None)
+        assert gen[0, ids.shape[1]:].tolist() == g["greedy_tokens"].tolist()
+        eng = model.engine
+        ks = torch.from_numpy(g["kv_sel"])
+
+        def check_state():
+            np.testing.assert_allclose(eng.k_cache[0][:, ks].cpu().numpy(), g["k_layer0"], atol=FP32_TOL)
+            np.testing.assert_allclose(eng.v_cache[0][:, ks].cpu().numpy(), g["v_layer0"], atol=FP32_TOL)
+            np.testing.assert_allclose(eng.k_cache[-1][:, ks].cpu().numpy(), g["k_last"], atol=FP32_TOL)
+            np.testing.assert_allclose(eng.vt_cache[-1][:, :, ks].transpose(1, 2).cpu().numpy(), g["v_last"], atol=FP32_TOL)
+            assert float((eng.d_logits.cpu() - torch.from_numpy(g["greedy_logits"][-1])).abs().max()) < FP32_TOL
+
+        check_state()
+        lg_graph = eng.d_logits.clone()
+        # the same steps launched eagerly (no hipGraph)
+        (_, _, _, _, emb, _) = model.prepare_inputs_labels_for_multimodal(ids.to(dev), None, None, None, None, imgs)
+        eng.reset_cache()
+        for caches in (eng.k_cache, eng.v_cache, eng.vt_cache):
+            for c in caches:
+                c.zero_()
+        first = int(eng.prefill(emb[0], last_only=True)[0].argmax())
+        eng.decode_begin(first)
+        eng.decode_steps(n_new - 1, use_graph=False)
+        assert [first] + eng.generated().tolist() == g["greedy_tokens"].tolist()
+        check_state()
+        assert torch.equal(lg_graph, eng.d_logits)
+    finally:
+        lib.teo_tune_set(b"rope_in_attn", -1)
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
 def test_forward_api_decode_steps_match_generate(name):
     """Manual loop around forward() with the returned past_key_values (what HF generate does) == generate()."""
     g = TY.load_npz(name)

@@ -47,6 +47,28 @@ def bench_gemv():
         del Ws
 
 
+def bench_gemv_mall():
+    """Infinity-Cache probe: the same weight matrix re-read every launch (resident if it fits 256 MiB) vs a >600 MB rotation."""
+    shapes = [("o", 4096, 4096, False, 0), ("qkv", 12288, 4096, True, 0), ("gateup", 22016, 4096, True, L.GEMM_SWIGLU16)]
+    for nt in (1, 0):
+        lib.teo_tune_set(b"gemv_nt", nt)
+        for name, N, K, norm, flags in shapes:
+            nrot = max(2, int(600e6 // (N * K * 2)))
+            Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(nrot)]
+            x = torch.randn(K, device="cuda").to(bf)
+            nw = torch.ones(K, device="cuda").to(bf) if norm else None
+            y = torch.empty(N, dtype=bf, device="cuda")
+            for n in (1, nrot):
+                arr, pp = L.ptr_array([w.data_ptr() for w in Ws[:n]])
+                avg = C.c_float(0)
+                L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, None, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K,
+                                                1e-5, flags, L.TEO_BF16, 20, C.byref(avg), G.stream()), "chain")
+                us = avg.value * 1e3
+                print(f"mall nt={nt} {name:7s} rot={n:2d} ({N * K * 2 / 1e6:6.1f} MB): {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s", flush=True)
+            del Ws
+    lib.teo_tune_set(b"gemv_nt", 1)
+
+
 def bench_gemv_fp8_sweep():
     for v in (10, 11, 12, 13):
         lib.teo_tune_set(b"gemv_variant", v)
@@ -82,9 +104,9 @@ def bench_gemv_sweep():
     for name, N, K, norm, flags in shapes:
         n = max(2, int(600e6 // (N * K * 2)))
         bufs[name] = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
-    for maxb in (768, 1024, 1376, 1536, 2048, 2752, 3072, 4096):
+    for maxb in (512, 768, 1024, 1376, 1536, 2048, 2752, 3072):
         for nt in (1,):
-            for v in (4, 11):
+            for v in (-1,):
                 lib.teo_tune_set(b"gemv_variant", v)
                 lib.teo_tune_set(b"gemv_nt", nt)
                 lib.teo_tune_set(b"gemv_max_blocks", maxb)
@@ -161,5 +183,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
