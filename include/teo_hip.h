@@ -43,6 +43,7 @@ typedef enum {
 /* GEMM epilogue flags (teo_gemm `flags`) */
 #define TEO_GEMM_SWIGLU16 1u /* W rows are [gate16|up16] interleaved; C[M, N/2] = silu(g) * u */
 #define TEO_GEMM_FORCE_SIMPLE 2u /* use the shape-agnostic VALU kernel even when the MFMA kernel applies */
+#define TEO_GEMM_WTILED 4u /* teo_gemm_skinny: W is stored as 1 KB operand tiles (16 rows x 32 k bf16 / 64 k fp8), see below */
 
 int teo_version(void);
 const char* teo_last_error(void);
@@ -159,6 +160,18 @@ int teo_gemv(const void* d_x, const void* d_W, const void* d_norm_w, const void*
 int teo_gemv_w8(const void* d_x, const void* d_W8, const float* d_w_scale, const void* d_norm_w, const void* d_residual,
                 void* d_y, int N, int K, float eps, unsigned flags, int out_dtype, teo_stream_t stream);
 
+/* Batched-decode GEMM: out[b, n] = sum_k x[b, k] * W[n, k] (+ residual[b, n]) for MB <= 16 conversations; the weights
+ * are streamed once for the whole batch (HF generate with batch > 1 through LlamaForCausalLM.forward,
+ * videollava/model/language_model/llava_llama.py:88-99).  bf16 activations x [MB, ldx]; W bf16 [N, K] or fp8 e4m3
+ * (w_fp8 = 1) with w_scale [N]; out bf16 / f32 [MB, ldo]; TEO_GEMM_SWIGLU16 as in teo_gemm (out [MB, N/2]).
+ * K % 32 == 0 (64 for fp8); returns TEO_ERR_UNSUPPORTED otherwise.
+ * TEO_GEMM_WTILED: W holds ceil(N/16) * (K/KS) tiles of 1 KB (KS = 32 k for bf16, 64 k for fp8; rows past N zero);
+ * tile (n/16, k/KS) starts at ((n/16) * (K/KS) + k/KS) KB and element (n, k) sits in it at 16-byte lane
+ * ((k % KS) / CH) * 16 + n % 16, position k % CH (CH = 8 bf16 / 16 fp8 per lane) -- the v_mfma_f32_16x16x32_bf16
+ * operand order, so every wave load is 1 KB contiguous. */
+int teo_gemm_skinny(const void* d_x, const void* d_W, const float* d_w_scale, int w_fp8, const void* d_residual, void* d_out,
+                    int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, teo_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Composed runtime entry points (the layer loops live in C++, not Python)
  * ------------------------------------------------------------------------------------------- */
@@ -271,11 +284,46 @@ int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_stat
 int teo_graph_launch(teo_graph* g, int n_times, teo_stream_t stream);
 int teo_graph_destroy(teo_graph* g);
 
+/* ---- batched decode (config C5's B conversations per GPU; HF generate with batch > 1) -------------------------
+ * B <= TEO_MAX_DECODE_BATCH conversations advance one token per step.  Every weight matrix is streamed from HBM once
+ * per step (teo_gemm_skinny), each conversation attends over its own KV cache at its own position, and the tail
+ * (argmax / sampler, append, stop test, next embedding) runs per conversation.  The descriptor is the one used for
+ * prefill except that k_cache/v_cache/vt_cache[l] point at conversation 0 of a [B][...] allocation and
+ * `cache_stride` (elements) separates consecutive conversations; with w_tiled = 1 its weight matrices (qkv/o/gateup/
+ * down/lm_head, bf16 or fp8) are in the TEO_GEMM_WTILED layout.  Finished conversations keep stepping (their d_stop
+ * is set; the host truncates), exactly like the single-conversation loop. */
+#define TEO_MAX_DECODE_BATCH 16
+typedef struct {
+    int batch;                /* 1..TEO_MAX_DECODE_BATCH */
+    int out_stride;           /* d_out_tokens is [batch][out_stride] */
+    long long cache_stride;   /* elements between conversations in each layer's K, V and V^T cache */
+    int w_tiled;              /* 1: the descriptor's decode weight matrices are TEO_GEMM_WTILED */
+    long long* d_token;       /* [batch] */
+    int* d_pos;               /* [batch] */
+    long long* d_out_tokens;  /* [batch][out_stride] */
+    int* d_out_count;         /* [batch] */
+    int* d_stop;              /* [batch] */
+    const long long* d_stop_ids; int n_stop_ids; /* shared by the batch; may be NULL/0 */
+    float* d_logits;          /* [batch][vocab] */
+    int do_sample; int top_k; float temperature;
+    unsigned long long* d_rng; /* [batch][2] = {seed, draws so far} per conversation */
+} teo_decode_batch_state;
+size_t teo_llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch);
+int teo_llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace,
+                                 size_t workspace_bytes, teo_stream_t stream);
+int teo_llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace,
+                                size_t workspace_bytes, teo_stream_t stream);
+int teo_llama_decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace,
+                                        size_t workspace_bytes, teo_stream_t stream, teo_graph** out);
+
 /* Bench helper: run the decode gate/up GEMV (the dominant kernel by bytes) over n weight matrices
  * back to back between two HIP events on `stream`; returns the average milliseconds per launch. */
 int teo_time_gemv_chain(const void* d_x, const void* const* d_Ws, const float* const* d_scales, int n, const void* d_norm_w,
                         void* d_y, int N, int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out,
                         teo_stream_t stream);   /* d_scales != NULL: the matrices are fp8-e4m3 with per-row scales */
+/* The same for teo_gemm_skinny with MB activation rows (x [MB, K] bf16, y [MB, N or N/2] bf16). */
+int teo_time_skinny_chain(const void* d_x, const void* const* d_Ws, const float* const* d_scales, int n, void* d_y, int MB,
+                          int N, int K, unsigned flags, int reps, float* avg_ms_out, teo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libteo_hip.so")
 
 TEO_F32, TEO_BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
-GEMM_SWIGLU16, GEMM_FORCE_SIMPLE = 1, 2
+GEMM_SWIGLU16, GEMM_FORCE_SIMPLE, GEMM_WTILED = 1, 2, 4
 ATTN_FORCE_SIMPLE = 1
 INT32_MIN = -(2 ** 31)
 
@@ -73,6 +73,17 @@ class DecodeState(C.Structure):
                 ("do_sample", C.c_int), ("top_k", C.c_int), ("temperature", C.c_float), ("d_rng", C.c_void_p)]
 
 
+MAX_DECODE_BATCH = 16
+
+
+class DecodeBatchState(C.Structure):
+    _fields_ = [("batch", C.c_int), ("out_stride", C.c_int), ("cache_stride", C.c_longlong), ("w_tiled", C.c_int),
+                ("d_token", C.c_void_p), ("d_pos", C.c_void_p), ("d_out_tokens", C.c_void_p),
+                ("d_out_count", C.c_void_p), ("d_stop", C.c_void_p), ("d_stop_ids", C.c_void_p),
+                ("n_stop_ids", C.c_int), ("d_logits", C.c_void_p),
+                ("do_sample", C.c_int), ("top_k", C.c_int), ("temperature", C.c_float), ("d_rng", C.c_void_p)]
+
+
 _SIGS = {
     "teo_version": (C.c_int, []),
     "teo_last_error": (C.c_char_p, []),
@@ -104,8 +115,17 @@ _SIGS = {
     "teo_llama_decode_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t,
                                                 C.c_void_p, C.POINTER(C.c_void_p)]),
+    "teo_llama_decode_batch_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc), C.c_int]),
+    "teo_llama_decode_batch_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_decode_batch_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_decode_batch_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t,
+                                                      C.c_void_p, C.POINTER(C.c_void_p)]),
     "teo_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "teo_graph_destroy": (C.c_int, [C.c_void_p]),
+    "teo_gemm_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 5
+                        + [C.c_uint, C.c_int, C.c_void_p]),
+    "teo_time_skinny_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int,
+                                        C.POINTER(C.c_float), C.c_void_p]),
     "teo_time_gemv_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                       C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }

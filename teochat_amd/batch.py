@@ -1,0 +1,185 @@
+"""Batched decode: B conversations share one pass over the weights per generated token (config C5's batched variant).
+
+Reference behaviour being reproduced: `GenerationMixin.generate` over a batch of prompts through
+`LlavaLlamaForCausalLM.forward` (videollava/model/language_model/llava_llama.py:88-99) -- every conversation has its
+own KV cache and position, finished conversations keep being stepped and are cut at their stop token by the caller.
+
+`BatchDecoder` borrows the weights of a `TeoEngine` and owns
+  * KV caches [layers][B][Hkv][S][hd] (+ V^T), conversation b = slot b,
+  * per-slot descriptors for the (unchanged, one conversation at a time) prefill kernels,
+  * a copy of the decode weight matrices in the TEO_GEMM_WTILED layout (include/teo_hip.h) when the activations are bf16,
+  * the device-resident batch state and the hipGraph of one batched step.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .engine import _p, tile_weights
+
+
+class BatchDecoder:
+    def __init__(self, engine, batch, max_new=1024, tiled=True):
+        if not 1 <= batch <= L.MAX_DECODE_BATCH:
+            raise ValueError(f"batch {batch} outside 1..{L.MAX_DECODE_BATCH}")
+        self.eng, self.B, self.lib = engine, int(batch), engine.lib
+        self.max_new = int(max_new)
+        c = engine.cfg
+        dev, dt = engine.device, engine.dtype
+        Lr, Hk, hd, S = c.num_hidden_layers, c.num_key_value_heads, c.head_dim, engine.max_seq
+        B = self.B
+        self.k_cache = torch.zeros(Lr, B, Hk, S, hd, dtype=dt, device=dev)
+        self.v_cache = torch.zeros(Lr, B, Hk, S, hd, dtype=dt, device=dev)
+        self.vt_cache = torch.zeros(Lr, B, Hk, hd, S, dtype=dt, device=dev)
+        self.cache_len = [0] * B
+        self._keep = []
+        # one prefill descriptor per slot: the engine's descriptor with the cache pointers of that slot
+        self.slot_desc = []
+        for b in range(B):
+            d = L.LlamaDesc.from_buffer_copy(engine.llama_desc)
+            d.k_cache = self._arr([self.k_cache[i, b] for i in range(Lr)])
+            d.v_cache = self._arr([self.v_cache[i, b] for i in range(Lr)])
+            d.vt_cache = self._arr([self.vt_cache[i, b] for i in range(Lr)])
+            self.slot_desc.append(d)
+        # batched-step descriptor: slot 0's caches + (optionally) operand-tiled weights
+        d = L.LlamaDesc.from_buffer_copy(self.slot_desc[0])
+        fp8 = engine.llama_w8 is not None
+        ks = 64 if fp8 else 32
+        self.tiled = bool(tiled) and dt == torch.bfloat16 and c.hidden_size % ks == 0 and c.intermediate_size % ks == 0 \
+            and (c.num_attention_heads * hd) % ks == 0
+        self.tiled_w = None
+        if self.tiled:
+            src = engine.llama_w8[0] if fp8 else engine.llama_w
+            tw = {k: [tile_weights(w) for w in src[k]] for k in ("qkv", "o", "gateup", "down")}
+            head = tile_weights(engine.lm_head8 if fp8 else engine.lm_head)
+            self.tiled_w = (tw, head)
+            if fp8:
+                d.qkv_w8, d.o_w8 = self._arr(tw["qkv"]), self._arr(tw["o"])
+                d.gateup_w8, d.down_w8 = self._arr(tw["gateup"]), self._arr(tw["down"])
+                d.lm_head8 = head.data_ptr()
+            else:
+                d.qkv_w, d.o_w = self._arr(tw["qkv"]), self._arr(tw["o"])
+                d.gateup_w, d.down_w = self._arr(tw["gateup"]), self._arr(tw["down"])
+                d.lm_head = head.data_ptr()
+        self.desc = d
+        # device state
+        self.d_token = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.d_pos = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.d_out = torch.zeros(B, self.max_new, dtype=torch.int64, device=dev)
+        self.d_count = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.d_stop = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.d_stop_ids = torch.zeros(16, dtype=torch.int64, device=dev)
+        self.d_logits = torch.zeros(B, c.vocab_size, dtype=torch.float32, device=dev)
+        self.d_rng = torch.zeros(B, 2, dtype=torch.int64, device=dev)
+        s = L.DecodeBatchState()
+        s.batch, s.out_stride = B, self.max_new
+        s.cache_stride = self.k_cache.stride(1)
+        assert self.v_cache.stride(1) == s.cache_stride and self.vt_cache.stride(1) == s.cache_stride
+        s.w_tiled = 1 if self.tiled else 0
+        s.d_token, s.d_pos, s.d_out_tokens = self.d_token.data_ptr(), self.d_pos.data_ptr(), self.d_out.data_ptr()
+        s.d_out_count, s.d_stop = self.d_count.data_ptr(), self.d_stop.data_ptr()
+        s.d_stop_ids, s.n_stop_ids, s.d_logits = self.d_stop_ids.data_ptr(), 0, self.d_logits.data_ptr()
+        s.do_sample, s.top_k, s.temperature, s.d_rng = 0, 0, 1.0, self.d_rng.data_ptr()
+        self.state = s
+        self._graph = None
+        self._steps_done = 0
+
+    def _arr(self, tensors):
+        arr, pp = L.ptr_array([t.data_ptr() for t in tensors])
+        self._keep.append((arr, tensors))
+        return pp
+
+    # ------------------------------------------------------------------ prefill (one conversation at a time)
+    def reset(self):
+        self.cache_len = [0] * self.B
+
+    def prefill(self, slot, embeds, last_only=True):
+        """Append embeds [S, D] to conversation `slot`; returns fp32 logits ([1, V] with last_only)."""
+        eng = self.eng
+        S = embeds.shape[0]
+        past = self.cache_len[slot]
+        if past + S > eng.max_seq:
+            raise ValueError(f"sequence length {past + S} exceeds the engine's max_seq {eng.max_seq}")
+        d = self.slot_desc[slot]
+        with eng.phase() as st:
+            e = embeds.to(device=eng.device, dtype=eng.dtype).contiguous()
+            pos = torch.arange(past, past + S, dtype=torch.int32, device=eng.device)
+            rows = 1 if last_only else S
+            logits = torch.empty(rows, eng.cfg.vocab_size, dtype=torch.float32, device=eng.device)
+            ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d), S))
+            L.check(self.lib.teo_llama_prefill(C.byref(d), _p(e), _p(pos), S, past, 1 if last_only else 0, _p(logits), _p(ws),
+                                               ws.numel(), st), "teo_llama_prefill")
+        self.cache_len[slot] = past + S
+        return logits
+
+    # ------------------------------------------------------------------ decode
+    def _workspace(self):
+        return self.eng._workspace("decode_batch", self.lib.teo_llama_decode_batch_workspace_bytes(C.byref(self.desc), self.B))
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            self.lib.teo_graph_destroy(self._graph)
+            self._graph = None
+
+    def begin(self, first_tokens, stop_ids=None, do_sample=False, temperature=1.0, top_k=0, seeds=None, draws_done=1):
+        """Arm the loop: first_tokens[b] is the input of conversation b's next step, at position cache_len[b]."""
+        eng = self.eng
+        if len(first_tokens) != self.B:
+            raise ValueError(f"need {self.B} first tokens")
+        with eng.phase():
+            self.d_token.copy_(torch.tensor([int(t) for t in first_tokens], dtype=torch.int64))
+            self.d_pos.copy_(torch.tensor(self.cache_len, dtype=torch.int32))
+            self.d_count.zero_()
+            self.d_stop.zero_()
+            seeds = list(seeds) if seeds is not None else [0] * self.B
+            self.d_rng.copy_(torch.tensor([[int(sd) & (2 ** 63 - 1), int(draws_done)] for sd in seeds], dtype=torch.int64))
+            n = 0
+            if stop_ids:
+                n = min(len(stop_ids), 16)
+                self.d_stop_ids[:n] = torch.tensor(list(stop_ids)[-n:], dtype=torch.int64, device=eng.device)
+            s = self.state
+            key = (n, int(bool(do_sample)), int(top_k or 0), C.c_float(float(temperature)).value)
+            if key != (s.n_stop_ids, s.do_sample, s.top_k, float(s.temperature)):
+                s.n_stop_ids, s.do_sample, s.top_k, s.temperature = key
+                self._drop_graph()
+        ws = self._workspace()
+        with eng.phase() as st:
+            L.check(self.lib.teo_llama_decode_batch_begin(C.byref(self.desc), C.byref(self.state), _p(ws), ws.numel(), st),
+                    "teo_llama_decode_batch_begin")
+        self._steps_done = 0
+
+    def steps(self, n, use_graph=True):
+        """n batched steps (every conversation advances n tokens) on the device."""
+        eng = self.eng
+        if max(self.cache_len) + n > eng.max_seq:
+            raise ValueError(f"decode would exceed max_seq {eng.max_seq}")
+        if self._steps_done + n > self.max_new:
+            raise ValueError(f"decode would exceed the output buffer ({self.max_new} tokens)")
+        ws = self._workspace()
+        with eng.phase() as st:
+            if use_graph:
+                if self._graph is None or self._graph_ws != ws.data_ptr():
+                    self._drop_graph()
+                    g = C.c_void_p()
+                    L.check(self.lib.teo_llama_decode_batch_graph_create(C.byref(self.desc), C.byref(self.state), _p(ws),
+                                                                         ws.numel(), st, C.byref(g)),
+                            "teo_llama_decode_batch_graph_create")
+                    self._graph, self._graph_ws = g, ws.data_ptr()
+                L.check(self.lib.teo_graph_launch(self._graph, n, st), "teo_graph_launch")
+            else:
+                for _ in range(n):
+                    L.check(self.lib.teo_llama_decode_batch_step(C.byref(self.desc), C.byref(self.state), _p(ws), ws.numel(),
+                                                                 st), "teo_llama_decode_batch_step")
+        self.cache_len = [x + n for x in self.cache_len]
+        self._steps_done += n
+
+    def generated(self):
+        """[B, steps] int64: the tokens produced by the steps so far (the first token of each conversation excluded)."""
+        n = self._steps_done
+        return self.d_out[:, :n].clone()
+
+    def __del__(self):
+        try:
+            self._drop_graph()
+        except Exception:  # noqa: BLE001
+            pass

@@ -32,6 +32,12 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
 int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
                         teo_graph** out);
 
+size_t llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch);
+int llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes, hipStream_t st);
+int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes, hipStream_t st);
+int decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes,
+                              hipStream_t st, teo_graph** out);
+
 static bool dtype_ok(int dt) { return dt == TEO_F32 || dt == TEO_BF16; }
 
 }  // namespace teo
@@ -51,7 +57,7 @@ int teo_version(void) { return TEO_ABI_VERSION; }
 const char* teo_last_error(void) { return g_err; }
 
 int teo_tune_set(const char* key, int value) {
-    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
+    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
     set_error("teo_tune_set: unknown key");
     return TEO_ERR_ARG;
 }
@@ -229,6 +235,45 @@ int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_stat
     return decode_graph_create(d, st, ws, wsb, ST(s), out);
 }
 
+// ---- batched decode ----
+static int check_batch_state(const teo_llama_desc* d, const teo_decode_batch_state* st) {
+    NEED(d, "desc"); NEED(st, "state"); NEED_DT(d->dtype);
+    TEO_CHECK_ARG(st->batch >= 1 && st->batch <= TEO_MAX_DECODE_BATCH, "decode batch %d outside 1..%d", st->batch, TEO_MAX_DECODE_BATCH);
+    NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
+    NEED(st->d_out_count, "d_out_count"); NEED(st->d_stop, "d_stop"); NEED(st->d_logits, "d_logits");
+    TEO_CHECK_ARG(st->batch == 1 || st->cache_stride > 0, "decode batch: cache_stride %lld", (long long)st->cache_stride);
+    TEO_CHECK_ARG(st->out_stride > 0, "decode batch: out_stride %d", st->out_stride);
+    if (st->do_sample) { NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "decode batch: temperature %g", st->temperature); }
+    return TEO_OK;
+}
+
+size_t teo_llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch) {
+    return (d && batch >= 1) ? llama_decode_batch_workspace_bytes(d, batch) : 0;
+}
+
+int teo_llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_state* st, void* ws, size_t wsb, teo_stream_t s) {
+    ENTER();
+    { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    NEED(ws, "workspace");
+    return llama_decode_batch_begin(d, st, ws, wsb, ST(s));
+}
+
+int teo_llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_state* st, void* ws, size_t wsb, teo_stream_t s) {
+    ENTER();
+    { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    NEED(ws, "workspace");
+    return llama_decode_batch_step(d, st, ws, wsb, ST(s));
+}
+
+int teo_llama_decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* st, void* ws, size_t wsb,
+                                        teo_stream_t s, teo_graph** out) {
+    ENTER();
+    { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    NEED(ws, "workspace"); NEED(out, "out");
+    TEO_CHECK_ARG(s != nullptr, "teo_llama_decode_batch_graph_create: needs a non-default stream to capture on");
+    return decode_batch_graph_create(d, st, ws, wsb, ST(s), out);
+}
+
 int teo_graph_launch(teo_graph* g, int n_times, teo_stream_t s) {
     ENTER();
     NEED(g, "graph");
@@ -272,6 +317,46 @@ int teo_time_gemv_chain(const void* x, const void* const* Ws, const float* const
     (void)hipEventDestroy(e1);
     if (rc != TEO_OK) return rc;
     if (e != hipSuccess) return hip_fail(e, "teo_time_gemv_chain events");
+    *avg_ms_out = ms / (float)(n * reps);
+    return TEO_OK;
+}
+
+int teo_gemm_skinny(const void* x, const void* W, const float* w_scale, int w_fp8, const void* res, void* out, int MB, int N,
+                    int K, int ldx, int ldo, unsigned flags, int out_dtype, teo_stream_t s) {
+    ENTER();
+    TEO_CHECK_ARG(MB >= 0 && N >= 0 && K > 0, "teo_gemm_skinny: MB %d N %d K %d", MB, N, K);
+    TEO_CHECK_ARG(out_dtype == TEO_BF16 || out_dtype == TEO_F32, "teo_gemm_skinny: out_dtype %d", out_dtype);
+    if (MB == 0 || N == 0) return TEO_OK;
+    NEED(x, "x"); NEED(W, "W"); NEED(out, "out");
+    return skinny_gemm(x, W, w_scale, w_fp8, res, out, MB, N, K, ldx, ldo, flags, out_dtype, ST(s));
+}
+
+int teo_time_skinny_chain(const void* x, const void* const* Ws, const float* const* scales, int n, void* y, int MB, int N, int K,
+                          unsigned flags, int reps, float* avg_ms_out, teo_stream_t s) {
+    ENTER();
+    NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
+    TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_skinny_chain: n %d reps %d", n, reps);
+    const int ldo = (flags & TEO_GEMM_SWIGLU16) ? N / 2 : N;
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return hip_fail(e, "hipEventCreate"); }
+    int rc = TEO_OK;
+    for (int i = 0; i < n && rc == TEO_OK; ++i)   // warm-up pass (not timed)
+        rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
+    (void)hipEventRecord(e0, ST(s));
+    for (int r = 0; r < reps && rc == TEO_OK; ++r)
+        for (int i = 0; i < n && rc == TEO_OK; ++i)
+            rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
+    (void)hipEventRecord(e1, ST(s));
+    e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != TEO_OK) return rc;
+    if (e != hipSuccess) return hip_fail(e, "teo_time_skinny_chain events");
     *avg_ms_out = ms / (float)(n * reps);
     return TEO_OK;
 }

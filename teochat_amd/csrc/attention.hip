@@ -13,6 +13,7 @@
 //                            replay; kv_len comes from device memory), then a combine kernel.  HBM-bound:
 //                            algorithmic bytes = 2 * kv_heads * kv_len * head_dim * sizeof(T) per layer.
 #include "common.h"
+#include "ops.h"
 
 namespace teo {
 
@@ -314,9 +315,19 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
                                                                   T* __restrict__ vc, T* __restrict__ vtc,
                                                                   const float* __restrict__ cs, const float* __restrict__ sn,
                                                                   float* __restrict__ part, const int* __restrict__ d_pos,
-                                                                  int S_max, int heads, int kv_heads, float scale, int nsplit) {
+                                                                  int S_max, int heads, int kv_heads, float scale, int nsplit,
+                                                                  AttnBatch bt) {
     constexpr int VE = Cvt16<T>::N;
     constexpr int HD = LPR * VE;
+    {   // conversation blockIdx.z of a batched step: its own query row, caches, position and partial slab
+        const long long bz = blockIdx.z;
+        q += bz * bt.q_stride;
+        kc += bz * bt.cache_stride;
+        vc += bz * bt.cache_stride;
+        if (vtc) vtc += bz * bt.cache_stride;
+        d_pos += bz;
+        part += bz * (long long)heads * nsplit * (HD + 2);
+    }
     constexpr int RPI = 64 / LPR;                       // rows (keys) per wave-wide load instruction
     constexpr int KPW = DEC_CHUNK / 4;                  // keys per wave
     constexpr int NI = KPW / RPI;                       // load instructions per wave per operand
@@ -459,11 +470,15 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
 // owns one output column and sums the active splits with independent loads (no dependent-latency chain).
 template <typename T>
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
-                                                                  const int* __restrict__ d_pos, int hd, int nsplit, int chunk) {
+                                                                  const int* __restrict__ d_pos, int hd, int nsplit, int chunk,
+                                                                  long long o_stride) {
     __shared__ float w[256];
     __shared__ float red[4];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int stride = hd + 2;
+    part += (long long)blockIdx.y * gridDim.x * nsplit * stride;
+    o += (long long)blockIdx.y * o_stride;
+    d_pos += blockIdx.y;
     const float* pb = part + (long long)h * nsplit * stride;
     const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys
     float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
@@ -495,19 +510,19 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
     }
 }
 
-size_t attn_decode_ws_bytes(int heads, int hd, int S_max) {
+size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
     const int nsplit = cdiv(S_max, 64);      // sized for the smallest chunk
-    return (size_t)heads * nsplit * (hd + 2) * sizeof(float);
+    return (size_t)batch * heads * nsplit * (hd + 2) * sizeof(float);
 }
 
 template <typename T, int LPR>
 static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o,
                                float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale,
-                               int nsplit, int chunk, bool rope, hipStream_t st) {
-    dim3 grid(heads, nsplit);
+                               int nsplit, int chunk, bool rope, AttnBatch bt, hipStream_t st) {
+    dim3 grid(heads, nsplit, bt.batch);
 #define TEO_PART(CH, RP)                                                                                              \
     attn_decode_partial_kernel<T, LPR, CH, RP><<<grid, 256, 0, st>>>((const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
-                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit)
+                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt)
 #define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
     if constexpr (64 / 4 >= 64 / LPR) {
         if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
@@ -516,13 +531,14 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
     }
 #undef TEO_PART_R
 #undef TEO_PART
-    attn_decode_combine_kernel<T><<<heads, 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk);
+    attn_decode_combine_kernel<T><<<dim3(heads, bt.batch), 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
 }
 
 // rope_cos != NULL: q is the raw qkv row; RoPE and the KV append of the new token happen inside the kernel
+// bt: batched step (bt.batch conversations: q/o rows, caches, positions and partial slabs strided per conversation)
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
-                hipStream_t st) {
+                hipStream_t st, AttnBatch bt) {
     const bool rope = rope_cos != nullptr;
     int chunk = g_dec_chunk;
     const int esz = dtype == TEO_F32 ? 4 : 2;
@@ -535,7 +551,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
         set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
         return TEO_ERR_UNSUPPORTED;
     }
-#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, st)
+#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, st)
     if (dtype == TEO_F32) {
         switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
                        case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }

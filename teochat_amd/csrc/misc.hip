@@ -374,7 +374,15 @@ int sample_topk(const float* logits, long long* tok, int vocab, float temperatur
 template <typename T>
 __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restrict__ logits, teo_decode_state st,
                                                            const T* __restrict__ embed, T* __restrict__ h, int vocab,
-                                                           int dim) {
+                                                           int dim, int out_stride) {
+    {   // conversation blockIdx.x of a batched step (out_stride = row length of d_out_tokens)
+        const long long b = blockIdx.x;
+        logits += b * vocab;
+        h += b * dim;
+        st.d_token += b; st.d_pos += b; st.d_out_count += b; st.d_stop += b;
+        st.d_out_tokens += b * out_stride;
+        if (st.d_rng) st.d_rng += 2 * b;
+    }
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ long long s_tok;
@@ -437,9 +445,11 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
 }
 
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
-                hipStream_t st) {
-    if (dtype == TEO_F32) decode_tail_kernel<float><<<1, 1024, 0, st>>>(logits, *s, (const float*)embed, (float*)h, vocab, dim);
-    else decode_tail_kernel<bf16_t><<<1, 1024, 0, st>>>(logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim);
+                hipStream_t st, int batch, int out_stride) {
+    if (dtype == TEO_F32)
+        decode_tail_kernel<float><<<batch, 1024, 0, st>>>(logits, *s, (const float*)embed, (float*)h, vocab, dim, out_stride);
+    else
+        decode_tail_kernel<bf16_t><<<batch, 1024, 0, st>>>(logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim, out_stride);
     TEO_LAUNCH_CHECK("decode_tail");
     return TEO_OK;
 }
@@ -477,12 +487,13 @@ int decode_advance(const teo_decode_state* s, hipStream_t st) {
 template <typename T>
 __global__ __launch_bounds__(256) void embed_token_kernel(const long long* __restrict__ tok, const T* __restrict__ embed,
                                                           T* __restrict__ h, int dim) {
-    const long long t = *tok;
+    const long long t = tok[blockIdx.y];
+    h += (long long)blockIdx.y * dim;
     for (int i = threadIdx.x + blockIdx.x * 256; i < dim; i += 256 * gridDim.x) h[i] = embed[t * dim + i];
 }
 
-int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st) {
-    const int blocks = cdiv(dim, 256);
+int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch) {
+    const dim3 blocks(cdiv(dim, 256), batch);
     if (dtype == TEO_F32) embed_token_kernel<float><<<blocks, 256, 0, st>>>(tok, (const float*)embed, (float*)h, dim);
     else embed_token_kernel<bf16_t><<<blocks, 256, 0, st>>>(tok, (const bf16_t*)embed, (bf16_t*)h, dim);
     TEO_LAUNCH_CHECK("embed_token");

@@ -20,10 +20,14 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
          int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
 int attention(const teo_attn_args* a, int dtype, hipStream_t st);
-size_t attn_decode_ws_bytes(int heads, int hd, int S_max);
+size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
+struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
+    int batch = 1;
+    long long q_stride = 0, cache_stride = 0, o_stride = 0;
+};
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
-                hipStream_t st);
+                hipStream_t st, AttnBatch bt = AttnBatch());
 
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                    void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,
@@ -38,13 +42,17 @@ int decode_advance(const teo_decode_state* s, hipStream_t st);
 int sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, unsigned long long seed,
                 unsigned long long draw, hipStream_t st);
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
-                hipStream_t st);
-int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st);
+                hipStream_t st, int batch = 1, int out_stride = 0);
+int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch = 1);
 
 int gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
          unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
 int gemv_tune_set(const char* key, int value);
+int skinny_tune_set(const char* key, int value);
+bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
+int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* res, void* out, int MB, int N, int K,
+                int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st);
 int gemm_tune_set(const char* key, int value);
 int attn_tune_set(const char* key, int value);
 int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,

@@ -267,6 +267,114 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     return decode_tail(s->d_logits, s, d->embed, w.h, d->vocab, D, dt, st);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// batched decode: B conversations advance one token per step; every weight matrix is streamed once per step
+// ------------------------------------------------------------------------------------------------
+struct DecodeBatchWs {
+    void *h, *xn, *qkv, *attn, *act;
+    float* part;
+    size_t total;
+};
+
+static DecodeBatchWs decode_batch_carve(const teo_llama_desc* d, int B, void* ws, size_t cap) {
+    const size_t e = esize(d->dtype);
+    const int QKV = (d->heads + 2 * d->kv_heads) * d->head_dim;
+    DecodeBatchWs w;
+    Carver c(ws, cap);
+    w.h = c.take((size_t)B * d->hidden * e);
+    w.xn = c.take((size_t)B * d->hidden * e);
+    w.qkv = c.take((size_t)B * QKV * e);
+    w.attn = c.take((size_t)B * d->heads * d->head_dim * e);
+    w.act = c.take((size_t)B * d->inter * e);
+    w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq, B));
+    w.total = c.off;
+    return w;
+}
+
+size_t llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch) {
+    return decode_batch_carve(d, batch, nullptr, 0).total;
+}
+
+// y[b] = f(norm(x[b])) W^T (+ res[b]) for the B rows of a batched step.  bf16 rows whose shape the MFMA kernel takes run
+// rmsnorm (B rows) + teo_gemm_skinny; anything else (fp32, odd K) loops the single-conversation GEMV over the rows.
+static int batch_linear(const teo_decode_batch_state* s, const void* x, int ldx, const void* W, const float* wscale, int w8,
+                        const void* norm_w, void* xn, const void* res, void* y, int ldy, int N, int K, float eps, unsigned flags,
+                        int dt, int out_dt, hipStream_t st) {
+    const int B = s->batch;
+    const size_t e = esize(dt), eo = esize(out_dt);
+    if (dt == TEO_BF16 && skinny_gemm_ok(B, N, K, norm_w ? K : ldx, w8, flags, norm_w ? xn : x, W)) {
+        const void* xin = x;
+        int ld = ldx;
+        if (norm_w) {
+            TEO_TRY(rmsnorm(x, norm_w, xn, B, K, eps, dt, st));
+            xin = xn;
+            ld = K;
+        }
+        return skinny_gemm(xin, W, wscale, w8, res, y, B, N, K, ld, ldy, flags | (s->w_tiled ? TEO_GEMM_WTILED : 0u), out_dt, st);
+    }
+    if (s->w_tiled) {
+        set_error("teo_llama_decode_batch_step: tiled weights need bf16 activations and K %% %d == 0 (N=%d K=%d)", w8 ? 64 : 32, N, K);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    for (int b = 0; b < B; ++b)
+        TEO_TRY(gemv_w((const char*)x + (size_t)b * ldx * e, W, wscale, w8, norm_w, res ? (const char*)res + (size_t)b * ldy * eo : nullptr,
+                       (char*)y + (size_t)b * ldy * eo, N, K, eps, flags, dt, out_dt, st));
+    return TEO_OK;
+}
+
+static teo_decode_state batch_as_state(const teo_decode_batch_state* s) {
+    teo_decode_state t;
+    t.d_token = s->d_token; t.d_pos = s->d_pos; t.d_out_tokens = s->d_out_tokens; t.d_out_count = s->d_out_count;
+    t.d_stop = s->d_stop; t.d_stop_ids = s->d_stop_ids; t.n_stop_ids = s->n_stop_ids; t.d_logits = s->d_logits;
+    t.do_sample = s->do_sample; t.top_k = s->top_k; t.temperature = s->temperature; t.d_rng = s->d_rng;
+    return t;
+}
+
+int llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes, hipStream_t st) {
+    const DecodeBatchWs w = decode_batch_carve(d, s->batch, ws, ws_bytes);
+    if (w.total > ws_bytes) {
+        set_error("teo_llama_decode_batch_begin: workspace %zu < %zu", ws_bytes, w.total);
+        return TEO_ERR_WORKSPACE;
+    }
+    return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch);
+}
+
+int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int B = s->batch;
+    const DecodeBatchWs w = decode_batch_carve(d, B, ws, ws_bytes);
+    if (w.total > ws_bytes) {
+        set_error("teo_llama_decode_batch_step: workspace %zu < %zu", ws_bytes, w.total);
+        return TEO_ERR_WORKSPACE;
+    }
+    const int dt = d->dtype;
+    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
+    const int QKV = (H + 2 * Hk) * hd;
+    const bool w8 = d->qkv_w8 != nullptr;
+    AttnBatch bt;
+    bt.batch = B; bt.q_stride = QKV; bt.cache_stride = s->cache_stride; bt.o_stride = (long long)H * hd;
+    for (int l = 0; l < d->layers; ++l) {
+        TEO_TRY(batch_linear(s, w.h, D, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.xn,
+                             nullptr, w.qkv, QKV, QKV, D, d->eps, 0, dt, dt, st));
+        // RoPE + KV append of the B new tokens inside the attention kernel, each conversation at its own position
+        TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
+                            s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt));
+        TEO_TRY(batch_linear(s, w.attn, H * hd, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, nullptr, w.h,
+                             w.h, D, D, H * hd, d->eps, 0, dt, dt, st));
+        TEO_TRY(batch_linear(s, w.h, D, w8 ? d->gateup_w8[l] : d->gateup_w[l], w8 ? d->gateup_s[l] : nullptr, w8,
+                             d->post_norm_w[l], w.xn, nullptr, w.act, F, 2 * F, D, d->eps, TEO_GEMM_SWIGLU16, dt, dt, st));
+        TEO_TRY(batch_linear(s, w.act, F, w8 ? d->down_w8[l] : d->down_w[l], w8 ? d->down_s[l] : nullptr, w8, nullptr, nullptr,
+                             w.h, w.h, D, D, F, d->eps, 0, dt, dt, st));
+    }
+    {
+        const bool h8 = d->lm_head8 != nullptr;
+        TEO_TRY(batch_linear(s, w.h, D, h8 ? d->lm_head8 : d->lm_head, h8 ? d->lm_head_s : nullptr, h8, d->final_norm_w, w.xn,
+                             nullptr, s->d_logits, d->vocab, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
+    }
+    const teo_decode_state t = batch_as_state(s);
+    return decode_tail(s->d_logits, &t, d->embed, w.h, d->vocab, D, dt, st, B, s->out_stride);
+}
+
 }  // namespace teo
 
 // ------------------------------------------------------------------------------------------------
@@ -284,12 +392,13 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st);
 }
 
-int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
-                        teo_graph** out) {
+// capture whatever `enqueue` launches on `st` into an instantiated hipGraph
+template <typename F>
+static int capture_graph(hipStream_t st, F enqueue, teo_graph** out) {
     *out = nullptr;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
-    const int rc = llama_decode_step(d, s, ws, ws_bytes, st);
+    const int rc = enqueue();
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(st, &g);
     if (rc != TEO_OK) {
@@ -308,6 +417,16 @@ int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void
     tg->exec = ex;
     *out = tg;
     return TEO_OK;
+}
+
+int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
+                        teo_graph** out) {
+    return capture_graph(st, [&]() { return llama_decode_step(d, s, ws, ws_bytes, st); }, out);
+}
+
+int decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes,
+                              hipStream_t st, teo_graph** out) {
+    return capture_graph(st, [&]() { return llama_decode_batch_step(d, s, ws, ws_bytes, st); }, out);
 }
 
 }  // namespace teo

@@ -1,0 +1,215 @@
+// Batched-decode ("skinny") GEMM for gfx950:  out[b][n] = sum_k x[b][k] * W[n][k],  b < MB <= 16 conversations.
+//
+// One decode step of B conversations multiplies the SAME weight matrices with B activation rows, so the weights
+// are streamed from HBM once per step instead of once per conversation (config C5's batched-decode variant;
+// reference: HF generate with batch>1 through LlamaForCausalLM.forward, videollava/model/language_model/
+// llava_llama.py:88-99).  The kernel is HBM-bound like the GEMV; the arithmetic goes to the matrix cores only
+// because 16 dot products per weight element would otherwise saturate the VALU:
+//
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the first operand (16 rows x 32 k, read straight from
+//     global memory into the operand registers -- no LDS staging: each weight byte is used exactly once; with the
+//     TEO_GEMM_WTILED layout every load instruction reads 1 KB contiguous, +25..35 % over row-major) and the
+//     activations x^T as the second operand (lane = (conversation b, k-group)); columns b >= MB compute garbage
+//     that is never written.
+//   * a workgroup = 8 waves = RT row tiles (16 weight rows each) x 8/RT contiguous K slices; a wave streams one
+//     tile row over its slice.  The partial 16x16 tiles are reduced through LDS in a fixed order (deterministic),
+//     then scale (fp8), SwiGLU, residual and rounding happen once.  x comes from L2 (K*MB*2 bytes per workgroup).
+//   * fp8-e4m3 weights: a lane's 16-byte chunk covers 16 k of one row = two MFMAs (the k-permutation inside a
+//     64-k step is the same for W and x, so the dot product is unchanged); fp8 -> bf16 is exact.
+#include "common.h"
+#include "ops.h"
+
+namespace teo {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef unsigned char fp8_t;
+
+constexpr int SK_WAVES = 8;
+constexpr int SK_THREADS = SK_WAVES * 64;
+constexpr int SK_TP = 16 * 17;      // padded 16x16 partial tile in LDS: [b][i] at b*17 + i
+
+static int g_sk_tiles = 0;          // 0 = auto
+static int g_sk_nt = 1;
+int skinny_tune_set(const char* key, int value) {
+    if (!strcmp(key, "skinny_tiles") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_sk_tiles = value; return 0; }
+    if (!strcmp(key, "skinny_nt")) { g_sk_nt = value != 0; return 0; }
+    return -1;
+}
+
+template <bool NT>
+__device__ __forceinline__ u32x4 sk_ldw(const void* p) {
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return *reinterpret_cast<const u32x4*>(p);
+}
+
+// 8 fp8 e4m3 (two dwords) -> 8 bf16, exact (3 mantissa bits; every e4m3 value is a bf16 value)
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
+    const f32x2 v0 = __builtin_amdgcn_cvt_pk_f32_fp8(a, false), v1 = __builtin_amdgcn_cvt_pk_f32_fp8(a, true);
+    const f32x2 v2 = __builtin_amdgcn_cvt_pk_f32_fp8(b, false), v3 = __builtin_amdgcn_cvt_pk_f32_fp8(b, true);
+    u32x4 r;
+    r.x = (__float_as_uint(v0.x) >> 16) | (__float_as_uint(v0.y) & 0xffff0000u);
+    r.y = (__float_as_uint(v1.x) >> 16) | (__float_as_uint(v1.y) & 0xffff0000u);
+    r.z = (__float_as_uint(v2.x) >> 16) | (__float_as_uint(v2.y) & 0xffff0000u);
+    r.w = (__float_as_uint(v3.x) >> 16) | (__float_as_uint(v3.y) & 0xffff0000u);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <typename WT, int UNR, bool NT, bool SWIGLU>
+__global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
+                                                                 const float* __restrict__ wscale,
+                                                                 const bf16_t* __restrict__ res, void* __restrict__ outv,
+                                                                 int MB, int N, int K, int ldx, int ldo, int ldr, int tiled,
+                                                                 int out_f32, int RT) {
+    constexpr bool F8 = sizeof(WT) == 1;
+    constexpr int KS = F8 ? 64 : 32;                     // k elements per step (one 16-byte chunk per lane)
+    constexpr int CH = F8 ? 16 : 8;                      // k elements per lane chunk
+    constexpr int XL = F8 ? 2 : 1;                       // 16-byte activation loads per step
+    __shared__ float red[SK_WAVES][SK_TP];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    // the 8 waves of a workgroup = RT row tiles (16 weight rows each) x KSPLIT contiguous K slices
+    const int KSPLIT = SK_WAVES / RT;
+    const int rt = wid / KSPLIT, ks = wid % KSPLIT;
+    const int n0 = blockIdx.x * 16 * RT;
+    const int nsteps = K / KS;
+    const int per = (nsteps + KSPLIT - 1) / KSPLIT;
+    const int s0 = ks * per, s1 = min(s0 + per, nsteps);
+
+    // weight addressing.  Row-major [N][K]: a wave instruction touches 16 rows x 64 B.  Tiled (TEO_GEMM_WTILED): the
+    // matrix is stored as 1 KB tiles of 16 rows x KS k in operand order (tile (n/16, k/KS) at ((n/16)*(K/KS) + k/KS) KB,
+    // lane l = (k%KS)/CH*16 + n%16 owns bytes [16 l, 16 l + 16)), so one instruction reads 1 KB contiguous.
+    const WT* wp;
+    long long pstep;
+    if (tiled) {
+        wp = W + ((long long)min(n0 / 16 + rt, (N + 15) / 16 - 1) * nsteps) * (64 * CH) + lane * CH;
+        pstep = 64 * CH;
+    } else {
+        wp = W + (long long)min(n0 + rt * 16 + fr, N - 1) * K + fg * CH;
+        pstep = KS;
+    }
+    const bf16_t* xp = x + (long long)min(fr, MB - 1) * ldx + fg * CH;
+
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Software pipeline over the wave's K slice: two register sets of UNR steps each; every load is unconditional
+    // (step index clamped to the slice, the x fragment of an out-of-range step is zeroed) so hipcc keeps counting
+    // vmcnt instead of draining the queue at a control-flow merge.
+#define TEO_SK_LOAD(WR, XR, BASE)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                          \
+        const long long si = min((BASE) + u, s1 - 1);                                                          \
+        WR[u] = sk_ldw<NT>(wp + si * pstep);                                                                   \
+        _Pragma("unroll") for (int j = 0; j < XL; ++j)                                                         \
+            XR[u][j] = *reinterpret_cast<const u32x4*>(xp + si * KS + j * 8);                                  \
+    }
+#define TEO_SK_COMP(WR, XR, BASE)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                          \
+        const bool ok = (BASE) + u < s1;                                                                       \
+        u32x4 x0 = XR[u][0], x1 = XR[u][XL - 1];                                                               \
+        if (!ok) { x0 = (u32x4){0u, 0u, 0u, 0u}; x1 = x0; }                                                    \
+        if (F8) {                                                                                              \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(WR[u].x, WR[u].y),                   \
+                                                          __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);       \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(WR[u].z, WR[u].w),                   \
+                                                          __builtin_bit_cast(bf16x8, x1), acc, 0, 0, 0);       \
+        } else {                                                                                               \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WR[u]),                   \
+                                                          __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);       \
+        }                                                                                                      \
+    }
+
+    if (s0 < s1) {
+        u32x4 wa[UNR], xa[UNR][XL], wb[UNR], xb[UNR][XL];
+        int s = s0;
+        TEO_SK_LOAD(wa, xa, s)
+        for (; s + 2 * UNR < s1; s += 2 * UNR) {
+            TEO_SK_LOAD(wb, xb, s + UNR)
+            TEO_SK_COMP(wa, xa, s)
+            TEO_SK_LOAD(wa, xa, s + 2 * UNR)
+            TEO_SK_COMP(wb, xb, s + UNR)
+        }
+        TEO_SK_LOAD(wb, xb, s + UNR)
+        TEO_SK_COMP(wa, xa, s)
+        TEO_SK_COMP(wb, xb, s + UNR)
+    }
+#undef TEO_SK_LOAD
+#undef TEO_SK_COMP
+
+    // partial tiles -> LDS: lane holds out[b = fr][row i = fg*4 + r] of its tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wid][fr * 17 + fg * 4 + r] = acc[r];
+    __syncthreads();
+
+    const int OUTC = SWIGLU ? 8 * RT : 16 * RT;          // output columns of this workgroup
+    for (int o = tid; o < 16 * OUTC; o += SK_THREADS) {
+        const int b = o / OUTC, c = o % OUTC;
+        if (b >= MB) break;
+        float v;
+        int col;
+        if (SWIGLU) {
+            const int tp = c >> 4, i = c & 15;               // tile pair: gate tile 2 tp, up tile 2 tp + 1
+            const int ng = n0 + tp * 32 + i;
+            if (ng >= N) continue;
+            float g = 0.f, u = 0.f;
+            for (int w = 0; w < KSPLIT; ++w) {
+                g += red[(2 * tp) * KSPLIT + w][b * 17 + i];
+                u += red[(2 * tp + 1) * KSPLIT + w][b * 17 + i];
+            }
+            if (wscale) { g *= wscale[ng]; u *= wscale[ng + 16]; }
+            v = silu(g) * u;
+            col = (n0 >> 1) + c;
+        } else {
+            const int t = c >> 4, i = c & 15;
+            col = n0 + c;
+            if (col >= N) continue;
+            v = 0.f;
+            for (int w = 0; w < KSPLIT; ++w) v += red[t * KSPLIT + w][b * 17 + i];
+            if (wscale) v *= wscale[col];
+        }
+        if (res) v += bf2f(res[(long long)b * ldr + col]);
+        if (out_f32) reinterpret_cast<float*>(outv)[(long long)b * ldo + col] = v;
+        else reinterpret_cast<bf16_t*>(outv)[(long long)b * ldo + col] = f2bf(v);
+    }
+}
+
+bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W) {
+    const int ks = w_fp8 ? 64 : 32;
+    if (MB < 1 || MB > 16 || N < 1 || K < ks || K % ks != 0 || ldx % 8 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return false;
+    if ((flags & TEO_GEMM_SWIGLU16) && N % 32 != 0) return false;
+    return true;
+}
+
+// bf16 activations; W bf16 or fp8 e4m3 (+ per-row scales), row-major or TEO_GEMM_WTILED; out bf16 or f32;
+// res (bf16, may alias out) optional
+int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* res, void* out, int MB, int N, int K,
+                int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st) {
+    const bool swiglu = flags & TEO_GEMM_SWIGLU16;
+    const int tiled = (flags & TEO_GEMM_WTILED) ? 1 : 0;
+    if (!skinny_gemm_ok(MB, N, K, ldx, w_fp8, flags, x, W)) {
+        set_error("skinny_gemm: unsupported MB=%d N=%d K=%d ldx=%d", MB, N, K, ldx);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    TEO_CHECK_ARG(!w_fp8 || wscale, "skinny_gemm: fp8 weights need per-row scales");
+    TEO_CHECK_ARG(!(swiglu && res), "skinny_gemm: SWIGLU16 takes no residual");
+    // row tiles per workgroup (8 waves = RT row tiles x 8/RT K slices)
+    int rt = g_sk_tiles;
+    if (rt == 0) rt = 2;
+    if (swiglu && rt < 2) rt = 2;
+    const int blocks = cdiv(N, 16 * rt);
+    const int ldr = ldo, of = out_dtype == TEO_F32;
+#define TEO_SK(WW, NTV, SW)                                                                                \
+    skinny_gemm_kernel<WW, 4, NTV, SW><<<blocks, SK_THREADS, 0, st>>>(                                     \
+        (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt)
+#define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK(WW, NTV, true); } else { TEO_SK(WW, NTV, false); }
+    if (w_fp8) { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }
+    else       { if (g_sk_nt) { TEO_SK_F(bf16_t, true) } else { TEO_SK_F(bf16_t, false) } }
+#undef TEO_SK_F
+#undef TEO_SK
+    TEO_LAUNCH_CHECK("skinny_gemm");
+    return TEO_OK;
+}
+
+}  // namespace teo

@@ -35,6 +35,19 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def tile_weights(W):
+    """Row-major [N, K] (bf16, or uint8 holding fp8-e4m3 bits) -> the TEO_GEMM_WTILED layout of include/teo_hip.h:
+    ceil(N/16) * (K/KS) tiles of 1 KB in v_mfma_f32_16x16x32_bf16 operand order (rows past N are zero)."""
+    N, K = W.shape
+    ks, ch = (64, 16) if W.element_size() == 1 else (32, 8)
+    if K % ks:
+        raise ValueError(f"tile_weights: K={K} must be a multiple of {ks}")
+    npad = (N + 15) // 16 * 16
+    if npad != N:
+        W = torch.cat([W, torch.zeros(npad - N, K, dtype=W.dtype, device=W.device)])
+    return W.view(npad // 16, 16, K // ks, 4, ch).permute(0, 2, 3, 1, 4).contiguous().view(npad, K)
+
+
 def interleave_gate_up(gate, up):
     """[F, D], [F, D] -> [2F, D] with 16-row blocks alternating gate/up."""
     F_, D = gate.shape

@@ -359,7 +359,22 @@ class LlavaLlamaForCausalLM:
         reference (eval/inference.py:75 slices at input_ids.shape[1]).  `eos_token_id=None` disables EOS stopping.
         """
         if input_ids.shape[0] != 1:
-            raise ValueError("generate() decodes one conversation at a time (the reference's eval path is batch 1)")
+            # batch of conversations: rows are cut by attention_mask, `images` is a list with one entry per conversation
+            B = input_ids.shape[0]
+            rows = [input_ids[b][attention_mask[b].to(torch.bool)] if attention_mask is not None else input_ids[b]
+                    for b in range(B)]
+            if images is not None and (not isinstance(images, (list, tuple)) or len(images) != B):
+                raise ValueError("batched generate(): `images` must be a list with one entry (frame list) per conversation")
+            outs = self.generate_batch(rows, images, do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
+                                       max_new_tokens=max_new_tokens, stopping_criteria=stopping_criteria,
+                                       eos_token_id=eos_token_id, generator=generator, chunk=chunk)
+            pad = getattr(self.config, "pad_token_id", None)
+            pad = 0 if pad is None else int(pad)
+            width = max(o.numel() for o in outs)
+            res = torch.full((B, width), pad, dtype=input_ids.dtype, device=input_ids.device)
+            for b, o in enumerate(outs):
+                res[b, :o.numel()] = o.to(res.device)
+            return res
         eng = self.engine
         if eos_token_id == "config":
             eos_token_id = getattr(self.config, "eos_token_id", None)
@@ -419,6 +434,88 @@ class LlavaLlamaForCausalLM:
             if stop_here:
                 break
         return self._finish(input_ids, new_tokens)
+
+    # --- batched decode (config C5's variant): B conversations, one pass over the weights per generated token
+    def batch_decoder(self, batch, max_new=1024):
+        from .batch import BatchDecoder
+        cur = getattr(self, "_batch_decoder", None)
+        if cur is None or cur.B != batch or cur.max_new < max_new:
+            self._batch_decoder = None          # free the old caches first
+            cur = BatchDecoder(self.engine, batch, max_new=max(max_new, 64))
+            self._batch_decoder = cur
+        return cur
+
+    @torch.no_grad()
+    def generate_batch(self, input_ids_list, images_list=None, do_sample=False, temperature=1.0, top_k=None, top_p=None,
+                       max_new_tokens=20, stopping_criteria=None, eos_token_id="config", generator=None, chunk=16):
+        """Decode B conversations together (B <= 16).  input_ids_list: B 1-D id tensors (with -200 sentinels);
+        images_list: per conversation what generate() takes as `images`.  stopping_criteria: None, or one list of
+        criteria per conversation.  Returns B 1-D tensors prompt + generated, each cut at its own EOS / stop keyword.
+
+        Prefill runs one conversation after the other (MFMA GEMMs already fill the chip); the decode loop is batched:
+        per step every weight matrix is streamed once for all conversations (teo_llama_decode_batch_step)."""
+        B = len(input_ids_list)
+        if eos_token_id == "config":
+            eos_token_id = getattr(self.config, "eos_token_id", None)
+        if max_new_tokens <= 0:
+            return [ids.clone() for ids in input_ids_list]
+        if do_sample and top_p is not None and top_p < 1.0:
+            raise NotImplementedError("top_p < 1 is not implemented by the device sampler (HF default is 1.0)")
+        crits = list(stopping_criteria) if stopping_criteria is not None else [[] for _ in range(B)]
+        if len(crits) != B:
+            raise ValueError("stopping_criteria must hold one list per conversation")
+        eng = self.engine
+        dec = self.batch_decoder(B, max_new_tokens)
+        dec.reset()
+        k = (self.generation_config.top_k if top_k is None else top_k) if do_sample else 0
+        base_seed = 0
+        if do_sample:
+            base_seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        seeds = [(base_seed + 0x9E3779B97F4A7C15 * b) & (2 ** 63 - 1) for b in range(B)]
+        firsts = []
+        for b in range(B):
+            ids = input_ids_list[b].view(1, -1)
+            imgs = images_list[b] if images_list is not None else None
+            (_, _, _, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, imgs)
+            if embeds is None:
+                embeds = self.get_model().embed_tokens(ids)
+            if embeds.shape[1] + max_new_tokens > eng.max_seq:
+                raise ValueError(f"prompt ({embeds.shape[1]}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
+            logits = dec.prefill(b, embeds[0], last_only=True)
+            firsts.append(eng.sample(logits[0], temperature, k, seeds[b], 0) if do_sample else self._argmax(logits[0]))
+        new_tokens = [[t] for t in firsts]
+        finished = [False] * B
+
+        def done(b):
+            toks = new_tokens[b]
+            if eos_token_id is not None and toks[-1] == eos_token_id:
+                return True
+            if crits[b]:
+                row = torch.cat([input_ids_list[b].cpu().view(-1), torch.tensor(toks, dtype=torch.long)]).unsqueeze(0)
+                return any(bool(c(row, None)) for c in crits[b])
+            return False
+
+        for b in range(B):
+            finished[b] = done(b) or max_new_tokens == 1
+        if not all(finished):
+            stop_ids = [int(eos_token_id)] if (eos_token_id is not None and not any(crits)) else None
+            dec.begin(firsts, stop_ids, do_sample=do_sample, temperature=temperature, top_k=k, seeds=seeds, draws_done=1)
+            remaining = max_new_tokens - 1
+            while remaining > 0 and not all(finished):
+                n = min(chunk, remaining)
+                dec.steps(n, use_graph=True)
+                got = dec.generated()[:, -n:].tolist()
+                for b in range(B):
+                    if finished[b]:
+                        continue
+                    for t in got[b]:
+                        new_tokens[b].append(int(t))
+                        if done(b):
+                            finished[b] = True
+                            break
+                remaining -= n
+        return [torch.cat([input_ids_list[b].view(-1), torch.tensor(new_tokens[b], dtype=input_ids_list[b].dtype,
+                                                                     device=input_ids_list[b].device)]) for b in range(B)]
 
     def _finish(self, input_ids, new_tokens):
         tail = torch.tensor([new_tokens], dtype=input_ids.dtype, device=input_ids.device)

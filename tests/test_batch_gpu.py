@@ -1,0 +1,174 @@
+"""Batched decode (config C5's variant, teochat_amd/batch.py + teo_llama_decode_batch_*): every conversation of a batch
+must produce what it produces alone.
+
+  fp32 : the batched step runs the same kernels row by row -> token streams, KV caches and logits are compared
+         bit-for-bit / to FP32_TOL with the single-conversation path, the reference golden tokens and the CPU oracle.
+  bf16 : the weights go through the MFMA skinny GEMM (operand-tiled copy) -> logits within BF16_REL of the
+         single-conversation path (fp32 accumulation order differs), tokens compared where the top-2 margin allows.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import teo_oracle as O
+from tests import _tiny as TY
+from tests.test_model_gpu import BF16_REL, FP32_TOL, build
+
+pytestmark = pytest.mark.gpu
+
+
+def conversations(name, n, vocab):
+    """n different (ids, frames) pairs: the golden conversation first, then seeded variations of different lengths."""
+    g = TY.load_npz(name)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    T = int(g["T"])
+    convs = [(torch.from_numpy(g["input_ids"])[0], O.synthetic_frames(T, vcfg.image_size, seed=0))]
+    for i in range(1, n):
+        t = 1 + (i % 3)
+        ids = O.synthetic_prompt_ids(12 + 5 * i, t, vocab, seed=10 + i)
+        convs.append((ids, O.synthetic_frames(t, vcfg.image_size, seed=20 + i)))
+    return g, convs
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_batched_decode_fp32_equals_single_and_reference(name):
+    model, sd = build(name, torch.float32)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs(name)
+    g, convs = conversations(name, 5, lcfg.vocab_size)
+    n_new = len(g["greedy_tokens"])
+    singles = []
+    for ids, frames in convs:
+        out = model.generate(input_ids=ids.view(1, -1).to(dev), images=[f.to(dev) for f in frames], do_sample=False,
+                             max_new_tokens=n_new, eos_token_id=None)
+        singles.append(out[0].cpu().tolist())
+    outs = model.generate_batch([ids.to(dev) for ids, _ in convs], [[f.to(dev) for f in fr] for _, fr in convs], do_sample=False,
+                                max_new_tokens=n_new, eos_token_id=None)
+    for b, o in enumerate(outs):
+        assert o.cpu().tolist() == singles[b], f"conversation {b} differs from its single-conversation run"
+    assert outs[0].cpu().tolist()[-n_new:] == g["greedy_tokens"].tolist()           # the reference's own tokens
+    # conversation 0's cache slot holds what the reference's cache held
+    dec = model._batch_decoder
+    assert not dec.tiled
+    ks = torch.from_numpy(g["kv_sel"])
+    np.testing.assert_allclose(dec.k_cache[0, 0][:, ks].cpu().numpy(), g["k_layer0"], atol=FP32_TOL)
+    np.testing.assert_allclose(dec.v_cache[-1, 0][:, ks].cpu().numpy(), g["v_last"], atol=FP32_TOL)
+    np.testing.assert_allclose(dec.vt_cache[-1, 0][:, :, ks].transpose(1, 2).cpu().numpy(), g["v_last"], atol=FP32_TOL)
+    assert float((dec.d_logits[0].cpu() - torch.from_numpy(g["greedy_logits"][-1])).abs().max()) < FP32_TOL
+    # an independent check of a non-golden conversation against the CPU oracle
+    ids, frames = convs[3]
+    toks, _, _ = O.greedy_generate(ids.view(1, -1), frames, sd, vcfg, lcfg, mm, max_new_tokens=n_new)
+    assert outs[3].cpu().tolist()[-n_new:] == toks
+    # eager steps == hipGraph replays
+    lg_graph = dec.d_logits.clone()
+    dec.reset()
+    firsts = []
+    for b, (ids, frames) in enumerate(convs):
+        (_, _, _, _, emb, _) = model.prepare_inputs_labels_for_multimodal(ids.view(1, -1).to(dev), None, None, None, None,
+                                                                          [f.to(dev) for f in frames])
+        firsts.append(int(dec.prefill(b, emb[0])[0].argmax()))
+    dec.begin(firsts)
+    dec.steps(n_new - 1, use_graph=False)
+    assert torch.equal(lg_graph, dec.d_logits)
+    assert [[f] + r for f, r in zip(firsts, dec.generated().tolist())] == [s[-n_new:] for s in singles]
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_batched_generate_api_padding_eos_and_sampling(name):
+    model, _ = build(name, torch.float32)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs(name)
+    g, convs = conversations(name, 3, lcfg.vocab_size)
+    imgs = [[f.to(dev) for f in fr] for _, fr in convs]
+    ref = model.generate_batch([ids.to(dev) for ids, _ in convs], imgs, max_new_tokens=8, eos_token_id=None)
+    # HF-style call: right-padded ids + attention_mask, one image list per row
+    width = max(ids.numel() for ids, _ in convs)
+    ids_p = torch.zeros(3, width, dtype=torch.long)
+    mask = torch.zeros(3, width, dtype=torch.long)
+    for b, (ids, _) in enumerate(convs):
+        ids_p[b, :ids.numel()] = ids
+        mask[b, :ids.numel()] = 1
+    out = model.generate(input_ids=ids_p.to(dev), attention_mask=mask.to(dev), images=imgs, max_new_tokens=8, eos_token_id=None)
+    for b in range(3):
+        n = ref[b].numel()
+        assert out[b, :n].tolist() == ref[b].tolist() and bool((out[b, n:] == 0).all())
+    # EOS: conversation 1 stops at its 3rd generated token, the others run on
+    eos = int(ref[1][convs[1][0].numel() + 2])
+    cut = model.generate_batch([ids.to(dev) for ids, _ in convs], imgs, max_new_tokens=8, eos_token_id=eos)
+    for b in range(3):
+        gen = ref[b][convs[b][0].numel():].tolist()
+        want = gen[:gen.index(eos) + 1] if eos in gen else gen
+        assert cut[b][convs[b][0].numel():].tolist() == want
+    # sampling: reproducible under a seeded generator, each conversation with its own stream
+    gen_a = torch.Generator().manual_seed(7)
+    gen_b = torch.Generator().manual_seed(7)
+    sa = model.generate_batch([ids.to(dev) for ids, _ in convs], imgs, do_sample=True, temperature=1.5, top_k=20, max_new_tokens=8,
+                              eos_token_id=None, generator=gen_a)
+    sb = model.generate_batch([ids.to(dev) for ids, _ in convs], imgs, do_sample=True, temperature=1.5, top_k=20, max_new_tokens=8,
+                              eos_token_id=None, generator=gen_b)
+    assert [x.tolist() for x in sa] == [x.tolist() for x in sb]
+    assert [x.tolist() for x in sa] != [x.tolist() for x in ref]
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_batched_decode_bf16_mfma_path_close_to_single(name):
+    """bf16: the batched step uses the tiled MFMA skinny GEMM; its logits stay within BF16_REL of the single path."""
+    model, _ = build(name, torch.bfloat16)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs(name)
+    g, convs = conversations(name, 4, lcfg.vocab_size)
+    eng = model.engine
+    single_logits, firsts = [], []
+    for ids, frames in convs:
+        imgs = [f.to(dev) for f in frames]
+        model.generate(input_ids=ids.view(1, -1).to(dev), images=imgs, do_sample=False, max_new_tokens=3, eos_token_id=None)
+        single_logits.append(eng.d_logits.clone())
+    dec = model.batch_decoder(len(convs), 16)
+    assert dec.tiled
+    dec.reset()
+    for b, (ids, frames) in enumerate(convs):
+        (_, _, _, _, emb, _) = model.prepare_inputs_labels_for_multimodal(ids.view(1, -1).to(dev), None, None, None, None,
+                                                                          [f.to(dev) for f in frames])
+        firsts.append(int(dec.prefill(b, emb[0])[0].argmax()))
+    dec.begin(firsts)
+    dec.steps(2)
+    worst = 0.0
+    for b in range(len(convs)):
+        rel = float((dec.d_logits[b] - single_logits[b]).abs().max()) / float(single_logits[b].abs().max())
+        worst = max(worst, rel)
+    print(f"[{name}] batched bf16 logits after 2 steps: worst rel-to-max diff vs single path {worst:.2e}")
+    assert worst < BF16_REL
+
+
+@pytest.mark.parametrize("weights", ["native", "fp8"])
+def test_batched_decode_real_width_vs_single(weights):
+    """LLaMA-2-7B widths, 2 layers, B = 8: tiled MFMA GEMMs at production shapes vs the single-conversation GEMV path."""
+    from teochat_amd.config import LlavaConfig, VisionConfig
+    from teochat_amd.engine import TeoEngine
+    from teochat_amd.model import LlavaLlamaForCausalLM
+    vit = dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, num_hidden_layers=3, hidden_act="gelu")
+    llm = dict(hidden_size=4096, num_attention_heads=32, num_key_value_heads=32, intermediate_size=11008, num_hidden_layers=2,
+               vocab_size=32000)
+    vcfg, lcfg, mm = O.VitCfg(**vit), O.LlamaCfg(**llm), O.MMCfg()
+    sd = O.make_state_dict(vcfg, lcfg, mm, seed=2, std=0.02)
+    cfg = LlavaConfig(**llm, max_position_embeddings=1024, vision_config=VisionConfig(**vit))
+    eng = TeoEngine(sd, cfg, dtype=torch.bfloat16, device="cuda:0", max_seq=512, weight_format=weights)
+    model = LlavaLlamaForCausalLM(cfg, eng)
+    B = 8
+    convs = [(O.synthetic_prompt_ids(20 + 3 * b, 0, 32000, seed=30 + b), []) for b in range(B)]     # text-only prompts
+    single_logits, single_tokens = [], []
+    for ids, _ in convs:
+        out = model.generate(input_ids=ids.view(1, -1).cuda(), images=None, do_sample=False, max_new_tokens=4, eos_token_id=None)
+        single_logits.append(eng.d_logits.clone())
+        single_tokens.append(out[0, -4:].tolist())
+    outs = model.generate_batch([ids.cuda() for ids, _ in convs], None, do_sample=False, max_new_tokens=4, eos_token_id=None)
+    dec = model._batch_decoder
+    assert dec.tiled
+    worst, same = 0.0, 0
+    for b in range(B):
+        rel = float((dec.d_logits[b] - single_logits[b]).abs().max()) / float(single_logits[b].abs().max())
+        worst = max(worst, rel)
+        same += int(outs[b][-4:].tolist() == single_tokens[b])
+    print(f"real-width batched ({weights}) logits worst rel diff vs single path {worst:.2e}; identical token streams {same}/{B}")
+    assert worst < BF16_REL
+    assert same >= B - 2

@@ -474,3 +474,84 @@ def test_gemv_fp8_weights(N, K, norm, swiglu):
     if res is not None:
         ref = ref + res
     torch.testing.assert_close(y8.cpu(), ref, atol=3e-4, rtol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------- batched-decode GEMM
+@pytest.mark.parametrize("MB", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(64, 64), (300, 128), (4096, 4096), (12288, 4096), (4096, 11008), (32000, 4096)])
+def test_gemm_skinny_bf16(MB, N, K):
+    bf = torch.bfloat16
+    x = G.bf16_round(rnd(MB, K, seed=1))
+    W = G.bf16_round(rnd(N, K, seed=2, scale=0.02 if K > 256 else 0.1))
+    res = G.bf16_round(rnd(MB, N, seed=3))
+    dx, dW, dr = G.dev(x, bf), G.dev(W, bf), G.dev(res, bf)
+    from teochat_amd.engine import tile_weights
+    y32 = G.gemm_skinny(dx, dW, out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(y32, x @ W.T, atol=2e-4, rtol=1e-4)
+    y = G.gemm_skinny(dx, dW, res=dr)
+    close_bf16(y, G.bf16_round(x @ W.T + res))
+    # the operand-tiled weight layout gives bit-identical results (same products, same summation order)
+    dWt = tile_weights(dW)
+    assert torch.equal(G.gemm_skinny(dx, dWt, out_dtype=torch.float32, flags=L.GEMM_WTILED, N=N).cpu(), y32)
+    assert torch.equal(G.gemm_skinny(dx, dWt, res=dr, flags=L.GEMM_WTILED, N=N), y)
+    # every conversation's row equals the single-conversation GEMV on that row (fp32 accumulation order aside)
+    yv = G.gemv(dx[MB - 1].contiguous(), dW, out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(y32[MB - 1], yv, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tiles", [0, 2, 4, 8])
+@pytest.mark.parametrize("MB", [2, 8, 16])
+def test_gemm_skinny_swiglu_and_tilings(MB, tiles):
+    from teochat_amd.engine import interleave_gate_up
+    bf = torch.bfloat16
+    K, Fd = 4096, 11008
+    x = G.bf16_round(rnd(MB, K, seed=1))
+    gate, up = G.bf16_round(rnd(Fd, K, seed=2, scale=0.02)), G.bf16_round(rnd(Fd, K, seed=3, scale=0.02))
+    gu = G.dev(interleave_gate_up(gate, up), bf)
+    dx = G.dev(x, bf)
+    assert G.lib().teo_tune_set(b"skinny_tiles", tiles) == 0
+    try:
+        from teochat_amd.engine import tile_weights
+        y = G.gemm_skinny(dx, gu, flags=L.GEMM_SWIGLU16)
+        assert torch.equal(G.gemm_skinny(dx, tile_weights(gu), flags=L.GEMM_SWIGLU16 | L.GEMM_WTILED), y)
+        yp = G.gemm_skinny(dx, gu, out_dtype=torch.float32).cpu()           # plain product on the interleaved rows
+    finally:
+        G.lib().teo_tune_set(b"skinny_tiles", 0)
+    close_bf16(y, G.bf16_round(F.silu(x @ gate.T) * (x @ up.T)))
+    torch.testing.assert_close(yp, x @ interleave_gate_up(gate, up).T, atol=2e-4, rtol=1e-4)
+    yg = G.gemm(dx, gu, flags=L.GEMM_SWIGLU16)                              # the prefill GEMM on the same rows
+    close_bf16(y, yg.float(), ulps=2.0)
+
+
+@pytest.mark.parametrize("MB", [1, 8, 16])
+@pytest.mark.parametrize("N,K,swiglu", [(4096, 4096, False), (22016, 4096, True), (4096, 11008, False), (320, 128, False)])
+def test_gemm_skinny_fp8_weights(MB, N, K, swiglu):
+    from teochat_amd.engine import quantize_fp8_rows
+    bf = torch.bfloat16
+    W = G.bf16_round(rnd(N, K, seed=2, scale=0.02))
+    q, s, dq = quantize_fp8_rows(W.to(bf))
+    x = G.bf16_round(rnd(MB, K, seed=1))
+    flags = L.GEMM_SWIGLU16 if swiglu else 0
+    dx, q_d, s_d, dq_d = G.dev(x, bf), q.cuda(), s.cuda(), dq.cuda()
+    from teochat_amd.engine import tile_weights
+    y8 = G.gemm_skinny(dx, q_d, scale=s_d, flags=flags, out_dtype=torch.float32)
+    y16 = G.gemm_skinny(dx, dq_d, flags=flags, out_dtype=torch.float32)
+    torch.testing.assert_close(y8, y16, atol=2e-4, rtol=1e-4)
+    y8t = G.gemm_skinny(dx, tile_weights(q_d), scale=s_d, flags=flags | L.GEMM_WTILED, out_dtype=torch.float32, N=N)
+    assert torch.equal(y8t, y8)
+    ref = x @ dq.float().T
+    if swiglu:
+        idx = torch.arange(N // 2)
+        g_rows = (idx // 16) * 32 + idx % 16
+        ref = F.silu(ref[:, g_rows]) * ref[:, g_rows + 16]
+    torch.testing.assert_close(y8.cpu(), ref, atol=3e-4, rtol=2e-4)
+
+
+def test_gemm_skinny_rejects_unsupported():
+    x = torch.zeros(2, 48, dtype=torch.bfloat16, device="cuda")
+    W = torch.zeros(16, 48, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(2, 16, dtype=torch.bfloat16, device="cuda")
+    rc = G.lib().teo_gemm_skinny(G.p(x), G.p(W), None, 0, None, G.p(out), 2, 16, 48, 48, 16, 0, L.TEO_BF16, G.stream())
+    assert rc == -2 and b"skinny" in G.lib().teo_last_error()
+    rc = G.lib().teo_gemm_skinny(G.p(x), G.p(W), None, 0, None, G.p(out), 17, 16, 64, 64, 16, 0, L.TEO_BF16, G.stream())
+    assert rc == -2

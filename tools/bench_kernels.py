@@ -69,6 +69,50 @@ def bench_gemv_mall():
     lib.teo_tune_set(b"gemv_nt", 1)
 
 
+def bench_skinny():
+    """Batched-decode GEMM: weights streamed once for MB conversations; GB/s counts the weight bytes."""
+    from teochat_amd.engine import quantize_fp8_rows
+    shapes = [("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gateup", 22016, 4096, L.GEMM_SWIGLU16), ("down", 4096, 11008, 0),
+              ("lm_head", 32000, 4096, 0)]
+    if os.environ.get("SK_SHAPES") == "gu":
+        shapes = [("gateup", 22016, 4096, L.GEMM_SWIGLU16), ("gu_plain", 22016, 4096, 0)]
+    tiled = L.GEMM_WTILED if int(os.environ.get("SK_TILED", "1")) else 0      # tiled and row-major cost the same to set up here
+    lib.teo_tune_set(b"skinny_nt", int(os.environ.get("SK_NT", "1")))
+    for fp8 in (False, True):
+        for name, N, K, flags in shapes:
+            wb = 1 if fp8 else 2
+            n = max(2, int(600e6 // (N * K * wb)))
+            if fp8:
+                qs = [quantize_fp8_rows((torch.randn(N, K, device="cuda") * 0.02).to(bf))[:2] for _ in range(n)]
+                Ws = [q for q, _ in qs]
+                Ss = [s_ for _, s_ in qs]
+                arr2, pp2 = L.ptr_array([s_.data_ptr() for s_ in Ss])
+            else:
+                Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
+                pp2 = None
+            arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
+            for MB in (8, 16):
+                x = torch.randn(MB, K, device="cuda").to(bf)
+                y = torch.empty(MB, N, dtype=bf, device="cuda")
+                line = f"skinny {'fp8 ' if fp8 else 'bf16'} {name:8s} MB={MB:2d}:"
+                for tiles in (1, 2, 4, 8):
+                    if tiles == 1 and flags:
+                        continue
+                    lib.teo_tune_set(b"skinny_tiles", tiles)
+                    avg = C.c_float(0)
+                    L.check(lib.teo_time_skinny_chain(x.data_ptr(), pp, pp2, n, y.data_ptr(), MB, N, K, flags | tiled, 10, C.byref(avg),
+                                                      G.stream()), "chain")
+                    us = avg.value * 1e3
+                    line += f"  T{tiles} {us:6.1f}us {N * K * wb / us / 1e3:6.0f}GB/s"
+                print(line, flush=True)
+            lib.teo_tune_set(b"skinny_tiles", 0)
+            if not fp8:                                   # the prefill GEMM at the same M for comparison
+                x = torch.randn(16, K, device="cuda").to(bf)
+                us = timeit(lambda: [G.gemm(x, w, flags=flags) for w in Ws], iters=5) / len(Ws)
+                print(f"   (prefill GEMM kernel at M=16: {us:6.1f}us {N * K * 2 / us / 1e3:6.0f}GB/s)", flush=True)
+            del Ws
+
+
 def bench_gemv_fp8_sweep():
     for v in (10, 11, 12, 13):
         lib.teo_tune_set(b"gemv_variant", v)
@@ -183,5 +227,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
