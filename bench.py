@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8 = config C5 weight path (decode streams fp8-e4m3 weights); the headline is bf16")
+    ap.add_argument("--batch", type=int, default=1, help="config C5 variant: B conversations per GPU decoded together (weights streamed once per step)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo for plumbing tests")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to teo_tune_set (perf knobs only)")
@@ -155,7 +156,16 @@ def main():
         tower_call = eng.vit_features
         model.get_model().image_tower.forward = lambda px: sharded_frame_features(tower_call, px)
 
+    B = args.batch
+    if B > 1:
+        batch_in = [synthetic_inputs(T, n_text, model.config.vocab_size, seed=100 * rank + 10 + b, device=device, dtype=dtype)
+                    for b in range(B)]
+
     def step():
+        if B > 1:
+            outs = model.generate_batch([i[0] for _, i in batch_in], [f for f, _ in batch_in], do_sample=False,
+                                        max_new_tokens=n_out, eos_token_id=None, chunk=n_out)
+            return torch.stack(outs)
         out = model.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=n_out, eos_token_id=None,
                              chunk=n_out)
         return out
@@ -179,7 +189,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    convs = args.steps * (1 if args.shard_frames else world)
+    convs = args.steps * (1 if args.shard_frames else world) * B
     value = convs * n_out / dt
 
     # ---- untimed: phase breakdown of one more step
@@ -200,6 +210,12 @@ def main():
     eng.decode_steps(n_out - 1, use_graph=not args.no_graph); torch.cuda.synchronize()
     phases["decode_ms"] = (time.perf_counter() - t) * 1e3
     phases["decode_ms_per_token"] = phases["decode_ms"] / (n_out - 1)
+    if B > 1:
+        dec = model._batch_decoder
+        dec.begin([int(lg[0].argmax())] * B); torch.cuda.synchronize(); t = time.perf_counter()
+        dec.steps(min(64, n_out - 1), use_graph=not args.no_graph); torch.cuda.synchronize()
+        phases["batched_decode_ms_per_step"] = (time.perf_counter() - t) * 1e3 / min(64, n_out - 1)
+        phases["batch"] = B
     phases = {k: round(v, 3) for k, v in phases.items()}
 
     # ---- roofline of the dominant kernel (decode gate/up GEMV: 43 % of the weight bytes of a token), HIP events
@@ -237,12 +253,12 @@ def main():
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
-        "config": {"workload": f"{'C4' if args.shard_frames else ('C3' if T == 8 else 'C2-like')}: T={T} frames 224x224 -> CLIP-ViT-L/14 (23 layers) -> mlp2x_gelu -> splice of a "
+        "config": {"workload": f"{'C4' if args.shard_frames else ((f'C5-batched (B={B} conversations per GPU)' if B > 1 else 'C3') if T == 8 else 'C2-like')}: T={T} frames 224x224 -> CLIP-ViT-L/14 (23 layers) -> mlp2x_gelu -> splice of a "
                                f"{n_text}-token prompt (L={Lseq}) -> LLaMA-2-7B prefill -> {n_out} forced greedy tokens; "
                                f"value = generated tokens / total time",
                    "frames": T, "prompt_tokens": n_text, "sequence_len": Lseq, "new_tokens": n_out,
                    "parallelism": ("frame-sharded ViT + all-gather, replicated LLM" if args.shard_frames
-                                   else f"dp{world} (one conversation per GPU, no collective)"),
+                                   else f"dp{world} ({B} conversation{'s' if B > 1 else ''} per GPU, no collective)"),
                    "weights": "random N(0,0.02^2) at LLaMA-2-7B / ViT-L/14 shapes"},
         "total_tokens_per_s_incl_prompt": round(convs * (Lseq + n_out) / dt, 1),
         "phases": phases,

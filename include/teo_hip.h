@@ -165,12 +165,16 @@ int teo_gemv_w8(const void* d_x, const void* d_W8, const float* d_w_scale, const
  * videollava/model/language_model/llava_llama.py:88-99).  bf16 activations x [MB, ldx]; W bf16 [N, K] or fp8 e4m3
  * (w_fp8 = 1) with w_scale [N]; out bf16 / f32 [MB, ldo]; TEO_GEMM_SWIGLU16 as in teo_gemm (out [MB, N/2]).
  * K % 32 == 0 (64 for fp8); returns TEO_ERR_UNSUPPORTED otherwise.
+ * d_norm_w != NULL fuses LlamaRMSNorm of the rows: out = rsqrt(mean(x^2) + eps) * (W . bf16(x * norm_w)) -- the row
+ * factor commutes with the product, so x is read once and no normalised copy exists (rounding: x*g once to bf16,
+ * the factor applied in fp32; HF rounds x/rms first: same order of error).
  * TEO_GEMM_WTILED: W holds ceil(N/16) * (K/KS) tiles of 1 KB (KS = 32 k for bf16, 64 k for fp8; rows past N zero);
  * tile (n/16, k/KS) starts at ((n/16) * (K/KS) + k/KS) KB and element (n, k) sits in it at 16-byte lane
  * ((k % KS) / CH) * 16 + n % 16, position k % CH (CH = 8 bf16 / 16 fp8 per lane) -- the v_mfma_f32_16x16x32_bf16
  * operand order, so every wave load is 1 KB contiguous. */
-int teo_gemm_skinny(const void* d_x, const void* d_W, const float* d_w_scale, int w_fp8, const void* d_residual, void* d_out,
-                    int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, teo_stream_t stream);
+int teo_gemm_skinny(const void* d_x, const void* d_W, const float* d_w_scale, int w_fp8, const void* d_norm_w, float eps,
+                    const void* d_residual, void* d_out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype,
+                    teo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Composed runtime entry points (the layer loops live in C++, not Python)
@@ -322,8 +326,8 @@ int teo_time_gemv_chain(const void* d_x, const void* const* d_Ws, const float* c
                         void* d_y, int N, int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out,
                         teo_stream_t stream);   /* d_scales != NULL: the matrices are fp8-e4m3 with per-row scales */
 /* The same for teo_gemm_skinny with MB activation rows (x [MB, K] bf16, y [MB, N or N/2] bf16). */
-int teo_time_skinny_chain(const void* d_x, const void* const* d_Ws, const float* const* d_scales, int n, void* d_y, int MB,
-                          int N, int K, unsigned flags, int reps, float* avg_ms_out, teo_stream_t stream);
+int teo_time_skinny_chain(const void* d_x, const void* const* d_Ws, const float* const* d_scales, int n, const void* d_norm_w,
+                          void* d_y, int MB, int N, int K, unsigned flags, int reps, float* avg_ms_out, teo_stream_t stream);
 
 #ifdef __cplusplus
 }

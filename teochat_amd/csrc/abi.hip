@@ -321,18 +321,18 @@ int teo_time_gemv_chain(const void* x, const void* const* Ws, const float* const
     return TEO_OK;
 }
 
-int teo_gemm_skinny(const void* x, const void* W, const float* w_scale, int w_fp8, const void* res, void* out, int MB, int N,
-                    int K, int ldx, int ldo, unsigned flags, int out_dtype, teo_stream_t s) {
+int teo_gemm_skinny(const void* x, const void* W, const float* w_scale, int w_fp8, const void* norm_w, float eps, const void* res,
+                    void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, teo_stream_t s) {
     ENTER();
     TEO_CHECK_ARG(MB >= 0 && N >= 0 && K > 0, "teo_gemm_skinny: MB %d N %d K %d", MB, N, K);
     TEO_CHECK_ARG(out_dtype == TEO_BF16 || out_dtype == TEO_F32, "teo_gemm_skinny: out_dtype %d", out_dtype);
     if (MB == 0 || N == 0) return TEO_OK;
     NEED(x, "x"); NEED(W, "W"); NEED(out, "out");
-    return skinny_gemm(x, W, w_scale, w_fp8, res, out, MB, N, K, ldx, ldo, flags, out_dtype, ST(s));
+    return skinny_gemm(x, W, w_scale, w_fp8, norm_w, eps, res, out, MB, N, K, ldx, ldo, flags, out_dtype, ST(s));
 }
 
-int teo_time_skinny_chain(const void* x, const void* const* Ws, const float* const* scales, int n, void* y, int MB, int N, int K,
-                          unsigned flags, int reps, float* avg_ms_out, teo_stream_t s) {
+int teo_time_skinny_chain(const void* x, const void* const* Ws, const float* const* scales, int n, const void* norm_w, void* y,
+                          int MB, int N, int K, unsigned flags, int reps, float* avg_ms_out, teo_stream_t s) {
     ENTER();
     NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
     TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_skinny_chain: n %d reps %d", n, reps);
@@ -344,11 +344,11 @@ int teo_time_skinny_chain(const void* x, const void* const* Ws, const float* con
     if (e != hipSuccess) { (void)hipEventDestroy(e0); return hip_fail(e, "hipEventCreate"); }
     int rc = TEO_OK;
     for (int i = 0; i < n && rc == TEO_OK; ++i)   // warm-up pass (not timed)
-        rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
+        rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, 1e-5f, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
     (void)hipEventRecord(e0, ST(s));
     for (int r = 0; r < reps && rc == TEO_OK; ++r)
         for (int i = 0; i < n && rc == TEO_OK; ++i)
-            rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
+            rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, 1e-5f, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
     (void)hipEventRecord(e1, ST(s));
     e = hipEventSynchronize(e1);
     float ms = 0.f;

@@ -31,16 +31,14 @@ int hip_fail(hipError_t e, const char* what);
 
 // ---- bf16 <-> f32 -----------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-// round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even (v_cvt_pk_bf16_f32: one instruction for two values, same rounding as torch's float->bfloat16)
+typedef float teo_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 teo_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    const teo_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, teo_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {

@@ -51,8 +51,8 @@ int gemv(const void* x, const void* W, const void* norm_w, const void* res, void
 int gemv_tune_set(const char* key, int value);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
-int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* res, void* out, int MB, int N, int K,
-                int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st);
+int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, float eps, const void* res,
+                void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st);
 int gemm_tune_set(const char* key, int value);
 int attn_tune_set(const char* key, int value);
 int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,

@@ -303,15 +303,10 @@ static int batch_linear(const teo_decode_batch_state* s, const void* x, int ldx,
                         int dt, int out_dt, hipStream_t st) {
     const int B = s->batch;
     const size_t e = esize(dt), eo = esize(out_dt);
-    if (dt == TEO_BF16 && skinny_gemm_ok(B, N, K, norm_w ? K : ldx, w8, flags, norm_w ? xn : x, W)) {
-        const void* xin = x;
-        int ld = ldx;
-        if (norm_w) {
-            TEO_TRY(rmsnorm(x, norm_w, xn, B, K, eps, dt, st));
-            xin = xn;
-            ld = K;
-        }
-        return skinny_gemm(xin, W, wscale, w8, res, y, B, N, K, ld, ldy, flags | (s->w_tiled ? TEO_GEMM_WTILED : 0u), out_dt, st);
+    if (dt == TEO_BF16 && skinny_gemm_ok(B, N, K, ldx, w8, flags, x, W)) {
+        // RMSNorm rides inside the GEMM (row factor applied in its epilogue): no norm launch, no normalised copy
+        return skinny_gemm(x, W, wscale, w8, norm_w, eps, res, y, B, N, K, ldx, ldy, flags | (s->w_tiled ? TEO_GEMM_WTILED : 0u),
+                           out_dt, st);
     }
     if (s->w_tiled) {
         set_error("teo_llama_decode_batch_step: tiled weights need bf16 activations and K %% %d == 0 (N=%d K=%d)", w8 ? 64 : 32, N, K);

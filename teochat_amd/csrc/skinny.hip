@@ -57,9 +57,28 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <typename WT, int UNR, bool NT, bool SWIGLU>
+// x (8 bf16) * g (8 bf16) -> 8 bf16 (one rounding), and the sum of squares of x
+__device__ __forceinline__ u32x4 sk_scale_frag(const u32x4& xv, const u32x4& gv, float& ssq) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = __uint_as_float(xv[i] << 16), x1 = __uint_as_float(xv[i] & 0xffff0000u);
+        const float g0 = __uint_as_float(gv[i] << 16), g1 = __uint_as_float(gv[i] & 0xffff0000u);
+        ssq = fmaf(x0, x0, ssq);
+        ssq = fmaf(x1, x1, ssq);
+        r[i] = pack_bf2(x0 * g0, x1 * g1);
+    }
+    return r;
+}
+
+// NORM: fused RMSNorm of the activation rows.  out[b][n] = inv_rms[b] * sum_k W[n][k] * bf16(x[b][k] * g[k]): the
+// per-row factor 1/rms commutes with the GEMM, so the kernel streams x once, accumulates sum(x^2) from the very
+// fragments it feeds to the matrix cores and applies inv_rms in the epilogue -- no separate norm launch, no
+// normalised copy of x.  (g is staged in LDS once per workgroup.)
+template <typename WT, int UNR, bool NT, bool SWIGLU, bool NORM>
 __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
                                                                  const float* __restrict__ wscale,
+                                                                 const bf16_t* __restrict__ norm_w, float eps,
                                                                  const bf16_t* __restrict__ res, void* __restrict__ outv,
                                                                  int MB, int N, int K, int ldx, int ldo, int ldr, int tiled,
                                                                  int out_f32, int RT) {
@@ -68,8 +87,17 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
     constexpr int CH = F8 ? 16 : 8;                      // k elements per lane chunk
     constexpr int XL = F8 ? 2 : 1;                       // 16-byte activation loads per step
     __shared__ float red[SK_WAVES][SK_TP];
+    __shared__ float ssq_part[SK_WAVES][16];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // NORM: g[K] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    if (NORM) {
+        for (int i = tid; i < K / 8; i += SK_THREADS)
+            reinterpret_cast<u32x4*>(sk_dyn)[i] = reinterpret_cast<const u32x4*>(norm_w)[i];
+        __syncthreads();
+    }
+    const bf16_t* gs = reinterpret_cast<const bf16_t*>(sk_dyn) + fg * (sizeof(WT) == 1 ? 16 : 8);
+    float ssq = 0.f;
     // the 8 waves of a workgroup = RT row tiles (16 weight rows each) x KSPLIT contiguous K slices
     const int KSPLIT = SK_WAVES / RT;
     const int rt = wid / KSPLIT, ks = wid % KSPLIT;
@@ -109,6 +137,11 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         const bool ok = (BASE) + u < s1;                                                                       \
         u32x4 x0 = XR[u][0], x1 = XR[u][XL - 1];                                                               \
         if (!ok) { x0 = (u32x4){0u, 0u, 0u, 0u}; x1 = x0; }                                                    \
+        if (NORM) {                                                                                            \
+            const long long sg = min((BASE) + u, s1 - 1);                                                      \
+            x0 = sk_scale_frag(x0, *reinterpret_cast<const u32x4*>(gs + sg * KS), ssq);                        \
+            if (F8) x1 = sk_scale_frag(x1, *reinterpret_cast<const u32x4*>(gs + sg * KS + 8), ssq);            \
+        }                                                                                                      \
         if (F8) {                                                                                              \
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(WR[u].x, WR[u].y),                   \
                                                           __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);       \
@@ -140,12 +173,23 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
     // partial tiles -> LDS: lane holds out[b = fr][row i = fg*4 + r] of its tile
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wid][fr * 17 + fg * 4 + r] = acc[r];
+    if (NORM) {                                          // lanes (fr, fg = 0..3) hold row fr's partial sum of squares
+        ssq += __shfl_xor(ssq, 16, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (fg == 0) ssq_part[wid][fr] = ssq;
+    }
     __syncthreads();
 
     const int OUTC = SWIGLU ? 8 * RT : 16 * RT;          // output columns of this workgroup
     for (int o = tid; o < 16 * OUTC; o += SK_THREADS) {
         const int b = o / OUTC, c = o % OUTC;
         if (b >= MB) break;
+        float inv = 1.f;
+        if (NORM) {                                      // the K slices of row tile 0 cover the whole row
+            float t = 0.f;
+            for (int w = 0; w < KSPLIT; ++w) t += ssq_part[w][b];
+            inv = rsqrtf(t / (float)K + eps);
+        }
         float v;
         int col;
         if (SWIGLU) {
@@ -157,6 +201,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
                 g += red[(2 * tp) * KSPLIT + w][b * 17 + i];
                 u += red[(2 * tp + 1) * KSPLIT + w][b * 17 + i];
             }
+            g *= inv; u *= inv;
             if (wscale) { g *= wscale[ng]; u *= wscale[ng + 16]; }
             v = silu(g) * u;
             col = (n0 >> 1) + c;
@@ -166,6 +211,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
             if (col >= N) continue;
             v = 0.f;
             for (int w = 0; w < KSPLIT; ++w) v += red[t * KSPLIT + w][b * 17 + i];
+            v *= inv;
             if (wscale) v *= wscale[col];
         }
         if (res) v += bf2f(res[(long long)b * ldr + col]);
@@ -184,8 +230,9 @@ bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, co
 
 // bf16 activations; W bf16 or fp8 e4m3 (+ per-row scales), row-major or TEO_GEMM_WTILED; out bf16 or f32;
 // res (bf16, may alias out) optional
-int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* res, void* out, int MB, int N, int K,
-                int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st) {
+// norm_w != NULL: fused RMSNorm of x (see the kernel)
+int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, float eps, const void* res,
+                void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st) {
     const bool swiglu = flags & TEO_GEMM_SWIGLU16;
     const int tiled = (flags & TEO_GEMM_WTILED) ? 1 : 0;
     if (!skinny_gemm_ok(MB, N, K, ldx, w_fp8, flags, x, W)) {
@@ -194,19 +241,24 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     }
     TEO_CHECK_ARG(!w_fp8 || wscale, "skinny_gemm: fp8 weights need per-row scales");
     TEO_CHECK_ARG(!(swiglu && res), "skinny_gemm: SWIGLU16 takes no residual");
+    TEO_CHECK_ARG(!norm_w || (K <= 16384 && (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0), "skinny_gemm: fused norm needs K <= 16384 and an aligned weight");
     // row tiles per workgroup (8 waves = RT row tiles x 8/RT K slices)
     int rt = g_sk_tiles;
-    if (rt == 0) rt = 2;
-    if (swiglu && rt < 2) rt = 2;
+    if (rt == 0) rt = 1;                  // measured: one row tile per workgroup (most waves in flight) wins at every N
+    if (swiglu && rt < 2) rt = 2;         // the gate tile and its up tile meet in the epilogue
     const int blocks = cdiv(N, 16 * rt);
     const int ldr = ldo, of = out_dtype == TEO_F32;
-#define TEO_SK(WW, NTV, SW)                                                                                \
-    skinny_gemm_kernel<WW, 4, NTV, SW><<<blocks, SK_THREADS, 0, st>>>(                                     \
-        (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt)
-#define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK(WW, NTV, true); } else { TEO_SK(WW, NTV, false); }
+    const size_t dyn = norm_w ? (size_t)K * 2 : 0;
+#define TEO_SK(WW, NTV, SW, NM)                                                                            \
+    skinny_gemm_kernel<WW, 4, NTV, SW, NM><<<blocks, SK_THREADS, dyn, st>>>(                               \
+        (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)norm_w, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, \
+        tiled, of, rt)
+#define TEO_SK_N(WW, NTV, SW) if (norm_w) { TEO_SK(WW, NTV, SW, true); } else { TEO_SK(WW, NTV, SW, false); }
+#define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK_N(WW, NTV, true) } else { TEO_SK_N(WW, NTV, false) }
     if (w_fp8) { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }
     else       { if (g_sk_nt) { TEO_SK_F(bf16_t, true) } else { TEO_SK_F(bf16_t, false) } }
 #undef TEO_SK_F
+#undef TEO_SK_N
 #undef TEO_SK
     TEO_LAUNCH_CHECK("skinny_gemm");
     return TEO_OK;

@@ -51,14 +51,15 @@ def gemm(A, W, bias=None, res=None, act=L.ACT_NONE, flags=0, out_dtype=None):
     return Cc
 
 
-def gemm_skinny(x, W, scale=None, res=None, flags=0, out_dtype=None, N=None):
+def gemm_skinny(x, W, scale=None, res=None, flags=0, out_dtype=None, N=None, norm_w=None, eps=1e-5):
     """x [MB,K] bf16; W [N,K] bf16 or uint8 (fp8 e4m3 bits) with scale [N] fp32 (N: logical rows of a tiled W)."""
     MB, K = x.shape
     N = N or W.shape[0]
     out_dtype = out_dtype or x.dtype
     Nc = N // 2 if flags & L.GEMM_SWIGLU16 else N
     out = torch.empty(MB, Nc, dtype=out_dtype, device=x.device)
-    L.check(lib().teo_gemm_skinny(p(x), p(W), p(scale), 1 if scale is not None else 0, p(res), p(out), MB, N, K, x.stride(0), Nc,
+    L.check(lib().teo_gemm_skinny(p(x), p(W), p(scale), 1 if scale is not None else 0, p(norm_w), eps, p(res), p(out), MB, N, K,
+                                  x.stride(0), Nc,
                                   flags, DT[out_dtype], stream()), "gemm_skinny")
     return out
 

@@ -158,17 +158,21 @@ def test_batched_decode_real_width_vs_single(weights):
     convs = [(O.synthetic_prompt_ids(20 + 3 * b, 0, 32000, seed=30 + b), []) for b in range(B)]     # text-only prompts
     single_logits, single_tokens = [], []
     for ids, _ in convs:
-        out = model.generate(input_ids=ids.view(1, -1).cuda(), images=None, do_sample=False, max_new_tokens=4, eos_token_id=None)
-        single_logits.append(eng.d_logits.clone())
-        single_tokens.append(out[0, -4:].tolist())
-    outs = model.generate_batch([ids.cuda() for ids, _ in convs], None, do_sample=False, max_new_tokens=4, eos_token_id=None)
+        out = model.generate(input_ids=ids.view(1, -1).cuda(), images=None, do_sample=False, max_new_tokens=2, eos_token_id=None)
+        single_logits.append(eng.d_logits.clone())          # logits of the first decode step (input: the prefill's argmax)
+        out = model.generate(input_ids=ids.view(1, -1).cuda(), images=None, do_sample=False, max_new_tokens=6, eos_token_id=None)
+        single_tokens.append(out[0, -6:].tolist())
+    # one batched step from the same prefill state: directly comparable logits (no token history to diverge)
+    model.generate_batch([ids.cuda() for ids, _ in convs], None, do_sample=False, max_new_tokens=2, eos_token_id=None)
     dec = model._batch_decoder
     assert dec.tiled
-    worst, same = 0.0, 0
+    worst = 0.0
     for b in range(B):
         rel = float((dec.d_logits[b] - single_logits[b]).abs().max()) / float(single_logits[b].abs().max())
         worst = max(worst, rel)
-        same += int(outs[b][-4:].tolist() == single_tokens[b])
-    print(f"real-width batched ({weights}) logits worst rel diff vs single path {worst:.2e}; identical token streams {same}/{B}")
+    outs = model.generate_batch([ids.cuda() for ids, _ in convs], None, do_sample=False, max_new_tokens=6, eos_token_id=None)
+    same = sum(int(outs[b][-6:].tolist() == single_tokens[b]) for b in range(B))
+    print(f"real-width batched ({weights}) first-step logits worst rel diff vs single path {worst:.2e}; "
+          f"identical 6-token streams {same}/{B}")
     assert worst < BF16_REL
-    assert same >= B - 2
+    assert same >= B - 3          # random-weight logits are nearly flat: a 1-ulp difference may flip a near-tie

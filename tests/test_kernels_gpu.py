@@ -551,7 +551,42 @@ def test_gemm_skinny_rejects_unsupported():
     x = torch.zeros(2, 48, dtype=torch.bfloat16, device="cuda")
     W = torch.zeros(16, 48, dtype=torch.bfloat16, device="cuda")
     out = torch.zeros(2, 16, dtype=torch.bfloat16, device="cuda")
-    rc = G.lib().teo_gemm_skinny(G.p(x), G.p(W), None, 0, None, G.p(out), 2, 16, 48, 48, 16, 0, L.TEO_BF16, G.stream())
+    rc = G.lib().teo_gemm_skinny(G.p(x), G.p(W), None, 0, None, 0.0, None, G.p(out), 2, 16, 48, 48, 16, 0, L.TEO_BF16, G.stream())
     assert rc == -2 and b"skinny" in G.lib().teo_last_error()
-    rc = G.lib().teo_gemm_skinny(G.p(x), G.p(W), None, 0, None, G.p(out), 17, 16, 64, 64, 16, 0, L.TEO_BF16, G.stream())
+    rc = G.lib().teo_gemm_skinny(G.p(x), G.p(W), None, 0, None, 0.0, None, G.p(out), 17, 16, 64, 64, 16, 0, L.TEO_BF16, G.stream())
     assert rc == -2
+
+
+@pytest.mark.parametrize("MB", [1, 8, 16])
+@pytest.mark.parametrize("N,K,swiglu,fp8", [(12288, 4096, False, False), (22016, 4096, True, False), (22016, 4096, True, True),
+                                            (32000, 4096, False, True), (320, 128, False, False)])
+def test_gemm_skinny_fused_rmsnorm(MB, N, K, swiglu, fp8):
+    """norm_w: rsqrt(mean x^2 + eps) * (W . bf16(x*g)) against the fp64-accumulated definition, and against the
+    unfused composition rmsnorm kernel -> skinny GEMM (differs only by where the bf16 rounding of x_normed sits)."""
+    from teochat_amd.engine import quantize_fp8_rows, tile_weights
+    bf = torch.bfloat16
+    x = G.bf16_round(rnd(MB, K, seed=1) * 3.0)
+    g = G.bf16_round(1 + 0.1 * rnd(K, seed=4))
+    W = G.bf16_round(rnd(N, K, seed=2, scale=0.02))
+    flags = L.GEMM_SWIGLU16 if swiglu else 0
+    dx, dg = G.dev(x, bf), G.dev(g, bf)
+    scale = None
+    if fp8:
+        q, s_, dq = quantize_fp8_rows(W.to(bf))
+        W = dq.float()
+        dW, scale = tile_weights(q.cuda()), s_.cuda()
+    else:
+        dW = tile_weights(G.dev(W, bf))
+    y = G.gemm_skinny(dx, dW, scale=scale, flags=flags | L.GEMM_WTILED, out_dtype=torch.float32, N=N, norm_w=dg, eps=1e-5).cpu()
+    inv = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-5)
+    ref = ((G.bf16_round(x * g).double() @ W.double().T) * inv).float()
+    if swiglu:
+        idx = torch.arange(N // 2)
+        g_rows = (idx // 16) * 32 + idx % 16
+        ref = F.silu(ref[:, g_rows]) * ref[:, g_rows + 16]
+    torch.testing.assert_close(y, ref, atol=3e-4, rtol=2e-4)
+    # unfused composition: one more bf16 rounding of the normalised activations -> bf16-level agreement
+    xn = torch.empty_like(dx)
+    L.check(G.lib().teo_rmsnorm(G.p(dx), G.p(dg), G.p(xn), MB, K, 1e-5, L.TEO_BF16, G.stream()), "rmsnorm")
+    y2 = G.gemm_skinny(xn, dW, scale=scale, flags=flags | L.GEMM_WTILED, out_dtype=torch.float32, N=N).cpu()
+    assert float((y - y2).abs().max()) <= 2e-2 * float(y2.abs().max())

@@ -91,6 +91,8 @@ def bench_skinny():
                 Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
                 pp2 = None
             arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
+            norm = name in ("qkv", "gateup", "lm_head") and int(os.environ.get("SK_NORM", "1"))
+            nw = torch.ones(K, device="cuda").to(bf)
             for MB in (8, 16):
                 x = torch.randn(MB, K, device="cuda").to(bf)
                 y = torch.empty(MB, N, dtype=bf, device="cuda")
@@ -100,7 +102,7 @@ def bench_skinny():
                         continue
                     lib.teo_tune_set(b"skinny_tiles", tiles)
                     avg = C.c_float(0)
-                    L.check(lib.teo_time_skinny_chain(x.data_ptr(), pp, pp2, n, y.data_ptr(), MB, N, K, flags | tiled, 10, C.byref(avg),
+                    L.check(lib.teo_time_skinny_chain(x.data_ptr(), pp, pp2, n, nw.data_ptr() if norm else None, y.data_ptr(), MB, N, K, flags | tiled, 10, C.byref(avg),
                                                       G.stream()), "chain")
                     us = avg.value * 1e3
                     line += f"  T{tiles} {us:6.1f}us {N * K * wb / us / 1e3:6.0f}GB/s"
