@@ -7,10 +7,19 @@ Supported sources:
   * "synthetic:<preset>" -- random weights of a named architecture (no network here for real ones):
         synthetic:teochat-7b   LLaMA-2-7B + CLIP-ViT-L/14 shapes
         synthetic:tiny         a KB-scale model for smoke tests
-LoRA / bitsandbytes branches of the reference are out of scope: `load_8bit/load_4bit` are accepted and
-ignored with a warning (bf16 weights are loaded instead); a LoRA checkpoint raises NotImplementedError.
+  * the reference's other two branches (builder.py:37-72 and :73-88):
+        LoRA       model_name contains "lora" and model_base is given: base weights from model_base, then
+                   non_lora_trainables.bin (prefix rules of builder.py:58-61), then the peft adapter of model_path merged
+                   as W += (lora_alpha / r) * B @ A  (= PeftModel.merge_and_unload, builder.py:63-70);
+        projector  model_base given without "lora": base weights + mm_projector.bin (builder.py:84-86).
+    A peft-wrapped image tower inside a checkpoint (modeling_image.py:775-793: `...encoder.base_model.model.layers...
+    q_proj.base_layer.weight` + `lora_A/B.default.weight`) is merged the same way with the vision config's lora_r / lora_alpha.
+bitsandbytes is CUDA-only: `load_8bit/load_4bit` are accepted and ignored with a warning (bf16 weights are loaded).
 """
+import json
+import re
 import glob
+import math
 import os
 import warnings
 
@@ -31,7 +40,8 @@ def tiny_config():
 
 
 class LazySafetensors:
-    """dict-like view over the shards of an HF checkpoint directory."""
+    """dict-like view over the safetensors shards of an HF checkpoint directory (kept for callers; CheckpointDir also
+    reads pytorch_model*.bin)."""
 
     def __init__(self, model_dir, device):
         from safetensors import safe_open
@@ -58,14 +68,189 @@ class LazySafetensors:
             return h.get_tensor(k).to(self.device)
 
 
+class CheckpointDir:
+    """dict-like, lazy view over every tensor file of an HF checkpoint directory: *.safetensors shards and
+    pytorch_model*.bin (the reference's checkpoints come in either form)."""
+
+    def __init__(self, model_dir, device):
+        from safetensors import safe_open
+        self._open = safe_open
+        self.device = device
+        self.where = {}
+        self._bins = {}
+        for f in sorted(glob.glob(os.path.join(model_dir, "*.safetensors"))):
+            if os.path.basename(f).startswith("adapter_model"):
+                continue
+            with safe_open(f, framework="pt", device="cpu") as h:
+                for k in h.keys():
+                    self.where[k] = f
+        for f in sorted(glob.glob(os.path.join(model_dir, "pytorch_model*.bin"))):
+            blob = torch.load(f, map_location="cpu", weights_only=True)
+            self._bins[f] = blob
+            for k in blob:
+                self.where.setdefault(k, f)
+        if not self.where:
+            raise FileNotFoundError(f"no *.safetensors / pytorch_model*.bin under {model_dir}")
+
+    def __contains__(self, k):
+        return k in self.where
+
+    def keys(self):
+        return self.where.keys()
+
+    def __getitem__(self, k):
+        if k not in self.where:
+            raise KeyError(k)
+        f = self.where[k]
+        if f in self._bins:
+            return self._bins[f][k].to(self.device)
+        with self._open(f, framework="pt", device="cpu") as h:
+            return h.get_tensor(k).to(self.device)
+
+
+def _load_tensor_file(path):
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def _strip_non_lora_prefixes(blob):
+    """builder.py:58-61 / merge_lora_weights.py:16-18."""
+    blob = {(k[11:] if k.startswith("base_model.") else k): v for k, v in blob.items()}
+    if any(k.startswith("model.model.") for k in blob):
+        blob = {(k[6:] if k.startswith("model.") else k): v for k, v in blob.items()}
+    return blob
+
+
+_LORA_RE = re.compile(r"^(?P<stem>.*)\.lora_(?P<ab>[AB])(?:\.(?P<adapter>[^.]+))?\.weight$")
+
+
+class MergedCheckpoint:
+    """A base tensor source + replacement tensors + LoRA pairs, resolved lazily per key:
+    W[k] = (override[k] or base[k]) + scale * B @ A   (fp32 product, rounded once to the stored dtype)."""
+
+    def __init__(self, base, overrides=None, lora=None, scale=1.0, rename=None):
+        self.base = base
+        self.overrides = dict(overrides or {})
+        self.lora = dict(lora or {})          # clean key -> (A [r, in], B [out, r], scale)
+        self.scale = scale
+        self.rename = dict(rename or {})      # clean key -> key in the base source
+
+    def keys(self):
+        ks = set(self.overrides) | set(self.rename)
+        ks |= {k for k in self.base.keys() if ".lora_" not in k and ".base_layer." not in k and "base_model.model." not in k}
+        return ks
+
+    def __contains__(self, k):
+        return k in self.overrides or k in self.rename or k in self.base
+
+    def __getitem__(self, k):
+        if k in self.overrides:
+            w = self.overrides[k]
+            dev = getattr(self.base, "device", w.device)
+            w = w.to(dev)
+        else:
+            w = self.base[self.rename.get(k, k)]
+        pair = self.lora.get(k)
+        if pair is not None:
+            A, B, sc = pair
+            delta = (B.to(w.device, torch.float32) @ A.to(w.device, torch.float32)) * sc
+            w = (w.to(torch.float32) + delta).to(w.dtype)
+        return w
+
+
+def merge_lora_adapter(base, adapter_dir):
+    """peft adapter directory (adapter_config.json + adapter_model.{safetensors,bin}) over `base`:
+    what PeftModel.from_pretrained(...).merge_and_unload() leaves in the model (builder.py:63-70)."""
+    with open(os.path.join(adapter_dir, "adapter_config.json")) as f:
+        acfg = json.load(f)
+    r, alpha = int(acfg["r"]), float(acfg["lora_alpha"])
+    if acfg.get("fan_in_fan_out"):
+        raise NotImplementedError("fan_in_fan_out LoRA adapters (Conv1D layers) do not occur in LLaMA")
+    scale = alpha / math.sqrt(r) if acfg.get("use_rslora") else alpha / r
+    files = [os.path.join(adapter_dir, n) for n in ("adapter_model.safetensors", "adapter_model.bin")]
+    files = [f for f in files if os.path.exists(f)]
+    if not files:
+        raise FileNotFoundError(f"no adapter_model.safetensors / adapter_model.bin under {adapter_dir}")
+    blob = _load_tensor_file(files[0])
+    halves = {}
+    for k, v in blob.items():
+        m = _LORA_RE.match(k)
+        if not m:
+            continue
+        stem = m.group("stem")
+        if stem.startswith("base_model.model."):
+            stem = stem[len("base_model.model."):]
+        halves.setdefault(stem + ".weight", {})[m.group("ab")] = v
+    lora = {}
+    for k, ab in halves.items():
+        if "A" not in ab or "B" not in ab:
+            raise ValueError(f"incomplete LoRA pair for {k}")
+        if k not in base:
+            raise KeyError(f"LoRA target {k} is not in the base checkpoint")
+        lora[k] = (ab["A"], ab["B"], scale)
+    return lora
+
+
+def unwrap_peft_tower(source, vision_cfg):
+    """Keys of a peft-wrapped LanguageBind encoder saved inside a checkpoint (modeling_image.py:775-793):
+    `<enc>.base_model.model.layers.N.self_attn.q_proj.base_layer.weight`, `...lora_A.default.weight`, ... ->
+    plain `<enc>.layers.N.self_attn.q_proj.weight` with the adapter merged (scale lora_alpha / lora_r)."""
+    keys = list(source.keys())
+    if not any(".lora_A." in k for k in keys):
+        return source
+    r = int(getattr(vision_cfg, "lora_r", 0) or 0)
+    alpha = float(getattr(vision_cfg, "lora_alpha", r) or r)
+    if r <= 0:
+        raise ValueError("checkpoint holds LoRA tensors for the image tower but vision_config.lora_r is 0")
+    scale = alpha / r
+
+    def clean(k):
+        return k.replace(".base_model.model.", ".").replace(".base_layer.", ".")
+
+    rename, halves = {}, {}
+    for k in keys:
+        m = _LORA_RE.match(k)
+        if m:
+            halves.setdefault(clean(m.group("stem")) + ".weight", {})[m.group("ab")] = k
+        elif clean(k) != k:
+            rename[clean(k)] = k
+    lora = {}
+    for k, ab in halves.items():
+        if "A" not in ab or "B" not in ab:
+            raise ValueError(f"incomplete LoRA pair for {k}")
+        lora[k] = (source[ab["A"]], source[ab["B"]], scale)
+    return MergedCheckpoint(source, lora=lora, rename=rename)
+
+
+def open_checkpoint(model_path, model_base, model_name, device):
+    """The tensor source for the three branches of builder.py:33-112 (LoRA / projector-only / merged)."""
+    lname = model_name.lower()
+    if "lora" in lname and model_base is None:
+        warnings.warn("There is `lora` in model name but no `model_base` is provided. If you are loading a LoRA model, "
+                      "please provide the `model_base` argument.")
+    if "lora" in lname and model_base is not None:
+        base = CheckpointDir(model_base, device)
+        overrides = {}
+        nl = os.path.join(model_path, "non_lora_trainables.bin")
+        if os.path.exists(nl):
+            overrides = _strip_non_lora_prefixes(torch.load(nl, map_location="cpu", weights_only=True))
+        probe = MergedCheckpoint(base, overrides)
+        return MergedCheckpoint(base, overrides, lora=merge_lora_adapter(probe, model_path))
+    if model_base is not None:
+        base = CheckpointDir(model_base, device)
+        proj = torch.load(os.path.join(model_path, "mm_projector.bin"), map_location="cpu", weights_only=True)
+        return MergedCheckpoint(base, proj)
+    return CheckpointDir(model_path, device)
+
+
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda", cache_dir=None, dtype=torch.bfloat16, max_seq=None, seed=2, weight_format=None):
     if device in (None, "cuda"):
         device = "cuda:0"
     if load_8bit or load_4bit:
         warnings.warn("bitsandbytes int8/nf4 loading is CUDA-only and out of scope; loading bf16 weights instead")
-    if "lora" in model_name.lower() and model_base is not None:
-        raise NotImplementedError("LoRA checkpoints must be merged first (scripts/merge_lora_weights.py in the reference)")
     if model_path.startswith("synthetic:"):
         from .synthetic import synthetic_state_dict
         preset = model_path.split(":", 1)[1]
@@ -80,13 +265,12 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     else:
         if "llava" not in model_name.lower() and "teochat" not in model_name.lower():
             raise ValueError(f"Unsupported model name {model_name!r}: expected a llava/teochat checkpoint (builder.py:33)")
-        cfg = LlavaConfig.from_pretrained(model_path)
-        sd = LazySafetensors(model_path, device)
-        if any(".lora_A." in k for k in sd.keys()):
-            raise NotImplementedError("peft-wrapped tower / LoRA tensors found; merge them first")
-        if os.path.exists(os.path.join(model_path, "tokenizer.model")):
+        cfg = LlavaConfig.from_pretrained(model_path)           # the LoRA / projector branches read the config of model_path too
+        sd = unwrap_peft_tower(open_checkpoint(model_path, model_base, model_name, device), cfg.vision_config)
+        tok_dir = model_base if model_base is not None else model_path       # builder.py:40,82 vs :111
+        if os.path.exists(os.path.join(tok_dir, "tokenizer.model")):
             from transformers import AutoTokenizer
-            tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
+            tokenizer = AutoTokenizer.from_pretrained(tok_dir, use_fast=False)
         else:
             tokenizer = ByteTokenizer()
     engine = TeoEngine(sd, cfg, dtype=dtype, device=device, max_seq=max_seq, weight_format=weight_format)

@@ -42,12 +42,124 @@ def test_config_and_lazy_safetensors_roundtrip(tmp_path):
         lz["nope"]
 
 
+def _write_lora(tmp_path, sd, cfg, r=4, alpha=8.0, as_bin=False):
+    """A peft adapter directory over the tiny checkpoint: q_proj / v_proj of every LLaMA layer + non_lora_trainables
+    (projector), named the way peft / the reference's trainer save them."""
+    from safetensors.torch import save_file
+    d = tmp_path / "llava-lora-tiny"
+    d.mkdir()
+    g = torch.Generator().manual_seed(5)
+    adapter, merged = {}, {k: v.clone() for k, v in sd.items()}
+    for i in range(cfg.num_hidden_layers):
+        for n in ("q_proj", "v_proj"):
+            k = f"model.layers.{i}.self_attn.{n}.weight"
+            out, inp = sd[k].shape
+            A = torch.randn(r, inp, generator=g) * 0.1
+            B = torch.randn(out, r, generator=g) * 0.1
+            adapter[f"base_model.model.model.layers.{i}.self_attn.{n}.lora_A.weight"] = A
+            adapter[f"base_model.model.model.layers.{i}.self_attn.{n}.lora_B.weight"] = B
+            merged[k] = sd[k] + (alpha / r) * (B @ A)
+    if as_bin:
+        torch.save(adapter, str(d / "adapter_model.bin"))
+    else:
+        save_file(adapter, str(d / "adapter_model.safetensors"))
+    json.dump({"r": r, "lora_alpha": alpha, "target_modules": ["q_proj", "v_proj"], "peft_type": "LORA"},
+              open(d / "adapter_config.json", "w"))
+    nl = {}
+    for k in sd:
+        if "mm_projector" in k:
+            merged[k] = sd[k] * 1.5 + 0.01
+            nl["base_model.model." + k] = merged[k].clone()
+    torch.save(nl, str(d / "non_lora_trainables.bin"))
+    json.dump(cfg.to_dict(), open(d / "config.json", "w"))
+    return str(d), merged
+
+
+@pytest.mark.parametrize("as_bin", [False, True])
+def test_lora_and_projector_branches_merge_like_the_reference(tmp_path, as_bin):
+    """builder.py:37-72 (LoRA: base + non_lora_trainables + merge_and_unload) and :73-88 (base + mm_projector.bin)."""
+    from teochat_amd.builder import CheckpointDir, open_checkpoint, unwrap_peft_tower
+    base, cfg, sd = _write_checkpoint(tmp_path)
+    lora_dir, merged = _write_lora(tmp_path, sd, cfg, as_bin=as_bin)
+    src = open_checkpoint(lora_dir, base, "llava-lora-tiny", "cpu")
+    assert set(src.keys()) == set(sd)
+    for k in sd:
+        torch.testing.assert_close(src[k], merged[k], atol=1e-6, rtol=1e-6)
+    # projector-only branch
+    pd = tmp_path / "llava-proj"
+    pd.mkdir()
+    proj = {k: v * 2 for k, v in sd.items() if "mm_projector" in k}
+    torch.save(proj, str(pd / "mm_projector.bin"))
+    src = open_checkpoint(str(pd), base, "llava-tiny", "cpu")
+    for k in sd:
+        assert torch.equal(src[k], proj.get(k, sd[k]))
+    # pytorch_model-*.bin shards instead of safetensors
+    bd = tmp_path / "llava-bin"
+    bd.mkdir()
+    keys = sorted(sd)
+    torch.save({k: sd[k] for k in keys[::2]}, str(bd / "pytorch_model-00001-of-00002.bin"))
+    torch.save({k: sd[k] for k in keys[1::2]}, str(bd / "pytorch_model-00002-of-00002.bin"))
+    cd = CheckpointDir(str(bd), "cpu")
+    assert set(cd.keys()) == set(sd) and all(torch.equal(cd[k], sd[k]) for k in keys)
+    # peft-wrapped tower inside a merged checkpoint (modeling_image.py:775-793)
+    from safetensors.torch import save_file
+    wd = tmp_path / "llava-wrapped"
+    wd.mkdir()
+    enc = O.VIT_PREFIX + "encoder."
+    wrapped, want = {}, {}
+    g = torch.Generator().manual_seed(9)
+    for k, v in sd.items():
+        if k.startswith(enc):
+            rest = k[len(enc):]
+            if any(rest.endswith(f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj", "out_proj")):
+                stem = enc + "base_model.model." + rest[:-len(".weight")]
+                A, B = torch.randn(2, v.shape[1], generator=g) * 0.1, torch.randn(v.shape[0], 2, generator=g) * 0.1
+                wrapped[stem + ".base_layer.weight"] = v
+                wrapped[stem + ".lora_A.default.weight"] = A
+                wrapped[stem + ".lora_B.default.weight"] = B
+                want[k] = v + (16.0 / 2) * (B @ A)
+            else:
+                wrapped[enc + "base_model.model." + rest.replace("self_attn.q_proj.bias", "self_attn.q_proj.base_layer.bias")] = v
+                want[k] = v
+        else:
+            wrapped[k] = v
+            want[k] = v
+    save_file({k: v.contiguous() for k, v in wrapped.items()}, str(wd / "model.safetensors"))
+    vcfg = cfg.vision_config
+    vcfg.lora_r, vcfg.lora_alpha = 2, 16.0
+    src = unwrap_peft_tower(CheckpointDir(str(wd), "cpu"), vcfg)
+    assert set(src.keys()) == set(sd)
+    for k in sd:
+        torch.testing.assert_close(src[k], want[k], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_load_lora_checkpoint_end_to_end(tmp_path):
+    """load_pretrained_model(lora_dir, base, 'llava-lora-...') == an engine built from the manually merged weights."""
+    from teochat_amd.builder import load_pretrained_model
+    from teochat_amd.engine import TeoEngine
+    from teochat_amd.model import LlavaLlamaForCausalLM
+    base, cfg, sd = _write_checkpoint(tmp_path)
+    lora_dir, merged = _write_lora(tmp_path, sd, cfg)
+    _, model, _, _ = load_pretrained_model(lora_dir, base, "llava-lora-tiny", device="cuda:0", dtype=torch.float32, max_seq=1024)
+    ref = LlavaLlamaForCausalLM(cfg, TeoEngine(merged, cfg, dtype=torch.float32, device="cuda:0", max_seq=1024))
+    g = TY.load_npz("tinyA")
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    frames = [f.cuda() for f in O.synthetic_frames(int(g["T"]), cfg.vision_config.image_size, seed=0)]
+    a = model(input_ids=ids, images=frames).logits
+    b = ref(input_ids=ids, images=frames).logits
+    assert torch.equal(a, b)
+    vcfg, lcfg, mm = TY.cfgs("tinyA")
+    want, _, _ = O.mm_forward(ids.cpu(), [f.cpu() for f in frames], merged, vcfg, lcfg, mm)
+    assert float((a[0].cpu() - want[0]).abs().max()) < 1e-4
+
+
 def test_product_fails_loudly_without_gpu_or_library(tmp_path, monkeypatch):
     from teochat_amd import _lib as L
     from teochat_amd.builder import load_pretrained_model
     path, _, _ = _write_checkpoint(tmp_path)
-    with pytest.raises(NotImplementedError):                       # LoRA checkpoints must be merged first
-        load_pretrained_model(path, "base", "llava-lora-tiny")
+    with pytest.raises(FileNotFoundError):                         # LoRA branch: the base directory must hold weights
+        load_pretrained_model(path, str(tmp_path / "no-such-base"), "llava-lora-tiny")
     with pytest.raises(ValueError):                                # not a llava/teochat checkpoint name (builder.py:33)
         load_pretrained_model(path, None, "vicuna-7b")
     if not torch.cuda.is_available():
