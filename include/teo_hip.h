@@ -135,6 +135,13 @@ int teo_rope_kv_append(void* d_qkv, int ld_qkv, const int* d_positions, const fl
 int teo_embed_splice(const int* d_plan, const void* d_embed, const void* d_visual, void* d_out, int rows, int dim,
                      int dtype, teo_stream_t stream);
 
+/* Image preprocessing on the device (languagebind/image/processing_image.py:15-25 get_image_transform):
+ * src uint8 [T, H, W, 3] (RGB, as PIL gives it) -> out [T, 3, S, S] = Normalize(CenterCrop(S)(Resize(S, bicubic,
+ * antialias)(ToTensor(src))), mean, std) in `dtype`; mean/std are HOST pointers to 3 floats.  The resampling is ATen's
+ * anti-aliased bicubic (a = -0.5, align_corners = False); H == W == S is the identity. */
+int teo_preprocess_frames(const unsigned char* d_src, void* d_out, int T, int H, int W, int S, const float* mean,
+                          const float* std, int dtype, teo_stream_t stream);
+
 /* out[t, p, :] = in[t, 1+p, :]  (feature_select 'patch', languagebind/__init__.py:121-129) */
 int teo_drop_cls(const void* d_in, void* d_out, int T, int n_tokens, int dim, int dtype, teo_stream_t stream);
 

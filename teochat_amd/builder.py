@@ -275,7 +275,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
             tokenizer = ByteTokenizer()
     engine = TeoEngine(sd, cfg, dtype=dtype, device=device, max_seq=max_seq, weight_format=weight_format)
     del sd
-    image_processor = TeoImageProcessor(size=cfg.vision_config.image_size)
+    image_processor = TeoImageProcessor(size=cfg.vision_config.image_size, engine=engine)     # uint8 frames -> device kernel
     model = LlavaLlamaForCausalLM(cfg, engine, image_processor)
     context_len = getattr(cfg, "max_sequence_length", 2048)
     return tokenizer, model, {"image": image_processor, "video": None}, context_len

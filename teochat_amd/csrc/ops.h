@@ -48,6 +48,8 @@ int embed_token(const long long* tok, const void* embed, void* h, int dim, int d
 int gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
          unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
+int preprocess_frames(const unsigned char* src, void* out, int T, int H, int W, int S, const float* mean, const float* stdv,
+                      int dtype, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);

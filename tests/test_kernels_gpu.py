@@ -590,3 +590,43 @@ def test_gemm_skinny_fused_rmsnorm(MB, N, K, swiglu, fp8):
     L.check(G.lib().teo_rmsnorm(G.p(dx), G.p(dg), G.p(xn), MB, K, 1e-5, L.TEO_BF16, G.stream()), "rmsnorm")
     y2 = G.gemm_skinny(xn, dW, scale=scale, flags=flags | L.GEMM_WTILED, out_dtype=torch.float32, N=N).cpu()
     assert float((y - y2).abs().max()) <= 2e-2 * float(y2.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------- preprocessing (N3)
+@pytest.mark.parametrize("H,W", [(224, 224), (256, 320), (320, 256), (1024, 1024), (100, 150), (231, 517), (2000, 1500)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_preprocess_frames_matches_torchvision_semantics(H, W, dtype):
+    """teo_preprocess_frames == ToTensor -> Resize(224, bicubic, antialias) -> CenterCrop(224) -> Normalize on the CPU
+    (teochat_amd.processor.TeoImageProcessor.transform restates processing_image.py:15-25 with torch ops)."""
+    import ctypes as C
+    from teochat_amd.processor import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD, TeoImageProcessor
+    g = torch.Generator().manual_seed(H * 7 + W)
+    T = 3
+    raw = torch.randint(0, 256, (T, H, W, 3), generator=g, dtype=torch.uint8)
+    # smooth content on top of the noise so that interpolation errors would show
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    raw[1] = ((torch.sin(yy / 9.0) * torch.cos(xx / 13.0) * 0.5 + 0.5) * 255).to(torch.uint8)[..., None].expand(H, W, 3)
+    proc = TeoImageProcessor()
+    want = torch.stack([proc.transform(raw[t]) for t in range(T)])
+    src = raw.cuda()
+    out = torch.empty(T, 3, 224, 224, dtype=dtype, device="cuda")
+    mean, std = (C.c_float * 3)(*OPENAI_DATASET_MEAN), (C.c_float * 3)(*OPENAI_DATASET_STD)
+    L.check(G.lib().teo_preprocess_frames(G.p(src), G.p(out), T, H, W, 224, mean, std, G.DT[dtype], G.stream()), "preprocess")
+    if dtype == torch.float32:
+        torch.testing.assert_close(out.cpu(), want, atol=3e-5, rtol=0)
+        if (H, W) == (224, 224):
+            exact = (raw.permute(0, 3, 1, 2).float() / 255.0 - torch.tensor(OPENAI_DATASET_MEAN).view(1, 3, 1, 1)) \
+                / torch.tensor(OPENAI_DATASET_STD).view(1, 3, 1, 1)
+            torch.testing.assert_close(out.cpu(), exact, atol=2e-6, rtol=0)
+    else:
+        close_bf16(out, G.bf16_round(want), ulps=1.0)
+
+
+def test_preprocess_frames_rejects_huge_downscale():
+    import ctypes as C
+    src = torch.zeros(1, 5000, 5000, 3, dtype=torch.uint8, device="cuda")
+    out = torch.empty(1, 3, 224, 224, device="cuda")
+    m = (C.c_float * 3)(0, 0, 0)
+    s_ = (C.c_float * 3)(1, 1, 1)
+    rc = G.lib().teo_preprocess_frames(G.p(src), G.p(out), 1, 5000, 5000, 224, m, s_, L.TEO_F32, G.stream())
+    assert rc == -2 and b"taps" in G.lib().teo_last_error()

@@ -320,3 +320,28 @@ def test_fp8_weight_path_matches_oracle_on_dequantised_weights():
             break
     if rel is not None:
         assert rel < 3e-2
+
+
+def test_engine_bound_processor_preprocesses_on_device(tmp_path):
+    """N3: with an engine bound, uint8 frames (paths / PIL / arrays) go through teo_preprocess_frames; float inputs and
+    the engine-less processor keep the host path; both agree."""
+    from PIL import Image
+    from teochat_amd.processor import TeoImageProcessor
+    model, _ = build("tinyA", torch.float32)
+    host = TeoImageProcessor()
+    dev = TeoImageProcessor(engine=model.engine)
+    g = torch.Generator().manual_seed(3)
+    frames = [torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8) for h, w in ((300, 260), (224, 224), (300, 260))]
+    paths = []
+    for i, f in enumerate(frames):
+        p = tmp_path / f"f{i}.png"
+        Image.fromarray(f.numpy()).save(p)
+        paths.append(str(p))
+    want = host.preprocess(paths)["pixel_values"]
+    got = dev.preprocess(paths)["pixel_values"]
+    assert got.is_cuda and got.dtype == torch.float32 and got.shape == want.shape
+    torch.testing.assert_close(got.cpu(), want, atol=3e-5, rtol=0)
+    got1 = dev.preprocess(Image.open(paths[0]))["pixel_values"]
+    torch.testing.assert_close(got1.cpu(), want[:1], atol=3e-5, rtol=0)
+    flt = want[0].clone()                                  # already-normalised float frames stay on the host path
+    assert not dev.preprocess(torch.rand(3, 224, 224))["pixel_values"].is_cuda
