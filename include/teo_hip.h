@@ -135,6 +135,14 @@ int teo_rope_kv_append(void* d_qkv, int ld_qkv, const int* d_positions, const fl
 int teo_embed_splice(const int* d_plan, const void* d_embed, const void* d_visual, void* d_out, int rows, int dim,
                      int dtype, teo_stream_t stream);
 
+/* Training-shape loss: mean over rows with label != ignore_index of (logsumexp(logits[r]) - logits[r, label[r]]) --
+ * torch.nn.CrossEntropyLoss as LlamaForCausalLM.forward applies it to the shifted logits/labels (call site
+ * videollava/model/language_model/llava_llama.py:88-99).  logits fp32 [rows, ld]; labels int64 [rows] (already shifted
+ * by the caller); loss_row fp32 [rows] scratch/output (0 on ignored rows); out fp32 [3] = {mean (nan if nothing is
+ * supervised), sum, count}. */
+int teo_cross_entropy(const float* d_logits, long long ld, const long long* d_labels, float* d_loss_row, float* d_out, int rows,
+                      int vocab, long long ignore_index, teo_stream_t stream);
+
 /* Image preprocessing on the device (languagebind/image/processing_image.py:15-25 get_image_transform):
  * src uint8 [T, H, W, 3] (RGB, as PIL gives it) -> out [T, 3, S, S] = Normalize(CenterCrop(S)(Resize(S, bicubic,
  * antialias)(ToTensor(src))), mean, std) in `dtype`; mean/std are HOST pointers to 3 floats.  The resampling is ATen's

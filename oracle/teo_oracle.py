@@ -594,6 +594,21 @@ def mm_forward(input_ids, images: List[torch.Tensor], sd, vcfg: VitCfg, lcfg: Ll
     return logits, cache, embeds
 
 
+def training_loss(input_ids, attention_mask, labels, images, sd, vcfg: VitCfg, lcfg: LlamaCfg, mm: MMCfg):
+    """Training-shape forward with labels: llava_llama.py:56-99 -> LlamaForCausalLM loss = CrossEntropyLoss over the
+    shifted positions of the SPLICED sequence (labels come back from prepare_inputs_labels_for_multimodal with
+    IGNORE_INDEX on visual rows and padding, llava_arch.py:251-340).  Returns (loss, logits, spliced labels)."""
+    pix = torch.stack([im.to(torch.float32) for im in images])
+    feats = encode_images(pix, sd, vcfg, mm, None)
+    flat = [feats[i] for i in range(feats.shape[0])]
+    emb_w = sd["model.embed_tokens.weight"].to(torch.float32)
+    _, pos, mask, _, embeds, lab = prepare_inputs_labels_for_multimodal(input_ids, None, attention_mask, None, labels, flat, emb_w, mm)
+    logits, _ = llama_forward(embeds, pos, mask, None, sd, lcfg, None)
+    V = logits.shape[-1]
+    loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, V), lab[:, 1:].reshape(-1), ignore_index=IGNORE_INDEX)
+    return loss, logits, lab
+
+
 def greedy_generate(input_ids, images, sd, vcfg, lcfg, mm, max_new_tokens, rounding=None, dtype=torch.float32,
                     eos_token_id=None):
     """inference.py:64-72 with do_sample=False: prefill, then 1-token steps with the KV cache

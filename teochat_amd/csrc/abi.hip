@@ -321,6 +321,15 @@ int teo_time_gemv_chain(const void* x, const void* const* Ws, const float* const
     return TEO_OK;
 }
 
+int teo_cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
+                      long long ignore_index, teo_stream_t s) {
+    ENTER();
+    TEO_CHECK_ARG(rows >= 0 && vocab > 0 && ld >= vocab, "teo_cross_entropy: rows %d vocab %d ld %lld", rows, vocab, ld);
+    NEED(out, "out");
+    if (rows) { NEED(logits, "logits"); NEED(labels, "labels"); NEED(loss_row, "loss_row"); }
+    return cross_entropy(logits, ld, labels, loss_row, out, rows, vocab, ignore_index, ST(s));
+}
+
 int teo_preprocess_frames(const unsigned char* src, void* out, int T, int H, int W, int S, const float* mean, const float* stdv,
                           int dtype, teo_stream_t s) {
     ENTER();

@@ -500,4 +500,53 @@ int embed_token(const long long* tok, const void* embed, void* h, int dim, int d
     return TEO_OK;
 }
 
+// ---- training-shape loss: CrossEntropyLoss(ignore_index) of LlamaForCausalLM.forward with labels
+// (the call at videollava/model/language_model/llava_llama.py:88-99).  One workgroup per row: max, log-sum-exp, picked
+// logit -> loss_row[r] (0 for ignored rows); a single workgroup then sums rows and counts in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, long long ld, const long long* __restrict__ labels,
+                                                      float* __restrict__ loss_row, int vocab, long long ignore_index) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const long long lab = labels[r];
+    if (lab == ignore_index || lab < 0 || lab >= vocab) {      // out-of-range labels are rejected on the host
+        if (threadIdx.x == 0) loss_row[r] = 0.f;
+        return;
+    }
+    const float* row = logits + (long long)r * ld;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < vocab; i += 256) m = fmaxf(m, row[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int i = threadIdx.x; i < vocab; i += 256) s += expf(row[i] - m);
+    s = block_sum<256>(s, red);
+    if (threadIdx.x == 0) loss_row[r] = logf(s) + m - row[lab];
+}
+
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ loss_row, const long long* __restrict__ labels,
+                                                        int rows, int vocab, long long ignore_index, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f, n = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        const long long lab = labels[i];
+        if (lab != ignore_index && lab >= 0 && lab < vocab) { s += loss_row[i]; n += 1.f; }
+    }
+    s = block_sum<256>(s, red);
+    n = block_sum<256>(n, red);
+    if (threadIdx.x == 0) { out[0] = s / n; out[1] = s; out[2] = n; }     // 0/0 = nan, as torch's mean reduction
+}
+
+int cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
+                  long long ignore_index, hipStream_t st) {
+    if (rows > 0) {
+        ce_rows_kernel<<<rows, 256, 0, st>>>(logits, ld, labels, loss_row, vocab, ignore_index);
+        TEO_LAUNCH_CHECK("ce_rows");
+    }
+    ce_reduce_kernel<<<1, 256, 0, st>>>(loss_row, labels, rows, vocab, ignore_index, out);
+    TEO_LAUNCH_CHECK("ce_reduce");
+    return TEO_OK;
+}
+
 }  // namespace teo

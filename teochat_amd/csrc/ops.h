@@ -50,6 +50,8 @@ int gemv(const void* x, const void* W, const void* norm_w, const void* res, void
 
 int preprocess_frames(const unsigned char* src, void* out, int T, int H, int W, int S, const float* mean, const float* stdv,
                       int dtype, hipStream_t st);
+int cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
+                  long long ignore_index, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);

@@ -325,10 +325,21 @@ class LlavaLlamaForCausalLM:
             logits[b, lo:hi] = out
         loss = None
         if labels is not None:
-            # N4 ("next" row): training-shape loss; plain torch on the fp32 logits, not part of the inference path
-            shift_logits = logits[:, :-1, :].reshape(-1, self.config.vocab_size)
-            shift_labels = labels[:, 1:].reshape(-1).to(shift_logits.device)
-            loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX)
+            # N4: training-shape loss (CrossEntropyLoss over the shifted positions) on the device: row (b, s) pairs
+            # logits[b, s] with labels[b, s + 1]; the last position of every sample is ignored
+            V = self.config.vocab_size
+            lab = labels.to(device=logits.device, dtype=torch.int64)
+            if bool(((lab != IGNORE_INDEX) & ((lab < 0) | (lab >= V))).any()):
+                raise IndexError("Target out of bounds")                    # what torch's cross_entropy reports
+            shifted = torch.cat([lab[:, 1:], torch.full_like(lab[:, :1], IGNORE_INDEX)], dim=1).reshape(-1).contiguous()
+            rows = shifted.numel()
+            loss_row = torch.empty(rows, dtype=torch.float32, device=logits.device)
+            out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+            with eng.phase() as st:
+                lg = logits.reshape(rows, V)
+                L.check(eng.lib.teo_cross_entropy(lg.data_ptr(), V, shifted.data_ptr(), loss_row.data_ptr(), out3.data_ptr(), rows,
+                                                  V, IGNORE_INDEX, st), "teo_cross_entropy")
+            loss = out3[0]
         pkv = TeoKVCache(eng) if (use_cache is None or use_cache) and B == 1 else None
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv)
         if return_dict is False:

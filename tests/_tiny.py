@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import torch
 
 from oracle import teo_oracle as O
 
@@ -51,3 +52,22 @@ def load_npz(name):
 
 def load_json(name):
     return json.load(open(os.path.join(GOLDEN, name + ".json")))
+
+
+def train_batch(vocab, image_size):
+    """Training-shape inputs (train.py:840-901 feeds the same forward): batch of 2, right padding, labels that mask the
+    prompt part, flat image list consumed in order (llava_arch.py:284-285)."""
+    a = O.synthetic_prompt_ids(20, 1, vocab, seed=7)
+    b = O.synthetic_prompt_ids(14, 2, vocab, seed=8)
+    W = 20
+    ids = torch.zeros(2, W, dtype=torch.long)
+    mask = torch.zeros(2, W, dtype=torch.long)
+    labels = torch.full((2, W), -100, dtype=torch.long)
+    for r, row in enumerate((a, b)):
+        n = row.numel()
+        ids[r, :n] = row
+        mask[r, :n] = 1
+        labels[r, 8:n] = row[8:]                      # supervise the answer part only
+    labels[ids == -200] = -100
+    frames = O.synthetic_frames(3, image_size, seed=3)
+    return ids, mask, labels, frames

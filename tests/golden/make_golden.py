@@ -387,10 +387,66 @@ def gen_numeric(name):
           os.path.getsize(os.path.join(HERE, name + ".npz")) // 1024)
 
 
+from tests._tiny import train_batch  # noqa: E402  (shared with the tests that replay the fixture)
+
+
+def gen_train(name):
+    """N4: loss + logits of the reference's training-shape forward on a padded batch."""
+    model, sd, (vcfg, lcfg, mm) = build_reference(name)
+    ids, mask, labels, frames = train_batch(lcfg.vocab_size, vcfg.image_size)
+    res = model(input_ids=ids, attention_mask=mask, labels=labels, images=frames)
+    out = {"loss": np.float64(float(res.loss)), "logits_shape": np.array(res.logits.shape),
+           "logits_sum_abs_row0": np.float64(float(res.logits[0].double().abs().sum())),
+           "logits_last_valid": np.stack([res.logits[0, -1].detach().numpy(), res.logits[1, res.logits.shape[1] - 1].detach().numpy()])}
+    # per-token losses of the shifted positions that carry a label (for a kernel-level check)
+    (_, _, _, _, _, lab) = model.prepare_inputs_labels_for_multimodal(ids.clone(), None, mask, None, labels, frames)
+    sl = res.logits[:, :-1].reshape(-1, res.logits.shape[-1])
+    tl = lab[:, 1:].reshape(-1)
+    per = torch.nn.functional.cross_entropy(sl, tl, ignore_index=-100, reduction="none")
+    out["n_supervised"] = np.int64(int((tl != -100).sum()))
+    out["per_token_loss_sum"] = np.float64(float(per.double().sum()))
+    np.savez_compressed(os.path.join(HERE, "train_" + name + ".npz"), **out)
+    print("train", name, "loss", float(res.loss), "supervised", int(out["n_supervised"]))
+
+
+def gen_metrics():
+    """N4: classification_metrics truth table from the reference (videollava/eval/classification.py:15-41)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_classification", os.path.join(ref_import.REF_ROOT, "videollava/eval/classification.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    outputs = [
+        {"response": "Yes.", "ground_truth": "yes", "task": "qa"},
+        {"response": "No", "ground_truth": "yes", "task": "qa"},
+        {"response": "Residential Area!", "ground_truth": "residential area", "task": "cls"},
+        {"response": "a port", "ground_truth": "Port", "task": "cls"},
+        {"response": "There is major damage here", "ground_truth": "Major Damage", "task": "dmg"},
+        {"response": "destroyed", "ground_truth": "no damage", "task": "dmg"},
+        {"response": "no-damage", "ground_truth": "No Damage.", "task": "dmg"},
+    ]
+    cases = {}
+    import contextlib
+    import io
+    for nm, kw in (("default", {}), ("case_sensitive", {"ignore_casing": False}), ("keep_punct", {"ignore_punctuation": False}),
+                   ("keywords", {"keywords": ["major damage", "no damage", "yes"]})):
+        with contextlib.redirect_stdout(io.StringIO()):
+            cases[nm] = {"kwargs": kw, "result": mod.classification_metrics(outputs, **kw)}
+    json.dump({"outputs": outputs, "cases": cases}, open(os.path.join(HERE, "metrics.json"), "w"), indent=1)
+    print("metrics.json", {k: v["result"] for k, v in cases.items()})
+
+
 if __name__ == "__main__":
     assert ref_import.available(), "reference tree required"
     torch.manual_seed(0)
-    gen_host()
-    gen_splice()
+    which = sys.argv[1:] or ["host", "splice", "numeric", "train", "metrics"]
+    if "host" in which:
+        gen_host()
+    if "splice" in which:
+        gen_splice()
     for nm in TINY:
-        gen_numeric(nm)
+        if "numeric" in which:
+            gen_numeric(nm)
+        if "train" in which:
+            gen_train(nm)
+    if "metrics" in which:
+        gen_metrics()

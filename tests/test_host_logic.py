@@ -183,3 +183,11 @@ def test_product_does_not_import_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("# oracle", ""), fn
             assert "/root/reference" not in src, fn
+
+
+def test_classification_metrics_match_reference_truth_table():
+    """N4: teochat_amd.metrics.classification_metrics == videollava/eval/classification.py on tests/golden/metrics.json."""
+    from teochat_amd.metrics import classification_metrics
+    g = TY.load_json("metrics")
+    for name, case in g["cases"].items():
+        assert classification_metrics(g["outputs"], **case["kwargs"]) == case["result"], name

@@ -630,3 +630,23 @@ def test_preprocess_frames_rejects_huge_downscale():
     s_ = (C.c_float * 3)(1, 1, 1)
     rc = G.lib().teo_preprocess_frames(G.p(src), G.p(out), 1, 5000, 5000, 224, m, s_, L.TEO_F32, G.stream())
     assert rc == -2 and b"taps" in G.lib().teo_last_error()
+
+
+# ---------------------------------------------------------------------------------------------- loss (N4)
+@pytest.mark.parametrize("rows,vocab", [(1, 300), (37, 512), (64, 32000)])
+def test_cross_entropy_matches_torch(rows, vocab):
+    lg = rnd(rows, vocab, seed=3, scale=4.0)
+    g = torch.Generator().manual_seed(9)
+    lab = torch.randint(0, vocab, (rows,), generator=g)
+    lab[::5] = -100
+    dl, dlab = lg.cuda(), lab.cuda()
+    per = torch.empty(rows, device="cuda")
+    out = torch.empty(3, device="cuda")
+    L.check(G.lib().teo_cross_entropy(G.p(dl), vocab, G.p(dlab), G.p(per), G.p(out), rows, vocab, -100, G.stream()), "ce")
+    want_per = F.cross_entropy(lg.double(), lab, ignore_index=-100, reduction="none")
+    torch.testing.assert_close(per.cpu().double(), want_per, atol=2e-5, rtol=1e-6)
+    n = int((lab != -100).sum())
+    if n:
+        assert abs(float(out[0]) - float(want_per.sum() / n)) < 2e-5 and int(out[2]) == n
+    else:
+        assert bool(torch.isnan(out[0]))

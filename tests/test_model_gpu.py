@@ -345,3 +345,30 @@ def test_engine_bound_processor_preprocesses_on_device(tmp_path):
     torch.testing.assert_close(got1.cpu(), want[:1], atol=3e-5, rtol=0)
     flt = want[0].clone()                                  # already-normalised float frames stay on the host path
     assert not dev.preprocess(torch.rand(3, 224, 224))["pixel_values"].is_cuda
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_training_shape_forward_loss_matches_reference(name):
+    """N4: forward(input_ids[2, W], attention_mask, labels, images) -> loss / logits of the reference (train_*.npz);
+    the loss comes from teo_cross_entropy on the device."""
+    g = TY.load_npz("train_" + name)
+    model, sd = build(name, torch.float32)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs(name)
+    ids, mask, labels, frames = TY.train_batch(lcfg.vocab_size, vcfg.image_size)
+    out = model(input_ids=ids.to(dev), attention_mask=mask.to(dev), labels=labels.to(dev), images=[f.to(dev) for f in frames])
+    assert list(out.logits.shape) == g["logits_shape"].tolist()
+    print(f"[{name}] training-shape loss {float(out.loss):.6f} vs reference {float(g['loss']):.6f}")
+    assert abs(float(out.loss) - float(g["loss"])) < 2e-5
+    # sample 1 is the longest of the batch: its last position is a real token (sample 0 ends in padding, where the
+    # product returns zero logits and the reference whatever the pad rows attend to -- INTEGRATION.md section 4)
+    np.testing.assert_allclose(out.logits[1, -1].cpu().numpy(), g["logits_last_valid"][1], atol=FP32_TOL)
+    assert bool((out.logits[0, -1] == 0).all())
+    # out-of-range label -> the error torch reports; nothing supervised -> nan
+    bad = labels.clone()
+    bad[0, 10] = lcfg.vocab_size + 5
+    with pytest.raises(IndexError):
+        model(input_ids=ids.to(dev), attention_mask=mask.to(dev), labels=bad.to(dev), images=[f.to(dev) for f in frames])
+    none = torch.full_like(labels, -100)
+    o2 = model(input_ids=ids.to(dev), attention_mask=mask.to(dev), labels=none.to(dev), images=[f.to(dev) for f in frames])
+    assert bool(torch.isnan(o2.loss))

@@ -152,3 +152,18 @@ def test_bf16_boundary_mode_is_close_to_reference_bf16(name):
     err_ours = np.abs(ours - truth).max() / scale
     err_ref = np.abs(ref16 - truth).max() / scale
     assert err_ours < 0.05 and err_ours < 2.0 * err_ref + 1e-2, (err_ours, err_ref)
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_oracle_training_shape_loss_matches_reference(name):
+    """N4: batch of 2, right padding, labels -> the reference's loss and logits (tests/golden/train_*.npz)."""
+    g = TY.load_npz("train_" + name)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd = TY.state_dict(name)
+    ids, mask, labels, frames = TY.train_batch(lcfg.vocab_size, vcfg.image_size)
+    loss, logits, lab = O.training_loss(ids, mask, labels, frames, sd, vcfg, lcfg, mm)
+    assert list(logits.shape) == g["logits_shape"].tolist()
+    assert int((lab[:, 1:] != -100).sum()) == int(g["n_supervised"])
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    assert abs(float(logits[0].double().abs().sum()) - float(g["logits_sum_abs_row0"])) < 1e-4 * float(g["logits_sum_abs_row0"])
+    np.testing.assert_allclose(logits[0, -1].numpy(), g["logits_last_valid"][0], atol=2e-5)
