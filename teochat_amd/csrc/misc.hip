@@ -368,17 +368,49 @@ int sample_topk(const float* logits, long long* tok, int vocab, float temperatur
     return TEO_OK;
 }
 
+// h[:] = embed[t][:]; optionally (batched bf16 step, ops.h SkinnyFuse) also hg = bf16(h * g) and the row's sum of squares
+// in ssq[0] (ssq[1..nparts) zeroed) for the first consumer GEMM.  Called by a whole 1024-thread workgroup.
+template <typename T>
+__device__ __forceinline__ void embed_row_emit(const T* __restrict__ embed, long long t, T* __restrict__ h, int dim,
+                                               const T* __restrict__ g, T* __restrict__ hg, float* __restrict__ ssq, int nparts,
+                                               float* red16) {
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < dim; i += 1024) {
+        const T e = embed[t * dim + i];
+        h[i] = e;
+        if (hg) {
+            const float ef = Elem<T>::ld(&e);
+            Elem<T>::st(hg + i, ef * Elem<T>::ld(g + i));
+            sq = fmaf(ef, ef, sq);
+        }
+    }
+    if (hg) {
+        sq = wave_sum(sq);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int k = 0; k < 16; ++k) tot += red16[k];
+            ssq[0] = tot;
+        }
+        for (int i = 1 + threadIdx.x; i < nparts; i += 1024) ssq[i] = 0.f;
+    }
+}
+
 // Decode tail in one launch: argmax over the fp32 logits (float4 loads), then thread 0 appends the token, advances the
 // position and runs the id-suffix stop test, then the whole workgroup copies the next token's embedding row into h.
 // (embed_next: the NEXT step's embedding lookup is hoisted here; the first step of a generation runs embed_token.)
 template <typename T>
 __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restrict__ logits, teo_decode_state st,
                                                            const T* __restrict__ embed, T* __restrict__ h, int vocab,
-                                                           int dim, int out_stride) {
+                                                           int dim, int out_stride, const T* __restrict__ g0,
+                                                           T* __restrict__ hg, float* __restrict__ ssq, int nparts) {
     {   // conversation blockIdx.x of a batched step (out_stride = row length of d_out_tokens)
         const long long b = blockIdx.x;
         logits += b * vocab;
         h += b * dim;
+        if (hg) { hg += b * dim; ssq += b * nparts; }
         st.d_token += b; st.d_pos += b; st.d_out_count += b; st.d_stop += b;
         st.d_out_tokens += b * out_stride;
         if (st.d_rng) st.d_rng += 2 * b;
@@ -441,15 +473,17 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
     }
     __syncthreads();
     const long long t = s_tok;
-    for (int i = threadIdx.x; i < dim; i += 1024) h[i] = embed[t * dim + i];
+    embed_row_emit<T>(embed, t, h, dim, g0, hg, ssq, nparts, sv);
 }
 
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
-                hipStream_t st, int batch, int out_stride) {
+                hipStream_t st, int batch, int out_stride, const void* g0, void* hg, float* ssq, int nparts) {
     if (dtype == TEO_F32)
-        decode_tail_kernel<float><<<batch, 1024, 0, st>>>(logits, *s, (const float*)embed, (float*)h, vocab, dim, out_stride);
+        decode_tail_kernel<float><<<batch, 1024, 0, st>>>(logits, *s, (const float*)embed, (float*)h, vocab, dim, out_stride,
+                                                          (const float*)g0, (float*)hg, ssq, nparts);
     else
-        decode_tail_kernel<bf16_t><<<batch, 1024, 0, st>>>(logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim, out_stride);
+        decode_tail_kernel<bf16_t><<<batch, 1024, 0, st>>>(logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim, out_stride,
+                                                           (const bf16_t*)g0, (bf16_t*)hg, ssq, nparts);
     TEO_LAUNCH_CHECK("decode_tail");
     return TEO_OK;
 }
@@ -490,6 +524,26 @@ __global__ __launch_bounds__(256) void embed_token_kernel(const long long* __res
     const long long t = tok[blockIdx.y];
     h += (long long)blockIdx.y * dim;
     for (int i = threadIdx.x + blockIdx.x * 256; i < dim; i += 256 * gridDim.x) h[i] = embed[t * dim + i];
+}
+
+// one 1024-thread workgroup per conversation: h = embed[tok], hg / ssq for the first consumer GEMM (embed_row_emit)
+template <typename T>
+__global__ __launch_bounds__(1024) void embed_emit_kernel(const long long* __restrict__ tok, const T* __restrict__ embed,
+                                                          T* __restrict__ h, int dim, const T* __restrict__ g, T* __restrict__ hg,
+                                                          float* __restrict__ ssq, int nparts) {
+    __shared__ float red16[16];
+    const long long b = blockIdx.x;
+    embed_row_emit<T>(embed, tok[b], h + b * dim, dim, g, hg + b * dim, ssq + b * nparts, nparts, red16);
+}
+
+int embed_token_emit(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch,
+                     const void* g, void* hg, float* ssq, int nparts) {
+    if (dtype == TEO_F32)
+        embed_emit_kernel<float><<<batch, 1024, 0, st>>>(tok, (const float*)embed, (float*)h, dim, (const float*)g, (float*)hg, ssq, nparts);
+    else
+        embed_emit_kernel<bf16_t><<<batch, 1024, 0, st>>>(tok, (const bf16_t*)embed, (bf16_t*)h, dim, (const bf16_t*)g, (bf16_t*)hg, ssq, nparts);
+    TEO_LAUNCH_CHECK("embed_token_emit");
+    return TEO_OK;
 }
 
 int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch) {

@@ -42,8 +42,11 @@ int decode_advance(const teo_decode_state* s, hipStream_t st);
 int sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, unsigned long long seed,
                 unsigned long long draw, hipStream_t st);
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
-                hipStream_t st, int batch = 1, int out_stride = 0);
+                hipStream_t st, int batch = 1, int out_stride = 0, const void* g0 = nullptr, void* hg = nullptr,
+                float* ssq = nullptr, int nparts = 0);
 int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch = 1);
+int embed_token_emit(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch,
+                     const void* g, void* hg, float* ssq, int nparts);
 
 int gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,
          unsigned flags, int dtype, int out_dtype, hipStream_t st);
@@ -55,8 +58,21 @@ int cross_entropy(const float* logits, long long ld, const long long* labels, fl
 int gemv_tune_set(const char* key, int value);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
+// Producer-side RMSNorm hand-off between the GEMMs of a batched decode step.  A residual-producing GEMM (o / down
+// projection, one row tile per workgroup) also emits xg_out = bf16(h * next_g) and ssq_out[b][workgroup] = its 16
+// columns' share of sum(h[b]^2); the consumer GEMM takes x = xg_out as a plain operand and rebuilds 1/rms per row from
+// the `nparts` partial sums (ssq_in) -- the norm costs no launch, no extra pass over x and no per-step VALU work.
+struct SkinnyFuse {
+    const unsigned short* next_g = nullptr;   // [N] norm weight the consumer would have applied
+    unsigned short* xg_out = nullptr;         // [MB][ldo]
+    float* ssq_out = nullptr;                 // [MB][gridDim.x]
+    const float* ssq_in = nullptr;            // [MB][nparts]
+    int nparts = 0;
+    float eps = 0.f;
+};
 int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, float eps, const void* res,
-                void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st);
+                void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st,
+                SkinnyFuse fuse = SkinnyFuse());
 int gemm_tune_set(const char* key, int value);
 int attn_tune_set(const char* key, int value);
 int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,

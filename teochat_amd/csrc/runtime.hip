@@ -272,8 +272,9 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
 // batched decode: B conversations advance one token per step; every weight matrix is streamed once per step
 // ------------------------------------------------------------------------------------------------
 struct DecodeBatchWs {
-    void *h, *xn, *qkv, *attn, *act;
-    float* part;
+    void *h, *hg, *qkv, *attn, *act;
+    float *ssq, *part;
+    int nparts;
     size_t total;
 };
 
@@ -282,8 +283,10 @@ static DecodeBatchWs decode_batch_carve(const teo_llama_desc* d, int B, void* ws
     const int QKV = (d->heads + 2 * d->kv_heads) * d->head_dim;
     DecodeBatchWs w;
     Carver c(ws, cap);
+    w.nparts = cdiv(d->hidden, 16);                       // one partial per 16-column workgroup of the o / down GEMM
     w.h = c.take((size_t)B * d->hidden * e);
-    w.xn = c.take((size_t)B * d->hidden * e);
+    w.hg = c.take((size_t)B * d->hidden * e);
+    w.ssq = (float*)c.take((size_t)B * w.nparts * sizeof(float));
     w.qkv = c.take((size_t)B * QKV * e);
     w.attn = c.take((size_t)B * d->heads * d->head_dim * e);
     w.act = c.take((size_t)B * d->inter * e);
@@ -296,22 +299,22 @@ size_t llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch) {
     return decode_batch_carve(d, batch, nullptr, 0).total;
 }
 
-// y[b] = f(norm(x[b])) W^T (+ res[b]) for the B rows of a batched step.  bf16 rows whose shape the MFMA kernel takes run
-// rmsnorm (B rows) + teo_gemm_skinny; anything else (fp32, odd K) loops the single-conversation GEMV over the rows.
-static int batch_linear(const teo_decode_batch_state* s, const void* x, int ldx, const void* W, const float* wscale, int w8,
-                        const void* norm_w, void* xn, const void* res, void* y, int ldy, int N, int K, float eps, unsigned flags,
-                        int dt, int out_dt, hipStream_t st) {
-    const int B = s->batch;
+// Can every Linear layer of the step run on the MFMA skinny GEMM?  (bf16 activations, K multiples of the k-step.)
+static bool batch_uses_skinny(const teo_llama_desc* d, int B) {
+    if (d->dtype != TEO_BF16) return false;
+    const int w8 = d->qkv_w8 != nullptr, h8 = d->lm_head8 != nullptr;
+    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
+    const void* al = reinterpret_cast<const void*>(16);   // alignment of the real pointers is checked at launch
+    return skinny_gemm_ok(B, (H + 2 * Hk) * hd, D, D, w8, 0, al, al) && skinny_gemm_ok(B, D, H * hd, H * hd, w8, 0, al, al) &&
+           skinny_gemm_ok(B, 2 * F, D, D, w8, TEO_GEMM_SWIGLU16, al, al) && skinny_gemm_ok(B, D, F, F, w8, 0, al, al) &&
+           skinny_gemm_ok(B, d->vocab, D, D, h8, 0, al, al);
+}
+
+// fallback row loop: y[b] = f(norm(x[b])) W^T (+ res[b]) with the single-conversation GEMV (fp32, odd K)
+static int batch_linear_rows(int B, const void* x, int ldx, const void* W, const float* wscale, int w8, const void* norm_w,
+                             const void* res, void* y, int ldy, int N, int K, float eps, unsigned flags, int dt, int out_dt,
+                             hipStream_t st) {
     const size_t e = esize(dt), eo = esize(out_dt);
-    if (dt == TEO_BF16 && skinny_gemm_ok(B, N, K, ldx, w8, flags, x, W)) {
-        // RMSNorm rides inside the GEMM (row factor applied in its epilogue): no norm launch, no normalised copy
-        return skinny_gemm(x, W, wscale, w8, norm_w, eps, res, y, B, N, K, ldx, ldy, flags | (s->w_tiled ? TEO_GEMM_WTILED : 0u),
-                           out_dt, st);
-    }
-    if (s->w_tiled) {
-        set_error("teo_llama_decode_batch_step: tiled weights need bf16 activations and K %% %d == 0 (N=%d K=%d)", w8 ? 64 : 32, N, K);
-        return TEO_ERR_UNSUPPORTED;
-    }
     for (int b = 0; b < B; ++b)
         TEO_TRY(gemv_w((const char*)x + (size_t)b * ldx * e, W, wscale, w8, norm_w, res ? (const char*)res + (size_t)b * ldy * eo : nullptr,
                        (char*)y + (size_t)b * ldy * eo, N, K, eps, flags, dt, out_dt, st));
@@ -332,6 +335,8 @@ int llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_sta
         set_error("teo_llama_decode_batch_begin: workspace %zu < %zu", ws_bytes, w.total);
         return TEO_ERR_WORKSPACE;
     }
+    if (batch_uses_skinny(d, s->batch))                   // also hand layer 0's RMSNorm its inputs (SkinnyFuse)
+        return embed_token_emit(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch, d->in_norm_w[0], w.hg, w.ssq, w.nparts);
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch);
 }
 
@@ -345,37 +350,61 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
     const int dt = d->dtype;
     const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
     const int QKV = (H + 2 * Hk) * hd;
-    const bool w8 = d->qkv_w8 != nullptr;
+    const bool w8 = d->qkv_w8 != nullptr, h8 = d->lm_head8 != nullptr;
+    const bool skinny = batch_uses_skinny(d, B);
+    if (!skinny && s->w_tiled) {
+        set_error("teo_llama_decode_batch_step: tiled weights need bf16 activations and K %% %d == 0", w8 ? 64 : 32);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    const unsigned tl = s->w_tiled ? TEO_GEMM_WTILED : 0u;
     AttnBatch bt;
     bt.batch = B; bt.q_stride = QKV; bt.cache_stride = s->cache_stride; bt.o_stride = (long long)H * hd;
+    // w.h holds the residual stream; on the skinny path w.hg = bf16(h * g) and w.ssq = partial sum(h^2) of the norm that
+    // comes next -- written by the producer of h (embed / o / down GEMM epilogue), consumed by the next GEMM.
+    SkinnyFuse take;                                       // consumer side
+    take.ssq_in = w.ssq; take.nparts = w.nparts; take.eps = d->eps;
     for (int l = 0; l < d->layers; ++l) {
-        TEO_TRY(batch_linear(s, w.h, D, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.xn,
-                             nullptr, w.qkv, QKV, QKV, D, d->eps, 0, dt, dt, st));
+        const void* qkv_w = w8 ? d->qkv_w8[l] : d->qkv_w[l];
+        const void* o_w = w8 ? d->o_w8[l] : d->o_w[l];
+        const void* gu_w = w8 ? d->gateup_w8[l] : d->gateup_w[l];
+        const void* dn_w = w8 ? d->down_w8[l] : d->down_w[l];
+        const float *qkv_s = w8 ? d->qkv_s[l] : nullptr, *o_s = w8 ? d->o_s[l] : nullptr;
+        const float *gu_s = w8 ? d->gateup_s[l] : nullptr, *dn_s = w8 ? d->down_s[l] : nullptr;
+        if (skinny) {
+            TEO_TRY(skinny_gemm(w.hg, qkv_w, qkv_s, w8, nullptr, 0.f, nullptr, w.qkv, B, QKV, D, D, QKV, tl, dt, st, take));
+        } else {
+            TEO_TRY(batch_linear_rows(B, w.h, D, qkv_w, qkv_s, w8, d->in_norm_w[l], nullptr, w.qkv, QKV, QKV, D, d->eps, 0, dt, dt, st));
+        }
         // RoPE + KV append of the B new tokens inside the attention kernel, each conversation at its own position
         TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
                             s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt));
-        TEO_TRY(batch_linear(s, w.attn, H * hd, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, nullptr, w.h,
-                             w.h, D, D, H * hd, d->eps, 0, dt, dt, st));
-        TEO_TRY(batch_linear(s, w.h, D, w8 ? d->gateup_w8[l] : d->gateup_w[l], w8 ? d->gateup_s[l] : nullptr, w8,
-                             d->post_norm_w[l], w.xn, nullptr, w.act, F, 2 * F, D, d->eps, TEO_GEMM_SWIGLU16, dt, dt, st));
-        TEO_TRY(batch_linear(s, w.act, F, w8 ? d->down_w8[l] : d->down_w[l], w8 ? d->down_s[l] : nullptr, w8, nullptr, nullptr,
-                             w.h, w.h, D, D, F, d->eps, 0, dt, dt, st));
+        if (skinny) {
+            SkinnyFuse give;                               // h += attn Wo^T; hand post_norm its inputs
+            give.next_g = (const unsigned short*)d->post_norm_w[l]; give.xg_out = (unsigned short*)w.hg; give.ssq_out = w.ssq;
+            TEO_TRY(skinny_gemm(w.attn, o_w, o_s, w8, nullptr, 0.f, w.h, w.h, B, D, H * hd, H * hd, D, tl, dt, st, give));
+            TEO_TRY(skinny_gemm(w.hg, gu_w, gu_s, w8, nullptr, 0.f, nullptr, w.act, B, 2 * F, D, D, F, tl | TEO_GEMM_SWIGLU16, dt, st, take));
+            give.next_g = (const unsigned short*)(l + 1 < d->layers ? d->in_norm_w[l + 1] : d->final_norm_w);
+            TEO_TRY(skinny_gemm(w.act, dn_w, dn_s, w8, nullptr, 0.f, w.h, w.h, B, D, F, F, D, tl, dt, st, give));
+        } else {
+            TEO_TRY(batch_linear_rows(B, w.attn, H * hd, o_w, o_s, w8, nullptr, w.h, w.h, D, D, H * hd, d->eps, 0, dt, dt, st));
+            TEO_TRY(batch_linear_rows(B, w.h, D, gu_w, gu_s, w8, d->post_norm_w[l], nullptr, w.act, F, 2 * F, D, d->eps,
+                                      TEO_GEMM_SWIGLU16, dt, dt, st));
+            TEO_TRY(batch_linear_rows(B, w.act, F, dn_w, dn_s, w8, nullptr, w.h, w.h, D, D, F, d->eps, 0, dt, dt, st));
+        }
     }
-    {
-        const bool h8 = d->lm_head8 != nullptr;
-        TEO_TRY(batch_linear(s, w.h, D, h8 ? d->lm_head8 : d->lm_head, h8 ? d->lm_head_s : nullptr, h8, d->final_norm_w, w.xn,
-                             nullptr, s->d_logits, d->vocab, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
+    const void* head_w = h8 ? d->lm_head8 : d->lm_head;
+    const float* head_s = h8 ? d->lm_head_s : nullptr;
+    if (skinny) {
+        TEO_TRY(skinny_gemm(w.hg, head_w, head_s, h8, nullptr, 0.f, nullptr, s->d_logits, B, d->vocab, D, D, d->vocab, tl, TEO_F32, st, take));
+    } else {
+        TEO_TRY(batch_linear_rows(B, w.h, D, head_w, head_s, h8, d->final_norm_w, nullptr, s->d_logits, d->vocab, d->vocab, D, d->eps, 0,
+                                  dt, TEO_F32, st));
     }
     const teo_decode_state t = batch_as_state(s);
+    if (skinny)
+        return decode_tail(s->d_logits, &t, d->embed, w.h, d->vocab, D, dt, st, B, s->out_stride, d->in_norm_w[0], w.hg, w.ssq, w.nparts);
     return decode_tail(s->d_logits, &t, d->embed, w.h, d->vocab, D, dt, st, B, s->out_stride);
 }
-
-}  // namespace teo
-
-// ------------------------------------------------------------------------------------------------
-// hipGraph wrapper
-// ------------------------------------------------------------------------------------------------
-namespace teo {
 
 // h <- embed[*d_token]: arms the first step of a generation (later steps get it from the previous step's tail)
 int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -387,6 +416,9 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// hipGraph wrapper
+// ------------------------------------------------------------------------------------------------
 // capture whatever `enqueue` launches on `st` into an instantiated hipGraph
 template <typename F>
 static int capture_graph(hipStream_t st, F enqueue, teo_graph** out) {

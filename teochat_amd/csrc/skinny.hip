@@ -81,13 +81,14 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ norm_w, float eps,
                                                                  const bf16_t* __restrict__ res, void* __restrict__ outv,
                                                                  int MB, int N, int K, int ldx, int ldo, int ldr, int tiled,
-                                                                 int out_f32, int RT) {
+                                                                 int out_f32, int RT, SkinnyFuse fuse) {
     constexpr bool F8 = sizeof(WT) == 1;
     constexpr int KS = F8 ? 64 : 32;                     // k elements per step (one 16-byte chunk per lane)
     constexpr int CH = F8 ? 16 : 8;                      // k elements per lane chunk
     constexpr int XL = F8 ? 2 : 1;                       // 16-byte activation loads per step
     __shared__ float red[SK_WAVES][SK_TP];
     __shared__ float ssq_part[SK_WAVES][16];
+    __shared__ float inv_s[16];
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // NORM: g[K] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -95,6 +96,15 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         for (int i = tid; i < K / 8; i += SK_THREADS)
             reinterpret_cast<u32x4*>(sk_dyn)[i] = reinterpret_cast<const u32x4*>(norm_w)[i];
         __syncthreads();
+    }
+    if (fuse.ssq_in) {
+        // producer-side RMSNorm (see SkinnyFuse): x already holds bf16(h * g); 1/rms from the producer's partial sums
+        for (int b = wid; b < MB; b += SK_WAVES) {
+            float t = 0.f;
+            for (int p_ = lane; p_ < fuse.nparts; p_ += 64) t += fuse.ssq_in[(long long)b * fuse.nparts + p_];
+            t = wave_sum(t);
+            if (lane == 0) inv_s[b] = rsqrtf(t / (float)K + fuse.eps);
+        }
     }
     const bf16_t* gs = reinterpret_cast<const bf16_t*>(sk_dyn) + fg * (sizeof(WT) == 1 ? 16 : 8);
     float ssq = 0.f;
@@ -181,10 +191,13 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
     __syncthreads();
 
     const int OUTC = SWIGLU ? 8 * RT : 16 * RT;          // output columns of this workgroup
+    float emit_v = 0.f;
+    bool emit_ok = false;
     for (int o = tid; o < 16 * OUTC; o += SK_THREADS) {
         const int b = o / OUTC, c = o % OUTC;
         if (b >= MB) break;
         float inv = 1.f;
+        if (fuse.ssq_in) inv = inv_s[b];
         if (NORM) {                                      // the K slices of row tile 0 cover the whole row
             float t = 0.f;
             for (int w = 0; w < KSPLIT; ++w) t += ssq_part[w][b];
@@ -216,7 +229,24 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         }
         if (res) v += bf2f(res[(long long)b * ldr + col]);
         if (out_f32) reinterpret_cast<float*>(outv)[(long long)b * ldo + col] = v;
-        else reinterpret_cast<bf16_t*>(outv)[(long long)b * ldo + col] = f2bf(v);
+        else {
+            const bf16_t hb = f2bf(v);
+            reinterpret_cast<bf16_t*>(outv)[(long long)b * ldo + col] = hb;
+            emit_v = bf2f(hb);
+            emit_ok = true;
+        }
+    }
+    if (!SWIGLU && fuse.xg_out && tid < 256) {
+        // RT == 1 (host-enforced): thread = (b = tid / 16, column c = tid % 16) and it has just produced h[b][n0 + c].
+        // Emit what the NEXT layer's RMSNorm needs: bf16(h * g_next) and this workgroup's share of sum(h^2) per row.
+        const int b = tid >> 4, c = tid & 15, col = n0 + c;
+        float sq = emit_ok ? emit_v * emit_v : 0.f;
+        if (emit_ok) fuse.xg_out[(long long)b * ldo + col] = f2bf(emit_v * bf2f(fuse.next_g[col]));
+        sq += __shfl_xor(sq, 8, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 1, 64);
+        if (c == 0 && b < MB) fuse.ssq_out[(long long)b * gridDim.x + blockIdx.x] = sq;
     }
 }
 
@@ -230,9 +260,9 @@ bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, co
 
 // bf16 activations; W bf16 or fp8 e4m3 (+ per-row scales), row-major or TEO_GEMM_WTILED; out bf16 or f32;
 // res (bf16, may alias out) optional
-// norm_w != NULL: fused RMSNorm of x (see the kernel)
+// norm_w != NULL: fused RMSNorm of x (see the kernel).  fuse: producer-side norm hand-off (ops.h SkinnyFuse).
 int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, float eps, const void* res,
-                void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st) {
+                void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st, SkinnyFuse fuse) {
     const bool swiglu = flags & TEO_GEMM_SWIGLU16;
     const int tiled = (flags & TEO_GEMM_WTILED) ? 1 : 0;
     if (!skinny_gemm_ok(MB, N, K, ldx, w_fp8, flags, x, W)) {
@@ -243,8 +273,11 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     TEO_CHECK_ARG(!(swiglu && res), "skinny_gemm: SWIGLU16 takes no residual");
     TEO_CHECK_ARG(!norm_w || (K <= 16384 && (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0), "skinny_gemm: fused norm needs K <= 16384 and an aligned weight");
     // row tiles per workgroup (8 waves = RT row tiles x 8/RT K slices)
+    TEO_CHECK_ARG(!(fuse.xg_out && (swiglu || out_dtype == TEO_F32 || !fuse.next_g || !fuse.ssq_out)),
+                  "skinny_gemm: the norm hand-off needs a plain bf16 output, next_g and ssq_out");
+    TEO_CHECK_ARG(!(fuse.ssq_in && norm_w), "skinny_gemm: ssq_in and norm_w are exclusive");
     int rt = g_sk_tiles;
-    if (rt == 0) rt = 1;                  // measured: one row tile per workgroup (most waves in flight) wins at every N
+    if (rt == 0 || fuse.xg_out) rt = 1;   // the hand-off epilogue is written for one row tile per workgroup                  // measured: one row tile per workgroup (most waves in flight) wins at every N
     if (swiglu && rt < 2) rt = 2;         // the gate tile and its up tile meet in the epilogue
     const int blocks = cdiv(N, 16 * rt);
     const int ldr = ldo, of = out_dtype == TEO_F32;
@@ -252,7 +285,7 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
 #define TEO_SK(WW, NTV, SW, NM)                                                                            \
     skinny_gemm_kernel<WW, 4, NTV, SW, NM><<<blocks, SK_THREADS, dyn, st>>>(                               \
         (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)norm_w, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, \
-        tiled, of, rt)
+        tiled, of, rt, fuse)
 #define TEO_SK_N(WW, NTV, SW) if (norm_w) { TEO_SK(WW, NTV, SW, true); } else { TEO_SK(WW, NTV, SW, false); }
 #define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK_N(WW, NTV, true) } else { TEO_SK_N(WW, NTV, false) }
     if (w_fp8) { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }
