@@ -274,11 +274,15 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // over its keys, lanes of different rows are summed with two xor-shuffles at the end.  No MFMA: 1 query row.
 // ------------------------------------------------------------------------------------------------
 static int g_dec_chunk = 128;     // keys per workgroup (tunable: 64 / 128 / 256)
+static int g_fused_combine = 0;   // 1: the last workgroup of a head merges the KV splits (no combine launch).  Measured: the
+                                  // agent-scope release/acquire fences cost far more than the launch they save (2.89 -> 3.51
+                                  // ms/token; batch 8: 5.2 -> 13 ms/step), so it stays off -- kept as a tested experiment.
 int g_rope_in_attn = -1;          // decode RoPE + KV append: 0 = in the QKV GEMV epilogue, 1 = inside the attention kernel,
                                    // -1 = auto (measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0,
                                    // fp8 weights 2.216 vs 2.234 in favour of 1)
 int attn_tune_set(const char* key, int value) {
     if (!strcmp(key, "attn_chunk") && (value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
+    if (!strcmp(key, "attn_fused_combine")) { g_fused_combine = value != 0; return 0; }
     if (!strcmp(key, "rope_in_attn") && (value >= -1 && value <= 1)) { g_rope_in_attn = value; return 0; }
     return -1;
 }
@@ -316,11 +320,12 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
                                                                   const float* __restrict__ cs, const float* __restrict__ sn,
                                                                   float* __restrict__ part, const int* __restrict__ d_pos,
                                                                   int S_max, int heads, int kv_heads, float scale, int nsplit,
-                                                                  AttnBatch bt) {
+                                                                  AttnBatch bt, int* __restrict__ counters, T* __restrict__ o_out) {
     constexpr int VE = Cvt16<T>::N;
     constexpr int HD = LPR * VE;
     {   // conversation blockIdx.z of a batched step: its own query row, caches, position and partial slab
         const long long bz = blockIdx.z;
+        if (counters) { counters += bz * heads; o_out += bz * bt.o_stride; }
         q += bz * bt.q_stride;
         kc += bz * bt.cache_stride;
         vc += bz * bt.cache_stride;
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     const int c0 = sp * DEC_CHUNK;
     float* out = part + ((long long)h * nsplit + sp) * (HD + 2);
     if (c0 >= kv_len) {                                 // nothing here: neutral partial
+        if (counters) return;                           // fused combine only looks at the splits that hold keys
         if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
         for (int d = tid; d < HD; d += 256) out[2 + d] = 0.f;
         return;
@@ -464,6 +470,54 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     __syncthreads();
     for (int d = tid; d < HD; d += 256) out[2 + d] = obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d];
     if (tid == 0) { out[0] = mx; out[1] = sum; }
+    if (!counters) return;
+    // ---- fused combine: the LAST workgroup of this head to finish merges the splits (saves the combine launch).
+    // Cross-workgroup visibility on gfx950 (per-XCD L2s are not coherent): every wave's stores are complete at the
+    // barrier (hipcc's __syncthreads waits vmcnt(0)), one lane publishes them with an agent-scope release fence, takes
+    // a ticket, and the last arriver runs an agent-scope acquire fence before anyone reads the other splits.
+    __shared__ int s_last;
+    __shared__ float wgt[256];
+    __syncthreads();
+    const int nact = (kv_len + DEC_CHUNK - 1) / DEC_CHUNK;
+    if (tid == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(&counters[h], 1);
+        const int last = ticket == nact - 1;
+        if (last) {
+            counters[h] = 0;                            // re-armed for the next launch
+            __threadfence();
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int stride = HD + 2;
+    const float* pb = part + (long long)h * nsplit * stride;
+    float m0 = -INFINITY, l0 = 0.f;
+    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
+    float M = wave_max(m0);
+    if (lane == 0) red[wid] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
+    wgt[tid] = w0;
+    float Ls = wave_sum(l0 * w0);
+    __syncthreads();
+    if (lane == 0) red[4 + wid] = Ls;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int d = tid; d < HD; d += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s_ = 0;
+        for (; s_ + 4 <= nact; s_ += 4) {
+            const float v0 = pb[s_ * stride + 2 + d], v1 = pb[(s_ + 1) * stride + 2 + d];
+            const float v2 = pb[(s_ + 2) * stride + 2 + d], v3 = pb[(s_ + 3) * stride + 2 + d];
+            a0 = fmaf(v0, wgt[s_], a0); a1 = fmaf(v1, wgt[s_ + 1], a1);
+            a2 = fmaf(v2, wgt[s_ + 2], a2); a3 = fmaf(v3, wgt[s_ + 3], a3);
+        }
+        for (; s_ < nact; ++s_) a0 = fmaf(pb[s_ * stride + 2 + d], wgt[s_], a0);
+        Elem<T>::st(o_out + h * HD + d, ((a0 + a1) + (a2 + a3)) * inv);
+    }
 }
 
 // one workgroup per head: split weights are computed by one thread per split (parallel loads), then each thread
@@ -518,11 +572,12 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
 template <typename T, int LPR>
 static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o,
                                float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale,
-                               int nsplit, int chunk, bool rope, AttnBatch bt, hipStream_t st) {
+                               int nsplit, int chunk, bool rope, AttnBatch bt, int* counters, hipStream_t st) {
     dim3 grid(heads, nsplit, bt.batch);
 #define TEO_PART(CH, RP)                                                                                              \
     attn_decode_partial_kernel<T, LPR, CH, RP><<<grid, 256, 0, st>>>((const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
-                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt)
+                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt, \
+                                                                     counters, (T*)o)
 #define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
     if constexpr (64 / 4 >= 64 / LPR) {
         if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
@@ -531,15 +586,17 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
     }
 #undef TEO_PART_R
 #undef TEO_PART
-    attn_decode_combine_kernel<T><<<dim3(heads, bt.batch), 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
+    if (!counters)
+        attn_decode_combine_kernel<T><<<dim3(heads, bt.batch), 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
 }
 
 // rope_cos != NULL: q is the raw qkv row; RoPE and the KV append of the new token happen inside the kernel
 // bt: batched step (bt.batch conversations: q/o rows, caches, positions and partial slabs strided per conversation)
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
-                hipStream_t st, AttnBatch bt) {
+                hipStream_t st, AttnBatch bt, int* counters) {
     const bool rope = rope_cos != nullptr;
+    if (!g_fused_combine) counters = nullptr;
     int chunk = g_dec_chunk;
     const int esz = dtype == TEO_F32 ? 4 : 2;
     const int lpr = hd * esz / 16;
@@ -551,7 +608,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
         set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
         return TEO_ERR_UNSUPPORTED;
     }
-#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, st)
+#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, counters, st)
     if (dtype == TEO_F32) {
         switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
                        case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }

@@ -27,7 +27,7 @@ struct AttnBatch {          // per-conversation strides (elements) of a batched 
 };
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
-                hipStream_t st, AttnBatch bt = AttnBatch());
+                hipStream_t st, AttnBatch bt = AttnBatch(), int* counters = nullptr);   // counters: [batch*heads] zeroed ints -> fused combine
 
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                    void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,

@@ -205,6 +205,7 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
 struct DecodeWs {
     void *h, *qkv, *attn, *act;
     float* part;
+    int* cnt;        // [heads] arrival counters of the fused attention combine (zeroed by decode_begin, self re-arming)
     size_t total;
 };
 
@@ -218,6 +219,7 @@ static DecodeWs decode_carve(const teo_llama_desc* d, void* ws, size_t cap) {
     w.attn = c.take((size_t)d->heads * d->head_dim * e);
     w.act = c.take((size_t)d->inter * e);
     w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq));
+    w.cnt = (int*)c.take((size_t)d->heads * sizeof(int));
     w.total = c.off;
     return w;
 }
@@ -242,14 +244,14 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
             TEO_TRY(gemv_w(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], nullptr,
                            w.qkv, QKV, D, d->eps, 0, dt, dt, st));
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
-                                s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
+                                s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, AttnBatch(), w.cnt));
         } else {
             // rmsnorm -> QKV projection -> RoPE -> KV append in the GEMV epilogue
             TEO_TRY(gemv_qkv_rope(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.qkv,
                                   d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->max_seq,
                                   H, Hk, hd, D, d->eps, dt, st));
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], nullptr, nullptr, nullptr, w.attn, w.part, s->d_pos,
-                                d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
+                                d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, AttnBatch(), w.cnt));
         }
         TEO_TRY(gemv_w(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps,
                        0, dt, dt, st));
@@ -274,6 +276,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
 struct DecodeBatchWs {
     void *h, *hg, *qkv, *attn, *act;
     float *ssq, *part;
+    int* cnt;        // [B][heads] arrival counters of the fused attention combine
     int nparts;
     size_t total;
 };
@@ -291,6 +294,7 @@ static DecodeBatchWs decode_batch_carve(const teo_llama_desc* d, int B, void* ws
     w.attn = c.take((size_t)B * d->heads * d->head_dim * e);
     w.act = c.take((size_t)B * d->inter * e);
     w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq, B));
+    w.cnt = (int*)c.take((size_t)B * d->heads * sizeof(int));
     w.total = c.off;
     return w;
 }
@@ -335,6 +339,8 @@ int llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_sta
         set_error("teo_llama_decode_batch_begin: workspace %zu < %zu", ws_bytes, w.total);
         return TEO_ERR_WORKSPACE;
     }
+    hipError_t e = hipMemsetAsync(w.cnt, 0, (size_t)s->batch * d->heads * sizeof(int), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     if (batch_uses_skinny(d, s->batch))                   // also hand layer 0's RMSNorm its inputs (SkinnyFuse)
         return embed_token_emit(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch, d->in_norm_w[0], w.hg, w.ssq, w.nparts);
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch);
@@ -377,7 +383,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
         }
         // RoPE + KV append of the B new tokens inside the attention kernel, each conversation at its own position
         TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
-                            s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt));
+                            s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt, w.cnt));
         if (skinny) {
             SkinnyFuse give;                               // h += attn Wo^T; hand post_norm its inputs
             give.next_g = (const unsigned short*)d->post_norm_w[l]; give.xg_out = (unsigned short*)w.hg; give.ssq_out = w.ssq;
@@ -413,6 +419,8 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
         set_error("teo_llama_decode_begin: workspace %zu < %zu", ws_bytes, w.total);
         return TEO_ERR_WORKSPACE;
     }
+    hipError_t e = hipMemsetAsync(w.cnt, 0, (size_t)d->heads * sizeof(int), st);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st);
 }
 

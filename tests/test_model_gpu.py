@@ -95,7 +95,7 @@ def test_fp32_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])
-@pytest.mark.parametrize("placement", [0, 1])
+@pytest.mark.parametrize("placement", [0, 1, 2])
 def test_decode_rope_placements_match_reference_golden(name, placement):
     """Both decode RoPE/KV-append placements (QKV-GEMV epilogue, decode-attention kernel) reproduce the reference's
     greedy tokens, KV snapshots and last-step logits (fp32), eager and through the hipGraph."""
@@ -106,7 +106,9 @@ def test_decode_rope_placements_match_reference_golden(name, placement):
     frames, ids = inputs(name, g)
     dev = model.device
     imgs = [f.to(dev) for f in frames]
-    assert lib.teo_tune_set(b"rope_in_attn", placement) == 0
+    # placement 2 = RoPE in the attention kernel + the (off by default) last-arriver fused combine
+    assert lib.teo_tune_set(b"rope_in_attn", min(placement, 1)) == 0
+    assert lib.teo_tune_set(b"attn_fused_combine", 1 if placement == 2 else 0) == 0
     try:
         n_new = len(g["greedy_tokens"])
         gen = model.generate(input_ids=ids.to(dev), images=imgs, do_sample=False, max_new_tokens=n_new, eos_token_id=None)
@@ -137,6 +139,7 @@ def test_decode_rope_placements_match_reference_golden(name, placement):
         assert torch.equal(lg_graph, eng.d_logits)
     finally:
         lib.teo_tune_set(b"rope_in_attn", -1)
+        lib.teo_tune_set(b"attn_fused_combine", 0)
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])
