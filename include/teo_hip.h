@@ -43,6 +43,7 @@ typedef enum {
 /* GEMM epilogue flags (teo_gemm `flags`) */
 #define TEO_GEMM_SWIGLU16 1u /* W rows are [gate16|up16] interleaved; C[M, N/2] = silu(g) * u */
 #define TEO_GEMM_FORCE_SIMPLE 2u /* use the shape-agnostic VALU kernel even when the MFMA kernel applies */
+#define TEO_GEMM_SWIGLU8 8u /* teo_gemm_skinny: like SWIGLU16 with gate/up rows interleaved in blocks of 8 */
 #define TEO_GEMM_WTILED 4u /* teo_gemm_skinny: W is stored as 1 KB operand tiles (16 rows x 32 k bf16 / 64 k fp8), see below */
 
 int teo_version(void);
@@ -319,6 +320,8 @@ typedef struct {
     int out_stride;           /* d_out_tokens is [batch][out_stride] */
     long long cache_stride;   /* elements between conversations in each layer's K, V and V^T cache */
     int w_tiled;              /* 1: the descriptor's decode weight matrices are TEO_GEMM_WTILED */
+    int gateup_block8;        /* 1: the descriptor's gate/up matrices (and their fp8 scales) interleave gate/up rows in blocks
+                               * of 8 (TEO_GEMM_SWIGLU8) instead of 16 -- one row tile per workgroup also for the SwiGLU GEMM */
     long long* d_token;       /* [batch] */
     int* d_pos;               /* [batch] */
     long long* d_out_tokens;  /* [batch][out_stride] */

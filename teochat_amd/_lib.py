@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libteo_hip.so")
 
 TEO_F32, TEO_BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
-GEMM_SWIGLU16, GEMM_FORCE_SIMPLE, GEMM_WTILED = 1, 2, 4
+GEMM_SWIGLU16, GEMM_FORCE_SIMPLE, GEMM_WTILED, GEMM_SWIGLU8 = 1, 2, 4, 8
 ATTN_FORCE_SIMPLE = 1
 INT32_MIN = -(2 ** 31)
 
@@ -77,7 +77,7 @@ MAX_DECODE_BATCH = 16
 
 
 class DecodeBatchState(C.Structure):
-    _fields_ = [("batch", C.c_int), ("out_stride", C.c_int), ("cache_stride", C.c_longlong), ("w_tiled", C.c_int),
+    _fields_ = [("batch", C.c_int), ("out_stride", C.c_int), ("cache_stride", C.c_longlong), ("w_tiled", C.c_int), ("gateup_block8", C.c_int),
                 ("d_token", C.c_void_p), ("d_pos", C.c_void_p), ("d_out_tokens", C.c_void_p),
                 ("d_out_count", C.c_void_p), ("d_stop", C.c_void_p), ("d_stop_ids", C.c_void_p),
                 ("n_stop_ids", C.c_int), ("d_logits", C.c_void_p),

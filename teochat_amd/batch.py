@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .engine import _p, tile_weights
+from .engine import _p, reinterleave_gate_up, tile_weights
 
 
 class BatchDecoder:
@@ -48,9 +48,16 @@ class BatchDecoder:
         self.tiled = bool(tiled) and dt == torch.bfloat16 and c.hidden_size % ks == 0 and c.intermediate_size % ks == 0 \
             and (c.num_attention_heads * hd) % ks == 0
         self.tiled_w = None
+        self.block8 = False
         if self.tiled:
             src = engine.llama_w8[0] if fp8 else engine.llama_w
-            tw = {k: [tile_weights(w) for w in src[k]] for k in ("qkv", "o", "gateup", "down")}
+            # gate/up: pairs re-interleaved in blocks of 8 rows so a gate row and its up row share one 16-row tile
+            self.block8 = c.intermediate_size % 16 == 0
+            tw = {k: [tile_weights(reinterleave_gate_up(w, 8) if (k == "gateup" and self.block8) else w) for w in src[k]]
+                  for k in ("qkv", "o", "gateup", "down")}
+            if fp8 and self.block8:
+                self.gateup_s8 = [reinterleave_gate_up(s_.view(-1, 1), 8).view(-1).contiguous() for s_ in engine.llama_w8[1]["gateup"]]
+                d.gateup_s = self._arr(self.gateup_s8)
             head = tile_weights(engine.lm_head8 if fp8 else engine.lm_head)
             self.tiled_w = (tw, head)
             if fp8:
@@ -76,6 +83,7 @@ class BatchDecoder:
         s.cache_stride = self.k_cache.stride(1)
         assert self.v_cache.stride(1) == s.cache_stride and self.vt_cache.stride(1) == s.cache_stride
         s.w_tiled = 1 if self.tiled else 0
+        s.gateup_block8 = 1 if self.block8 else 0
         s.d_token, s.d_pos, s.d_out_tokens = self.d_token.data_ptr(), self.d_pos.data_ptr(), self.d_out.data_ptr()
         s.d_out_count, s.d_stop = self.d_count.data_ptr(), self.d_stop.data_ptr()
         s.d_stop_ids, s.n_stop_ids, s.d_logits = self.d_stop_ids.data_ptr(), 0, self.d_logits.data_ptr()

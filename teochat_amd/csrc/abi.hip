@@ -355,7 +355,7 @@ int teo_time_skinny_chain(const void* x, const void* const* Ws, const float* con
     ENTER();
     NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
     TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_skinny_chain: n %d reps %d", n, reps);
-    const int ldo = (flags & TEO_GEMM_SWIGLU16) ? N / 2 : N;
+    const int ldo = (flags & (TEO_GEMM_SWIGLU16 | TEO_GEMM_SWIGLU8)) ? N / 2 : N;
     hipEvent_t e0, e1;
     hipError_t e = hipEventCreate(&e0);
     if (e != hipSuccess) return hip_fail(e, "hipEventCreate");

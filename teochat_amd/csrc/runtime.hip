@@ -358,7 +358,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
     const int QKV = (H + 2 * Hk) * hd;
     const bool w8 = d->qkv_w8 != nullptr, h8 = d->lm_head8 != nullptr;
     const bool skinny = batch_uses_skinny(d, B);
-    if (!skinny && s->w_tiled) {
+    if (!skinny && (s->w_tiled || s->gateup_block8)) {
         set_error("teo_llama_decode_batch_step: tiled weights need bf16 activations and K %% %d == 0", w8 ? 64 : 32);
         return TEO_ERR_UNSUPPORTED;
     }
@@ -388,7 +388,8 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
             SkinnyFuse give;                               // h += attn Wo^T; hand post_norm its inputs
             give.next_g = (const unsigned short*)d->post_norm_w[l]; give.xg_out = (unsigned short*)w.hg; give.ssq_out = w.ssq;
             TEO_TRY(skinny_gemm(w.attn, o_w, o_s, w8, nullptr, 0.f, w.h, w.h, B, D, H * hd, H * hd, D, tl, dt, st, give));
-            TEO_TRY(skinny_gemm(w.hg, gu_w, gu_s, w8, nullptr, 0.f, nullptr, w.act, B, 2 * F, D, D, F, tl | TEO_GEMM_SWIGLU16, dt, st, take));
+            TEO_TRY(skinny_gemm(w.hg, gu_w, gu_s, w8, nullptr, 0.f, nullptr, w.act, B, 2 * F, D, D, F,
+                                tl | (s->gateup_block8 ? TEO_GEMM_SWIGLU8 : TEO_GEMM_SWIGLU16), dt, st, take));
             give.next_g = (const unsigned short*)(l + 1 < d->layers ? d->in_norm_w[l + 1] : d->final_norm_w);
             TEO_TRY(skinny_gemm(w.act, dn_w, dn_s, w8, nullptr, 0.f, w.h, w.h, B, D, F, F, D, tl, dt, st, give));
         } else {

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ norm_w, float eps,
                                                                  const bf16_t* __restrict__ res, void* __restrict__ outv,
                                                                  int MB, int N, int K, int ldx, int ldo, int ldr, int tiled,
-                                                                 int out_f32, int RT, SkinnyFuse fuse) {
+                                                                 int out_f32, int RT, SkinnyFuse fuse, int sw8) {
     constexpr bool F8 = sizeof(WT) == 1;
     constexpr int KS = F8 ? 64 : 32;                     // k elements per step (one 16-byte chunk per lane)
     constexpr int CH = F8 ? 16 : 8;                      // k elements per lane chunk
@@ -96,15 +96,6 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         for (int i = tid; i < K / 8; i += SK_THREADS)
             reinterpret_cast<u32x4*>(sk_dyn)[i] = reinterpret_cast<const u32x4*>(norm_w)[i];
         __syncthreads();
-    }
-    if (fuse.ssq_in) {
-        // producer-side RMSNorm (see SkinnyFuse): x already holds bf16(h * g); 1/rms from the producer's partial sums
-        for (int b = wid; b < MB; b += SK_WAVES) {
-            float t = 0.f;
-            for (int p_ = lane; p_ < fuse.nparts; p_ += 64) t += fuse.ssq_in[(long long)b * fuse.nparts + p_];
-            t = wave_sum(t);
-            if (lane == 0) inv_s[b] = rsqrtf(t / (float)K + fuse.eps);
-        }
     }
     const bf16_t* gs = reinterpret_cast<const bf16_t*>(sk_dyn) + fg * (sizeof(WT) == 1 ? 16 : 8);
     float ssq = 0.f;
@@ -163,10 +154,47 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         }                                                                                                      \
     }
 
+#define TEO_SK_SSQ_LOAD \
+        float sq0 = 0.f, sq1 = 0.f; \
+        if (fuse.ssq_in) { \
+            const float* r0 = fuse.ssq_in + (long long)min(wid, MB - 1) * fuse.nparts; \
+            const float* r1 = fuse.ssq_in + (long long)min(wid + 8, MB - 1) * fuse.nparts; \
+            for (int p0 = lane; p0 < fuse.nparts; p0 += 256) { \
+                float a0[4], a1[4]; \
+_Pragma("unroll") \
+                for (int i = 0; i < 4; ++i) { \
+                    const int p_ = min(p0 + 64 * i, fuse.nparts - 1); \
+                    a0[i] = r0[p_]; \
+                    a1[i] = r1[p_]; \
+                } \
+_Pragma("unroll") \
+                for (int i = 0; i < 4; ++i) { \
+                    const bool in = p0 + 64 * i < fuse.nparts; \
+                    sq0 += in ? a0[i] : 0.f; \
+                    sq1 += in ? a1[i] : 0.f; \
+                } \
+            } \
+        }
+#define TEO_SK_SSQ_REDUCE \
+        if (fuse.ssq_in) { \
+            sq0 = wave_sum(sq0); \
+            sq1 = wave_sum(sq1); \
+            if (lane == 0) { \
+                if (wid < MB) inv_s[wid] = rsqrtf(sq0 / (float)K + fuse.eps); \
+                if (wid + 8 < MB) inv_s[wid + 8] = rsqrtf(sq1 / (float)K + fuse.eps); \
+            } \
+        }
+
     if (s0 < s1) {
         u32x4 wa[UNR], xa[UNR][XL], wb[UNR], xb[UNR][XL];
         int s = s0;
+        // producer-side RMSNorm (SkinnyFuse): 1/rms of the rows from the producer's partial sums.  Wave w owns rows w
+        // and w + 8.  The partials are requested FIRST and the wave's first weight batch right behind them, so the
+        // reduction's L2 round trip runs under the HBM latency of the weight stream (vmcnt counts in order: waiting for
+        // the older ssq loads does not wait for the weights).
+        TEO_SK_SSQ_LOAD
         TEO_SK_LOAD(wa, xa, s)
+        TEO_SK_SSQ_REDUCE
         for (; s + 2 * UNR < s1; s += 2 * UNR) {
             TEO_SK_LOAD(wb, xb, s + UNR)
             TEO_SK_COMP(wa, xa, s)
@@ -176,7 +204,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         TEO_SK_LOAD(wb, xb, s + UNR)
         TEO_SK_COMP(wa, xa, s)
         TEO_SK_COMP(wb, xb, s + UNR)
+    } else {                                             // K shorter than 8 slices: this wave only owes its rows' 1/rms
+        TEO_SK_SSQ_LOAD
+        TEO_SK_SSQ_REDUCE
     }
+#undef TEO_SK_SSQ_LOAD
+#undef TEO_SK_SSQ_REDUCE
 #undef TEO_SK_LOAD
 #undef TEO_SK_COMP
 
@@ -206,16 +239,18 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         float v;
         int col;
         if (SWIGLU) {
-            const int tp = c >> 4, i = c & 15;               // tile pair: gate tile 2 tp, up tile 2 tp + 1
-            const int ng = n0 + tp * 32 + i;
+            // 16-row interleave: tile pair (gate tile 2 tp, up tile 2 tp + 1); 8-row interleave: rows i / i + 8 of one tile
+            const int tp = sw8 ? (c >> 3) : (c >> 4), i = sw8 ? (c & 7) : (c & 15);
+            const int tg = sw8 ? tp : 2 * tp, tu = sw8 ? tp : 2 * tp + 1, iu = sw8 ? i + 8 : i;
+            const int ng = n0 + (sw8 ? tp * 16 : tp * 32) + i, nu = ng + (sw8 ? 8 : 16);
             if (ng >= N) continue;
             float g = 0.f, u = 0.f;
             for (int w = 0; w < KSPLIT; ++w) {
-                g += red[(2 * tp) * KSPLIT + w][b * 17 + i];
-                u += red[(2 * tp + 1) * KSPLIT + w][b * 17 + i];
+                g += red[tg * KSPLIT + w][b * 17 + i];
+                u += red[tu * KSPLIT + w][b * 17 + iu];
             }
             g *= inv; u *= inv;
-            if (wscale) { g *= wscale[ng]; u *= wscale[ng + 16]; }
+            if (wscale) { g *= wscale[ng]; u *= wscale[nu]; }
             v = silu(g) * u;
             col = (n0 >> 1) + c;
         } else {
@@ -255,6 +290,7 @@ bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, co
     if (MB < 1 || MB > 16 || N < 1 || K < ks || K % ks != 0 || ldx % 8 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return false;
     if ((flags & TEO_GEMM_SWIGLU16) && N % 32 != 0) return false;
+    if ((flags & TEO_GEMM_SWIGLU8) && (N % 16 != 0 || (flags & TEO_GEMM_SWIGLU16))) return false;
     return true;
 }
 
@@ -263,7 +299,7 @@ bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, co
 // norm_w != NULL: fused RMSNorm of x (see the kernel).  fuse: producer-side norm hand-off (ops.h SkinnyFuse).
 int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, float eps, const void* res,
                 void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st, SkinnyFuse fuse) {
-    const bool swiglu = flags & TEO_GEMM_SWIGLU16;
+    const bool swiglu = (flags & (TEO_GEMM_SWIGLU16 | TEO_GEMM_SWIGLU8)) != 0;
     const int tiled = (flags & TEO_GEMM_WTILED) ? 1 : 0;
     if (!skinny_gemm_ok(MB, N, K, ldx, w_fp8, flags, x, W)) {
         set_error("skinny_gemm: unsupported MB=%d N=%d K=%d ldx=%d", MB, N, K, ldx);
@@ -276,16 +312,18 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     TEO_CHECK_ARG(!(fuse.xg_out && (swiglu || out_dtype == TEO_F32 || !fuse.next_g || !fuse.ssq_out)),
                   "skinny_gemm: the norm hand-off needs a plain bf16 output, next_g and ssq_out");
     TEO_CHECK_ARG(!(fuse.ssq_in && norm_w), "skinny_gemm: ssq_in and norm_w are exclusive");
+    TEO_CHECK_ARG(!fuse.ssq_in || fuse.nparts >= 1, "skinny_gemm: nparts %d", fuse.nparts);
     int rt = g_sk_tiles;
-    if (rt == 0 || fuse.xg_out) rt = 1;   // the hand-off epilogue is written for one row tile per workgroup                  // measured: one row tile per workgroup (most waves in flight) wins at every N
-    if (swiglu && rt < 2) rt = 2;         // the gate tile and its up tile meet in the epilogue
+    if (rt == 0 || fuse.xg_out) rt = 1;   // measured: one row tile per workgroup (most waves in flight) wins at every N
+    const int sw8 = (flags & TEO_GEMM_SWIGLU8) ? 1 : 0;   // gate/up interleaved in blocks of 8 rows: a pair fits one tile
+    if (swiglu && !sw8 && rt < 2) rt = 2; // 16-row interleave: the gate tile and its up tile meet in the epilogue
     const int blocks = cdiv(N, 16 * rt);
     const int ldr = ldo, of = out_dtype == TEO_F32;
     const size_t dyn = norm_w ? (size_t)K * 2 : 0;
 #define TEO_SK(WW, NTV, SW, NM)                                                                            \
     skinny_gemm_kernel<WW, 4, NTV, SW, NM><<<blocks, SK_THREADS, dyn, st>>>(                               \
         (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)norm_w, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, \
-        tiled, of, rt, fuse)
+        tiled, of, rt, fuse, sw8)
 #define TEO_SK_N(WW, NTV, SW) if (norm_w) { TEO_SK(WW, NTV, SW, true); } else { TEO_SK(WW, NTV, SW, false); }
 #define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK_N(WW, NTV, true) } else { TEO_SK_N(WW, NTV, false) }
     if (w_fp8) { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }

@@ -48,6 +48,15 @@ def tile_weights(W):
     return W.view(npad // 16, 16, K // ks, 4, ch).permute(0, 2, 3, 1, 4).contiguous().view(npad, K)
 
 
+def reinterleave_gate_up(gu, block):
+    """gate/up rows interleaved in blocks of 16 (the engine's layout) -> blocks of `block` rows (same pairs)."""
+    n, k = gu.shape
+    f = n // 2
+    g16 = gu.view(f // 16, 2, 16, k)
+    gate, up = g16[:, 0].reshape(f, k), g16[:, 1].reshape(f, k)
+    return torch.stack([gate.view(f // block, block, k), up.view(f // block, block, k)], dim=1).reshape(n, k)
+
+
 def interleave_gate_up(gate, up):
     """[F, D], [F, D] -> [2F, D] with 16-row blocks alternating gate/up."""
     F_, D = gate.shape

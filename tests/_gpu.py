@@ -56,7 +56,7 @@ def gemm_skinny(x, W, scale=None, res=None, flags=0, out_dtype=None, N=None, nor
     MB, K = x.shape
     N = N or W.shape[0]
     out_dtype = out_dtype or x.dtype
-    Nc = N // 2 if flags & L.GEMM_SWIGLU16 else N
+    Nc = N // 2 if flags & (L.GEMM_SWIGLU16 | L.GEMM_SWIGLU8) else N
     out = torch.empty(MB, Nc, dtype=out_dtype, device=x.device)
     L.check(lib().teo_gemm_skinny(p(x), p(W), p(scale), 1 if scale is not None else 0, p(norm_w), eps, p(res), p(out), MB, N, K,
                                   x.stride(0), Nc,

@@ -650,3 +650,29 @@ def test_cross_entropy_matches_torch(rows, vocab):
         assert abs(float(out[0]) - float(want_per.sum() / n)) < 2e-5 and int(out[2]) == n
     else:
         assert bool(torch.isnan(out[0]))
+
+
+@pytest.mark.parametrize("MB", [3, 8, 16])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_gemm_skinny_swiglu_block8_layout(MB, fp8):
+    """TEO_GEMM_SWIGLU8: gate/up pairs interleaved in blocks of 8 rows (one 16-row tile holds 8 pairs) == SWIGLU16."""
+    from teochat_amd.engine import interleave_gate_up, quantize_fp8_rows, reinterleave_gate_up, tile_weights
+    bf = torch.bfloat16
+    K, Fd = 4096, 11008
+    x = G.bf16_round(rnd(MB, K, seed=1))
+    gate, up = G.bf16_round(rnd(Fd, K, seed=2, scale=0.02)), G.bf16_round(rnd(Fd, K, seed=3, scale=0.02))
+    gu16 = interleave_gate_up(gate, up).to(bf).cuda()
+    dx = G.dev(x, bf)
+    if fp8:
+        q, s_, dq = quantize_fp8_rows(gu16)
+        y16 = G.gemm_skinny(dx, tile_weights(q), scale=s_, flags=L.GEMM_SWIGLU16 | L.GEMM_WTILED, out_dtype=torch.float32, N=2 * Fd)
+        q8 = reinterleave_gate_up(q, 8)
+        s8 = reinterleave_gate_up(s_.view(-1, 1), 8).view(-1).contiguous()
+        y8 = G.gemm_skinny(dx, tile_weights(q8), scale=s8, flags=L.GEMM_SWIGLU8 | L.GEMM_WTILED, out_dtype=torch.float32, N=2 * Fd)
+    else:
+        y16 = G.gemm_skinny(dx, tile_weights(gu16), flags=L.GEMM_SWIGLU16 | L.GEMM_WTILED, out_dtype=torch.float32, N=2 * Fd)
+        gu8 = reinterleave_gate_up(gu16, 8)
+        assert torch.equal(gu8.view(Fd // 8, 2, 8, K)[:, 0].reshape(Fd, K).cpu().float(), gate)
+        y8 = G.gemm_skinny(dx, tile_weights(gu8), flags=L.GEMM_SWIGLU8 | L.GEMM_WTILED, out_dtype=torch.float32, N=2 * Fd)
+        torch.testing.assert_close(y8.cpu(), F.silu(x @ gate.T) * (x @ up.T), atol=3e-4, rtol=2e-4)
+    torch.testing.assert_close(y8, y16, atol=2e-4, rtol=1e-4)
