@@ -310,6 +310,13 @@ template <> struct Cvt16<float> {
     }
 };
 
+// K/V rows are read once per step: non-temporal 16-byte loads (streamed past L2 like the GEMV weight stream)
+typedef __attribute__((ext_vector_type(4))) unsigned int kv_u32x4;
+__device__ __forceinline__ uint4 ld_kv(const void* p) {
+    const kv_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const kv_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // q: [heads*hd] (already rotated), K/V cache [kv_heads][S_max][hd]; partial: [heads][nsplit][hd + 2] fp32 (m, l, o[hd])
 // ROPE: `q` is the raw [q | k | v] row of the new token (GEMV output, not yet rotated).  The kernel rotates q on load,
 // and the one lane group that owns key `pos` rotates the new k, takes the new v, appends both to the caches (K, V, V^T)
@@ -358,12 +365,12 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = min(kw0 + i * RPI + grp, kv_len - 1);
-        kr[i] = *reinterpret_cast<const uint4*>(kb + (long long)j * HD);
+        kr[i] = ld_kv(kb + (long long)j * HD);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = min(kw0 + i * RPI + grp, kv_len - 1);
-        vr[i] = *reinterpret_cast<const uint4*>(vb + (long long)j * HD);
+        vr[i] = ld_kv(vb + (long long)j * HD);
     }
     float qf[VE];
     float knew[VE], vnew[VE];
