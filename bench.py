@@ -245,7 +245,7 @@ def main():
                 "algorithmic_bytes_per_launch": gemv_bytes, "avg_launch_ms": round(avg.value, 5)}
     # whole decode step against the HBM roofline (weights + KV per token)
     kv_ctx = Lseq + n_out / 2.0
-    tok_bytes = 6.738e9 * 2 + 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * kv_ctx
+    tok_bytes = 6.738e9 * (1 if args.weights == "fp8" else 2) + 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * kv_ctx
     roofline["decode_step_frac_of_hbm_peak"] = round(tok_bytes / (phases["decode_ms_per_token"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     result = {
