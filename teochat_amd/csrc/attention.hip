@@ -273,7 +273,8 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // scores: per-row partial dot + xor-shuffle over the LPR lanes; PV: each lane accumulates its 16-byte column slice
 // over its keys, lanes of different rows are summed with two xor-shuffles at the end.  No MFMA: 1 query row.
 // ------------------------------------------------------------------------------------------------
-static int g_dec_chunk = 128;     // keys per workgroup (tunable: 64 / 128 / 256)
+static int g_dec_chunk = 0;       // keys per workgroup (32 / 64 / 128 / 256); 0 = auto: 64 for one conversation (2.83 vs 2.86 ms/token
+                                  // at 128, 2.87 at 32, 2.94 at 256), 128 for a batched step (4.74 vs 4.79 ms/step at 64)
 static int g_fused_combine = 0;   // 1: the last workgroup of a head merges the KV splits (no combine launch).  Measured: the
                                   // agent-scope release/acquire fences cost far more than the launch they save (2.89 -> 3.51
                                   // ms/token; batch 8: 5.2 -> 13 ms/step), so it stays off -- kept as a tested experiment.
@@ -281,7 +282,7 @@ int g_rope_in_attn = -1;          // decode RoPE + KV append: 0 = in the QKV GEM
                                    // -1 = auto (measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0,
                                    // fp8 weights 2.216 vs 2.234 in favour of 1)
 int attn_tune_set(const char* key, int value) {
-    if (!strcmp(key, "attn_chunk") && (value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
+    if (!strcmp(key, "attn_chunk") && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
     if (!strcmp(key, "attn_fused_combine")) { g_fused_combine = value != 0; return 0; }
     if (!strcmp(key, "rope_in_attn") && (value >= -1 && value <= 1)) { g_rope_in_attn = value; return 0; }
     return -1;
@@ -433,11 +434,14 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     }
     __syncthreads();
     // ---- chunk max / exp / sum (every wave redundantly over the chunk's scores: DEC_CHUNK/64 per lane)
-    constexpr int SPL = DEC_CHUNK / 64;
+    constexpr int SPL = (DEC_CHUNK + 63) / 64;
     float sv[SPL];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) { sv[i] = sc[lane + 64 * i]; mx = fmaxf(mx, sv[i]); }
+    for (int i = 0; i < SPL; ++i) {
+        sv[i] = (DEC_CHUNK >= 64 || lane + 64 * i < DEC_CHUNK) ? sc[(lane + 64 * i) % DEC_CHUNK] : -INFINITY;
+        mx = fmaxf(mx, sv[i]);
+    }
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
@@ -446,7 +450,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     __syncthreads();
     if (wid == 0) {
 #pragma unroll
-        for (int i = 0; i < SPL; ++i) sc[lane + 64 * i] = Elem<T>::round(sv[i]);
+        for (int i = 0; i < SPL; ++i)
+            if (DEC_CHUNK >= 64 || lane + 64 * i < DEC_CHUNK) sc[lane + 64 * i] = Elem<T>::round(sv[i]);
     }
     __syncthreads();
     // ---- PV on this wave's keys
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* _
 }
 
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
-    const int nsplit = cdiv(S_max, 64);      // sized for the smallest chunk
+    const int nsplit = cdiv(S_max, 32);      // sized for the smallest chunk
     return (size_t)batch * heads * nsplit * (hd + 2) * sizeof(float);
 }
 
@@ -586,7 +591,9 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
                                                                      d_pos, S_max, heads, kv_heads, scale, nsplit, bt, \
                                                                      counters, (T*)o)
 #define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
-    if constexpr (64 / 4 >= 64 / LPR) {
+    if constexpr (32 / 4 >= 64 / LPR) {
+        if (chunk == 32) { TEO_PART_R(32) } else if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
+    } else if constexpr (64 / 4 >= 64 / LPR) {
         if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
     } else {
         if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
@@ -604,12 +611,12 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
                 hipStream_t st, AttnBatch bt, int* counters) {
     const bool rope = rope_cos != nullptr;
     if (!g_fused_combine) counters = nullptr;
-    int chunk = g_dec_chunk;
+    int chunk = g_dec_chunk ? g_dec_chunk : (bt.batch > 1 ? 128 : 64);
     const int esz = dtype == TEO_F32 ? 4 : 2;
     const int lpr = hd * esz / 16;
     if (chunk / 4 < 64 / lpr) chunk = 4 * (64 / lpr);          // every wave needs at least one load instruction of keys
-    if (chunk != 64 && chunk != 128 && chunk != 256) chunk = 128;
-    if (cdiv(S_max, chunk) > 256) chunk = 256;
+    if (chunk != 32 && chunk != 64 && chunk != 128 && chunk != 256) chunk = 128;
+    while (chunk < 256 && cdiv(S_max, chunk) > 256) chunk *= 2;        // the combine handles at most 256 splits
     const int nsplit = cdiv(S_max, chunk);
     if (nsplit > 256 || (hd * esz) % 16 != 0 || (lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16 && lpr != 32)) {
         set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
