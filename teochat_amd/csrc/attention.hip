@@ -532,47 +532,57 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     }
 }
 
-// one workgroup per head: split weights are computed by one thread per split (parallel loads), then each thread
-// owns one output column and sums the active splits with independent loads (no dependent-latency chain).
+// one workgroup (512 threads) per head.  Split weights: one thread per split (parallel loads).  Output: thread =
+// (column d, split group g); a thread owns every G-th split (G = 512 / hd) and keeps 8 loads in flight, the G partial
+// sums of a column meet in LDS -- one or two L2 round trips instead of a dependent chain over all splits.
 template <typename T>
-__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
+__global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
                                                                   const int* __restrict__ d_pos, int hd, int nsplit, int chunk,
                                                                   long long o_stride) {
     __shared__ float w[256];
-    __shared__ float red[4];
+    __shared__ float red[16];
+    __shared__ float accs[512];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int stride = hd + 2;
     part += (long long)blockIdx.y * gridDim.x * nsplit * stride;
     o += (long long)blockIdx.y * o_stride;
     d_pos += blockIdx.y;
     const float* pb = part + (long long)h * nsplit * stride;
-    const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys
-    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+    const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys (<= 256)
+    const int G = 512 / hd;                                                 // hd is a power of two <= 256
+    const int g = tid / hd, d = tid % hd;
+    // the first 8 splits of this thread are requested together with the split statistics (they do not depend on them)
+    float v0[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v0[i] = pb[(long long)min(g + i * G, nact - 1) * stride + 2 + d];
+    float m0 = -INFINITY, l0 = 0.f;
     if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
-    if (tid + 128 < nact) { m1 = pb[(tid + 128) * stride]; l1 = pb[(tid + 128) * stride + 1]; }
-    float M = wave_max(fmaxf(m0, m1));
+    float M = wave_max(m0);
     if (lane == 0) red[wid] = M;
     __syncthreads();
-    M = fmaxf(red[0], red[1]);
-    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M), w1 = (m1 == -INFINITY) ? 0.f : expf(m1 - M);
-    if (tid < nact) w[tid] = w0;
-    if (tid + 128 < nact) w[tid + 128] = w1;
-    float L = wave_sum(l0 * w0 + l1 * w1);
+    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));               // splits live in threads 0..255 = waves 0..3
+    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
+    if (tid < 256) w[tid] = w0;
+    float L = wave_sum(l0 * w0);
+    if (lane == 0) red[8 + wid] = L;
     __syncthreads();
-    if (lane == 0) red[2 + wid] = L;
+    const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += (g + i * G < nact) ? v0[i] * w[min(g + i * G, 255)] : 0.f;
+    for (int s0 = g + 8 * G; s0 < nact; s0 += 8 * G) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = pb[(long long)min(s0 + i * G, nact - 1) * stride + 2 + d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * w[min(s0 + i * G, 255)] : 0.f;
+    }
+    accs[tid] = a;
     __syncthreads();
-    const float inv = 1.0f / (red[2] + red[3]);
-    for (int d = tid; d < hd; d += 128) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int s_ = 0;
-        for (; s_ + 4 <= nact; s_ += 4) {
-            const float v0 = pb[s_ * stride + 2 + d], v1 = pb[(s_ + 1) * stride + 2 + d];
-            const float v2 = pb[(s_ + 2) * stride + 2 + d], v3 = pb[(s_ + 3) * stride + 2 + d];
-            a0 = fmaf(v0, w[s_], a0); a1 = fmaf(v1, w[s_ + 1], a1);
-            a2 = fmaf(v2, w[s_ + 2], a2); a3 = fmaf(v3, w[s_ + 3], a3);
-        }
-        for (; s_ < nact; ++s_) a0 = fmaf(pb[s_ * stride + 2 + d], w[s_], a0);
-        Elem<T>::st(o + h * hd + d, ((a0 + a1) + (a2 + a3)) * inv);
+    if (g == 0) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += accs[d + k * hd];
+        Elem<T>::st(o + h * hd + d, t * inv);
     }
 }
 
@@ -601,7 +611,7 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
 #undef TEO_PART_R
 #undef TEO_PART
     if (!counters)
-        attn_decode_combine_kernel<T><<<dim3(heads, bt.batch), 128, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
+        attn_decode_combine_kernel<T><<<dim3(heads, bt.batch), 512, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
 }
 
 // rope_cos != NULL: q is the raw qkv row; RoPE and the KV append of the new token happen inside the kernel

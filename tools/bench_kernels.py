@@ -150,9 +150,9 @@ def bench_gemv_sweep():
     for name, N, K, norm, flags in shapes:
         n = max(2, int(600e6 // (N * K * 2)))
         bufs[name] = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
-    for maxb in (512, 768, 1024, 1376, 1536, 2048, 2752, 3072):
+    for maxb in [int(v_) for v_ in os.environ.get("GV_MAXB", "512,768,1024,1376,1536,2048,2752,3072").split(",")]:
         for nt in (1,):
-            for v in (-1,):
+            for v in [int(v_) for v_ in os.environ.get("GV_VARIANTS", "-1").split(",")]:
                 lib.teo_tune_set(b"gemv_variant", v)
                 lib.teo_tune_set(b"gemv_nt", nt)
                 lib.teo_tune_set(b"gemv_max_blocks", maxb)
