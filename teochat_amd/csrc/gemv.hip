@@ -84,12 +84,13 @@ __device__ __forceinline__ uint4 ld16(const void* p) {
 }
 
 // Tunables (teo_tune_set): non-temporal loads on/off, workgroup cap, variant of the row-group kernel.
-struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; };
+struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; };
 static GemvTune g_tune;
 int gemv_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemv_variant")) g_tune.variant = value;
     else if (!strcmp(key, "gemv_nt")) g_tune.nt = value;
     else if (!strcmp(key, "gemv_max_blocks")) g_tune.max_blocks = value;
+    else if (!strcmp(key, "gemv_splitk_u") && (value == 0 || value == 2 || value == 4 || value == 6)) g_tune.splitk_u = value;
     else return -1;
     return 0;
 }
@@ -529,9 +530,14 @@ static int launch_splitk(const void* x, const void* W, const float* ws, const vo
 template <typename T, typename TO, typename WT>
 static int gemv_launch(const void* x, const void* W, const float* ws, const void* norm_w, const void* res, void* y, int N, int K,
                        float eps, bool swiglu, hipStream_t st) {
-    // few long rows without a fused norm (o / down projections): split-K workgroups, 2 rows each (measured best)
+    // few long rows without a fused norm (o / down projections): split-K workgroups, 2 rows each (measured best).
+    // U is chosen so that ONE step covers the whole row (256*U chunks): every load of the workgroup is in flight at once
+    // instead of 2-3 dependent steps (down projection, K = 11008: 3 steps of U = 2 -> 1 step of U = 6).
     if (!swiglu && norm_w == nullptr && N <= 8192 && g_tune.variant < 0) {
-        if (sizeof(WT) == 1) return launch_splitk<T, TO, WT, 2, 2>(x, W, ws, res, y, N, K, st);
+        const int nchunk = K / Vec16<WT>::N;
+        const int u = g_tune.splitk_u > 0 ? g_tune.splitk_u : (nchunk <= 512 ? 2 : (nchunk <= 1024 ? 4 : (nchunk <= 1536 ? 6 : 2)));
+        if (u == 4) return launch_splitk<T, TO, WT, 2, 4>(x, W, ws, res, y, N, K, st);
+        if (u == 6) return launch_splitk<T, TO, WT, 2, 6>(x, W, ws, res, y, N, K, st);
         return launch_splitk<T, TO, WT, 2, 2>(x, W, ws, res, y, N, K, st);
     }
     switch (g_tune.variant) {          // tuning sweep (tools/bench_kernels.py): R rows x U chunks, prefetch on/off
