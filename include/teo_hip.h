@@ -138,6 +138,20 @@ int teo_rope_kv_append(void* d_qkv, int ld_qkv, const int* d_positions, const fl
 int teo_embed_splice(const int* d_plan, const void* d_embed, const void* d_visual, void* d_out, int rows, int dim,
                      int dtype, teo_stream_t stream);
 
+/* Decode attention (one new query row per conversation; tf llama eager attention with a KV cache, the H15 row of
+ * SURVEY.md section 8a at q_len == 1).  Conversation b < batch: query row at d_q + b*q_stride, caches at + b*cache_stride
+ * (elements; K and V are [kv_heads][max_seq][head_dim], V^T [kv_heads][head_dim][max_seq]), position d_pos[b] (= number
+ * of cached tokens; attends over d_pos[b] + 1 keys), output [heads*head_dim] at d_out + b*o_stride.
+ *   rope_cos == NULL : d_q holds the rotated query [heads*head_dim]; the caches already contain the new token's K/V.
+ *   rope_cos != NULL : d_q holds the raw [q | k | v] row of the QKV projection; the kernel applies RoPE at d_pos[b] to q
+ *                      and k and appends k, v (and V^T when d_vt_cache != NULL) to the caches before attending.
+ * KV-split partials + combine; d_partials is teo_attn_decode_workspace_bytes(...) of scratch. */
+size_t teo_attn_decode_workspace_bytes(int heads, int head_dim, int max_seq, int batch);
+int teo_attn_decode(const void* d_q, void* d_k_cache, void* d_v_cache, void* d_vt_cache, const float* d_rope_cos,
+                    const float* d_rope_sin, void* d_out, float* d_partials, const int* d_pos, int max_seq, int heads,
+                    int kv_heads, int head_dim, float scale, int dtype, int batch, long long q_stride, long long cache_stride,
+                    long long o_stride, teo_stream_t stream);
+
 /* Training-shape loss: mean over rows with label != ignore_index of (logsumexp(logits[r]) - logits[r, label[r]]) --
  * torch.nn.CrossEntropyLoss as LlamaForCausalLM.forward applies it to the shifted logits/labels (call site
  * videollava/model/language_model/llava_llama.py:88-99).  logits fp32 [rows, ld]; labels int64 [rows] (already shifted

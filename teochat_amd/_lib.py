@@ -122,6 +122,9 @@ _SIGS = {
                                                       C.c_void_p, C.POINTER(C.c_void_p)]),
     "teo_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "teo_graph_destroy": (C.c_int, [C.c_void_p]),
+    "teo_attn_decode_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "teo_attn_decode": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_longlong, C.c_longlong,
+                                                                      C.c_longlong, C.c_void_p]),
     "teo_cross_entropy": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
                                     C.c_void_p]),
     "teo_preprocess_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),

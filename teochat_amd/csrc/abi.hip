@@ -321,6 +321,25 @@ int teo_time_gemv_chain(const void* x, const void* const* Ws, const float* const
     return TEO_OK;
 }
 
+size_t teo_attn_decode_workspace_bytes(int heads, int head_dim, int max_seq, int batch) {
+    return (heads > 0 && head_dim > 0 && max_seq > 0 && batch > 0) ? attn_decode_ws_bytes(heads, head_dim, max_seq, batch) : 0;
+}
+
+int teo_attn_decode(const void* q, void* k_cache, void* v_cache, void* vt_cache, const float* rope_cos, const float* rope_sin,
+                    void* out, float* partials, const int* d_pos, int max_seq, int heads, int kv_heads, int head_dim, float scale,
+                    int dtype, int batch, long long q_stride, long long cache_stride, long long o_stride, teo_stream_t s) {
+    ENTER();
+    NEED_DT(dtype);
+    TEO_CHECK_ARG(batch >= 1 && heads > 0 && kv_heads > 0 && heads % kv_heads == 0 && head_dim > 0 && max_seq > 0,
+                  "teo_attn_decode: batch %d heads %d kv_heads %d head_dim %d max_seq %d", batch, heads, kv_heads, head_dim, max_seq);
+    NEED(q, "q"); NEED(k_cache, "k_cache"); NEED(v_cache, "v_cache"); NEED(out, "out"); NEED(partials, "partials"); NEED(d_pos, "d_pos");
+    TEO_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "teo_attn_decode: rope_cos and rope_sin go together");
+    AttnBatch bt;
+    bt.batch = batch; bt.q_stride = q_stride; bt.cache_stride = cache_stride; bt.o_stride = o_stride;
+    return attn_decode(q, k_cache, v_cache, vt_cache, rope_cos, rope_sin, out, partials, d_pos, max_seq, heads, kv_heads, head_dim,
+                       scale, dtype, ST(s), bt, nullptr);
+}
+
 int teo_cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
                       long long ignore_index, teo_stream_t s) {
     ENTER();

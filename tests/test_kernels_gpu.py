@@ -676,3 +676,49 @@ def test_gemm_skinny_swiglu_block8_layout(MB, fp8):
         y8 = G.gemm_skinny(dx, tile_weights(gu8), flags=L.GEMM_SWIGLU8 | L.GEMM_WTILED, out_dtype=torch.float32, N=2 * Fd)
         torch.testing.assert_close(y8.cpu(), F.silu(x @ gate.T) * (x @ up.T), atol=3e-4, rtol=2e-4)
     torch.testing.assert_close(y8, y16, atol=2e-4, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- decode attention
+def _decode_attn_ref(q, K, V, n):
+    """q [H, d]; K, V [Hk, S, d]; n keys -> [H*d] (fp64 softmax(q K^T / sqrt(d)) V, GQA by head // (H/Hk))."""
+    H, d = q.shape
+    rep = H // K.shape[0]
+    out = []
+    for h in range(H):
+        k, v = K[h // rep, :n].double(), V[h // rep, :n].double()
+        p = torch.softmax((k @ q[h].double()) / d ** 0.5, dim=0)
+        out.append(p @ v)
+    return torch.cat(out).float()
+
+
+@pytest.mark.parametrize("dtype,H,Hk,d,S,ctx", [(torch.bfloat16, 32, 32, 128, 2560, [2299, 64, 1, 2559]),
+                                                (torch.bfloat16, 8, 2, 64, 512, [300, 511]),
+                                                (torch.float32, 4, 2, 16, 256, [17, 200, 255])])
+@pytest.mark.parametrize("chunk", [0, 32, 128, 256])
+def test_attn_decode_batched_vs_reference(dtype, H, Hk, d, S, ctx, chunk):
+    """teo_attn_decode (pre-rotated q, caches already hold every key): every conversation of the batch against an fp64
+    softmax reference, for every KV-split size."""
+    B = len(ctx)
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, H, d, generator=g)
+    K = torch.randn(B, Hk, S, d, generator=g)
+    V = torch.randn(B, Hk, S, d, generator=g)
+    if dtype == torch.bfloat16:
+        q, K, V = G.bf16_round(q), G.bf16_round(K), G.bf16_round(V)
+    dq, dK, dV = q.to("cuda", dtype).contiguous(), K.to("cuda", dtype).contiguous(), V.to("cuda", dtype).contiguous()
+    pos = torch.tensor([n - 1 for n in ctx], dtype=torch.int32, device="cuda")
+    out = torch.empty(B, H * d, dtype=dtype, device="cuda")
+    lib = G.lib()
+    part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, B), dtype=torch.uint8, device="cuda")
+    assert lib.teo_tune_set(b"attn_chunk", chunk) == 0
+    try:
+        L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), None, None, None, G.p(out), G.p(part), G.p(pos), S, H, Hk, d,
+                                    1.0 / d ** 0.5, G.DT[dtype], B, H * d, Hk * S * d, H * d, G.stream()), "attn_decode")
+    finally:
+        lib.teo_tune_set(b"attn_chunk", 0)
+    for b, n in enumerate(ctx):
+        ref = _decode_attn_ref(q[b], K[b], V[b], n)
+        if dtype == torch.float32:
+            torch.testing.assert_close(out[b].cpu(), ref, atol=2e-5, rtol=1e-5)
+        else:
+            close_bf16(out[b], G.bf16_round(ref), ulps=2.0, floor=4e-3)    # P is rounded to bf16 before the PV product
