@@ -19,6 +19,7 @@ namespace teo {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // ------------------------------------------------------------------------------------------------
 // generic kernel
@@ -105,37 +106,62 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(teo_attn_args a) {
     if (CAUSAL) kv_end = min(a.kv_len, qb + 63 + off + 1);
     const int ntiles = (kv_end + 63) >> 6;
 
+    // Register prefetch: tile t+1 is requested from global memory before tile t is computed, so the HBM/L2 latency of
+    // the K / V^T stream hides under the MFMAs (the loads are unconditional: the tile index is clamped).
+    constexpr int NKC = (64 * CH) / 256, NVC = (D * 8) / 256;
+    u32x4 rk[NKC], rv[NVC];
+#define TEO_FA_LOAD(T_)                                                                                           \
+    {                                                                                                             \
+        const int jt = (T_) * 64;                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NKC; ++i) {                                                         \
+            const int id = tid + 256 * i;                                                                         \
+            const int r = id / CH, c = id % CH;                                                                   \
+            const int gj = min(jt + r, a.kv_len - 1);                                                             \
+            rk[i] = *reinterpret_cast<const u32x4*>(K + (long long)gj * a.k_rs + c * 8);                          \
+        }                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < NVC; ++i) {                                                         \
+            const int id = tid + 256 * i;                                                                         \
+            const int d = id >> 3, c = id & 7;                                                                    \
+            rv[i] = *reinterpret_cast<const u32x4*>(VT + (long long)d * a.vt_rs + jt + c * 8);                    \
+        }                                                                                                         \
+    }
+    TEO_FA_LOAD(0)
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 64;
         __syncthreads();   // previous tile fully consumed
         // ---- stage K tile: 64 rows x CH chunks
 #pragma unroll
-        for (int i = 0; i < (64 * CH) / 256; ++i) {
+        for (int i = 0; i < NKC; ++i) {
             const int id = tid + 256 * i;
             const int r = id / CH, c = id % CH;
-            const int gj = min(j0 + r, a.kv_len - 1);
-            const uint4 val = *reinterpret_cast<const uint4*>(K + (long long)gj * a.k_rs + c * 8);
-            *reinterpret_cast<uint4*>(sK + r * KROW + ((c ^ (r & (CH - 1))) << 4)) = val;
+            *reinterpret_cast<u32x4*>(sK + r * KROW + ((c ^ (r & (CH - 1))) << 4)) = rk[i];
         }
-        // ---- stage V^T tile: D rows x 8 chunks (64 keys); keys >= kv_len must read as zero
+        // ---- stage V^T tile: D rows x 64 keys; keys >= kv_len must read as zero.  Inside each 32-key block the keys
+        // are stored in the order the P operand of the PV MFMA holds them (lane group fg owns keys fg*4..+4 and
+        // 16+fg*4..+4), so the MFMA reads one 16-byte chunk per lane: global chunk cc of a block -> 8-byte units
+        // (cc%2)*4 + cc/2 and that + 2.
 #pragma unroll
-        for (int i = 0; i < (D * 8) / 256; ++i) {
+        for (int i = 0; i < NVC; ++i) {
             const int id = tid + 256 * i;
             const int d = id >> 3, c = id & 7;
-            uint4 val = *reinterpret_cast<const uint4*>(VT + (long long)d * a.vt_rs + j0 + c * 8);
+            u32x4 val = rv[i];
             const int valid = a.kv_len - (j0 + c * 8);     // number of valid keys in this chunk
             if (valid < 8) {
-                unsigned w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (2 * e >= valid) w[e] = 0u;
-                    else if (2 * e + 1 >= valid) w[e] &= 0xffffu;
+                    if (2 * e >= valid) val[e] = 0u;
+                    else if (2 * e + 1 >= valid) val[e] &= 0xffffu;
                 }
-                val = make_uint4(w[0], w[1], w[2], w[3]);
             }
-            *reinterpret_cast<uint4*>(sV + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = val;
+            const int kb = c >> 2, cc = c & 3;
+            const int u0 = (cc & 1) * 4 + (cc >> 1), u1 = u0 + 2;
+            unsigned char* rowp = sV + d * 128;
+            const int sw = d & 7;
+            *reinterpret_cast<uint2*>(rowp + (((kb * 4 + (u0 >> 1)) ^ sw) << 4) + ((u0 & 1) << 3)) = make_uint2(val[0], val[1]);
+            *reinterpret_cast<uint2*>(rowp + (((kb * 4 + (u1 >> 1)) ^ sw) << 4) + ((u1 & 1) << 3)) = make_uint2(val[2], val[3]);
         }
         __syncthreads();
+        if (t + 1 < ntiles) TEO_FA_LOAD(t + 1)
 
         // ---- S^T = K . Q^T : 4 key fragments x (D/32) k-steps
         f32x4 s[4];
@@ -194,18 +220,13 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(teo_attn_args a) {
 #pragma unroll
             for (int df = 0; df < NDF; ++df) {
                 const int d = df * 16 + fr;
-                const int sw = (d >> 1) & 7;
-                // keys (2kb)*16 + fg*4 .. +4  -> 8-byte unit u0 = 8*kb + fg ; keys (2kb+1)*16 + fg*4 -> u1 = u0 + 4
-                const int u0 = 8 * kb + fg, u1 = u0 + 4;
-                const unsigned char* rowp = sV + d * 128;
-                const uint2 lo = *reinterpret_cast<const uint2*>(rowp + (((u0 >> 1) ^ sw) << 4) + ((u0 & 1) << 3));
-                const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((u1 >> 1) ^ sw) << 4) + ((u1 & 1) << 3));
                 union { bf16x8 v; unsigned u[4]; } vf;
-                vf.u[0] = lo.x; vf.u[1] = lo.y; vf.u[2] = hi.x; vf.u[3] = hi.y;
+                vf.v = *reinterpret_cast<const bf16x8*>(sV + d * 128 + (((kb * 4 + fg) ^ (d & 7)) << 4));
                 acc_o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, acc_o[df], 0, 0, 0);
             }
         }
     }
+#undef TEO_FA_LOAD
     // ---- finish: l over the four lanes that share a query, normalise, store O[q][h*D + df*16 + fg*4 + r]
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
