@@ -104,7 +104,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <bool SWIGLU, bool OUT_F32, int DEPTH>
+// MF = 16-row fragments per wave along M: workgroup tile = (32*MF) x 128 (MF = 4: 128 x 128; MF = 2: 64 x 128 for shapes
+// whose 128-row tiles quantise badly over the 512 resident workgroup slots, e.g. M = 2168, N = 4096 -> 544 tiles).
+template <bool SWIGLU, bool OUT_F32, int DEPTH, int MF>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __restrict__ A,
                                                              const bf16_t* __restrict__ W,
                                                              const bf16_t* __restrict__ bias,
@@ -116,43 +118,44 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
     const int wm = wid >> 1, wn = wid & 1;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = tile % tiles_m, tn = tile / tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
+    constexpr int BMT = 32 * MF;
+    const int m0 = tm * BMT, n0 = tn * BN;
 
     // staging: thread owns 4 chunks (16 B) of each operand tile: chunk id = tid + 256*i -> row id>>3, chunk id&7.
     // NOTE: plain arrays + fully unrolled loops only -- lambdas capturing these arrays made hipcc spill them to scratch.
-    const bf16_t* ag[4];
+    const bf16_t* ag[MF];                      // the A tile has 32*MF rows: MF chunks per thread
     const bf16_t* wg[4];
     int soff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = tid + 256 * i;
         const int row = id >> 3, c = id & 7;
-        const int gm = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);
-        ag[i] = A + (long long)gm * lda + c * 8;
+        const int gn = min(n0 + row, N - 1);
+        if (i < MF) ag[i] = A + (long long)min(m0 + row, M - 1) * lda + c * 8;
         wg[i] = W + (long long)gn * K + c * 8;
         soff[i] = row * (BK * 2) + ((c ^ (row & 7)) << 4);
     }
-    u32x4 ra0[4], rb0[4], ra1[4], rb1[4];     // two register stages: tiles kt+1 and kt+2 are in flight during compute(kt)
+    u32x4 ra0[MF], rb0[4], ra1[MF], rb1[4];   // two register stages: tiles kt+1 and kt+2 are in flight during compute(kt)
 
 #define TEO_GLOAD(RA, RB, KT)                                                   \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
-        RA[i] = *reinterpret_cast<const u32x4*>(ag[i] + (long long)(KT) * BK);  \
+        if (i < MF) RA[i] = *reinterpret_cast<const u32x4*>(ag[i] + (long long)(KT) * BK);  \
         RB[i] = *reinterpret_cast<const u32x4*>(wg[i] + (long long)(KT) * BK);  \
     }
 #define TEO_SWRITE(RA, RB, BUF)                                                 \
     {                                                                           \
         unsigned char* sa_ = smem + (BUF) * (2 * TILE_BYTES);                   \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                         \
-            *reinterpret_cast<u32x4*>(sa_ + soff[i]) = RA[i];                   \
+            if (i < MF) *reinterpret_cast<u32x4*>(sa_ + soff[i]) = RA[i];       \
             *reinterpret_cast<u32x4*>(sa_ + TILE_BYTES + soff[i]) = RB[i];      \
         }                                                                       \
     }
 
-    f32x4 acc[4][4];   // [ni][mi]
+    f32x4 acc[4][MF];   // [ni][mi]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets: row = base + i*16 + (lane&15); logical chunk = ks*4 + (lane>>4)
     const int fr = lane & 15, fg = lane >> 4;
@@ -163,15 +166,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
         const unsigned char* sA = smem + (BUF) * (2 * TILE_BYTES);                                                   \
         const unsigned char* sB = sA + TILE_BYTES;                                                                   \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
-            bf16x8 af[4], wf[4];                                                                                     \
+            bf16x8 af[MF], wf[4];                                                                                    \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-                const int ra_ = wm * 64 + i * 16 + fr;                                                               \
-                af[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * (BK * 2) + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));  \
+                if (i < MF) {                                                                                        \
+                    const int ra_ = wm * (16 * MF) + i * 16 + fr;                                                    \
+                    af[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * (BK * 2) + (((ks * 4 + fg) ^ (ra_ & 7)) << 4)); \
+                }                                                                                                    \
                 const int rw_ = wn * 64 + i * 16 + fr;                                                               \
                 wf[i] = *reinterpret_cast<const bf16x8*>(sB + rw_ * (BK * 2) + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));  \
             }                                                                                                        \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                         \
-                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                     \
+                _Pragma("unroll") for (int mi = 0; mi < MF; ++mi)                                                    \
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);     \
         }                                                                                                            \
     }
@@ -212,9 +217,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
 #undef TEO_COMPUTE
 
     // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3
-    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    const int mw = m0 + wm * (16 * MF), nw = n0 + wn * 64;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MF; ++mi) {
         const int m = mw + mi * 16 + fr;
         if (m >= M) continue;
         if (SWIGLU) {
@@ -283,7 +288,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
+static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
 int gemm_tune_set(const char* key, int value) {
+    if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
     if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
     return -1;
 }
@@ -319,21 +326,27 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         return TEO_ERR_ARG;
     }
     if (gemm_mfma_ok(M, N, K, lda, ldc, dtype, flags, A, W, bias, res, C)) {
-        const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+        // tile height: 128 rows; 64 rows only for small problems whose 128-row tiling leaves more than half of the 512
+        // resident workgroup slots empty (ViT o / fc2: 136 tiles; +7 % there).  Measured at M = 2168: 64-row tiles lose
+        // 10-25 % on every LLaMA shape (half the weight reuse per tile), wave quantisation notwithstanding.
+        const int tiles_n = cdiv(N, BN);
+        int bm = g_gemm_bm;
+        if (bm == 0) bm = (cdiv(M, 128) * tiles_n <= 256 && !swiglu) ? 64 : 128;
+        const int tiles_m = cdiv(M, bm);
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
+#define TEO_GEMM_K(SW, OF, DP, MFV)                                                                                   \
+    gemm_mfma_bf16_kernel<SW, OF, DP, MFV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+                                                                  (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
+                                                                  tiles_n)
 #define TEO_GEMM_LAUNCH(SW, OF)                                                                                      \
-    if ((g_gemm_depth == 0 && !(SW)) || g_gemm_depth == 2)                                                            \
-        gemm_mfma_bf16_kernel<SW, OF, 2><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
-                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
-                                                                tiles_n);                                            \
-    else                                                                                                             \
-        gemm_mfma_bf16_kernel<SW, OF, 1><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
-                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
-                                                                tiles_n)
-        if (swiglu) { if (of32) { TEO_GEMM_LAUNCH(true, true); } else { TEO_GEMM_LAUNCH(true, false); } }
-        else        { if (of32) { TEO_GEMM_LAUNCH(false, true); } else { TEO_GEMM_LAUNCH(false, false); } }
+    if (bm == 64) { TEO_GEMM_K(SW, OF, 2, 2); }                                                                       \
+    else if ((g_gemm_depth == 0 && !(SW)) || g_gemm_depth == 2) { TEO_GEMM_K(SW, OF, 2, 4); }                         \
+    else { TEO_GEMM_K(SW, OF, 1, 4); }
+        if (swiglu) { if (of32) { TEO_GEMM_LAUNCH(true, true) } else { TEO_GEMM_LAUNCH(true, false) } }
+        else        { if (of32) { TEO_GEMM_LAUNCH(false, true) } else { TEO_GEMM_LAUNCH(false, false) } }
+#undef TEO_GEMM_K
 #undef TEO_GEMM_LAUNCH
         TEO_LAUNCH_CHECK("gemm_mfma_bf16");
         return TEO_OK;
