@@ -48,6 +48,46 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, int ld, const int* __
     }
 }
 
+// bf16, head_dim % 16 == 0: one thread rotates 8 pairs (16-byte loads of both halves, 32-byte cos / sin rows) or copies
+// 2 x 16 bytes of V.  grid (S, ceil((heads + 2 kv_heads) * hd/16 / 256)); the V^T scatter is left to vt_append_kernel.
+__global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(bf16_t* __restrict__ qkv, int ld, const int* __restrict__ positions,
+                                                                 const float* __restrict__ cs, const float* __restrict__ sn,
+                                                                 bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int past,
+                                                                 int S_max, int heads, int kv_heads, int hd) {
+    const int s = blockIdx.x, half = hd >> 1, tph = half >> 3;
+    const int t = blockIdx.y * 256 + threadIdx.x;
+    const int hh = t / tph, i0 = (t % tph) * 8;
+    if (hh >= heads + 2 * kv_heads) return;
+    const int pos = positions ? positions[s] : past + s;
+    const int slot = past + s;
+    bf16_t* x = qkv + (long long)s * ld + hh * hd;
+    const uint4 lo = *reinterpret_cast<const uint4*>(x + i0), hi = *reinterpret_cast<const uint4*>(x + i0 + half);
+    if (hh >= heads + kv_heads) {
+        bf16_t* dst = vc + ((long long)(hh - heads - kv_heads) * S_max + slot) * hd;
+        *reinterpret_cast<uint4*>(dst + i0) = lo;
+        *reinterpret_cast<uint4*>(dst + i0 + half) = hi;
+        return;
+    }
+    const float4 c0 = *reinterpret_cast<const float4*>(cs + (long long)pos * half + i0);
+    const float4 c1 = *reinterpret_cast<const float4*>(cs + (long long)pos * half + i0 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sn + (long long)pos * half + i0);
+    const float4 s1 = *reinterpret_cast<const float4*>(sn + (long long)pos * half + i0 + 4);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const unsigned lw[4] = {lo.x, lo.y, lo.z, lo.w}, hw[4] = {hi.x, hi.y, hi.z, hi.w};
+    unsigned o1[4], o2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = __uint_as_float(lw[j] << 16), a1 = __uint_as_float(lw[j] & 0xffff0000u);
+        const float b0 = __uint_as_float(hw[j] << 16), b1 = __uint_as_float(hw[j] & 0xffff0000u);
+        o1[j] = pack_bf2(a0 * c[2 * j] - b0 * sv[2 * j], a1 * c[2 * j + 1] - b1 * sv[2 * j + 1]);
+        o2[j] = pack_bf2(b0 * c[2 * j] + a0 * sv[2 * j], b1 * c[2 * j + 1] + a1 * sv[2 * j + 1]);
+    }
+    bf16_t* dst = hh < heads ? x : kc + ((long long)(hh - heads) * S_max + slot) * hd;
+    *reinterpret_cast<uint4*>(dst + i0) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    *reinterpret_cast<uint4*>(dst + i0 + half) = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+}
+
 // tiled V -> V^T append for long prefills: block = (64 positions, one kv head); 128-byte rows out
 template <typename T>
 __global__ __launch_bounds__(256) void vt_append_kernel(const T* __restrict__ qkv, int ld, T* __restrict__ vtc, int S,
@@ -69,6 +109,35 @@ __global__ __launch_bounds__(256) void vt_append_kernel(const T* __restrict__ qk
     }
 }
 
+// bf16 variant with 16-byte global accesses on both sides: block = (64 positions, one kv head, 128 dims per pass).
+// Positions >= S inside the last 8-position store chunk are written as zeros (slots past the sequence end, rewritten by
+// whoever appends there).  Needs (past + s0) % 8 == 0 for the aligned 16-byte stores.
+__global__ __launch_bounds__(256) void vt_append_vec_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ vtc, int S,
+                                                            int past, int S_max, int v_off, int hd) {
+    __shared__ bf16_t tile[64][136];                       // row stride 272 B: 16-byte aligned rows, column reads spread over banks
+    const int s0 = blockIdx.x * 64, hk = blockIdx.y;
+    for (int d0 = 0; d0 < hd; d0 += 128) {
+        const int dw = min(128, hd - d0), nc = dw >> 3;    // 16-byte chunks per row
+        for (int id = threadIdx.x; id < 64 * nc; id += 256) {
+            const int r = id / nc, c = id % nc;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (s0 + r < S) v = *reinterpret_cast<const uint4*>(qkv + (long long)(s0 + r) * ld + v_off + hk * hd + d0 + c * 8);
+            *reinterpret_cast<uint4*>(&tile[r][c * 8]) = v;
+        }
+        __syncthreads();
+        for (int id = threadIdx.x; id < dw * 8; id += 256) {
+            const int d = id >> 3, pc = id & 7;            // 8 positions pc*8 .. +8 of dim d
+            if (s0 + pc * 8 >= S) continue;
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = (unsigned)tile[pc * 8 + 2 * e][d] | ((unsigned)tile[pc * 8 + 2 * e + 1][d] << 16);
+            *reinterpret_cast<uint4*>(vtc + ((long long)hk * hd + d0 + d) * S_max + past + s0 + pc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();
+    }
+}
+
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                    void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,
                    hipStream_t st) {
@@ -85,12 +154,28 @@ int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, con
             vt_append_kernel<float><<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const float*)qkv, ld, (float*)vtc, S, past,
                                                                                  S_max, (heads + kv_heads) * hd, hd);
     } else {
-        rope_kv_append_kernel<bf16_t><<<grid, threads, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
-                                                                (bf16_t*)vc, (bf16_t*)vtc, past, d_past, S_max, heads,
-                                                                kv_heads, hd, wvt);
-        if (tiled_vt)
-            vt_append_kernel<bf16_t><<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const bf16_t*)qkv, ld, (bf16_t*)vtc, S,
-                                                                                  past, S_max, (heads + kv_heads) * hd, hd);
+        const bool vec = hd % 16 == 0 && ld % 8 == 0 && d_past == nullptr && wvt == 0 &&
+                         ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(kc) | reinterpret_cast<uintptr_t>(vc) |
+                           reinterpret_cast<uintptr_t>(cs) | reinterpret_cast<uintptr_t>(sn)) & 15) == 0;
+        if (vec) {
+            const int nthr = (heads + 2 * kv_heads) * (hd / 16);
+            rope_kv_append_vec_kernel<<<dim3(S, cdiv(nthr, 256)), 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
+                                                                                (bf16_t*)vc, past, S_max, heads, kv_heads, hd);
+        } else {
+            rope_kv_append_kernel<bf16_t><<<grid, threads, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
+                                                                    (bf16_t*)vc, (bf16_t*)vtc, past, d_past, S_max, heads,
+                                                                    kv_heads, hd, wvt);
+        }
+        if (tiled_vt) {
+            const bool vvec = hd % 8 == 0 && ld % 8 == 0 && past % 8 == 0 && S_max % 8 == 0 &&
+                              ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(vtc)) & 15) == 0;
+            if (vvec)
+                vt_append_vec_kernel<<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const bf16_t*)qkv, ld, (bf16_t*)vtc, S, past, S_max,
+                                                                                  (heads + kv_heads) * hd, hd);
+            else
+                vt_append_kernel<bf16_t><<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const bf16_t*)qkv, ld, (bf16_t*)vtc, S,
+                                                                                      past, S_max, (heads + kv_heads) * hd, hd);
+        }
     }
     TEO_LAUNCH_CHECK("rope_kv_append");
     return TEO_OK;
