@@ -483,16 +483,30 @@ class LlavaLlamaForCausalLM:
         if do_sample:
             base_seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
         seeds = [(base_seed + 0x9E3779B97F4A7C15 * b) & (2 ** 63 - 1) for b in range(B)]
+        # one multimodal preparation for the whole batch: every frame of every conversation goes through the tower and
+        # the projector in ONE call (flat image list consumed in order, llava_arch.py:284-285), one splice launch
+        dev_ids = input_ids_list[0].device
+        width = max(int(ids.numel()) for ids in input_ids_list)
+        ids_p = torch.zeros(B, width, dtype=torch.long, device=dev_ids)
+        mask_p = torch.zeros(B, width, dtype=torch.long, device=dev_ids)
+        for b, ids in enumerate(input_ids_list):
+            ids_p[b, :ids.numel()] = ids.view(-1)
+            mask_p[b, :ids.numel()] = 1
+        flat = []
+        for b in range(B):
+            imgs = images_list[b] if images_list is not None else None
+            if imgs is not None:
+                flat.extend(list(imgs))
+        (_, _, new_mask, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(ids_p, None, mask_p, None, None, flat or None)
+        if embeds is None:
+            embeds, new_mask = self.get_model().embed_tokens(ids_p), mask_p
         firsts = []
         for b in range(B):
-            ids = input_ids_list[b].view(1, -1)
-            imgs = images_list[b] if images_list is not None else None
-            (_, _, _, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, imgs)
-            if embeds is None:
-                embeds = self.get_model().embed_tokens(ids)
-            if embeds.shape[1] + max_new_tokens > eng.max_seq:
-                raise ValueError(f"prompt ({embeds.shape[1]}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
-            logits = dec.prefill(b, embeds[0], last_only=True)
+            rows = torch.nonzero(new_mask[b].to(torch.bool), as_tuple=False).flatten()
+            lo, hi = int(rows[0]), int(rows[-1]) + 1
+            if hi - lo + max_new_tokens > eng.max_seq:
+                raise ValueError(f"prompt ({hi - lo}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
+            logits = dec.prefill(b, embeds[b, lo:hi], last_only=True)
             firsts.append(eng.sample(logits[0], temperature, k, seeds[b], 0) if do_sample else self._argmax(logits[0]))
         new_tokens = [[t] for t in firsts]
         finished = [False] * B
