@@ -120,6 +120,26 @@ class BatchDecoder:
         self.cache_len[slot] = past + S
         return logits
 
+    def prefill_all(self, embeds_list):
+        """Prefill every slot at once from fresh caches: embeds_list[b] is [S_b, D].  The rows are concatenated so norms
+        and GEMMs run over sum(S_b) rows (teo_llama_prefill_batch).  Returns fp32 logits [B, V] (last positions)."""
+        eng = self.eng
+        if len(embeds_list) != self.B:
+            raise ValueError(f"need {self.B} sequences")
+        lens = [int(e.shape[0]) for e in embeds_list]
+        if max(lens) > eng.max_seq:
+            raise ValueError(f"sequence length {max(lens)} exceeds the engine's max_seq {eng.max_seq}")
+        total = sum(lens)
+        with eng.phase() as st:
+            rows = torch.cat([e.to(device=eng.device, dtype=eng.dtype) for e in embeds_list], dim=0).contiguous()
+            logits = torch.empty(self.B, eng.cfg.vocab_size, dtype=torch.float32, device=eng.device)
+            ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(self.slot_desc[0]), total))
+            arr = (C.c_int * self.B)(*lens)
+            L.check(self.lib.teo_llama_prefill_batch(C.byref(self.slot_desc[0]), _p(rows), arr, self.B, self.k_cache.stride(1),
+                                                     _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill_batch")
+        self.cache_len = list(lens)
+        return logits
+
     # ------------------------------------------------------------------ decode
     def _workspace(self):
         return self.eng._workspace("decode_batch", self.lib.teo_llama_decode_batch_workspace_bytes(C.byref(self.desc), self.B))

@@ -199,6 +199,69 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
     return gemm(w.n, d->lm_head, nullptr, nullptr, logits, S, d->vocab, D, D, d->vocab, TEO_ACT_NONE, 0, dt, TEO_F32, st);
 }
 
+// Multi-sequence prefill (batched generate): the rows of nseq new conversations are concatenated so the norms and the
+// GEMMs run once over sum(S_b) rows (better tile quantisation than nseq separate M = S_b problems); RoPE + KV append and
+// the causal attention run per sequence on its row block and its own cache slot (slot b = cache pointer + b*cache_stride
+// elements, fresh caches: past = 0).  logits [nseq, vocab]: last position of every sequence.
+int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* seq_lens, int nseq, long long cache_stride,
+                        float* logits, void* ws, size_t ws_bytes, hipStream_t st) {
+    int total = 0;
+    for (int b = 0; b < nseq; ++b) {
+        TEO_CHECK_ARG(seq_lens[b] >= 1 && seq_lens[b] <= d->max_seq, "teo_llama_prefill_batch: seq_lens[%d] = %d", b, seq_lens[b]);
+        total += seq_lens[b];
+    }
+    const PrefillWs w = prefill_carve(d, total, ws, ws_bytes);
+    if (w.total > ws_bytes) {
+        set_error("teo_llama_prefill_batch: workspace %zu < %zu", ws_bytes, w.total);
+        return TEO_ERR_WORKSPACE;
+    }
+    const int dt = d->dtype;
+    const size_t e = esize(dt);
+    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
+    const int QKV = (H + 2 * Hk) * hd;
+    const int S = total;
+    hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
+    if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
+    for (int l = 0; l < d->layers; ++l) {
+        TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st));
+        int row0 = 0;
+        for (int b = 0; b < nseq; ++b) {
+            const int Sb = seq_lens[b];
+            unsigned char* qkv_b = (unsigned char*)w.qkv + (size_t)row0 * QKV * e;
+            unsigned char* kc = (unsigned char*)d->k_cache[l] + (size_t)b * cache_stride * e;
+            unsigned char* vc = (unsigned char*)d->v_cache[l] + (size_t)b * cache_stride * e;
+            unsigned char* vtc = (unsigned char*)d->vt_cache[l] + (size_t)b * cache_stride * e;
+            TEO_TRY(rope_kv_append(qkv_b, QKV, nullptr, d->rope_cos, d->rope_sin, kc, vc, vtc, Sb, 0, nullptr, d->max_seq, H, Hk,
+                                   hd, dt, st));
+            teo_attn_args a;
+            memset(&a, 0, sizeof(a));
+            a.q = qkv_b; a.k = kc; a.v = vc; a.vt = vtc; a.o = (unsigned char*)w.attn + (size_t)row0 * H * hd * e;
+            a.q_bs = 0; a.q_hs = hd; a.q_rs = QKV;
+            a.k_bs = 0; a.k_hs = (long long)d->max_seq * hd; a.k_rs = hd;
+            a.v_bs = 0; a.v_hs = (long long)d->max_seq * hd; a.v_rs = hd;
+            a.vt_bs = 0; a.vt_hs = (long long)hd * d->max_seq; a.vt_rs = d->max_seq;
+            a.o_bs = 0; a.o_rs = (long long)H * hd;
+            a.batch = 1; a.heads = H; a.kv_heads = Hk; a.head_dim = hd; a.q_len = Sb; a.kv_len = Sb;
+            a.causal = 1;
+            a.scale = 1.0f / sqrtf((float)hd);
+            TEO_TRY(attention(&a, dt, st));
+            row0 += Sb;
+        }
+        TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(rmsnorm(w.h, d->post_norm_w[l], w.n, S, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st));
+        TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st));
+    }
+    int row_end = 0;
+    for (int b = 0; b < nseq; ++b) {
+        row_end += seq_lens[b];
+        const void* hl = (const unsigned char*)w.h + (size_t)(row_end - 1) * D * e;
+        TEO_TRY(gemv(hl, d->lm_head, d->final_norm_w, nullptr, logits + (size_t)b * d->vocab, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
+    }
+    return TEO_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LLaMA greedy decode step
 // ------------------------------------------------------------------------------------------------

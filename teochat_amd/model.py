@@ -500,14 +500,15 @@ class LlavaLlamaForCausalLM:
         (_, _, new_mask, _, embeds, _) = self.prepare_inputs_labels_for_multimodal(ids_p, None, mask_p, None, None, flat or None)
         if embeds is None:
             embeds, new_mask = self.get_model().embed_tokens(ids_p), mask_p
-        firsts = []
+        seqs = []
         for b in range(B):
             rows = torch.nonzero(new_mask[b].to(torch.bool), as_tuple=False).flatten()
             lo, hi = int(rows[0]), int(rows[-1]) + 1
             if hi - lo + max_new_tokens > eng.max_seq:
                 raise ValueError(f"prompt ({hi - lo}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
-            logits = dec.prefill(b, embeds[b, lo:hi], last_only=True)
-            firsts.append(eng.sample(logits[0], temperature, k, seeds[b], 0) if do_sample else self._argmax(logits[0]))
+            seqs.append(embeds[b, lo:hi])
+        logits = dec.prefill_all(seqs)             # one pass over the concatenated rows of all conversations
+        firsts = [eng.sample(logits[b], temperature, k, seeds[b], 0) if do_sample else self._argmax(logits[b]) for b in range(B)]
         new_tokens = [[t] for t in firsts]
         finished = [False] * B
 

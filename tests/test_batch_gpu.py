@@ -176,3 +176,32 @@ def test_batched_decode_real_width_vs_single(weights):
           f"identical 6-token streams {same}/{B}")
     assert worst < BF16_REL
     assert same >= B - 3          # random-weight logits are nearly flat: a 1-ulp difference may flip a near-tie
+
+
+@pytest.mark.parametrize("name,dtype", [("tinyA", torch.float32), ("tinyB", torch.float32), ("tinyB", torch.bfloat16)])
+def test_prefill_all_equals_per_slot_prefill(name, dtype):
+    """teo_llama_prefill_batch (rows of all conversations concatenated) == teo_llama_prefill slot by slot: same logits,
+    same K / V / V^T caches (a row's GEMM result does not depend on how many other rows share the launch)."""
+    model, _ = build(name, dtype)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs(name)
+    g, convs = conversations(name, 4, lcfg.vocab_size)
+    dec = model.batch_decoder(len(convs), 16)
+    embs = []
+    for ids, frames in convs:
+        (_, _, _, _, emb, _) = model.prepare_inputs_labels_for_multimodal(ids.view(1, -1).to(dev), None, None, None, None,
+                                                                          [f.to(dev) for f in frames])
+        embs.append(emb[0])
+    dec.reset()
+    one = torch.cat([dec.prefill(b, e) for b, e in enumerate(embs)])
+    k1, v1, vt1 = dec.k_cache.clone(), dec.v_cache.clone(), dec.vt_cache.clone()
+    for c in (dec.k_cache, dec.v_cache, dec.vt_cache):
+        c.zero_()
+    dec.reset()
+    allb = dec.prefill_all(embs)
+    assert dec.cache_len == [int(e.shape[0]) for e in embs]
+    assert torch.equal(allb, one)
+    for b, e in enumerate(embs):
+        n = int(e.shape[0])
+        assert torch.equal(dec.k_cache[:, b, :, :n], k1[:, b, :, :n]) and torch.equal(dec.v_cache[:, b, :, :n], v1[:, b, :, :n])
+        assert torch.equal(dec.vt_cache[:, b, :, :, :n], vt1[:, b, :, :, :n])
