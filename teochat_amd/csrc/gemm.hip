@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename TO, bool SWIGLU>
 __global__ __launch_bounds__(256) void gemm_simple_kernel(const T* __restrict__ A, const T* __restrict__ W,
-                                                          const T* __restrict__ bias, const T* __restrict__ res,
+                                                          const T* __restrict__ bias, const T* res,
                                                           TO* __restrict__ C, int M, int N, int K, int lda, int ldc,
                                                           int act) {
     __shared__ float As[16][65];
@@ -110,7 +110,7 @@ template <bool SWIGLU, bool OUT_F32, int DEPTH, int MF>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __restrict__ A,
                                                              const bf16_t* __restrict__ W,
                                                              const bf16_t* __restrict__ bias,
-                                                             const bf16_t* __restrict__ res, void* __restrict__ Cv,
+                                                             const bf16_t* res, void* Cv,
                                                              int M, int N, int K, int lda, int ldc, int act,
                                                              int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

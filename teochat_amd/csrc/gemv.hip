@@ -235,7 +235,7 @@ __device__ __forceinline__ void consume_block(const uint4 (&w)[U][R], const floa
 template <typename T, typename TO, typename WT, int R, int U, bool PF, bool NT, bool SWIGLU>
 __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ x, const WT* __restrict__ W,
                                                           const float* __restrict__ wscale, const T* __restrict__ norm_w,
-                                                          const T* __restrict__ res, TO* __restrict__ y, int N, int K,
+                                                          const T* res, TO* y, int N, int K,
                                                           float eps) {
     extern __shared__ __attribute__((aligned(16))) float xs[];     // [K] fp32 (+8 floats of reduction scratch)
     constexpr int VE = Vec16<WT>::N;
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename TO, typename WT, int R, int U, bool NT>
 __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __restrict__ x, const WT* __restrict__ W,
-                                                                 const float* __restrict__ wscale, const T* __restrict__ res,
-                                                                 TO* __restrict__ y, int N, int K) {
+                                                                 const float* __restrict__ wscale, const T* res,
+                                                                 TO* y, int N, int K) {
     constexpr int VE = Vec16<WT>::N, VX = Vec16<T>::N;
     constexpr int XL = VE / VX;                           // 16-byte x loads per weight chunk (1, or 2 for fp8 weights)
     __shared__ float part[GV_WAVES][R];
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// host dispatch
+// host dispatch  (kernels: `res` and the output may be the same buffer -- in-place residual add -- so neither is __restrict__)
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename TO, typename WT, int R, int U, bool PF>
 static int launch_rows(const void* x, const void* W, const float* ws, const void* norm_w, const void* res, void* y, int N,

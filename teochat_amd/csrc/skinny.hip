@@ -45,15 +45,15 @@ __device__ __forceinline__ u32x4 sk_ldw(const void* p) {
     return *reinterpret_cast<const u32x4*>(p);
 }
 
-// 8 fp8 e4m3 (two dwords) -> 8 bf16, exact (3 mantissa bits; every e4m3 value is a bf16 value)
+// 8 fp8 e4m3 (two dwords) -> 8 bf16, exact (3 mantissa bits; every e4m3 value is a bf16 value): four
+// v_cvt_scalef32_pk_bf16_fp8 (two values per instruction, scale 1)
+typedef __bf16 sk_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
-    const f32x2 v0 = __builtin_amdgcn_cvt_pk_f32_fp8(a, false), v1 = __builtin_amdgcn_cvt_pk_f32_fp8(a, true);
-    const f32x2 v2 = __builtin_amdgcn_cvt_pk_f32_fp8(b, false), v3 = __builtin_amdgcn_cvt_pk_f32_fp8(b, true);
     u32x4 r;
-    r.x = (__float_as_uint(v0.x) >> 16) | (__float_as_uint(v0.y) & 0xffff0000u);
-    r.y = (__float_as_uint(v1.x) >> 16) | (__float_as_uint(v1.y) & 0xffff0000u);
-    r.z = (__float_as_uint(v2.x) >> 16) | (__float_as_uint(v2.y) & 0xffff0000u);
-    r.w = (__float_as_uint(v3.x) >> 16) | (__float_as_uint(v3.y) & 0xffff0000u);
+    r.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, false));
+    r.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(a, 1.0f, true));
+    r.z = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, false));
+    r.w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(b, 1.0f, true));
     return __builtin_bit_cast(bf16x8, r);
 }
 
@@ -79,7 +79,7 @@ template <typename WT, int UNR, bool NT, bool SWIGLU, bool NORM>
 __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
                                                                  const float* __restrict__ wscale,
                                                                  const bf16_t* __restrict__ norm_w, float eps,
-                                                                 const bf16_t* __restrict__ res, void* __restrict__ outv,
+                                                                 const bf16_t* res, void* outv,
                                                                  int MB, int N, int K, int ldx, int ldo, int ldr, int tiled,
                                                                  int out_f32, int RT, SkinnyFuse fuse, int sw8) {
     constexpr bool F8 = sizeof(WT) == 1;
