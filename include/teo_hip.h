@@ -174,10 +174,12 @@ int teo_drop_cls(const void* d_in, void* d_out, int T, int n_tokens, int dim, in
  * Replaces the greedy branch of GenerationMixin (call at eval/inference.py:64-72 with do_sample=False). */
 int teo_argmax(const float* d_logits, long long* d_token, int rows, int vocab, teo_stream_t stream);
 
-/* token = multinomial(softmax(top_k(logits / temperature))) with u = uniform(seed, draw).  Same filter order as HF's
+/* token = multinomial(softmax(top_p(top_k(logits / temperature)))) with u = uniform(seed, draw).  Same filter order as HF's
  * TemperatureLogitsWarper -> TopKLogitsWarper -> softmax -> multinomial (the sampled branch the reference uses,
- * eval/inference.py:64-72 with do_sample=True).  top_k <= 0 or >= vocab disables the filter (capped at 1024). */
-int teo_sample_topk(const float* d_logits, long long* d_token, int vocab, float temperature, int top_k,
+ * eval/inference.py:64-72 with do_sample=True).  top_k <= 0 or >= vocab disables the filter (capped at 1024);
+ * top_p outside (0, 1) disables the nucleus filter (HF TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is
+ * dropped, the most probable token always stays); it acts on the top-k survivors, i.e. on at most 1024 candidates. */
+int teo_sample_topk(const float* d_logits, long long* d_token, int vocab, float temperature, int top_k, float top_p,
                     unsigned long long seed, unsigned long long draw, teo_stream_t stream);
 
 /* Decode GEMV: y[N] = W[N,K] . f(x) (+ residual), x one row.
@@ -299,6 +301,7 @@ typedef struct {
      * counter-based generator: draw i of a generation uses (seed, i).  d_rng = {seed, draws so far} on the device. */
     int do_sample; int top_k; float temperature;
     unsigned long long* d_rng; /* [2] */
+    float top_p;             /* nucleus filter after top-k; outside (0, 1) = off */
 } teo_decode_state;
 
 /* Prefill of nseq NEW conversations at once (batched generate): d_embeds holds the spliced embedding rows of all
@@ -353,6 +356,7 @@ typedef struct {
     float* d_logits;          /* [batch][vocab] */
     int do_sample; int top_k; float temperature;
     unsigned long long* d_rng; /* [batch][2] = {seed, draws so far} per conversation */
+    float top_p;              /* nucleus filter after top-k; outside (0, 1) = off */
 } teo_decode_batch_state;
 size_t teo_llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch);
 int teo_llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace,

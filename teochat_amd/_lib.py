@@ -70,7 +70,8 @@ class DecodeState(C.Structure):
     _fields_ = [("d_token", C.c_void_p), ("d_pos", C.c_void_p), ("d_out_tokens", C.c_void_p),
                 ("d_out_count", C.c_void_p), ("d_stop", C.c_void_p), ("d_stop_ids", C.c_void_p),
                 ("n_stop_ids", C.c_int), ("d_logits", C.c_void_p),
-                ("do_sample", C.c_int), ("top_k", C.c_int), ("temperature", C.c_float), ("d_rng", C.c_void_p)]
+                ("do_sample", C.c_int), ("top_k", C.c_int), ("temperature", C.c_float), ("d_rng", C.c_void_p),
+                ("top_p", C.c_float)]
 
 
 MAX_DECODE_BATCH = 16
@@ -81,7 +82,8 @@ class DecodeBatchState(C.Structure):
                 ("d_token", C.c_void_p), ("d_pos", C.c_void_p), ("d_out_tokens", C.c_void_p),
                 ("d_out_count", C.c_void_p), ("d_stop", C.c_void_p), ("d_stop_ids", C.c_void_p),
                 ("n_stop_ids", C.c_int), ("d_logits", C.c_void_p),
-                ("do_sample", C.c_int), ("top_k", C.c_int), ("temperature", C.c_float), ("d_rng", C.c_void_p)]
+                ("do_sample", C.c_int), ("top_k", C.c_int), ("temperature", C.c_float), ("d_rng", C.c_void_p),
+                ("top_p", C.c_float)]
 
 
 _SIGS = {
@@ -100,7 +102,8 @@ _SIGS = {
     "teo_embed_splice": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "teo_drop_cls": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "teo_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "teo_sample_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_void_p]),
+    "teo_sample_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_ulonglong, C.c_ulonglong,
+                                  C.c_void_p]),
     "teo_gemv": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_uint, C.c_int, C.c_int, C.c_void_p]),
     "teo_gemv_w8": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.c_uint, C.c_int, C.c_void_p]),
     "teo_vit_workspace_bytes": (C.c_size_t, [C.POINTER(VitDesc), C.c_int]),

@@ -87,7 +87,7 @@ class BatchDecoder:
         s.d_token, s.d_pos, s.d_out_tokens = self.d_token.data_ptr(), self.d_pos.data_ptr(), self.d_out.data_ptr()
         s.d_out_count, s.d_stop = self.d_count.data_ptr(), self.d_stop.data_ptr()
         s.d_stop_ids, s.n_stop_ids, s.d_logits = self.d_stop_ids.data_ptr(), 0, self.d_logits.data_ptr()
-        s.do_sample, s.top_k, s.temperature, s.d_rng = 0, 0, 1.0, self.d_rng.data_ptr()
+        s.do_sample, s.top_k, s.temperature, s.d_rng, s.top_p = 0, 0, 1.0, self.d_rng.data_ptr(), 1.0
         self.state = s
         self._graph = None
         self._steps_done = 0
@@ -149,7 +149,7 @@ class BatchDecoder:
             self.lib.teo_graph_destroy(self._graph)
             self._graph = None
 
-    def begin(self, first_tokens, stop_ids=None, do_sample=False, temperature=1.0, top_k=0, seeds=None, draws_done=1):
+    def begin(self, first_tokens, stop_ids=None, do_sample=False, temperature=1.0, top_k=0, seeds=None, draws_done=1, top_p=1.0):
         """Arm the loop: first_tokens[b] is the input of conversation b's next step, at position cache_len[b]."""
         eng = self.eng
         if len(first_tokens) != self.B:
@@ -166,9 +166,9 @@ class BatchDecoder:
                 n = min(len(stop_ids), 16)
                 self.d_stop_ids[:n] = torch.tensor(list(stop_ids)[-n:], dtype=torch.int64, device=eng.device)
             s = self.state
-            key = (n, int(bool(do_sample)), int(top_k or 0), C.c_float(float(temperature)).value)
-            if key != (s.n_stop_ids, s.do_sample, s.top_k, float(s.temperature)):
-                s.n_stop_ids, s.do_sample, s.top_k, s.temperature = key
+            key = (n, int(bool(do_sample)), int(top_k or 0), C.c_float(float(temperature)).value, C.c_float(float(top_p or 1.0)).value)
+            if key != (s.n_stop_ids, s.do_sample, s.top_k, float(s.temperature), float(s.top_p)):
+                s.n_stop_ids, s.do_sample, s.top_k, s.temperature, s.top_p = key
                 self._drop_graph()
         ws = self._workspace()
         with eng.phase() as st:

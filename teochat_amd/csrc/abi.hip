@@ -162,12 +162,12 @@ int teo_argmax(const float* logits, long long* tok, int rows, int vocab, teo_str
     return argmax(logits, tok, rows, vocab, ST(s));
 }
 
-int teo_sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, unsigned long long seed,
-                    unsigned long long draw, teo_stream_t s) {
+int teo_sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, float top_p,
+                    unsigned long long seed, unsigned long long draw, teo_stream_t s) {
     ENTER();
     TEO_CHECK_ARG(vocab > 0 && temperature > 0.f, "teo_sample_topk: vocab %d temperature %g", vocab, temperature);
     NEED(logits, "logits"); NEED(tok, "token");
-    return sample_topk(logits, tok, vocab, temperature, top_k, seed, draw, ST(s));
+    return sample_topk(logits, tok, vocab, temperature, top_k, top_p, seed, draw, ST(s));
 }
 
 int teo_gemv(const void* x, const void* W, const void* norm_w, const void* res, void* y, int N, int K, float eps,

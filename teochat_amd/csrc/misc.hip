@@ -352,7 +352,7 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
 }
 
 // returns the sampled index to every thread; smem: caller provides the shared arrays
-__device__ int sample_topk_block(const float* __restrict__ logits, int vocab, float temperature, int top_k, float u,
+__device__ int sample_topk_block(const float* __restrict__ logits, int vocab, float temperature, int top_k, float top_p, float u,
                                  unsigned* hist, int* sel_idx, float* sel_val, int* s_misc) {
     const int tid = threadIdx.x;
     int k = top_k;
@@ -419,6 +419,35 @@ __device__ int sample_topk_block(const float* __restrict__ logits, int vocab, fl
     __syncthreads();
     for (int j = tid; j < n; j += 1024) sel_val[j] = expf(sel_val[j] * invt - mx);
     __syncthreads();
+    if (top_p > 0.f && top_p < 1.f) {
+        // nucleus filter (HF TopPLogitsWarper, applied after temperature and top-k): sort ascending by probability, drop
+        // every token whose cumulative probability (itself included) is <= 1 - top_p, always keep the most probable one.
+        // Survivors are few (<= TOPK_CAP): thread j sums the mass of everything ranked at or below j (ties by index).
+        __shared__ float s_tot;
+        if (tid == 0) {
+            float t = 0.f;
+            for (int j = 0; j < n; ++j) t += sel_val[j];
+            s_tot = t;
+        }
+        __syncthreads();
+        float keepv = 0.f;
+        bool mine = false;
+        if (tid < n) {
+            const float pj = sel_val[tid];
+            float below = 0.f;
+            bool is_max = true;
+            for (int i = 0; i < n; ++i) {
+                const float pi = sel_val[i];
+                if (pi < pj || (pi == pj && i <= tid)) below += pi;
+                if (pi > pj || (pi == pj && i > tid)) is_max = false;
+            }
+            mine = true;
+            keepv = (below > (1.0f - top_p) * s_tot || is_max) ? pj : 0.f;
+        }
+        __syncthreads();
+        if (mine) sel_val[tid] = keepv;
+        __syncthreads();
+    }
     if (tid == 0) {
         float tot = 0.f;
         for (int j = 0; j < n; ++j) tot += sel_val[j];
@@ -436,19 +465,19 @@ __device__ int sample_topk_block(const float* __restrict__ logits, int vocab, fl
 }
 
 __global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restrict__ logits, long long* __restrict__ tok,
-                                                           int vocab, float temperature, int top_k,
+                                                           int vocab, float temperature, int top_k, float top_p,
                                                            unsigned long long seed, unsigned long long draw) {
     __shared__ unsigned hist[256];
     __shared__ int sel_idx[TOPK_CAP];
     __shared__ float sel_val[TOPK_CAP];
     __shared__ int s_misc[4];
-    const int pick = sample_topk_block(logits, vocab, temperature, top_k, uniform01(seed, draw), hist, sel_idx, sel_val, s_misc);
+    const int pick = sample_topk_block(logits, vocab, temperature, top_k, top_p, uniform01(seed, draw), hist, sel_idx, sel_val, s_misc);
     if (threadIdx.x == 0) *tok = pick;
 }
 
-int sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, unsigned long long seed,
+int sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, float top_p, unsigned long long seed,
                 unsigned long long draw, hipStream_t st) {
-    sample_topk_kernel<<<1, 1024, 0, st>>>(logits, tok, vocab, temperature, top_k, seed, draw);
+    sample_topk_kernel<<<1, 1024, 0, st>>>(logits, tok, vocab, temperature, top_k, top_p, seed, draw);
     TEO_LAUNCH_CHECK("sample_topk");
     return TEO_OK;
 }
@@ -510,7 +539,7 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
     int sampled = -1;
     if (st.do_sample) {
         const unsigned long long draw = st.d_rng[1];
-        sampled = sample_topk_block(logits, vocab, st.temperature, st.top_k, uniform01(st.d_rng[0], draw), hist, sel_idx,
+        sampled = sample_topk_block(logits, vocab, st.temperature, st.top_k, st.top_p, uniform01(st.d_rng[0], draw), hist, sel_idx,
                                     sel_val, s_misc);
         if (threadIdx.x == 0) st.d_rng[1] = draw + 1;
     }

@@ -392,7 +392,7 @@ static teo_decode_state batch_as_state(const teo_decode_batch_state* s) {
     teo_decode_state t;
     t.d_token = s->d_token; t.d_pos = s->d_pos; t.d_out_tokens = s->d_out_tokens; t.d_out_count = s->d_out_count;
     t.d_stop = s->d_stop; t.d_stop_ids = s->d_stop_ids; t.n_stop_ids = s->n_stop_ids; t.d_logits = s->d_logits;
-    t.do_sample = s->do_sample; t.top_k = s->top_k; t.temperature = s->temperature; t.d_rng = s->d_rng;
+    t.do_sample = s->do_sample; t.top_k = s->top_k; t.temperature = s->temperature; t.d_rng = s->d_rng; t.top_p = s->top_p;
     return t;
 }
 

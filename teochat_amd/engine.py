@@ -274,7 +274,7 @@ class TeoEngine:
         s.d_token, s.d_pos, s.d_out_tokens = self.d_token.data_ptr(), self.d_pos.data_ptr(), self.d_out.data_ptr()
         s.d_out_count, s.d_stop = self.d_count.data_ptr(), self.d_stop.data_ptr()
         s.d_stop_ids, s.n_stop_ids, s.d_logits = self.d_stop_ids.data_ptr(), 0, self.d_logits.data_ptr()
-        s.do_sample, s.top_k, s.temperature, s.d_rng = 0, 0, 1.0, self.d_rng.data_ptr()
+        s.do_sample, s.top_k, s.temperature, s.d_rng, s.top_p = 0, 0, 1.0, self.d_rng.data_ptr(), 1.0
         self.decode_state = s
 
     # ------------------------------------------------------------------ plumbing
@@ -377,16 +377,16 @@ class TeoEngine:
         self.cache_len = past + S
         return logits
 
-    def sample(self, logits, temperature, top_k, seed, draw):
+    def sample(self, logits, temperature, top_k, seed, draw, top_p=1.0):
         """One draw of the device sampler (temperature -> top-k -> softmax -> multinomial) from fp32 logits [V]."""
         tok = torch.empty(1, dtype=torch.int64, device=self.device)
         with self.phase() as st:
             lg = logits.to(device=self.device, dtype=torch.float32).contiguous()
-            L.check(self.lib.teo_sample_topk(_p(lg), _p(tok), lg.numel(), float(temperature), int(top_k or 0),
+            L.check(self.lib.teo_sample_topk(_p(lg), _p(tok), lg.numel(), float(temperature), int(top_k or 0), float(top_p or 1.0),
                                              int(seed) & (2 ** 64 - 1), int(draw), st), "teo_sample_topk")
         return int(tok.item())
 
-    def decode_begin(self, first_token, stop_ids=None, do_sample=False, temperature=1.0, top_k=0, seed=0, draws_done=0):
+    def decode_begin(self, first_token, stop_ids=None, do_sample=False, temperature=1.0, top_k=0, seed=0, draws_done=0, top_p=1.0):
         """Arm the device-side decode loop: first_token is the input of the next step, at position cache_len.
         With do_sample the steps draw from the device sampler (counter-based RNG: draw index = draws so far)."""
         with self.phase():
@@ -401,9 +401,9 @@ class TeoEngine:
                 n = min(len(stop_ids), 16)
                 self.d_stop_ids[:n] = torch.tensor(list(stop_ids)[-n:], dtype=torch.int64, device=self.device)
             s = self.decode_state
-            key = (n, int(bool(do_sample)), int(top_k or 0), C.c_float(float(temperature)).value)
-            if key != (s.n_stop_ids, s.do_sample, s.top_k, float(s.temperature)):
-                s.n_stop_ids, s.do_sample, s.top_k, s.temperature = key     # baked into the captured launch: re-capture
+            key = (n, int(bool(do_sample)), int(top_k or 0), C.c_float(float(temperature)).value, C.c_float(float(top_p or 1.0)).value)
+            if key != (s.n_stop_ids, s.do_sample, s.top_k, float(s.temperature), float(s.top_p)):
+                s.n_stop_ids, s.do_sample, s.top_k, s.temperature, s.top_p = key     # baked into the captured launch: re-capture
                 self._drop_graph()
         ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
         with self.phase() as st:

@@ -402,13 +402,12 @@ class LlavaLlamaForCausalLM:
             raise ValueError(f"prompt ({embeds.shape[1]}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
         logits = eng.prefill(embeds[0], last_only=True)
         if do_sample:
-            if top_p is not None and top_p < 1.0:
-                raise NotImplementedError("top_p < 1 is not implemented by the device sampler (HF default is 1.0)")
+            tp = 1.0 if top_p is None else float(top_p)
             k = self.generation_config.top_k if top_k is None else top_k
             seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
-            first = eng.sample(logits[0], temperature, k, seed, 0)
+            first = eng.sample(logits[0], temperature, k, seed, 0, top_p=tp)
         else:
-            k, seed = 0, 0
+            k, seed, tp = 0, 0, 1.0
             first = self._argmax(logits[0])
         new_tokens = [first]
 
@@ -428,7 +427,7 @@ class LlavaLlamaForCausalLM:
         if eos_token_id is not None:
             cands.append([int(eos_token_id)])
         stop_ids = cands[0] if len(cands) == 1 else None
-        eng.decode_begin(first, stop_ids, do_sample=do_sample, temperature=temperature, top_k=k, seed=seed, draws_done=1)
+        eng.decode_begin(first, stop_ids, do_sample=do_sample, temperature=temperature, top_k=k, seed=seed, draws_done=1, top_p=tp)
         remaining = max_new_tokens - 1
         while remaining > 0:
             n = min(chunk, remaining)
@@ -470,8 +469,7 @@ class LlavaLlamaForCausalLM:
             eos_token_id = getattr(self.config, "eos_token_id", None)
         if max_new_tokens <= 0:
             return [ids.clone() for ids in input_ids_list]
-        if do_sample and top_p is not None and top_p < 1.0:
-            raise NotImplementedError("top_p < 1 is not implemented by the device sampler (HF default is 1.0)")
+        tp = 1.0 if (top_p is None or not do_sample) else float(top_p)
         crits = list(stopping_criteria) if stopping_criteria is not None else [[] for _ in range(B)]
         if len(crits) != B:
             raise ValueError("stopping_criteria must hold one list per conversation")
@@ -508,7 +506,8 @@ class LlavaLlamaForCausalLM:
                 raise ValueError(f"prompt ({hi - lo}) + max_new_tokens ({max_new_tokens}) exceeds max_seq {eng.max_seq}")
             seqs.append(embeds[b, lo:hi])
         logits = dec.prefill_all(seqs)             # one pass over the concatenated rows of all conversations
-        firsts = [eng.sample(logits[b], temperature, k, seeds[b], 0) if do_sample else self._argmax(logits[b]) for b in range(B)]
+        firsts = [eng.sample(logits[b], temperature, k, seeds[b], 0, top_p=tp) if do_sample else self._argmax(logits[b])
+                  for b in range(B)]
         new_tokens = [[t] for t in firsts]
         finished = [False] * B
 
@@ -525,7 +524,7 @@ class LlavaLlamaForCausalLM:
             finished[b] = done(b) or max_new_tokens == 1
         if not all(finished):
             stop_ids = [int(eos_token_id)] if (eos_token_id is not None and not any(crits)) else None
-            dec.begin(firsts, stop_ids, do_sample=do_sample, temperature=temperature, top_k=k, seeds=seeds, draws_done=1)
+            dec.begin(firsts, stop_ids, do_sample=do_sample, temperature=temperature, top_k=k, seeds=seeds, draws_done=1, top_p=tp)
             remaining = max_new_tokens - 1
             while remaining > 0 and not all(finished):
                 n = min(chunk, remaining)

@@ -399,9 +399,9 @@ def test_abi_error_convention():
 
 
 # ---------------------------------------------------------------------------------------------- sampler (N1)
-def _sample(lg, temperature, top_k, seed, draw):
+def _sample(lg, temperature, top_k, seed, draw, top_p=1.0):
     tok = torch.empty(1, dtype=torch.int64, device="cuda")
-    L.check(G.lib().teo_sample_topk(G.p(lg), G.p(tok), lg.numel(), temperature, top_k, seed, draw, G.stream()), "sample")
+    L.check(G.lib().teo_sample_topk(G.p(lg), G.p(tok), lg.numel(), temperature, top_k, top_p, seed, draw, G.stream()), "sample")
     return int(tok.item())
 
 
@@ -722,3 +722,44 @@ def test_attn_decode_batched_vs_reference(dtype, H, Hk, d, S, ctx, chunk):
             torch.testing.assert_close(out[b].cpu(), ref, atol=2e-5, rtol=1e-5)
         else:
             close_bf16(out[b], G.bf16_round(ref), ulps=2.0, floor=4e-3)    # P is rounded to bf16 before the PV product
+
+
+def _hf_top_p_keep(logits, temperature, top_k, top_p):
+    """HF order: temperature -> TopKLogitsWarper -> TopPLogitsWarper (ascending sort, cumulative <= 1 - top_p removed,
+    at least one token kept).  Returns (kept index set, renormalised probabilities)."""
+    x = logits.double() / temperature
+    if top_k and top_k < x.numel():
+        kth = torch.topk(x, top_k).values[-1]
+        x = torch.where(x < kth, torch.full_like(x, -float("inf")), x)
+    srt, idx = torch.sort(x, descending=False)
+    cum = torch.softmax(srt, dim=-1).cumsum(-1)
+    remove = cum <= (1 - top_p)
+    remove[-1:] = False
+    x[idx[remove]] = -float("inf")
+    p = torch.softmax(x, dim=-1)
+    return set(torch.nonzero(p > 0).flatten().tolist()), p
+
+
+@pytest.mark.parametrize("top_k,top_p", [(50, 0.9), (8, 0.5), (50, 0.999), (50, 0.05)])
+def test_sampler_top_p_matches_hf_warper(top_k, top_p):
+    g = torch.Generator().manual_seed(21)
+    lg = torch.randn(1000, generator=g) * 2.5
+    keep, p = _hf_top_p_keep(lg, 0.8, top_k, top_p)
+    dl = lg.cuda()
+    draws = [_sample(dl, 0.8, top_k, 77, d, top_p) for d in range(1500)]
+    assert set(draws) <= keep, sorted(set(draws) - keep)
+    counts = torch.bincount(torch.tensor(draws), minlength=1000).double() / len(draws)
+    assert float((counts - p).abs().max()) < 0.05
+    if len(keep) == 1:
+        assert set(draws) == keep
+
+
+def test_sampler_top_p_without_top_k_small_vocab():
+    g = torch.Generator().manual_seed(22)
+    lg = torch.randn(1000, generator=g) * 3.0
+    keep, p = _hf_top_p_keep(lg, 1.0, 0, 0.6)
+    dl = lg.cuda()
+    draws = [_sample(dl, 1.0, 0, 5, d, 0.6) for d in range(1500)]
+    assert set(draws) <= keep
+    counts = torch.bincount(torch.tensor(draws), minlength=1000).double() / len(draws)
+    assert float((counts - p).abs().max()) < 0.05
