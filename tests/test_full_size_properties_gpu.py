@@ -1,0 +1,84 @@
+"""Size-independent properties at BASELINE.json's full model size (LLaMA-2-7B + CLIP-ViT-L/14 shapes, 32 + 23 layers,
+synthetic weights): the oracle cannot run this size in seconds, these invariants can.
+
+  determinism          two runs of the same conversation give bit-identical logits and tokens
+  causality            logits of a prefix do not change when the suffix changes (bit-identical: same kernels, same rows)
+  prefill == decode    the decode step after a prompt reproduces the prefill logits of prompt + token up to the bf16
+                       noise of a 32-layer stack (measured, see the comment in the test)
+  frame locality       changing frame j only changes logits at and after the position where its tokens are spliced
+  batched == single    a conversation decoded in a batch of 3 follows the same tokens as alone (near-tie flips aside)
+"""
+import pytest
+import torch
+
+from oracle import teo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model7b():
+    from teochat_amd.builder import load_pretrained_model
+    _, model, _, _ = load_pretrained_model("synthetic:teochat-7b", None, "synthetic:teochat-7b", device="cuda:0",
+                                           dtype=torch.bfloat16, max_seq=1024)
+    return model
+
+
+def test_determinism_and_causality_full_size(model7b):
+    m = model7b
+    ids = O.synthetic_prompt_ids(200, 0, 32000, seed=3).view(1, -1).cuda()
+    a = m(input_ids=ids, images=None).logits[0]
+    b = m(input_ids=ids, images=None).logits[0]
+    assert torch.equal(a, b)
+    assert bool(torch.isfinite(a).all())
+    ids2 = ids.clone()
+    ids2[0, 150:] = torch.randint(3, 32000, (50,), device="cuda")
+    c = m(input_ids=ids2, images=None).logits[0]
+    assert torch.equal(a[:150], c[:150])                   # the prefix never sees the suffix
+    assert not torch.equal(a[150:], c[150:])
+
+
+def test_prefill_equals_decode_full_size(model7b):
+    m = model7b
+    ids = O.synthetic_prompt_ids(96, 0, 32000, seed=4).view(1, -1).cuda()
+    out = m.generate(input_ids=ids, images=None, do_sample=False, max_new_tokens=3, eos_token_id=None)
+    step_logits = m.engine.d_logits.clone()                 # logits produced by the 2nd decode step: they chose token 3
+    full = m(input_ids=out[:, :-1], images=None).logits[0]  # prefill over prompt + first 2 generated tokens
+    rel = float((full[-1] - step_logits).abs().max()) / float(full[-1].abs().max())
+    print(f"full-size prefill vs decode logits: rel-to-max diff {rel:.2e}")
+    # 32 layers x ~7 bf16 roundings per layer accumulate like a random walk: against an fp32 run on the same weights the
+    # bf16 prefill is off by 5.5e-2 and the bf16 decode by 4.8e-2 of max|logit| (tools/diag_full_size.py); the two bf16
+    # paths differ by 3.3e-2.  The bound below only guards against a broken path, per-kernel exactness is tested elsewhere.
+    assert rel < 8e-2
+    top2 = torch.topk(full[-1], 2).values
+    if float(top2[0] - top2[1]) > 4 * float((full[-1] - step_logits).abs().max()):
+        assert int(full[-1].argmax()) == int(out[0, -1])
+    again = m.generate(input_ids=ids, images=None, do_sample=False, max_new_tokens=3, eos_token_id=None)
+    assert torch.equal(out, again)
+
+
+def test_frame_locality_full_size(model7b):
+    m = model7b
+    frames = [f.to("cuda:0", dtype=torch.bfloat16) for f in O.synthetic_frames(2, 224, seed=0)]
+    ids = O.synthetic_prompt_ids(24, 2, 32000, seed=5).view(1, -1).cuda()
+    pos = (ids[0] == -200).nonzero().flatten().tolist()     # sentinels; the 2nd image's rows start at pos[1] + 255
+    a = m(input_ids=ids, images=frames).logits[0]
+    frames2 = [frames[0], (frames[1] * 0.5).contiguous()]
+    b = m(input_ids=ids, images=frames2).logits[0]
+    start2 = pos[1] + 255
+    assert a.shape[0] == 24 - 2 + 2 * 256
+    assert torch.equal(a[:start2], b[:start2])              # everything before the 2nd image's tokens is untouched
+    assert not torch.equal(a[start2:], b[start2:])
+
+
+def test_batched_decode_follows_single_full_size(model7b):
+    m = model7b
+    prompts = [O.synthetic_prompt_ids(40 + 7 * i, 0, 32000, seed=60 + i).cuda() for i in range(3)]
+    single = [m.generate(input_ids=p.view(1, -1), images=None, do_sample=False, max_new_tokens=6, eos_token_id=None)[0, -6:].tolist()
+              for p in prompts]
+    batch = m.generate_batch(prompts, None, do_sample=False, max_new_tokens=6, eos_token_id=None)
+    same = sum(int(b[-6:].tolist() == s) for b, s in zip(batch, single))
+    firsts = sum(int(int(b[-6]) == s[0]) for b, s in zip(batch, single))
+    print(f"full-size batched vs single: identical 6-token streams {same}/3, identical first tokens {firsts}/3")
+    assert firsts == 3                                       # the first token comes from the same prefill kernels
+    assert same >= 1
