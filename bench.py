@@ -210,6 +210,7 @@ def main():
     eng.decode_steps(n_out - 1, use_graph=not args.no_graph); torch.cuda.synchronize()
     phases["decode_ms"] = (time.perf_counter() - t) * 1e3
     phases["decode_ms_per_token"] = phases["decode_ms"] / (n_out - 1)
+    phases["ttft_ms"] = phases["encode_plus_splice_ms"] + phases["prefill_ms"]      # frames in -> first token out
     if B > 1:
         dec = model._batch_decoder
         dec.begin([int(lg[0].argmax())] * B); torch.cuda.synchronize(); t = time.perf_counter()
