@@ -76,6 +76,41 @@ __device__ __forceinline__ float dot16<fp8_t>(const uint4& w, const float* xv, f
     return acc;
 }
 
+// ---- bf16 activations: x lives in LDS as bf16 (it IS bf16: the input row, or the normalised row after its one rounding)
+// and meets a 16-byte weight chunk through v_dot2c_f32_bf16 (two exact products + fp32 accumulate per instruction): 4
+// VALU instructions and one ds_read_b128 per 8 weights instead of 16 unpack + 8 FMA and two reads of an fp32 image.
+typedef __bf16 gv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(gv_bf16x2, a), __builtin_bit_cast(gv_bf16x2, b), acc, false);
+}
+// xv: VE/8 chunks of 8 bf16 activations matching the weight chunk
+template <typename WT>
+__device__ __forceinline__ float dotb(const uint4& w, const uint4* xv, float acc) {      // bf16 weights
+    acc = dot2bf(w.x, xv[0].x, acc); acc = dot2bf(w.y, xv[0].y, acc);
+    acc = dot2bf(w.z, xv[0].z, acc); acc = dot2bf(w.w, xv[0].w, acc);
+    return acc;
+}
+template <>
+__device__ __forceinline__ float dotb<fp8_t>(const uint4& w, const uint4* xv, float acc) {   // 16 fp8 weights, exact -> bf16
+    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+    const unsigned xx[8] = {xv[0].x, xv[0].y, xv[0].z, xv[0].w, xv[1].x, xv[1].y, xv[1].z, xv[1].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(ww[i], 1.0f, false));
+        const unsigned hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(ww[i], 1.0f, true));
+        acc = dot2bf(lo, xx[2 * i], acc);
+        acc = dot2bf(hi, xx[2 * i + 1], acc);
+    }
+    return acc;
+}
+template <typename T> struct IsBf { static constexpr bool v = false; };
+template <> struct IsBf<bf16_t> { static constexpr bool v = true; };
+// Row-group kernels keep x in LDS.  Measured on one box: the bf16 image + v_dot2c is a win for fp8 weights (VALU-bound:
+// qkv 12.2 -> 11.7 us, gate/up 17.0 -> 16.5) but a loss for bf16 weights (gate/up 29.3 -> 30.8 us: v_dot2c_f32_bf16 issues
+// slower than the unpack + FMA pairs it replaces), so bf16 weights keep the fp32 image.  The split-K kernel reads x from
+// global memory as bf16 and uses v_dot2c for both (down projection 16.6 -> 15.6 us).
+template <typename T, typename WT> struct BfImage { static constexpr bool v = IsBf<T>::v && sizeof(WT) == 1; };
+
 template <bool NT>
 __device__ __forceinline__ uint4 ld16(const void* p) {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -106,12 +141,28 @@ __device__ __forceinline__ int xs_off(int k) {
 }
 template <int VE>
 static size_t xs_lds_bytes(int K) { return ((size_t)((K / VE + 63) / 64) * 64 * VE + 8) * sizeof(float); }
+// bf16 image: 16-byte pieces, lane-linear per piece index g = (k % VE) / 8 (VE = 8: the plain row)
+template <int VE>
+__device__ __forceinline__ int xb_off(int k) {
+    const int c = k / VE, g = (k % VE) >> 3;
+    return ((((c >> 6) * (VE / 8) + g) << 6) + (c & 63)) * 8 + (k & 7);
+}
+template <int VE>
+static size_t xb_lds_bytes(int K) { return (size_t)((K / VE + 63) / 64) * 64 * VE * 2 + 8 * sizeof(float); }
+template <bool XB, int VE>
+static size_t x_image_bytes(int K) { return XB ? xb_lds_bytes<VE>(K) : xs_lds_bytes<VE>(K); }
+// scratch floats behind the image
+template <bool XB, int VE>
+__device__ __forceinline__ float* x_image_end(float* xs, int nchunk) {
+    const int padded = ((nchunk + 63) / 64) * 64 * VE;
+    return XB ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(xs) + padded) : xs + padded;
+}
 
 // ------------------------------------------------------------------------------------------------
 // prologue shared by the row-group kernels: xs (fp32, LDS, xs_off layout) = f(x), f = identity or rmsnorm(x)*norm_w rounded to T.
 // `after_loads()` runs once the x / norm_w loads are in flight (the caller issues its weight prefetch there).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VE, typename F>
+template <typename T, int VE, bool XB, typename F>
 __device__ __forceinline__ void stage_x(const T* __restrict__ x, const T* __restrict__ norm_w, float* xs, float* red, int K,
                                         float eps, F after_loads) {
     constexpr int VX = Vec16<T>::N;
@@ -154,34 +205,54 @@ __device__ __forceinline__ void stage_x(const T* __restrict__ x, const T* __rest
 #pragma unroll
                     for (int e = 0; e < VX; ++e) f[e] = Elem<T>::round(f[e] * rr * g[e]);
                 }
+                if constexpr (XB) {          // bf16 image: the raw row, or the rounded normalised values repacked
+                    uint4 o = xr[i];
+                    if (norm_w) o = make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(xs) + xb_off<VE>(c * VX)) = o;
+                } else {
 #pragma unroll
-                for (int e = 0; e < VX; e += 4)
-                    *reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e)) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+                    for (int e = 0; e < VX; e += 4)
+                        *reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e)) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+                }
             }
         }
     } else {
         after_loads();
         for (int c = tid; c < nx; c += GV_THREADS) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(x + (long long)c * VX);
             float f[VX];
-            Vec16<T>::cvt(*reinterpret_cast<const uint4*>(x + (long long)c * VX), f);
+            Vec16<T>::cvt(raw, f);
 #pragma unroll
             for (int e = 0; e < VX; ++e) ss = fmaf(f[e], f[e], ss);
+            if constexpr (XB) {
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(xs) + xb_off<VE>(c * VX)) = raw;
+            } else {
 #pragma unroll
-            for (int e = 0; e < VX; e += 4)
-                *reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e)) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+                for (int e = 0; e < VX; e += 4)
+                    *reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e)) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
+            }
         }
         if (norm_w) {
             const float rr = rsqrtf(block_sum<GV_THREADS>(ss, red) / K + eps);
             for (int c = tid; c < nx; c += GV_THREADS) {
                 float f[VX];
                 Vec16<T>::cvt(*reinterpret_cast<const uint4*>(norm_w + (long long)c * VX), f);
+                if constexpr (XB) {
+                    uint4* p4 = reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(xs) + xb_off<VE>(c * VX));
+                    float v[VX];
+                    Vec16<T>::cvt(*p4, v);
 #pragma unroll
-                for (int e = 0; e < VX; e += 4) {
-                    float4* p4 = reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e));
-                    float4 v = *p4;
-                    v.x = Elem<T>::round(v.x * rr * f[e]); v.y = Elem<T>::round(v.y * rr * f[e + 1]);
-                    v.z = Elem<T>::round(v.z * rr * f[e + 2]); v.w = Elem<T>::round(v.w * rr * f[e + 3]);
-                    *p4 = v;
+                    for (int e = 0; e < VX; ++e) v[e] = v[e] * rr * f[e];
+                    *p4 = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VX; e += 4) {
+                        float4* p4 = reinterpret_cast<float4*>(xs + xs_off<VE>(c * VX + e));
+                        float4 v = *p4;
+                        v.x = Elem<T>::round(v.x * rr * f[e]); v.y = Elem<T>::round(v.y * rr * f[e + 1]);
+                        v.z = Elem<T>::round(v.z * rr * f[e + 2]); v.w = Elem<T>::round(v.w * rr * f[e + 3]);
+                        *p4 = v;
+                    }
                 }
             }
         }
@@ -203,10 +274,34 @@ __device__ __forceinline__ void issue_block(uint4 (&w)[U][R], const WT* const (&
         }
     }
 }
-template <typename WT, int R, int U, bool FULL>
+template <typename T, typename WT, int R, int U, bool FULL>
 __device__ __forceinline__ void consume_block(const uint4 (&w)[U][R], const float* xs, int c0, int lane, int nchunk,
                                               float (&acc)[R]) {
     constexpr int VE = Vec16<WT>::N;
+    if constexpr (BfImage<T, WT>::v) {
+        // one accumulator per (row, chunk): v_dot2c chains of 4 instead of 4 U (the instruction accumulates in place, so
+        // a single accumulator per row serialises the whole step)
+        float part[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 64 + lane;
+            uint4 xb[VE / 8];
+#pragma unroll
+            for (int j = 0; j < VE / 8; ++j)
+                xb[j] = (FULL || c < nchunk) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(xs) + xb_off<VE>(c * VE + j * 8))
+                                             : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) part[u][r] = dotb<WT>(w[u][r], xb, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float t = part[0][r];
+#pragma unroll
+            for (int u = 1; u < U; ++u) t += part[u][r];
+            acc[r] += t;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int c = c0 + u * 64 + lane;
@@ -242,7 +337,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     constexpr int STEP = 64 * U;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nchunk = K / VE;                    // 16-byte weight chunks per row
-    float* red = xs + ((nchunk + 63) / 64) * 64 * VE;
+    float* red = x_image_end<BfImage<T, WT>::v, VE>(xs, nchunk);
     const int nwaves = gridDim.x * GV_WAVES;
     const int ngroups = SWIGLU ? (N / 2 + (R / 2) - 1) / (R / 2) : (N + R - 1) / R;
 
@@ -258,7 +353,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     int grp = blockIdx.x * GV_WAVES + wid;
     // PF (host guarantees nchunk >= STEP): NO branch around the prefetch -- at a control-flow merge hipcc waits vmcnt(0),
     // which would drain the weights before the prologue.  Waves past the last group prefetch a clamped (valid) row.
-    stage_x<T, VE>(x, norm_w, xs, red, K, eps, [&]() {
+    stage_x<T, VE, BfImage<T, WT>::v>(x, norm_w, xs, red, K, eps, [&]() {
         if (PF) {
             const int gp = min(grp, ngroups - 1);
             const WT* rowp[R];
@@ -281,15 +376,15 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
         int c0 = 0;
-        if (have) { consume_block<WT, R, U, true>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
+        if (have) { consume_block<T, WT, R, U, true>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
         const int cfull = (nchunk / STEP) * STEP;          // steady state: no bounds checks, no exec masking
         for (; c0 < cfull; c0 += STEP) {
             issue_block<WT, R, U, NT, true>(wa, rowp, c0, lane, nchunk);
-            consume_block<WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
+            consume_block<T, WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
         }
         if (c0 < nchunk) {
             issue_block<WT, R, U, NT, false>(wa, rowp, c0, lane, nchunk);
-            consume_block<WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
+            consume_block<T, WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
@@ -360,11 +455,16 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float xv[VE];
+            if constexpr (IsBf<T>::v) {                  // raw bf16 activations straight into v_dot2c_f32_bf16
 #pragma unroll
-            for (int j = 0; j < XL; ++j) Vec16<T>::cvt(xr[u][j], xv + j * VX);
+                for (int r = 0; r < R; ++r) acc[r] = dotb<WT>(w[u][r], xr[u], acc[r]);
+            } else {
+                float xv[VE];
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = dot16<WT>(w[u][r], xv, acc[r]);
+                for (int j = 0; j < XL; ++j) Vec16<T>::cvt(xr[u][j], xv + j * VX);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = dot16<WT>(w[u][r], xv, acc[r]);
+            }
         }
     };
     const int cfull = (nchunk / (256 * U)) * (256 * U);       // steady state: every lane in range, no exec masking
@@ -409,7 +509,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
     constexpr int R = 2, STEP = 64 * U;                  // U chunks per row per step (4 for 2-byte weights, 2 for fp8)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nchunk = K / VE;
-    float* red = xs + ((nchunk + 63) / 64) * 64 * VE;
+    float* red = x_image_end<BfImage<T, WT>::v, VE>(xs, nchunk);
     const int half = hd >> 1;
     const int qk_groups = (H + Hk) * half;              // rotation pairs
     const int ngroups = qk_groups + (Hk * hd) / 2;
@@ -432,7 +532,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
 
     uint4 wa[U][R];
     const int grp0 = blockIdx.x * GV_WAVES + wid;
-    stage_x<T, VE>(x, norm_w, xs, red, K, eps, [&]() {
+    stage_x<T, VE, BfImage<T, WT>::v>(x, norm_w, xs, red, K, eps, [&]() {
         if (PF) {                                         // branch-free (see gemv_kernel)
             long long rows[R];
             int head, i0;
@@ -454,15 +554,15 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
         const float sc0 = wscale ? wscale[rows[0]] : 1.f, sc1 = wscale ? wscale[rows[1]] : 1.f;
         float acc[R] = {0.f, 0.f};
         int c0 = 0;
-        if (have) { consume_block<WT, R, U, true>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
+        if (have) { consume_block<T, WT, R, U, true>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
         const int cfull = (nchunk / STEP) * STEP;
         for (; c0 < cfull; c0 += STEP) {
             issue_block<WT, R, U, NT, true>(wa, rowp, c0, lane, nchunk);
-            consume_block<WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
+            consume_block<T, WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
         }
         if (c0 < nchunk) {
             issue_block<WT, R, U, NT, false>(wa, rowp, c0, lane, nchunk);
-            consume_block<WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
+            consume_block<T, WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
@@ -505,7 +605,7 @@ static int launch_rows(const void* x, const void* W, const float* ws, const void
     const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
-    const size_t lds = xs_lds_bytes<Vec16<WT>::N>(K);
+    const size_t lds = x_image_bytes<BfImage<T, WT>::v, Vec16<WT>::N>(K);
 #define TEO_GV(NTV, SW)                                                                                              \
     gemv_kernel<T, TO, WT, R, U, PF, NTV, SW><<<blocks, GV_THREADS, lds, st>>>((const T*)x, (const WT*)W, ws, (const T*)norm_w, \
                                                                                (const T*)res, (TO*)y, N, K, eps)
@@ -606,7 +706,7 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
     const int ngroups = (H + Hk) * (hd / 2) + Hk * hd / 2;
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
-    const size_t lds = w_fp8 ? xs_lds_bytes<16>(K) : (dtype == TEO_F32 ? xs_lds_bytes<4>(K) : xs_lds_bytes<8>(K));
+    const size_t lds = w_fp8 ? xb_lds_bytes<16>(K) : (dtype == TEO_F32 ? xs_lds_bytes<4>(K) : xs_lds_bytes<8>(K));
     const int uu = w_fp8 ? 2 : 4;
     const bool pf = K / ve >= 64 * uu;
 #define TEO_QR(TT, WW, NTV)                                                                                             \
