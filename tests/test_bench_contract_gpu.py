@@ -31,3 +31,20 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.3 < rf["frac"] < 1.0
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N > 1 plumbing of bench.py (rank env, barrier, max-over-ranks time, whole-job value) with two ranks sharing
+    cuda:0 over gloo -- the RCCL path itself needs a multi-GPU node."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "1", "--frames", "2", "--prompt", "32", "--new", "8", "--dist-backend", "gloo", "--same-gpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # only rank 0 prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]      # both ranks' tokens over the max time
+    assert "dp2" in d["config"]["parallelism"]
