@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
         Elem<T>::st(yr + i, (Elem<T>::ld(xr + i) - mean) * rstd * Elem<T>::ld(w + i) + Elem<T>::ld(b + i));
 }
 
-template <typename T, bool VEC, int VPT>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, const T* __restrict__ w,
+// NT threads per row: 256, or 128 for many-row launches (16 instead of 8 workgroups per CU: a 2168-row prefill norm fits
+// one round of resident workgroups instead of 1.06)
+template <typename T, bool VEC, int VPT, int NT>
+__global__ __launch_bounds__(NT) void rmsnorm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                       T* __restrict__ y, int dim, float eps) {
     __shared__ float red[4];
     const long long row = blockIdx.x;
@@ -103,17 +105,17 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-            const int c = threadIdx.x + i * 256;
+            const int c = threadIdx.x + i * NT;
             if (c < nv) {
                 V16<T>::unpack(*reinterpret_cast<const uint4*>(xr + (long long)c * VE), v[i]);
 #pragma unroll
                 for (int e = 0; e < VE; ++e) s = fmaf(v[i][e], v[i][e], s);
             }
         }
-        const float r = rsqrtf(block_sum<256>(s, red) / dim + eps);
+        const float r = rsqrtf(block_sum<NT>(s, red) / dim + eps);
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-            const int c = threadIdx.x + i * 256;
+            const int c = threadIdx.x + i * NT;
             if (c < nv) {
                 float wv[VE], o[VE];
                 V16<T>::unpack(*reinterpret_cast<const uint4*>(w + (long long)c * VE), wv);
@@ -125,12 +127,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
         return;
     }
     float s = 0.f;
-    for (int i = threadIdx.x; i < dim; i += 256) {
+    for (int i = threadIdx.x; i < dim; i += NT) {
         float v = Elem<T>::ld(xr + i);
         s += v * v;
     }
-    const float r = rsqrtf(block_sum<256>(s, red) / dim + eps);
-    for (int i = threadIdx.x; i < dim; i += 256) Elem<T>::st(yr + i, Elem<T>::ld(xr + i) * r * Elem<T>::ld(w + i));
+    const float r = rsqrtf(block_sum<NT>(s, red) / dim + eps);
+    for (int i = threadIdx.x; i < dim; i += NT) Elem<T>::st(yr + i, Elem<T>::ld(xr + i) * r * Elem<T>::ld(w + i));
 }
 
 // row (t, n): n == 0 -> cls + pos[0]; else patch[t*NP + n-1] + pos[n]; the sum is rounded to T (the
@@ -190,14 +192,16 @@ int rmsnorm(const void* x, const void* w, void* y, int rows, int dim, float eps,
     if (rows == 0) return TEO_OK;
     if (dtype == TEO_F32) {
         if (vec_ok(dim, 4, 4, x, w, nullptr, y))
-            rmsnorm_kernel<float, true, 4><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, dim, eps);
+            rmsnorm_kernel<float, true, 4, 256><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, dim, eps);
         else
-            rmsnorm_kernel<float, false, 1><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, dim, eps);
+            rmsnorm_kernel<float, false, 1, 256><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, dim, eps);
     } else {
-        if (vec_ok(dim, 8, 2, x, w, nullptr, y))
-            rmsnorm_kernel<bf16_t, true, 2><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, dim, eps);
+        if (rows >= 1024 && vec_ok(dim, 8, 2, x, w, nullptr, y))        // dim/8 <= 512 chunks = 4 per thread at 128 threads
+            rmsnorm_kernel<bf16_t, true, 4, 128><<<rows, 128, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, dim, eps);
+        else if (vec_ok(dim, 8, 2, x, w, nullptr, y))
+            rmsnorm_kernel<bf16_t, true, 2, 256><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, dim, eps);
         else
-            rmsnorm_kernel<bf16_t, false, 1><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, dim, eps);
+            rmsnorm_kernel<bf16_t, false, 1, 256><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, dim, eps);
     }
     TEO_LAUNCH_CHECK("rmsnorm");
     return TEO_OK;
