@@ -19,7 +19,7 @@ __device__ __forceinline__ unsigned long long ld_sc1(const unsigned long long* p
 }
 
 extern "C" __global__ __launch_bounds__(256) void handoff_allgather(unsigned long long* vec, int gpw, int iters, int* err,
-                                                                    unsigned long long* sink) {
+                                                                    unsigned long long* sink, int batched) {
     const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
     const int total = nb * gpw;
     unsigned long long acc = 0;
@@ -27,7 +27,29 @@ extern "C" __global__ __launch_bounds__(256) void handoff_allgather(unsigned lon
         // publish this workgroup's granules (lane-parallel)
         for (int g = tid; g < gpw; g += 256)
             st_sc1(vec + (size_t)b * gpw + g, ((unsigned long long)(unsigned)e << 32) | (unsigned)(b * gpw + g + e));
-        // gather everything
+        // gather everything: 8 polls in flight per lane (mode 1) or one at a time (mode 0)
+        if (batched) {
+            for (int g0 = tid; g0 < total; g0 += 256 * 8) {
+                unsigned long long v[8];
+                int spins = 0;
+                for (;;) {
+                    // all 8 polls are issued back to back (clamped index), one wait for the batch
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const unsigned long long* q = vec + min(g0 + i * 256, total - 1);
+                        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[i]) : "v"(q) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    bool all = true;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) all = all && ((unsigned)(v[i] >> 32) >= (unsigned)e);
+                    if (all) break;
+                    if (++spins > 2000000) { atomicExch(err, 1); break; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += v[i] & 0xffffffffull;
+            }
+        } else
         for (int g = tid; g < total; g += 256) {
             unsigned long long v = 0;
             int spins = 0;
@@ -45,8 +67,8 @@ extern "C" __global__ __launch_bounds__(256) void handoff_allgather(unsigned lon
     if (acc == 0x1234567ull) *sink = acc;
 }
 
-extern "C" int handoff_run(void* vec, int blocks, int gpw, int iters, void* err, void* sink, void* stream) {
+extern "C" int handoff_run(void* vec, int blocks, int gpw, int iters, void* err, void* sink, void* stream, int batched) {
     hipLaunchKernelGGL(handoff_allgather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)vec, gpw, iters,
-                       (int*)err, (unsigned long long*)sink);
+                       (int*)err, (unsigned long long*)sink, batched);
     return (int)hipGetLastError();
 }

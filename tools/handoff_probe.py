@@ -14,10 +14,10 @@ if not os.path.exists(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
                            os.path.join(here, "handoff_probe.hip"), "-o", so])
 lib = C.CDLL(so)
-lib.handoff_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.handoff_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 st = torch.cuda.current_stream().cuda_stream
-for blocks in (64, 128, 256):
-    for gpw in (1, 4, 16, 64):            # granules per workgroup: vector of blocks*gpw*4 payload bytes
+for batched, blocks in ((0, 256), (1, 64), (1, 128), (1, 256)):
+    for gpw in (1, 4, 8, 16, 22, 64):            # granules per workgroup: vector of blocks*gpw*4 payload bytes
         vec = torch.zeros(blocks * gpw, dtype=torch.int64, device="cuda")
         err = torch.zeros(1, dtype=torch.int32, device="cuda")
         sink = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -26,7 +26,7 @@ for blocks in (64, 128, 256):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = lib.handoff_run(vec.data_ptr(), blocks, gpw, iters, err.data_ptr(), sink.data_ptr(), st)
+            rc = lib.handoff_run(vec.data_ptr(), blocks, gpw, iters, err.data_ptr(), sink.data_ptr(), st, batched)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)
@@ -34,5 +34,5 @@ for blocks in (64, 128, 256):
                 t20 = ms
             else:
                 per = (ms - t20) / 200.0 * 1e3
-                print(f"blocks {blocks:3d} granules/wg {gpw:3d} (vector {blocks * gpw * 4 / 1024:6.1f} KB payload): "
+                print(f"{'8 polls in flight' if batched else '1 poll in flight '} blocks {blocks:3d} granules/wg {gpw:3d} (vector {blocks * gpw * 4 / 1024:6.1f} KB payload): "
                       f"{per:6.2f} us per all-gather round  err={int(err.item())} rc={rc}", flush=True)
