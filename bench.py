@@ -247,6 +247,13 @@ def main():
     # whole decode step against the HBM roofline (weights + KV per token)
     kv_ctx = Lseq + n_out / 2.0
     tok_bytes = 6.738e9 * (1 if args.weights == "fp8" else 2) + 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * kv_ctx
+    # the MFMA-bound phases against the dense bf16 peak (algorithmic FLOPs of SURVEY.md section 8d)
+    MFMA_PEAK_TFLOPS = 2500.0
+    prefill_tf = (2.0 * Lseq * 6.476e9 + 2.0 * 4096 * 32000 + float(Lseq) ** 2 * 262144.0) / 1e12
+    vit_tf = T * (155.3e9 + 10.74e9) / 1e12
+    roofline["prefill_tflops"] = round(prefill_tf / (phases["prefill_ms"] * 1e-3), 1)
+    roofline["prefill_frac_of_mfma_peak"] = round(roofline["prefill_tflops"] / MFMA_PEAK_TFLOPS, 4)
+    roofline["vit_projector_tflops"] = round(vit_tf / (phases["encode_plus_splice_ms"] * 1e-3), 1)
     roofline["decode_step_frac_of_hbm_peak"] = round(tok_bytes / (phases["decode_ms_per_token"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     result = {
