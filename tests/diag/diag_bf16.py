@@ -1,7 +1,7 @@
 """Where does the bf16 path diverge from the boundary-rounding oracle?  Stage-by-stage max|diff|/max|ref|."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import teo_oracle as O
 from tests import _tiny as TY

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import teo_oracle as O  # noqa: E402  (inputs only)
 from teochat_amd.config import teochat_7b_config  # noqa: E402
 from teochat_amd.engine import TeoEngine  # noqa: E402

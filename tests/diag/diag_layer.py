@@ -1,7 +1,7 @@
 """tinyB LLaMA layer 0, primitive by primitive, bf16 kernels vs the boundary oracle on identical inputs."""
 import math, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import teo_oracle as O
 from teochat_amd import _lib as L
