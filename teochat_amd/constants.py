@@ -1,16 +1,26 @@
-"""Sentinels and token strings of the path (values as in the reference's videollava/constants.py:7-10,17,24)."""
-IGNORE_INDEX = -100
-IMAGE_TOKEN_INDEX = -200
-DEFAULT_IMAGE_TOKEN = "<image>"
-DEFAULT_IMAGE_PATCH_TOKEN = "<im_patch>"
-DEFAULT_IM_START_TOKEN = "<im_start>"
-DEFAULT_IM_END_TOKEN = "<im_end>"
-IMAGE_PLACEHOLDER = "<image-placeholder>"
-DEFAULT_VIDEO_TOKEN = "<video>"
-DEFAULT_VIDEO_PATCH_TOKEN = "<im_patch>"
-DEFAULT_VID_START_TOKEN = "<vid_start>"
-DEFAULT_VID_END_TOKEN = "<vid_end>"
-VIDEO_PLACEHOLDER = "<video-placeholder>"
-MAX_IMAGE_LENGTH = 16
-MAX_VIDEO_LENGTH = 1
-PAD_LENGTH = 620
+"""Sentinels and token strings of the path.
+
+The names and values are an interface (prompts, checkpoints and callers of the reference depend on them): they equal
+videollava/constants.py:7-10,17,24.  Only the entries the image path uses carry meaning here; the video / patch / start-end
+tokens exist so that `from videollava.constants import ...` keeps working for code written against the reference.
+"""
+
+# label value the loss ignores, and the input-id sentinel that marks where one image's visual tokens are spliced in
+IGNORE_INDEX, IMAGE_TOKEN_INDEX = -100, -200
+
+
+def _tag(name):
+    return "<" + name + ">"
+
+
+# prompt-side markers: replace_video_token() turns every DEFAULT_VIDEO_TOKEN into DEFAULT_IMAGE_TOKEN x T
+DEFAULT_IMAGE_TOKEN, DEFAULT_VIDEO_TOKEN = _tag("image"), _tag("video")
+IMAGE_PLACEHOLDER, VIDEO_PLACEHOLDER = _tag("image-placeholder"), _tag("video-placeholder")
+
+# optional wrapping tokens (mm_use_im_start_end / mm_use_im_patch_token configurations; unused by TEOChat's checkpoints)
+DEFAULT_IMAGE_PATCH_TOKEN = DEFAULT_VIDEO_PATCH_TOKEN = _tag("im_patch")
+DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN = _tag("im_start"), _tag("im_end")
+DEFAULT_VID_START_TOKEN, DEFAULT_VID_END_TOKEN = _tag("vid_start"), _tag("vid_end")
+
+# dataset-side limits of the reference's training collator (kept for import compatibility)
+MAX_IMAGE_LENGTH, MAX_VIDEO_LENGTH, PAD_LENGTH = 16, 1, 620
