@@ -47,8 +47,8 @@ def test_prefill_equals_decode_full_size(model7b):
     rel = float((full[-1] - step_logits).abs().max()) / float(full[-1].abs().max())
     print(f"full-size prefill vs decode logits: rel-to-max diff {rel:.2e}")
     # 32 layers x ~7 bf16 roundings per layer accumulate like a random walk: against an fp32 run on the same weights the
-    # bf16 prefill is off by 5.5e-2 and the bf16 decode by 4.8e-2 of max|logit| (tests/diag/diag_full_size.py); the two bf16
-    # paths differ by 3.3e-2.  The bound below only guards against a broken path, per-kernel exactness is tested elsewhere.
+    # bf16 prefill is off by 5.5e-2 and the bf16 decode by 5.8e-2 of max|logit| (tests/diag/diag_full_size.py); the two bf16
+    # paths differ by 3.5e-2.  The bound below only guards against a broken path, per-kernel exactness is tested elsewhere.
     assert rel < 8e-2
     top2 = torch.topk(full[-1], 2).values
     if float(top2[0] - top2[1]) > 4 * float((full[-1] - step_logits).abs().max()):
