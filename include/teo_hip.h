@@ -231,11 +231,13 @@ typedef struct {
     const void* const* ln2_w; const void* const* ln2_b;
     const void* const* fc1_w; const void* const* fc1_b;
     const void* const* fc2_w; const void* const* fc2_b;
+    int keep_cls;   /* feature_select (languagebind/__init__.py:121-129): 0 = 'patch' (drop the CLS row), 1 = 'cls_patch' */
 } teo_vit_desc;
 
 size_t teo_vit_workspace_bytes(const teo_vit_desc* d, int T);
 /* features[T, n_patches, hidden] = hidden_states[layers_run][:, 1:]  (H7-H11 of SURVEY.md section 8a):
- * LanguageBindImageTower.forward + feature_select (languagebind/__init__.py:121-146). */
+ * LanguageBindImageTower.forward + feature_select (languagebind/__init__.py:121-146).  With d->keep_cls the CLS row
+ * stays: features[T, n_patches + 1, hidden] = hidden_states[layers_run]  ('cls_patch'). */
 int teo_vit_encode(const teo_vit_desc* d, const void* d_pixels, int T, void* d_features, void* d_workspace,
                    size_t workspace_bytes, teo_stream_t stream);
 

@@ -46,7 +46,8 @@ class VitDesc(C.Structure):
                 ("patch_w", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
                 ("pre_ln_w", C.c_void_p), ("pre_ln_b", C.c_void_p),
                 ("ln1_w", PP), ("ln1_b", PP), ("qkv_w", PP), ("qkv_b", PP), ("out_w", PP), ("out_b", PP),
-                ("ln2_w", PP), ("ln2_b", PP), ("fc1_w", PP), ("fc1_b", PP), ("fc2_w", PP), ("fc2_b", PP)]
+                ("ln2_w", PP), ("ln2_b", PP), ("fc1_w", PP), ("fc1_b", PP), ("fc2_w", PP), ("fc2_b", PP),
+                ("keep_cls", C.c_int)]
 
 
 class ProjDesc(C.Structure):

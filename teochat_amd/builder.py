@@ -25,7 +25,7 @@ import warnings
 
 import torch
 
-from .config import LlavaConfig, VisionConfig, teochat_7b_config
+from .config import LlavaConfig, VisionConfig, teochat_7b_config, vision_config_from_tower_dir
 from .engine import TeoEngine
 from .model import LlavaLlamaForCausalLM
 from .processor import TeoImageProcessor
@@ -37,35 +37,6 @@ def tiny_config():
                        num_key_value_heads=2, vocab_size=512, mm_hidden_size=128, max_position_embeddings=2048,
                        vision_config=VisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3,
                                                   num_attention_heads=2, hidden_act="gelu"))
-
-
-class LazySafetensors:
-    """dict-like view over the safetensors shards of an HF checkpoint directory (kept for callers; CheckpointDir also
-    reads pytorch_model*.bin)."""
-
-    def __init__(self, model_dir, device):
-        from safetensors import safe_open
-        self._open = safe_open
-        self.device = device
-        self.where = {}
-        for f in sorted(glob.glob(os.path.join(model_dir, "*.safetensors"))):
-            with safe_open(f, framework="pt", device="cpu") as h:
-                for k in h.keys():
-                    self.where[k] = f
-        if not self.where:
-            raise FileNotFoundError(f"no *.safetensors under {model_dir}")
-
-    def __contains__(self, k):
-        return k in self.where
-
-    def keys(self):
-        return self.where.keys()
-
-    def __getitem__(self, k):
-        if k not in self.where:
-            raise KeyError(k)
-        with self._open(self.where[k], framework="pt", device="cpu") as h:
-            return h.get_tensor(k).to(self.device)
 
 
 class CheckpointDir:
@@ -245,6 +216,80 @@ def open_checkpoint(model_path, model_base, model_name, device):
     return CheckpointDir(model_path, device)
 
 
+TOWER_KEY = "model.image_tower.image_tower.embeddings.class_embedding"
+
+
+class TowerBackedCheckpoint:
+    """`main` for every key it holds; `model.image_tower.image_tower.X` falls back to `vision_model.X` of the image
+    tower's own checkpoint -- what `image_tower.load_model()` does in the reference when the LLM checkpoint carries no
+    tower weights (builder.py:136-147 -> languagebind/__init__.py:112-119)."""
+    PRE = "model.image_tower.image_tower."
+
+    def __init__(self, main, tower):
+        self.main, self.tower = main, tower
+        self.device = getattr(main, "device", None)
+
+    def _map(self, k):
+        return "vision_model." + k[len(self.PRE):] if k.startswith(self.PRE) else None
+
+    def keys(self):
+        ks = set(self.main.keys())
+        ks |= {self.PRE + k[len("vision_model."):] for k in self.tower.keys() if k.startswith("vision_model.")}
+        return ks
+
+    def __contains__(self, k):
+        return k in self.main or (self._map(k) is not None and self._map(k) in self.tower)
+
+    def __getitem__(self, k):
+        if k in self.main:
+            return self.main[k]
+        m = self._map(k)
+        if m is not None and m in self.tower:
+            return self.tower[m]
+        raise KeyError(k)
+
+
+def find_tower_dir(cfg, model_path, model_base=None):
+    """Local directory of the `mm_image_tower` checkpoint (there is no hub access): the name itself if it is a directory,
+    $TEOCHAT_IMAGE_TOWER, or a sibling / child directory named like the repo (LanguageBind/LanguageBind_Image ->
+    LanguageBind_Image)."""
+    name = getattr(cfg, "mm_image_tower", None)
+    cands = [os.environ.get("TEOCHAT_IMAGE_TOWER")]
+    if name:
+        base = os.path.basename(str(name).rstrip("/"))
+        cands += [name]
+        for root in (model_path, model_base):
+            if root:
+                cands += [os.path.join(root, base), os.path.join(os.path.dirname(os.path.abspath(root)), base)]
+    for c in cands:
+        if c and os.path.isdir(c) and os.path.exists(os.path.join(c, "config.json")):
+            return c
+    return None
+
+
+def resolve_image_tower(cfg, source, model_path, model_base, device):
+    """Fill in what the reference takes from the tower repo: the vision config (when config.json has none) and the tower
+    weights (when the checkpoint has none).  Fails loudly instead of defaulting the activation."""
+    need_cfg = not getattr(cfg, "vision_config_resolved", True)
+    need_w = TOWER_KEY not in source and TOWER_KEY.replace(".embeddings.", ".embeddings.base_layer.") not in source
+    if not need_cfg and not need_w:
+        return source
+    tower_dir = find_tower_dir(cfg, model_path, model_base)
+    if tower_dir is None:
+        what = " and ".join(x for x, n in (("a `vision_config` block in config.json", need_cfg),
+                                            ("`model.image_tower.image_tower.*` weights in the checkpoint", need_w)) if n)
+        raise FileNotFoundError(
+            f"cannot resolve the image tower {getattr(cfg, 'mm_image_tower', None)!r}: the checkpoint lacks {what} and no local "
+            "copy of the tower was found (set TEOCHAT_IMAGE_TOWER=<dir with config.json + weights>, or place it next to the "
+            "checkpoint).  The tower's hidden_act / LoRA rank are never guessed.")
+    if need_cfg:
+        cfg.vision_config = vision_config_from_tower_dir(tower_dir)
+        cfg.vision_config_resolved = True
+    if need_w:
+        source = TowerBackedCheckpoint(source, CheckpointDir(tower_dir, device))
+    return source
+
+
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda", cache_dir=None, dtype=torch.bfloat16, max_seq=None, seed=2, weight_format=None):
     if device in (None, "cuda"):
@@ -266,7 +311,8 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         if "llava" not in model_name.lower() and "teochat" not in model_name.lower():
             raise ValueError(f"Unsupported model name {model_name!r}: expected a llava/teochat checkpoint (builder.py:33)")
         cfg = LlavaConfig.from_pretrained(model_path)           # the LoRA / projector branches read the config of model_path too
-        sd = unwrap_peft_tower(open_checkpoint(model_path, model_base, model_name, device), cfg.vision_config)
+        src = resolve_image_tower(cfg, open_checkpoint(model_path, model_base, model_name, device), model_path, model_base, device)
+        sd = unwrap_peft_tower(src, cfg.vision_config)
         tok_dir = model_base if model_base is not None else model_path       # builder.py:40,82 vs :111
         if os.path.exists(os.path.join(tok_dir, "tokenizer.model")):
             from transformers import AutoTokenizer

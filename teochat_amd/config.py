@@ -59,6 +59,7 @@ class LlavaConfig(SimpleNamespace):
         if isinstance(vision_config, dict):
             vision_config = VisionConfig(**vision_config)
         self.vision_config = vision_config or VisionConfig(hidden_size=mm_hidden_size)
+        self.vision_config_resolved = True        # False only for a config.json without a vision_config (from_json_file)
         self.pretraining_tp = kw.pop("pretraining_tp", 1)
         for k, v in kw.items():
             setattr(self, k, v)
@@ -73,7 +74,12 @@ class LlavaConfig(SimpleNamespace):
             d = json.load(f)
         d.pop("model_type", None)
         d.pop("architectures", None)
-        return cls(**d)
+        cfg = cls(**d)
+        # A llava/teochat config.json carries no vision_config: the reference takes the tower's architecture from the
+        # `mm_image_tower` repo (LanguageBindImageConfig, languagebind/__init__.py:108,113).  Never default it silently
+        # (hidden_act decides the MLP activation): builder.resolve_image_tower() fills it in or fails loudly.
+        cfg.vision_config_resolved = "vision_config" in d
+        return cfg
 
     @classmethod
     def from_pretrained(cls, model_dir):
@@ -81,9 +87,23 @@ class LlavaConfig(SimpleNamespace):
 
     def to_dict(self):
         d = dict(self.__dict__)
+        d.pop("vision_config_resolved", None)
         d["vision_config"] = dict(self.vision_config.__dict__)
         d["model_type"] = self.model_type
         return d
+
+
+def vision_config_from_tower_dir(tower_dir):
+    """VisionConfig from a LanguageBind_Image checkpoint directory: the `vision_config` block of its config.json
+    (configuration_image.py:105-123), incl. hidden_act and the LoRA rank/alpha of a peft-wrapped encoder (:73-75)."""
+    with open(os.path.join(tower_dir, "config.json")) as f:
+        d = json.load(f)
+    v = d.get("vision_config", d)
+    if "hidden_size" not in v or "hidden_act" not in v:
+        raise ValueError(f"{tower_dir}/config.json has no usable vision_config (hidden_size / hidden_act missing)")
+    keep = ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_channels", "image_size",
+            "patch_size", "hidden_act", "layer_norm_eps", "lora_r", "lora_alpha", "add_time_attn", "num_frames")
+    return VisionConfig(**{k: v[k] for k in keep if k in v})
 
 
 def teochat_7b_config(**over):

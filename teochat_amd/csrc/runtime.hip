@@ -98,6 +98,10 @@ int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features,
         TEO_TRY(gemm(w.ln, d->fc1_w[l], d->fc1_b[l], nullptr, w.mlp, rows, d->inter, D, D, d->inter, d->act, 0, dt, dt, st));
         TEO_TRY(gemm(w.mlp, d->fc2_w[l], d->fc2_b[l], w.h, w.h, rows, D, d->inter, d->inter, D, TEO_ACT_NONE, 0, dt, dt, st));
     }
+    if (d->keep_cls) {                                   // feature_select 'cls_patch': the whole hidden state
+        hipError_t he = hipMemcpyAsync(features, w.h, (size_t)rows * D * esize(dt), hipMemcpyDeviceToDevice, st);
+        return he == hipSuccess ? TEO_OK : hip_fail(he, "vit_encode copy features");
+    }
     return drop_cls(w.h, features, T, N, D, dt, st);
 }
 

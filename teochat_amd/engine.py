@@ -165,6 +165,11 @@ class TeoEngine:
         d.pre_ln_w, d.pre_ln_b = w["pre_w"].data_ptr(), w["pre_b"].data_ptr()
         for k in per:
             setattr(d, k, self._arr(per[k]))
+        sf = getattr(self.cfg, "mm_vision_select_feature", "patch")
+        if sf not in ("patch", "cls_patch"):
+            raise ValueError(f"Unexpected select feature: {sf}")        # languagebind/__init__.py:128
+        d.keep_cls = 1 if sf == "cls_patch" else 0
+        self.vit_tokens = v.num_patches + d.keep_cls                    # rows per frame the tower returns
         self.vit_desc = d
 
     def _load_projector(self, sd):
@@ -312,12 +317,10 @@ class TeoEngine:
         if pixels.dim() != 4 or pixels.shape[1] != v.num_channels or pixels.shape[2] != v.image_size or pixels.shape[3] != v.image_size:
             raise ValueError(f"Input image size ({tuple(pixels.shape)}) doesn't match model "
                              f"({v.num_channels}x{v.image_size}x{v.image_size}).")
-        if self.cfg.mm_vision_select_feature not in ("patch",):
-            raise ValueError(f"Unexpected select feature: {self.cfg.mm_vision_select_feature}")
         T = pixels.shape[0]
         with self.phase() as st:
             px = pixels.to(device=self.device, dtype=self.dtype).contiguous()
-            out = torch.empty(T, v.num_patches, v.hidden_size, dtype=self.dtype, device=self.device)
+            out = torch.empty(T, self.vit_tokens, v.hidden_size, dtype=self.dtype, device=self.device)
             need = self.lib.teo_vit_workspace_bytes(C.byref(self.vit_desc), T)
             ws = self._workspace("vit", need)
             L.check(self.lib.teo_vit_encode(C.byref(self.vit_desc), _p(px), T, _p(out), _p(ws), ws.numel(), st), "teo_vit_encode")

@@ -27,14 +27,15 @@ def _write_checkpoint(tmp_path, name="tinyA"):
 
 
 def test_config_and_lazy_safetensors_roundtrip(tmp_path):
-    from teochat_amd.builder import LazySafetensors
+    from teochat_amd.builder import CheckpointDir
     from teochat_amd.config import LlavaConfig
     path, cfg, sd = _write_checkpoint(tmp_path)
     c2 = LlavaConfig.from_pretrained(path)
     for k in ("hidden_size", "num_key_value_heads", "mm_projector_type", "mm_vision_select_layer", "rms_norm_eps"):
         assert getattr(c2, k) == getattr(cfg, k)
     assert c2.vision_config.hidden_act == cfg.vision_config.hidden_act and c2.head_dim == cfg.head_dim
-    lz = LazySafetensors(path, "cpu")
+    assert c2.vision_config_resolved                                       # config.json carried a vision_config block
+    lz = CheckpointDir(path, "cpu")
     assert set(lz.keys()) == set(sd)
     for k in ("model.embed_tokens.weight", "model.mm_projector.2.bias", O.VIT_PREFIX + "pre_layrnorm.weight"):
         assert torch.equal(lz[k], sd[k])
@@ -284,3 +285,60 @@ def test_real_width_two_layer_model_bf16_vs_oracle():
     gen = model.generate(input_ids=ids.cuda(), images=imgs, do_sample=False, max_new_tokens=4, eos_token_id=None)
     assert gen.shape[1] == ids.shape[1] + 4
     print("greedy", gen[0, ids.shape[1]:].tolist(), "oracle", toks)
+
+
+def _write_tower_dir(root, vit_cfg_dict, tower_sd=None):
+    """A LanguageBind_Image-style checkpoint directory: config.json with a `vision_config` block and (optionally) the
+    tower weights under `vision_model.*` (the names LanguageBindImage.state_dict() uses, modeling_image.py:763)."""
+    from safetensors.torch import save_file
+    d = root / "LanguageBind_Image"
+    d.mkdir()
+    json.dump({"model_type": "LanguageBindImage", "vision_config": vit_cfg_dict, "text_config": {}}, open(d / "config.json", "w"))
+    if tower_sd is not None:
+        save_file({k: v.contiguous() for k, v in tower_sd.items()}, str(d / "model.safetensors"))
+    return str(d)
+
+
+def test_image_tower_is_resolved_from_mm_image_tower_not_defaulted(tmp_path, monkeypatch):
+    """a real llava/teochat config.json has no vision_config and (for a plain-LLaMA model_base) the
+    checkpoint has no tower weights; the reference reads both from the `mm_image_tower` repo.  The loader must take
+    hidden_act / lora_r / the weights from a local copy of that repo, or fail with an explicit error -- never default."""
+    from teochat_amd import builder as B
+    from teochat_amd.config import LlavaConfig
+    path, cfg, sd = _write_checkpoint(tmp_path)
+    # (1) strip the vision_config from config.json and the tower weights from the shards
+    cj = json.load(open(os.path.join(path, "config.json")))
+    vit = cj.pop("vision_config")
+    cj["mm_image_tower"] = "LanguageBind/LanguageBind_Image"
+    json.dump(cj, open(os.path.join(path, "config.json"), "w"))
+    from safetensors.torch import save_file
+    for f in os.listdir(path):
+        if f.endswith(".safetensors"):
+            os.remove(os.path.join(path, f))
+    llm_only = {k: v.contiguous() for k, v in sd.items() if not k.startswith(O.VIT_PREFIX)}
+    save_file(llm_only, os.path.join(path, "model.safetensors"))
+    c2 = LlavaConfig.from_pretrained(path)
+    assert not c2.vision_config_resolved
+    src = B.CheckpointDir(path, "cpu")
+    monkeypatch.delenv("TEOCHAT_IMAGE_TOWER", raising=False)
+    with pytest.raises(FileNotFoundError, match="never guessed"):
+        B.resolve_image_tower(c2, src, path, None, "cpu")
+    # (2) a local copy of the tower next to the checkpoint: config (gelu, not the quick_gelu default) and weights come from it
+    vit["hidden_act"] = "gelu"                                               # differs from VisionConfig's quick_gelu default
+    tower_sd = {"vision_model." + k[len(O.VIT_PREFIX):]: v for k, v in sd.items() if k.startswith(O.VIT_PREFIX)}
+    tdir = _write_tower_dir(tmp_path, dict(vit, lora_r=0), tower_sd)
+    assert B.find_tower_dir(c2, path) == tdir                                # sibling directory named like the repo
+    merged = B.resolve_image_tower(c2, src, path, None, "cpu")
+    assert c2.vision_config_resolved and c2.vision_config.hidden_act == "gelu"
+    assert c2.vision_config.num_hidden_layers == vit["num_hidden_layers"]
+    for k in (O.VIT_PREFIX + "embeddings.class_embedding", O.VIT_PREFIX + "encoder.layers.1.mlp.fc2.bias", "model.norm.weight"):
+        assert torch.equal(merged[k], sd[k])
+    assert set(merged.keys()) == set(sd)
+    # (3) $TEOCHAT_IMAGE_TOWER wins; a tower config without hidden_act is rejected
+    bad = tmp_path / "bad_tower"
+    bad.mkdir()
+    json.dump({"vision_config": {"hidden_size": 64}}, open(bad / "config.json", "w"))
+    monkeypatch.setenv("TEOCHAT_IMAGE_TOWER", str(bad))
+    c3 = LlavaConfig.from_pretrained(path)
+    with pytest.raises(ValueError, match="hidden_act"):
+        B.resolve_image_tower(c3, src, path, None, "cpu")

@@ -19,7 +19,7 @@ from tests import _tiny as TY
 pytestmark = pytest.mark.gpu
 
 FP32_TOL = 1e-5      # absolute, logits O(1..10) -- north_star's fp32 bar (measured worst case 7.7e-6; kernels are deterministic)
-BF16_REL = 2e-2     # end to end; the tight per-kernel statement (<= 1 ulp everywhere) is tests/test_bf16_walk_gpu.py
+BF16_REL = 1.4e-2   # end to end: measured 0.9e-2 (tinyA) / 1.1e-2 (tinyB) + 25 %; the tight per-kernel statement (<= 1 ulp everywhere) is tests/test_bf16_walk_gpu.py
 
 
 def build(name, dtype, **cfg_over):

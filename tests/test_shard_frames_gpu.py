@@ -1,0 +1,81 @@
+"""Config C4's frame-sharded tower with the REAL `TeoEngine.vit_features` (CLIP-ViT-L/14 shapes, 23 layers): two ranks share
+cuda:0, each encodes its contiguous block of the T frames with the HIP tower, the visual tokens are all-gathered (gloo here;
+RCCL through teo_allgather_visual on a multi-GPU node) and must equal the unsharded encode BIT FOR BIT on every rank --
+frames are independent through the tower (T is the batch dim, modeling_image.py:641-643) and the kernels' reduction order
+does not depend on how many frames share a launch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _engine():
+    """Full-size tower + projector in front of a two-layer LLaMA (the LLM is not under test here)."""
+    from teochat_amd.config import LlavaConfig, VisionConfig
+    from teochat_amd.engine import TeoEngine
+    from teochat_amd.synthetic import synthetic_state_dict
+    cfg = LlavaConfig(hidden_size=4096, num_attention_heads=32, num_key_value_heads=32, intermediate_size=11008,
+                      num_hidden_layers=2, vocab_size=32000, mm_hidden_size=1024, max_position_embeddings=4096,
+                      vision_config=VisionConfig(hidden_act="gelu"))
+    sd = synthetic_state_dict(cfg, seed=2, device="cuda:0")
+    return TeoEngine(sd, cfg, dtype=torch.bfloat16, device="cuda:0", max_seq=256)
+
+
+def _worker(rank, ws, port, T, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        from oracle import teo_oracle as O
+        from teochat_amd.parallel import frame_partition, sharded_frame_features
+        eng = _engine()
+        px = torch.stack(O.synthetic_frames(T, 224, seed=0)).to("cuda:0", dtype=torch.bfloat16)
+        whole = eng.vit_features(px)
+        calls = []
+
+        def encode(p):
+            calls.append(p.shape[0])
+            return eng.vit_features(p)
+
+        got = sharded_frame_features(encode, px)
+        torch.cuda.synchronize()
+        proj_equal = torch.equal(eng.project(got), eng.project(whole))
+        q.put((rank, bool(torch.equal(got, whole)), tuple(got.shape), calls, frame_partition(T, ws)[rank][1], bool(proj_equal),
+               float(whole.float().abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T", [16, 5])
+def test_sharded_real_tower_equals_unsharded_bitwise(T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sums = set()
+    for rank, equal, shape, calls, mine, proj_equal, s in res:
+        assert shape == (T, 256, 1024), (rank, shape)
+        assert calls == [mine], (rank, calls)          # the rank encoded only its own block of frames
+        assert equal, f"rank {rank}: gathered features differ from the unsharded encode"
+        assert proj_equal
+        sums.add(s)
+    assert len(sums) == 1                               # both ranks hold the same features
