@@ -176,9 +176,11 @@ int teo_argmax(const float* d_logits, long long* d_token, int rows, int vocab, t
 
 /* token = multinomial(softmax(top_p(top_k(logits / temperature)))) with u = uniform(seed, draw).  Same filter order as HF's
  * TemperatureLogitsWarper -> TopKLogitsWarper -> softmax -> multinomial (the sampled branch the reference uses,
- * eval/inference.py:64-72 with do_sample=True).  top_k <= 0 or >= vocab disables the filter (capped at 1024);
- * top_p outside (0, 1) disables the nucleus filter (HF TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is
- * dropped, the most probable token always stays); it acts on the top-k survivors, i.e. on at most 1024 candidates. */
+ * eval/inference.py:64-72 with do_sample=True).  top_k <= 0 or >= vocab disables the top-k filter (multinomial over the whole
+ * vocabulary); 0 < top_k <= 1024 otherwise (larger: TEO_ERR_UNSUPPORTED).  top_p outside (0, 1) disables the nucleus filter
+ * (HF TopPLogitsWarper: ascending cumulative probability <= 1 - top_p is dropped, the most probable token always stays);
+ * it acts on the top-k survivors and needs the top-k filter on when vocab > 1024 (else TEO_ERR_UNSUPPORTED -- never a
+ * silently truncated distribution). */
 int teo_sample_topk(const float* d_logits, long long* d_token, int vocab, float temperature, int top_k, float top_p,
                     unsigned long long seed, unsigned long long draw, teo_stream_t stream);
 
@@ -367,6 +369,27 @@ int teo_llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_
                                 size_t workspace_bytes, teo_stream_t stream);
 int teo_llama_decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace,
                                         size_t workspace_bytes, teo_stream_t stream, teo_graph** out);
+
+/* ---- multi-GPU context and the one collective of the path ---------------------------
+ * One process per GPU.  The T-frame tower shards over the ranks (frames are independent through the tower: T is the batch
+ * dimension, languagebind/image/modeling_image.py:641-643); rank r encodes a contiguous block of frames and ONE all-gather
+ * of the visual tokens (tower width, before the projector) rebuilds the full, chronologically ordered tensor on every rank.
+ * The reference has no counterpart (single GPU: scripts/eval_teochat.sh:9-10); it stacks all frames on one device
+ * (llava_arch.py:194).  teo_ctx is opaque: it holds the rank, the device properties and the RCCL communicator.
+ *   teo_comm_unique_id : 128 bytes (ncclUniqueId) generated on ONE rank; the host code hands them to every rank by any
+ *                        control-plane means (a torch.distributed store, MPI, a file) -- never the data path.
+ *   teo_ctx_create     : collective over all ranks (ncclCommInitRank); world_size == 1 accepts unique_id == NULL.
+ *   teo_allgather_visual : out[r * rows_per_rank + i, :] = local_of_rank_r[i, :] on every rank (ncclAllGather over xGMI),
+ *                        enqueued on `stream`; every rank passes the same rows_per_rank (ragged blocks are padded by the
+ *                        caller).  dtype TEO_F32 / TEO_BF16. */
+#define TEO_COMM_ID_BYTES 128
+typedef struct teo_ctx teo_ctx;
+int teo_comm_unique_id(void* out_id /* TEO_COMM_ID_BYTES */);
+int teo_ctx_create(int rank, int world_size, const void* unique_id, int device, teo_ctx** out);
+int teo_ctx_destroy(teo_ctx* ctx);
+int teo_ctx_info(const teo_ctx* ctx, int* rank, int* world_size, int* cu_count, size_t* hbm_bytes);
+int teo_allgather_visual(teo_ctx* ctx, const void* d_local, void* d_out, int rows_per_rank, int dim, int dtype,
+                         teo_stream_t stream);
 
 /* Bench helper: run the decode gate/up GEMV (the dominant kernel by bytes) over n weight matrices
  * back to back between two HIP events on `stream`; returns the average milliseconds per launch. */

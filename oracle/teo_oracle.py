@@ -510,12 +510,43 @@ def rotate_half(x):
 
 @dataclass
 class KVCache:
+    """tf DynamicCache / the legacy tuple cache: per layer K and V [B, H_kv, S, d], grown along S.
+    capacity > 0: the buffers are allocated once at [B, H_kv, capacity, d] and k[i] / v[i] are views of the filled part
+    (what a CPU run that is being TIMED should do: `torch.cat` per layer per step re-copies the whole cache)."""
     k: List[torch.Tensor] = field(default_factory=list)     # per layer [B, H_kv, S, d]
     v: List[torch.Tensor] = field(default_factory=list)
+    capacity: int = 0
+    _kbuf: List[torch.Tensor] = field(default_factory=list)
+    _vbuf: List[torch.Tensor] = field(default_factory=list)
 
     @property
     def length(self):
         return 0 if not self.k else self.k[0].shape[2]
+
+    def append(self, i, k, v):
+        """Add the new positions of layer i; returns the full (K, V) of that layer."""
+        if not self.capacity:
+            if len(self.k) > i:
+                self.k[i] = torch.cat((self.k[i], k), dim=2)
+                self.v[i] = torch.cat((self.v[i], v), dim=2)
+            else:
+                self.k.append(k)
+                self.v.append(v)
+            return self.k[i], self.v[i]
+        if len(self._kbuf) <= i:
+            B, Hk, _, d = k.shape
+            self._kbuf.append(torch.empty(B, Hk, self.capacity, d, dtype=k.dtype))
+            self._vbuf.append(torch.empty(B, Hk, self.capacity, d, dtype=v.dtype))
+            self.k.append(self._kbuf[i][:, :, :0])
+            self.v.append(self._vbuf[i][:, :, :0])
+        n0, S = self.k[i].shape[2], k.shape[2]
+        if n0 + S > self.capacity:
+            raise ValueError(f"KVCache capacity {self.capacity} exceeded")
+        self._kbuf[i][:, :, n0:n0 + S] = k
+        self._vbuf[i][:, :, n0:n0 + S] = v
+        self.k[i] = self._kbuf[i][:, :, :n0 + S]
+        self.v[i] = self._vbuf[i][:, :, :n0 + S]
+        return self.k[i], self.v[i]
 
 
 def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, mode="exact"):
@@ -530,13 +561,7 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, m
     c, s = cos.unsqueeze(1), sin.unsqueeze(1)
     q = R(q * c + rotate_half(q) * s)
     k = R(k * c + rotate_half(k) * s)
-    if len(cache.k) > i:
-        cache.k[i] = torch.cat((cache.k[i], k), dim=2)
-        cache.v[i] = torch.cat((cache.v[i], v), dim=2)
-    else:
-        cache.k.append(k)
-        cache.v.append(v)
-    kk, vv = cache.k[i], cache.v[i]
+    kk, vv = cache.append(i, k, v)
     if Hk != H:                                                                  # repeat_kv
         rep = H // Hk
         kk = kk[:, :, None].expand(B, Hk, rep, kk.shape[2], d).reshape(B, H, -1, d)
@@ -686,6 +711,25 @@ def make_state_dict(vcfg: VitCfg, lcfg: LlamaCfg, mm: MMCfg, seed=2, std=0.02, d
     sd["model.mm_projector.0.bias"] = rn(D)
     sd["model.mm_projector.2.weight"] = rn(D, D)
     sd["model.mm_projector.2.bias"] = rn(D)
+    return sd
+
+
+def make_state_dict_for_timing(vcfg: VitCfg, lcfg: LlamaCfg, mm: MMCfg, seed=2, std=0.02, dtype=torch.float32, base=None):
+    """Full-depth synthetic weights for the CPU-baseline TIMING run (bench.py cpu_baseline): drawing 7e9 normals on one host
+    thread takes minutes, so ONE encoder layer and ONE decoder layer are drawn like make_state_dict draws them and the
+    other layers are rolled copies of those (torch.roll: distinct memory for every layer, same value statistics) -- a
+    timing run streams exactly as many distinct bytes as with independent weights; its numbers mean nothing."""
+    sd = dict(base) if base is not None else make_state_dict(vcfg, lcfg, mm, seed=seed, std=std, dtype=dtype, vit_layers=1,
+                                                               llm_layers=1)
+    for i in range(1, lcfg.num_hidden_layers):
+        for k in [k for k in sd if k.startswith("model.layers.0.")]:
+            w = sd[k]
+            sd[k.replace("model.layers.0.", f"model.layers.{i}.")] = torch.roll(w, shifts=977 * i, dims=-1) if w.dim() > 1 else w.clone()
+    p0 = VIT_PREFIX + "encoder.layers.0."
+    for i in range(1, vcfg.num_hidden_layers):
+        for k in [k for k in sd if k.startswith(p0)]:
+            w = sd[k]
+            sd[k.replace(p0, VIT_PREFIX + f"encoder.layers.{i}.")] = torch.roll(w, shifts=131 * i, dims=-1) if w.dim() > 1 else w.clone()
     return sd
 
 

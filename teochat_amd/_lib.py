@@ -76,6 +76,7 @@ class DecodeState(C.Structure):
 
 
 MAX_DECODE_BATCH = 16
+COMM_ID_BYTES = 128
 
 
 class DecodeBatchState(C.Structure):
@@ -139,6 +140,11 @@ _SIGS = {
                         + [C.c_int] * 5 + [C.c_uint, C.c_int, C.c_void_p]),
     "teo_time_skinny_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint,
                                         C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "teo_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "teo_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "teo_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "teo_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "teo_allgather_visual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "teo_time_gemv_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                       C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }

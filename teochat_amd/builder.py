@@ -290,6 +290,22 @@ def resolve_image_tower(cfg, source, model_path, model_base, device):
     return source
 
 
+def load_generation_config(model, model_dir):
+    """generation_config.json of the checkpoint -> model.generation_config (what GenerationMixin.generate falls back to for
+    every knob the caller leaves unset: LLaMA-2 ships do_sample / temperature 0.6 / top_p 0.9; top_k stays HF's default 50).
+    The reference's call (eval/inference.py:64-72) passes do_sample, temperature and max_new_tokens only, so top_p / top_k
+    of a real checkpoint come from this file."""
+    path = os.path.join(model_dir, "generation_config.json") if os.path.isdir(str(model_dir)) else None
+    if not path or not os.path.exists(path):
+        return False
+    with open(path) as f:
+        d = json.load(f)
+    for k in ("do_sample", "temperature", "top_k", "top_p", "eos_token_id", "bos_token_id", "pad_token_id", "max_length"):
+        if k in d:
+            setattr(model.generation_config, k, d[k])
+    return True
+
+
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
                           device="cuda", cache_dir=None, dtype=torch.bfloat16, max_seq=None, seed=2, weight_format=None):
     if device in (None, "cuda"):
@@ -323,5 +339,6 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     del sd
     image_processor = TeoImageProcessor(size=cfg.vision_config.image_size, engine=engine)     # uint8 frames -> device kernel
     model = LlavaLlamaForCausalLM(cfg, engine, image_processor)
+    load_generation_config(model, model_path)
     context_len = getattr(cfg, "max_sequence_length", 2048)
     return tokenizer, model, {"image": image_processor, "video": None}, context_len

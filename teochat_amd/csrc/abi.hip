@@ -167,6 +167,7 @@ int teo_sample_topk(const float* logits, long long* tok, int vocab, float temper
     ENTER();
     TEO_CHECK_ARG(vocab > 0 && temperature > 0.f, "teo_sample_topk: vocab %d temperature %g", vocab, temperature);
     NEED(logits, "logits"); NEED(tok, "token");
+    { const int rc = sampler_check(vocab, top_k, top_p); if (rc != TEO_OK) return rc; }
     return sample_topk(logits, tok, vocab, temperature, top_k, top_p, seed, draw, ST(s));
 }
 
@@ -229,7 +230,10 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
     NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
     NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
-    if (st->do_sample) { NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "teo_llama_decode_step: temperature %g", st->temperature); }
+    if (st->do_sample) {
+        NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "teo_llama_decode_step: temperature %g", st->temperature);
+        const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc;
+    }
     return llama_decode_step(d, st, ws, wsb, ST(s));
 }
 
@@ -244,6 +248,7 @@ int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_stat
     ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED(out, "out"); NEED_DT(d->dtype);
     TEO_CHECK_ARG(s != nullptr, "teo_llama_decode_graph_create: needs a non-default stream to capture on");
+    if (st->do_sample) { const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc; }
     return decode_graph_create(d, st, ws, wsb, ST(s), out);
 }
 
@@ -255,7 +260,10 @@ static int check_batch_state(const teo_llama_desc* d, const teo_decode_batch_sta
     NEED(st->d_out_count, "d_out_count"); NEED(st->d_stop, "d_stop"); NEED(st->d_logits, "d_logits");
     TEO_CHECK_ARG(st->batch == 1 || st->cache_stride > 0, "decode batch: cache_stride %lld", (long long)st->cache_stride);
     TEO_CHECK_ARG(st->out_stride > 0, "decode batch: out_stride %d", st->out_stride);
-    if (st->do_sample) { NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "decode batch: temperature %g", st->temperature); }
+    if (st->do_sample) {
+        NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "decode batch: temperature %g", st->temperature);
+        const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc;
+    }
     return TEO_OK;
 }
 

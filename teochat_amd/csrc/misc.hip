@@ -351,13 +351,59 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// top-k disabled (top_k <= 0 or >= vocab, HF TopKLogitsWarper is then not applied) and vocab > TOPK_CAP: multinomial over the
+// WHOLE vocabulary.  Thread t owns the contiguous index range [t*C, (t+1)*C): softmax in fp32, block scan of the range masses,
+// inverse CDF in index order (the order torch.multinomial's CDF walks).  sel_val (>= 1024 floats) is the scan scratch.
+__device__ int sample_full_block(const float* __restrict__ logits, int vocab, float temperature, float u, float* sel_val, int* s_misc) {
+    const int tid = threadIdx.x;
+    const float invt = 1.0f / fmaxf(temperature, 1e-6f);
+    const int Cn = (vocab + 1023) / 1024;
+    const int lo = min(tid * Cn, vocab), hi = min(lo + Cn, vocab);
+    __shared__ float redf[16];
+    float mx = -INFINITY;
+    for (int i = lo; i < hi; ++i) mx = fmaxf(mx, logits[i] * invt);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) redf[tid >> 6] = mx;
+    __syncthreads();
+    mx = redf[0];
+    for (int ww = 1; ww < 16; ++ww) mx = fmaxf(mx, redf[ww]);
+    float mass = 0.f;
+    for (int i = lo; i < hi; ++i) mass += expf(logits[i] * invt - mx);
+    sel_val[tid] = mass;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int j = 0; j < 1024; ++j) tot += sel_val[j];
+        const float target = u * tot;
+        float run = 0.f;
+        int owner = 1023;
+        for (int j = 0; j < 1024; ++j) {
+            if (run + sel_val[j] > target) { owner = j; break; }
+            run += sel_val[j];
+        }
+        // walk the owner's range; `run` is the mass before it
+        const int olo = min(owner * Cn, vocab), ohi = min(olo + Cn, vocab);
+        int pick = max(ohi - 1, 0);
+        for (int i = olo; i < ohi; ++i) {
+            run += expf(logits[i] * invt - mx);
+            if (run > target) { pick = i; break; }
+        }
+        if (ohi <= olo) pick = vocab - 1;
+        s_misc[3] = pick;
+    }
+    __syncthreads();
+    return s_misc[3];
+}
+
 // returns the sampled index to every thread; smem: caller provides the shared arrays
 __device__ int sample_topk_block(const float* __restrict__ logits, int vocab, float temperature, int top_k, float top_p, float u,
                                  unsigned* hist, int* sel_idx, float* sel_val, int* s_misc) {
     const int tid = threadIdx.x;
     int k = top_k;
     if (k <= 0 || k > vocab) k = vocab;
-    if (k > TOPK_CAP) k = TOPK_CAP;
+    if (k == vocab && vocab > TOPK_CAP && !(top_p > 0.f && top_p < 1.f))      // filter off: full-vocabulary multinomial
+        return sample_full_block(logits, vocab, temperature, u, sel_val, s_misc);
+    if (k > TOPK_CAP) k = TOPK_CAP;                 // host entry points reject this case (teo_sampler_supported)
     // ---- radix select of the k-th largest key
     unsigned prefix = 0, mask = 0;
     int want = k;                                   // rank (1 = largest) still to find inside the current prefix class
@@ -473,6 +519,22 @@ __global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restri
     __shared__ int s_misc[4];
     const int pick = sample_topk_block(logits, vocab, temperature, top_k, top_p, uniform01(seed, draw), hist, sel_idx, sel_val, s_misc);
     if (threadIdx.x == 0) *tok = pick;
+}
+
+int sampler_check(int vocab, int top_k, float top_p) {
+    const bool k_off = top_k <= 0 || top_k >= vocab;         // HF: TopKLogitsWarper not applied
+    const bool p_on = top_p > 0.f && top_p < 1.f;
+    if (!k_off && top_k > TOPK_CAP) {
+        set_error("sampler: top_k %d above the device sampler's candidate cap %d (use top_k <= %d, or 0 to disable the filter)",
+                  top_k, TOPK_CAP, TOPK_CAP);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    if (k_off && p_on && vocab > TOPK_CAP) {
+        set_error("sampler: top_p %g without a top_k <= %d needs a nucleus filter over the whole vocabulary (%d): not implemented",
+                  top_p, TOPK_CAP, vocab);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    return TEO_OK;
 }
 
 int sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, float top_p, unsigned long long seed,

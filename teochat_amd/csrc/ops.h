@@ -39,6 +39,8 @@ int embed_splice(const int* plan, const void* embed, const void* visual, void* o
 int drop_cls(const void* in, void* out, int T, int ntok, int dim, int dtype, hipStream_t st);
 int argmax(const float* logits, long long* tok, int rows, int vocab, hipStream_t st);
 int decode_advance(const teo_decode_state* s, hipStream_t st);
+// TEO_OK when the device sampler implements this (top_k, top_p) combination exactly as HF's warpers would apply it
+int sampler_check(int vocab, int top_k, float top_p);
 int sample_topk(const float* logits, long long* tok, int vocab, float temperature, int top_k, float top_p, unsigned long long seed,
                 unsigned long long draw, hipStream_t st);
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,

@@ -14,6 +14,7 @@ Weights arrive keyed by the reference's state-dict names (SURVEY.md section 8a r
 """
 import ctypes as C
 import math
+import warnings
 
 import torch
 
@@ -21,6 +22,7 @@ from . import _lib as L
 
 _ACT = {"quick_gelu": L.ACT_QUICK_GELU, "gelu": L.ACT_GELU_ERF}
 VIT_PREFIX = "model.image_tower.image_tower."
+SEED_MASK = 2 ** 63 - 1            # d_rng is int64 on the host side: one mask for the first draw and the device loop
 
 
 def _dt(dtype):
@@ -91,6 +93,12 @@ class TeoEngine:
             raise RuntimeError("TeoEngine needs an MI355X (no CPU fallback exists for the product path)")
         self.cfg = config
         self.vcfg = config.vision_config
+        if dtype == torch.float16:
+            # the reference runs fp16 (builder.py:105, eval/inference.py:53) and real checkpoints ship fp16 tensors; the kernels
+            # here compute in bf16 (same 16-bit storage, fp32 accumulation, wider exponent): weights are cast once at load
+            warnings.warn("TeoEngine: torch.float16 requested; fp16 weights are cast to bfloat16 at load (the HIP kernels "
+                          "are bf16 / fp32) -- logits differ from an fp16 run by bf16 rounding (8 vs 11 mantissa bits)")
+            dtype = torch.bfloat16
         self.dtype = dtype
         self.dt = _dt(dtype)
         self.device = torch.device(device)
@@ -108,7 +116,7 @@ class TeoEngine:
         self._load_projector(state_dict)
         self._load_llama(state_dict)
         self._alloc_cache()
-        self._alloc_decode_state()
+        self._alloc_decode_state(max_new=max(4096, self.max_seq))
 
     # ------------------------------------------------------------------ weights
     def _dev(self, t):
@@ -386,7 +394,7 @@ class TeoEngine:
         with self.phase() as st:
             lg = logits.to(device=self.device, dtype=torch.float32).contiguous()
             L.check(self.lib.teo_sample_topk(_p(lg), _p(tok), lg.numel(), float(temperature), int(top_k or 0), float(top_p or 1.0),
-                                             int(seed) & (2 ** 64 - 1), int(draw), st), "teo_sample_topk")
+                                             int(seed) & SEED_MASK, int(draw), st), "teo_sample_topk")
         return int(tok.item())
 
     def decode_begin(self, first_token, stop_ids=None, do_sample=False, temperature=1.0, top_k=0, seed=0, draws_done=0, top_p=1.0):
@@ -397,7 +405,8 @@ class TeoEngine:
             self.d_pos.fill_(self.cache_len)
             self.d_count.zero_()
             self.d_stop.zero_()
-            self.d_rng[0] = int(seed) & (2 ** 63 - 1)
+            self.d_rng[0] = int(seed) & SEED_MASK            # the same 63-bit seed teo_sample_topk gets for draw 0
+            self.steps_since_begin = 0
             self.d_rng[1] = int(draws_done)
             n = 0
             if stop_ids:
@@ -422,6 +431,9 @@ class TeoEngine:
         """Run n greedy steps on the device (hipGraph replay by default).  The caller bounds n by max_seq."""
         if self.cache_len + n > self.max_seq:
             raise ValueError(f"decode would exceed max_seq {self.max_seq}")
+        if getattr(self, "steps_since_begin", 0) + n > self.max_new_cap:
+            raise ValueError(f"decode_steps: {self.steps_since_begin + n} tokens since decode_begin exceed the output buffer "
+                             f"({self.max_new_cap}); call decode_begin again or build the engine with a larger max_new")
         ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
         with self.phase() as st:
             if use_graph:
@@ -438,6 +450,7 @@ class TeoEngine:
                     L.check(self.lib.teo_llama_decode_step(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws),
                                                            ws.numel(), st), "teo_llama_decode_step")
         self.cache_len += n
+        self.steps_since_begin = getattr(self, "steps_since_begin", 0) + n
 
     def generated(self):
         n = int(self.d_count.item())

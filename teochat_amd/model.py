@@ -67,10 +67,19 @@ class TeoImageTower:
     def __call__(self, images):
         return self.forward(images)
 
+    def shard_frames(self, comm=None, group=None):
+        """Config C4: from now on a batched forward() encodes only this rank's contiguous block of frames and all-gathers
+        the visual tokens (teochat_amd/parallel.py).  comm: TeoComm (RCCL behind the C ABI); else torch.distributed `group`."""
+        self._shard = (comm, group)
+
     @torch.no_grad()
     def forward(self, images):
         if type(images) is list:
             return [self._engine.vit_features(im.unsqueeze(0)).to(im.dtype) for im in images]
+        shard = getattr(self, "_shard", None)
+        if shard is not None:
+            from .parallel import sharded_frame_features
+            return sharded_frame_features(self._engine.vit_features, images, group=shard[1], comm=shard[0]).to(images.dtype)
         return self._engine.vit_features(images).to(images.dtype)
 
     @property
@@ -203,7 +212,8 @@ class LlavaLlamaForCausalLM:
         self.model = LlavaLlamaModel(engine, processor)
         self.vocab_size = config.vocab_size
         self.pretraining_tp = getattr(config, "pretraining_tp", 1)
-        self.generation_config = SimpleNamespace(eos_token_id=getattr(config, "eos_token_id", None), top_k=50,
+        # HF GenerationConfig defaults; builder.load_generation_config overlays the checkpoint's generation_config.json
+        self.generation_config = SimpleNamespace(eos_token_id=getattr(config, "eos_token_id", None), do_sample=False, top_k=50,
                                                  top_p=1.0, temperature=1.0)
         self.training = False
 
@@ -360,7 +370,7 @@ class LlavaLlamaForCausalLM:
 
     # --- H16
     @torch.no_grad()
-    def generate(self, input_ids=None, images=None, do_sample=False, temperature=1.0, top_k=None, top_p=None,
+    def generate(self, input_ids=None, images=None, do_sample=None, temperature=None, top_k=None, top_p=None,
                  max_new_tokens=20, use_cache=True, stopping_criteria=None, eos_token_id="config", attention_mask=None,
                  generator=None, chunk=16, **kwargs):
         """Greedy or sampled (temperature / top-k, device sampler) decoding of ONE sequence; the loop is device-resident
@@ -369,6 +379,12 @@ class LlavaLlamaForCausalLM:
         Returns int64 [1, n_prompt + n_generated]; the prompt part still contains the -200 sentinels, as with the
         reference (eval/inference.py:75 slices at input_ids.shape[1]).  `eos_token_id=None` disables EOS stopping.
         """
+        # unspecified sampling knobs come from the checkpoint's generation_config.json (HF GenerationMixin semantics)
+        gc = self.generation_config
+        do_sample = bool(getattr(gc, "do_sample", False)) if do_sample is None else do_sample
+        temperature = float(getattr(gc, "temperature", 1.0) or 1.0) if temperature is None else temperature
+        top_k = getattr(gc, "top_k", 50) if top_k is None else top_k
+        top_p = getattr(gc, "top_p", 1.0) if top_p is None else top_p
         if input_ids.shape[0] != 1:
             # batch of conversations: rows are cut by attention_mask, `images` is a list with one entry per conversation
             B = input_ids.shape[0]
@@ -403,7 +419,7 @@ class LlavaLlamaForCausalLM:
         logits = eng.prefill(embeds[0], last_only=True)
         if do_sample:
             tp = 1.0 if top_p is None else float(top_p)
-            k = self.generation_config.top_k if top_k is None else top_k
+            k = int(top_k or 0)                    # 0 = top-k filter off (HF: top_k=0 / None disables TopKLogitsWarper)
             seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
             first = eng.sample(logits[0], temperature, k, seed, 0, top_p=tp)
         else:
@@ -456,7 +472,7 @@ class LlavaLlamaForCausalLM:
         return cur
 
     @torch.no_grad()
-    def generate_batch(self, input_ids_list, images_list=None, do_sample=False, temperature=1.0, top_k=None, top_p=None,
+    def generate_batch(self, input_ids_list, images_list=None, do_sample=False, temperature=None, top_k=None, top_p=None,
                        max_new_tokens=20, stopping_criteria=None, eos_token_id="config", generator=None, chunk=16):
         """Decode B conversations together (B <= 16).  input_ids_list: B 1-D id tensors (with -200 sentinels);
         images_list: per conversation what generate() takes as `images`.  stopping_criteria: None, or one list of
@@ -469,6 +485,10 @@ class LlavaLlamaForCausalLM:
             eos_token_id = getattr(self.config, "eos_token_id", None)
         if max_new_tokens <= 0:
             return [ids.clone() for ids in input_ids_list]
+        gc = self.generation_config
+        temperature = float(getattr(gc, "temperature", 1.0) or 1.0) if temperature is None else temperature
+        top_k = getattr(gc, "top_k", 50) if top_k is None else top_k
+        top_p = getattr(gc, "top_p", 1.0) if top_p is None else top_p
         tp = 1.0 if (top_p is None or not do_sample) else float(top_p)
         crits = list(stopping_criteria) if stopping_criteria is not None else [[] for _ in range(B)]
         if len(crits) != B:
@@ -476,7 +496,7 @@ class LlavaLlamaForCausalLM:
         eng = self.engine
         dec = self.batch_decoder(B, max_new_tokens)
         dec.reset()
-        k = (self.generation_config.top_k if top_k is None else top_k) if do_sample else 0
+        k = int(top_k or 0) if do_sample else 0
         base_seed = 0
         if do_sample:
             base_seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2 ** 62, (1,)).item())

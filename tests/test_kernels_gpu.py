@@ -763,3 +763,41 @@ def test_sampler_top_p_without_top_k_small_vocab():
     assert set(draws) <= keep
     counts = torch.bincount(torch.tensor(draws), minlength=1000).double() / len(draws)
     assert float((counts - p).abs().max()) < 0.05
+
+
+def test_sampler_full_vocabulary_when_top_k_is_disabled():
+    """HF: top_k = 0 (or >= vocab) means TopKLogitsWarper is not applied -> multinomial over the WHOLE vocabulary, not over
+    the device sampler's 1024-candidate cap.  Mass outside the top 1024 must be reachable and the frequencies
+    must follow softmax(logits / T)."""
+    V, n, temp = 5000, 3000, 1.0
+    lg = torch.zeros(V)
+    lg[:40] = 2.0                      # 40 likely tokens ...
+    p = torch.softmax(lg.double() / temp, dim=0)
+    tail_mass = float(p[40:].sum())    # ... and 4960 tokens that together hold ~94 % of the mass
+    assert tail_mass > 0.9
+    dl = lg.cuda()
+    for top_k in (0, V, V + 5):
+        draws = torch.tensor([_sample(dl, temp, top_k, 9, d) for d in range(n)])
+        assert int(draws.min()) >= 0 and int(draws.max()) < V
+        frac_tail = float((draws >= 40).double().mean())
+        assert abs(frac_tail - tail_mass) < 0.03, (top_k, frac_tail, tail_mass)
+        assert int((draws >= 1024).sum()) > 0.5 * n           # indices far beyond any 1024-candidate window
+        assert len(set(draws.tolist())) > 1500
+    # index-ordered inverse CDF: a one-hot distribution returns its index for every uniform
+    lg2 = torch.full((40000,), -50.0)
+    lg2[31999] = 50.0
+    assert all(_sample(lg2.cuda(), 1.0, 0, s, 0) == 31999 for s in range(5))
+    # determinism: (seed, draw) fixes the token
+    assert [_sample(dl, temp, 0, 4, d) for d in range(32)] == [_sample(dl, temp, 0, 4, d) for d in range(32)]
+
+
+def test_sampler_rejects_what_it_cannot_do_exactly():
+    lg = torch.randn(32000).cuda()
+    tok = torch.empty(1, dtype=torch.int64, device="cuda")
+    # top_k above the candidate cap but not "off"
+    assert G.lib().teo_sample_topk(G.p(lg), G.p(tok), 32000, 1.0, 2000, 1.0, 1, 0, G.stream()) == -2
+    assert b"top_k" in G.lib().teo_last_error()
+    # nucleus filter over the whole vocabulary
+    assert G.lib().teo_sample_topk(G.p(lg), G.p(tok), 32000, 1.0, 0, 0.9, 1, 0, G.stream()) == -2
+    assert b"top_p" in G.lib().teo_last_error()
+    assert G.lib().teo_sample_topk(G.p(lg), G.p(tok), 32000, 1.0, 50, 0.9, 1, 0, G.stream()) == 0

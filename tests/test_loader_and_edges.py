@@ -342,3 +342,17 @@ def test_image_tower_is_resolved_from_mm_image_tower_not_defaulted(tmp_path, mon
     c3 = LlavaConfig.from_pretrained(path)
     with pytest.raises(ValueError, match="hidden_act"):
         B.resolve_image_tower(c3, src, path, None, "cpu")
+
+
+def test_generation_config_json_overlays_the_defaults(tmp_path):
+    from types import SimpleNamespace
+    from teochat_amd.builder import load_generation_config
+    m = SimpleNamespace(generation_config=SimpleNamespace(do_sample=False, top_k=50, top_p=1.0, temperature=1.0, eos_token_id=2))
+    assert load_generation_config(m, str(tmp_path)) is False                  # no file: HF defaults stay
+    assert (m.generation_config.top_p, m.generation_config.top_k) == (1.0, 50)
+    json.dump({"do_sample": True, "temperature": 0.6, "top_p": 0.9, "eos_token_id": 2, "transformers_version": "4.31.0"},
+              open(tmp_path / "generation_config.json", "w"))                 # what LLaMA-2 ships
+    assert load_generation_config(m, str(tmp_path)) is True
+    gc = m.generation_config
+    assert (gc.do_sample, gc.temperature, gc.top_p, gc.top_k) == (True, 0.6, 0.9, 50)
+    assert load_generation_config(m, "synthetic:teochat-7b") is False

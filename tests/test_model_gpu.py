@@ -375,3 +375,60 @@ def test_training_shape_forward_loss_matches_reference(name):
     none = torch.full_like(labels, -100)
     o2 = model(input_ids=ids.to(dev), attention_mask=mask.to(dev), labels=none.to(dev), images=[f.to(dev) for f in frames])
     assert bool(torch.isnan(o2.loss))
+
+
+@pytest.mark.parametrize("name", ["tinyA"])
+def test_cls_patch_select_feature(name):
+    """feature_select 'cls_patch' (languagebind/__init__.py:125-126): the CLS row stays -> [T, 257, D]; rows 1.. equal the
+    'patch' features bit for bit, the whole tensor equals the oracle's hidden_states[-2] (fp32)."""
+    g = TY.load_npz(name)
+    frames, ids = inputs(name, g)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    m_patch, sd = build(name, torch.float32)
+    m_cls, _ = build(name, torch.float32, mm_vision_select_feature="cls_patch")
+    pix = torch.stack(frames).to(m_cls.device)
+    fp = m_patch.get_image_tower()(pix)
+    fc = m_cls.get_image_tower()(pix)
+    assert fc.shape == (pix.shape[0], vcfg.num_positions, vcfg.hidden_size) and fp.shape[1] == fc.shape[1] - 1
+    assert torch.equal(fc[:, 1:], fp)
+    ref = O.vit_features(torch.stack(frames), sd, vcfg, -2, "cls_patch")
+    assert float((fc.cpu() - ref).abs().max()) < FP32_TOL
+    with pytest.raises(ValueError, match="Unexpected select feature"):
+        build(name, torch.float32, mm_vision_select_feature="cls")
+
+
+def test_decode_steps_is_bounded_by_the_output_buffer():
+    """d_out_tokens has max_new_cap entries; stepping past it must raise, not overrun the device buffer."""
+    model, _ = build("tinyA", torch.float32)
+    eng = model.engine
+    eng.max_new_cap = 8                                        # pretend the buffer is tiny
+    ids = torch.tensor([[1, 5, 9]], device=eng.device)
+    eng.reset_cache()
+    lg = eng.prefill(model.get_model().embed_tokens(ids)[0], last_only=True)
+    eng.decode_begin(int(lg[0].argmax()))
+    eng.decode_steps(8)
+    with pytest.raises(ValueError, match="output buffer"):
+        eng.decode_steps(1)
+    eng.decode_begin(3)                                        # re-arming resets the count
+    eng.decode_steps(2)
+
+
+def test_sampling_defaults_come_from_generation_config():
+    """HF semantics: knobs the caller leaves unset fall back to generation_config (top_p = 0.9 of a LLaMA-2 checkpoint)."""
+    model, _ = build("tinyA", torch.float32)
+    ids = torch.tensor([[1, 5, 9, 11]], device=model.device)
+    gen = torch.Generator().manual_seed(5)
+    model.generation_config.top_p, model.generation_config.top_k = 0.5, 7
+    a = model.generate(input_ids=ids, do_sample=True, temperature=0.9, max_new_tokens=12, eos_token_id=None, generator=gen)
+    b = model.generate(input_ids=ids, do_sample=True, temperature=0.9, top_k=7, top_p=0.5, max_new_tokens=12, eos_token_id=None,
+                       generator=gen)
+    c = model.generate(input_ids=ids, do_sample=True, temperature=0.9, top_k=7, top_p=1.0, max_new_tokens=12, eos_token_id=None,
+                       generator=gen)
+    assert torch.equal(a, b)                                   # unset knobs == the generation_config's values
+    assert a.shape == c.shape
+    big = 2 ** 63 + 12345                                      # seeds >= 2^63: first draw and device loop use the same masked seed
+    g2 = torch.Generator().manual_seed(big & (2 ** 63 - 1))
+    g3 = torch.Generator().manual_seed(big & (2 ** 63 - 1))
+    x = model.generate(input_ids=ids, do_sample=True, temperature=1.0, max_new_tokens=6, eos_token_id=None, generator=g2)
+    y = model.generate(input_ids=ids, do_sample=True, temperature=1.0, max_new_tokens=6, eos_token_id=None, generator=g3)
+    assert torch.equal(x, y)

@@ -215,3 +215,26 @@ def test_kernel_emulating_modes_agree_with_exact_on_masked_ragged_shapes():
         for mode in ("flash64", "split128"):
             out = O.attention_core(q, k, v, vis, d ** -0.5, ident, mode)
             assert float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (mode, Sq, Sk)
+
+
+def test_preallocated_kv_cache_equals_the_growing_cache():
+    """bench.py's cpu_baseline times the oracle with KVCache(capacity=...): same numbers as the torch.cat cache, bit for bit."""
+    name = "tinyA"
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd = TY.state_dict(name)
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(1, 11, lcfg.hidden_size, generator=g)
+    a_log, a_cache = O.llama_forward(emb, None, None, None, sd, lcfg)
+    b_log, b_cache = O.llama_forward(emb, None, None, O.KVCache(capacity=16), sd, lcfg)
+    assert torch.equal(a_log, b_log)
+    for _ in range(3):
+        e = torch.randn(1, 1, lcfg.hidden_size, generator=g)
+        a_log, a_cache = O.llama_forward(e, None, None, a_cache, sd, lcfg)
+        b_log, b_cache = O.llama_forward(e, None, None, b_cache, sd, lcfg)
+        assert torch.equal(a_log, b_log)
+    assert a_cache.length == b_cache.length == 14
+    assert all(torch.equal(x, y) for x, y in zip(a_cache.k + a_cache.v, b_cache.k + b_cache.v))
+    with pytest.raises(ValueError, match="capacity"):
+        O.llama_forward(torch.randn(1, 3, lcfg.hidden_size), None, None, b_cache, sd, lcfg)
+    sdt = O.make_state_dict_for_timing(vcfg, lcfg, mm)
+    assert set(sdt) == set(sd) and all(sdt[k].shape == sd[k].shape for k in sd)

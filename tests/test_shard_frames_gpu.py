@@ -79,3 +79,35 @@ def test_sharded_real_tower_equals_unsharded_bitwise(T):
         assert proj_equal
         sums.add(s)
     assert len(sums) == 1                               # both ranks hold the same features
+
+
+def test_rccl_allgather_behind_the_c_abi_single_rank():
+    """teo_ctx_create / teo_allgather_visual run RCCL itself (ncclCommInitRank + ncclAllGather) on this GPU: a one-rank
+    communicator is all a single-GPU box can host (two ranks on one device are refused by RCCL), the N-rank path is the same
+    call with a shared unique id.  Also the sharded tower routed through it (world 1: rank 0 owns every frame)."""
+    import ctypes as C
+    from teochat_amd import _lib as L
+    from teochat_amd.parallel import TeoComm, sharded_frame_features
+    comm = TeoComm(0, 1, 0)
+    r, w, cu, hbm = C.c_int(-1), C.c_int(-1), C.c_int(0), C.c_size_t(0)
+    L.check(comm.lib.teo_ctx_info(comm.handle, C.byref(r), C.byref(w), C.byref(cu), C.byref(hbm)), "teo_ctx_info")
+    assert (r.value, w.value) == (0, 1) and cu.value == 256 and hbm.value > 200 * 2 ** 30      # MI355X: 256 CUs, 288 GB
+    for dtype in (torch.bfloat16, torch.float32):
+        send = torch.randn(512, 1024, device="cuda:0").to(dtype)
+        recv = torch.zeros_like(send)
+        comm.all_gather_rows(send, recv)
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+    # a second unique id can be drawn and is 128 opaque bytes
+    uid = (C.c_char * L.COMM_ID_BYTES)()
+    L.check(comm.lib.teo_comm_unique_id(uid), "teo_comm_unique_id")
+    assert any(b != 0 for b in uid.raw)
+    # the sharded tower through the communicator
+    from oracle import teo_oracle as O
+    eng = _engine()
+    px = torch.stack(O.synthetic_frames(3, 224, seed=1)).to("cuda:0", dtype=torch.bfloat16)
+    assert torch.equal(sharded_frame_features(eng.vit_features, px, comm=comm), eng.vit_features(px))
+    # argument errors come back as status codes, not crashes
+    assert comm.lib.teo_allgather_visual(comm.handle, None, None, 4, 8, L.TEO_BF16, None) == -1
+    assert comm.lib.teo_allgather_visual(None, None, None, 4, 8, L.TEO_BF16, None) == -1
+    comm.close()
