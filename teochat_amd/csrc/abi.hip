@@ -342,7 +342,8 @@ int teo_time_gemv_chain(const void* x, const void* const* Ws, const float* const
 }
 
 size_t teo_attn_decode_workspace_bytes(int heads, int head_dim, int max_seq, int batch) {
-    return (heads > 0 && head_dim > 0 && max_seq > 0 && batch > 0) ? attn_decode_ws_bytes(heads, head_dim, max_seq, batch) : 0;
+    if (!(heads > 0 && head_dim > 0 && max_seq > 0 && batch > 0)) return 0;
+    return attn_decode_counters_offset(heads, head_dim, max_seq, batch) + (size_t)batch * heads * sizeof(int);
 }
 
 int teo_attn_decode(const void* q, void* k_cache, void* v_cache, void* vt_cache, const float* rope_cos, const float* rope_sin,
@@ -356,8 +357,14 @@ int teo_attn_decode(const void* q, void* k_cache, void* v_cache, void* vt_cache,
     TEO_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "teo_attn_decode: rope_cos and rope_sin go together");
     AttnBatch bt;
     bt.batch = batch; bt.q_stride = q_stride; bt.cache_stride = cache_stride; bt.o_stride = o_stride;
+    int* counters = nullptr;
+    if (attn_decode_fused_enabled()) {                  // in-kernel merge of the KV splits: arrival counters behind the records
+        counters = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(partials) + attn_decode_counters_offset(heads, head_dim, max_seq, batch));
+        hipError_t e = hipMemsetAsync(counters, 0, (size_t)batch * heads * sizeof(int), ST(s));
+        if (e != hipSuccess) return hip_fail(e, "teo_attn_decode: hipMemsetAsync");
+    }
     return attn_decode(q, k_cache, v_cache, vt_cache, rope_cos, rope_sin, out, partials, d_pos, max_seq, heads, kv_heads, head_dim,
-                       scale, dtype, ST(s), bt, nullptr);
+                       scale, dtype, ST(s), bt, counters);
 }
 
 int teo_cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,

@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(teo_attn_args a) {
     }
 }
 
+static int g_attn_flash = 1;      // 1: attn_flash32_kernel (flash.hip, 32x32x16 MFMA, 128 queries per workgroup); 0: the round-1 kernel
+
 bool attn_mfma_ok(const teo_attn_args& a, int dtype) {
     if (dtype != TEO_BF16 || (a.flags & TEO_ATTN_FORCE_SIMPLE) || a.vt == nullptr) return false;
     if (a.head_dim != 64 && a.head_dim != 128) return false;
@@ -259,6 +261,7 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
     if (a.q_len == 0 || a.batch == 0) return TEO_OK;
     TEO_CHECK_ARG(a.heads % a.kv_heads == 0, "teo_attention: heads %d not a multiple of kv_heads %d", a.heads, a.kv_heads);
     TEO_CHECK_ARG(a.kv_len >= a.q_len || !a.causal, "teo_attention: causal needs kv_len >= q_len");
+    if (attn_mfma_ok(a, dtype) && g_attn_flash) return attention_flash32(a, st);
     if (attn_mfma_ok(a, dtype)) {
         dim3 grid(cdiv(a.q_len, 64), a.heads, a.batch);
         const size_t lds = 64 * a.head_dim * 2 + a.head_dim * 128;
@@ -303,6 +306,7 @@ int g_rope_in_attn = -1;          // decode RoPE + KV append: 0 = in the QKV GEM
                                    // -1 = auto (measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0,
                                    // fp8 weights 2.216 vs 2.234 in favour of 1)
 int attn_tune_set(const char* key, int value) {
+    if (!strcmp(key, "attn_flash")) { g_attn_flash = value != 0; return 0; }
     if (!strcmp(key, "attn_chunk") && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
     if (!strcmp(key, "attn_fused_combine")) { g_fused_combine = value != 0; return 0; }
     if (!strcmp(key, "rope_in_attn") && (value >= -1 && value <= 1)) { g_rope_in_attn = value; return 0; }
@@ -518,33 +522,58 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
         for (int e = 0; e < VE; ++e) obuf[wid][sub * VE + e] = acc[e];
     }
     __syncthreads();
-    for (int d = tid; d < HD; d += 256) out[2 + d] = obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d];
-    if (tid == 0) { out[0] = mx; out[1] = sum; }
-    if (!counters) return;
-    // ---- fused combine: the LAST workgroup of this head to finish merges the splits (saves the combine launch).
-    // Cross-workgroup visibility on gfx950 (per-XCD L2s are not coherent): every wave's stores are complete at the
-    // barrier (hipcc's __syncthreads waits vmcnt(0)), one lane publishes them with an agent-scope release fence, takes
-    // a ticket, and the last arriver runs an agent-scope acquire fence before anyone reads the other splits.
+    if (!counters) {
+        for (int d = tid; d < HD; d += 256) out[2 + d] = obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d];
+        if (tid == 0) { out[0] = mx; out[1] = sum; }
+        return;
+    }
+    // ---- fused combine: the LAST workgroup of this head to finish merges the splits (no combine launch, no fences).
+    // Hand-off protocol (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores):
+    //   producer : the partial record is stored WRITE-THROUGH (relaxed agent-scope atomic stores = `global_store ... sc1`),
+    //              every storing wave drains its stores (`s_waitcnt vmcnt(0)`), the workgroup meets at a barrier, ONE lane
+    //              takes a ticket with a relaxed agent-scope fetch_add;
+    //   consumer : the workgroup that draws the last ticket reads every record with sc1 loads (relaxed agent-scope atomic
+    //              loads: they bypass this CU's L1 and are coherent with the write-through stores of the other XCDs).
+    // No release/acquire fence anywhere: an agent-scope release writes back the XCD's whole dirty L2 (that is what made the
+    // round-1 form of this path 20 % slower than a separate combine launch).  The records are re-used every token, so a
+    // stale line would show up at once: the result is compared bit for bit with the two-launch path in the tests (the merge
+    // below adds the splits in exactly the order attn_decode_combine_kernel does).
+    for (int d = tid; d < HD; d += 256)
+        __hip_atomic_store(out + 2 + d, obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        __hip_atomic_store(out, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(out + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave: its write-through stores have landed
     __shared__ int s_last;
     __shared__ float wgt[256];
+    __shared__ float accs[512];
     __syncthreads();
     const int nact = (kv_len + DEC_CHUNK - 1) / DEC_CHUNK;
     if (tid == 0) {
-        __threadfence();
-        const int ticket = atomicAdd(&counters[h], 1);
+        const int ticket = __hip_atomic_fetch_add(&counters[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = ticket == nact - 1;
-        if (last) {
-            counters[h] = 0;                            // re-armed for the next launch
-            __threadfence();
-        }
+        if (last) __hip_atomic_store(&counters[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
         s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
     const int stride = HD + 2;
     const float* pb = part + (long long)h * nsplit * stride;
+#define TEO_LD_SC1(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+    // Same arithmetic, same order as attn_decode_combine_kernel (G = 512 / HD split groups per column, group g sums the
+    // splits g, g + G, ... in order, the G group sums are added in order): a thread here carries two of those groups.
+    constexpr int G = 512 / HD;                                  // HD is a power of two in [32, 256] -> G in [2, 16]
+    constexpr int GP = G / (256 / HD) > 0 ? G / (256 / HD) : 1;  // groups per thread (256 threads cover 256 / HD groups at once)
+    const int dcol = tid % HD, g0 = tid / HD;                    // thread owns groups g0 + j * (256 / HD), j < GP
+    float v0[GP][8];
+#pragma unroll
+    for (int j = 0; j < GP; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v0[j][i] = TEO_LD_SC1(pb + (long long)min(g0 + j * (256 / HD) + i * G, nact - 1) * stride + 2 + dcol);
     float m0 = -INFINITY, l0 = 0.f;
-    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
+    if (tid < nact) { m0 = TEO_LD_SC1(pb + tid * stride); l0 = TEO_LD_SC1(pb + tid * stride + 1); }
     float M = wave_max(m0);
     if (lane == 0) red[wid] = M;
     __syncthreads();
@@ -552,21 +581,30 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
     wgt[tid] = w0;
     float Ls = wave_sum(l0 * w0);
-    __syncthreads();
     if (lane == 0) red[4 + wid] = Ls;
     __syncthreads();
     const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-    for (int d = tid; d < HD; d += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int s_ = 0;
-        for (; s_ + 4 <= nact; s_ += 4) {
-            const float v0 = pb[s_ * stride + 2 + d], v1 = pb[(s_ + 1) * stride + 2 + d];
-            const float v2 = pb[(s_ + 2) * stride + 2 + d], v3 = pb[(s_ + 3) * stride + 2 + d];
-            a0 = fmaf(v0, wgt[s_], a0); a1 = fmaf(v1, wgt[s_ + 1], a1);
-            a2 = fmaf(v2, wgt[s_ + 2], a2); a3 = fmaf(v3, wgt[s_ + 3], a3);
+#pragma unroll
+    for (int j = 0; j < GP; ++j) {
+        const int g = g0 + j * (256 / HD);
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += (g + i * G < nact) ? v0[j][i] * wgt[min(g + i * G, 255)] : 0.f;
+        for (int s0 = g + 8 * G; s0 < nact; s0 += 8 * G) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = TEO_LD_SC1(pb + (long long)min(s0 + i * G, nact - 1) * stride + 2 + dcol);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * wgt[min(s0 + i * G, 255)] : 0.f;
         }
-        for (; s_ < nact; ++s_) a0 = fmaf(pb[s_ * stride + 2 + d], wgt[s_], a0);
-        Elem<T>::st(o_out + h * HD + d, ((a0 + a1) + (a2 + a3)) * inv);
+        accs[g * HD + dcol] = a;
+    }
+#undef TEO_LD_SC1
+    __syncthreads();
+    if (tid < HD) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += accs[tid + k * HD];
+        Elem<T>::st(o_out + h * HD + tid, t * inv);
     }
 }
 
@@ -628,6 +666,11 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
     const int nsplit = cdiv(S_max, 32);      // sized for the smallest chunk
     return (size_t)batch * heads * nsplit * (hd + 2) * sizeof(float);
 }
+// the exported primitive (teo_attn_decode) keeps the arrival counters of the fused combine behind the partial records
+size_t attn_decode_counters_offset(int heads, int hd, int S_max, int batch) {
+    return (attn_decode_ws_bytes(heads, hd, S_max, batch) + 255) / 256 * 256;
+}
+bool attn_decode_fused_enabled() { return g_fused_combine != 0; }
 
 template <typename T, int LPR>
 static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o,

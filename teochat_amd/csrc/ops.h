@@ -20,6 +20,9 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
          int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
 int attention(const teo_attn_args* a, int dtype, hipStream_t st);
+int attention_flash32(const teo_attn_args& a, hipStream_t st);
+size_t attn_decode_counters_offset(int heads, int hd, int S_max, int batch);
+bool attn_decode_fused_enabled();
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;

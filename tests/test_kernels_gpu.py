@@ -801,3 +801,68 @@ def test_sampler_rejects_what_it_cannot_do_exactly():
     assert G.lib().teo_sample_topk(G.p(lg), G.p(tok), 32000, 1.0, 0, 0.9, 1, 0, G.stream()) == -2
     assert b"top_p" in G.lib().teo_last_error()
     assert G.lib().teo_sample_topk(G.p(lg), G.p(tok), 32000, 1.0, 50, 0.9, 1, 0, G.stream()) == 0
+
+
+@pytest.mark.parametrize("dtype,H,Hk,d,S", [(torch.bfloat16, 32, 32, 128, 2560), (torch.bfloat16, 8, 2, 64, 1024),
+                                            (torch.float32, 4, 2, 32, 512)])
+@pytest.mark.parametrize("chunk", [0, 128])
+def test_attn_decode_fused_combine_is_bitwise_the_two_launch_path(dtype, H, Hk, d, S, chunk):
+    """The in-kernel merge of the KV splits (last-arriving workgroup of a head; write-through sc1 records + relaxed ticket, no
+    fences) against the separate combine launch: same arithmetic in the same order -> BIT-identical outputs.  The records
+    and counters are re-used launch after launch with changing positions, alone and under a concurrent HBM stream on another
+    HIP stream (uneven load), consumer lines warm from the previous launch: any stale read shows up as a mismatch."""
+    B = 3
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, H, d, generator=g)
+    K = torch.randn(B, Hk, S, d, generator=g)
+    V = torch.randn(B, Hk, S, d, generator=g)
+    dq, dK, dV = q.to("cuda", dtype).contiguous(), K.to("cuda", dtype).contiguous(), V.to("cuda", dtype).contiguous()
+    lib = G.lib()
+    part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, B), dtype=torch.uint8, device="cuda")
+    part2 = torch.empty_like(part)
+    pos = torch.zeros(B, dtype=torch.int32, device="cuda")
+    out_f = torch.empty(B, H * d, dtype=dtype, device="cuda")
+    out_u = torch.empty_like(out_f)
+    assert lib.teo_tune_set(b"attn_chunk", chunk) == 0
+    side = torch.cuda.Stream()
+    big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")       # 256 MB: copies stream through HBM
+    big2 = torch.empty_like(big)
+
+    def run(fused, out, ws):
+        assert lib.teo_tune_set(b"attn_fused_combine", 1 if fused else 0) == 0
+        L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), None, None, None, G.p(out), G.p(ws), G.p(pos), S, H, Hk, d,
+                                    1.0 / d ** 0.5, G.DT[dtype], B, H * d, Hk * S * d, H * d, G.stream()), "attn_decode")
+
+    try:
+        rng = torch.Generator().manual_seed(9)
+        n_mismatch = 0
+        for it in range(60):
+            ctx = torch.randint(1, S + 1, (B,), generator=rng)
+            if it % 7 == 0:
+                ctx[0] = S                                                       # every split active
+            if it % 11 == 0:
+                ctx[1] = 1                                                       # a single key
+            pos.copy_((ctx - 1).to(torch.int32))
+            if it % 2:
+                with torch.cuda.stream(side):                                    # load on the memory system while the hand-offs run
+                    for _ in range(3):
+                        big2.copy_(big)
+            run(True, out_f, part)
+            run(False, out_u, part2)
+            torch.cuda.synchronize()
+            n_mismatch += int(not torch.equal(out_f, out_u))
+            # and the fused path again on the SAME records right away (previous launch's lines still cached)
+            run(True, out_u, part)
+            torch.cuda.synchronize()
+            n_mismatch += int(not torch.equal(out_f, out_u))
+        assert n_mismatch == 0, f"{n_mismatch} of 120 comparisons differ"
+        ref = _decode_attn_ref(q[0] if dtype == torch.float32 else G.bf16_round(q[0]),
+                               K[0] if dtype == torch.float32 else G.bf16_round(K[0]),
+                               V[0] if dtype == torch.float32 else G.bf16_round(V[0]), int(pos[0]) + 1)
+        if dtype == torch.float32:
+            torch.testing.assert_close(out_f[0].cpu(), ref, atol=2e-5, rtol=1e-5)
+        else:
+            close_bf16(out_f[0], G.bf16_round(ref), ulps=2.0, floor=4e-3)
+    finally:
+        lib.teo_tune_set(b"attn_chunk", 0)
+        lib.teo_tune_set(b"attn_fused_combine", 0)

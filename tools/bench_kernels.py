@@ -186,14 +186,23 @@ def bench_gemm():
 
 
 def bench_attn_prefill():
-    for (H, S, d, causal) in [(32, 2168, 128, True), (128, 257, 64, False)]:
-        q = torch.randn(1, H, S, d, device="cuda").to(bf)
-        k = torch.randn(1, H, S, d, device="cuda").to(bf)
-        v = torch.randn(1, H, S, d, device="cuda").to(bf)
+    """flash32 (flash.hip) vs the round-1 kernel (attn_flash = 0), interleaved in one process."""
+    for (B, H, S, d, causal) in [(1, 32, 2168, 128, True), (1, 32, 4208, 128, True), (8, 16, 257, 64, False), (1, 32, 638, 128, True)]:
+        q = torch.randn(B, H, S, d, device="cuda").to(bf)
+        k = torch.randn(B, H, S, d, device="cuda").to(bf)
+        v = torch.randn(B, H, S, d, device="cuda").to(bf)
         vt = G.make_vt(v)
-        us = timeit(lambda: G.attention(q, k, v, causal, d ** -0.5, vt=vt))
-        fl = 4.0 * H * S * S * d * (0.5 if causal else 1.0)
-        print(f"attn prefill H={H} S={S} d={d} causal={causal}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+        fl = 4.0 * B * H * S * S * d * (0.5 if causal else 1.0)
+        res = {}
+        for rnd_ in range(3):
+            for flash in (1, 0):
+                lib.teo_tune_set(b"attn_flash", flash)
+                us = timeit(lambda: G.attention(q, k, v, causal, d ** -0.5, vt=vt))
+                res.setdefault(flash, []).append(us)
+        lib.teo_tune_set(b"attn_flash", 1)
+        a, b_ = min(res[1]), min(res[0])
+        print(f"attn prefill B={B} H={H} S={S} d={d} causal={causal}: flash32 {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s | "
+              f"round-1 kernel {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s", flush=True)
 
 
 def bench_norm():
