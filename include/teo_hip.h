@@ -166,6 +166,11 @@ int teo_cross_entropy(const float* d_logits, long long ld, const long long* d_la
  * anti-aliased bicubic (a = -0.5, align_corners = False); H == W == S is the identity. */
 int teo_preprocess_frames(const unsigned char* d_src, void* d_out, int T, int H, int W, int S, const float* mean,
                           const float* std, int dtype, teo_stream_t stream);
+/* The same behind expand2square (videollava/mm_utils.py:14-25,28-36: `image_aspect_ratio == 'pad'`): the frame is first pasted,
+ * centred (offset (side - n) // 2), on a square canvas of its longer side filled with pad_rgb (HOST pointer to 3 bytes, the
+ * reference passes tuple(int(m * 255) for m in image_mean)); the canvas is never materialised. */
+int teo_preprocess_frames_pad(const unsigned char* d_src, void* d_out, int T, int H, int W, int S, const float* mean,
+                              const float* std, const unsigned char* pad_rgb, int dtype, teo_stream_t stream);
 
 /* out[t, p, :] = in[t, 1+p, :]  (feature_select 'patch', languagebind/__init__.py:121-129) */
 int teo_drop_cls(const void* d_in, void* d_out, int T, int n_tokens, int dim, int dtype, teo_stream_t stream);

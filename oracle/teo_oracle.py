@@ -202,6 +202,56 @@ def preprocess_uint8(img_hwc_u8: torch.Tensor) -> torch.Tensor:
 
 
 
+def resize_geometry(h: int, w: int, size: int = 224):
+    """torchvision 0.17.1 (pyproject.toml:16) `Resize(size)` with an int size: the shorter edge becomes `size`, the other
+    int(size * long / short); then `CenterCrop(size)`: offsets int(round((n - size) / 2.0)) (Python round = half-to-even).
+    Returns (new_h, new_w, crop_top, crop_left)."""
+    if h <= w:
+        nh, nw = size, int(size * w / h)
+    else:
+        nh, nw = int(size * h / w), size
+    return nh, nw, int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+
+
+def preprocess_image(img_hwc_u8: torch.Tensor, size: int = 224) -> torch.Tensor:
+    """processing_image.py:15-25 get_image_transform for an arbitrary uint8 HWC RGB image:
+        ToTensor()                                      uint8 HWC -> float32 CHW / 255
+        Resize(224, interpolation=BICUBIC)              on a TENSOR: torchvision 0.17.1 calls
+                                                        F.interpolate(mode="bicubic", align_corners=False, antialias=True)
+                                                        (antialias defaults to True since 0.17; float input is not clamped)
+        CenterCrop(224)
+        Normalize(OPENAI_DATASET_MEAN, OPENAI_DATASET_STD)
+    torchvision is not installed here; the ATen op it dispatches to is (same torch call).  Pinned by
+    tests/test_oracle_golden.py: identity / analytic cases and a PIL-bicubic cross-check."""
+    x = img_hwc_u8.to(torch.float32).div(255.0).permute(2, 0, 1)
+    _, h, w = x.shape
+    nh, nw, top, left = resize_geometry(h, w, size)
+    if (nh, nw) != (h, w):
+        x = F.interpolate(x[None], size=(nh, nw), mode="bicubic", align_corners=False, antialias=True)[0]
+    x = x[:, top:top + size, left:left + size]
+    mean = torch.tensor(OPENAI_DATASET_MEAN, dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor(OPENAI_DATASET_STD, dtype=torch.float32).view(3, 1, 1)
+    return (x - mean) / std
+
+
+def expand2square_u8(img_hwc_u8: torch.Tensor, background_rgb) -> torch.Tensor:
+    """mm_utils.py:14-25 expand2square on an array: square canvas of the longer side filled with `background_rgb`, the image
+    pasted centred (offset (side - n) // 2 along the shorter axis)."""
+    h, w, _ = img_hwc_u8.shape
+    if h == w:
+        return img_hwc_u8
+    side = max(h, w)
+    canvas = torch.tensor(list(background_rgb), dtype=torch.uint8).view(1, 1, 3).expand(side, side, 3).clone()
+    oy, ox = (side - h) // 2, (side - w) // 2
+    canvas[oy:oy + h, ox:ox + w] = img_hwc_u8
+    return canvas
+
+
+def pad_fill_from_mean(image_mean):
+    """mm_utils.py:34: tuple(int(x * 255) for x in image_processor.image_mean)."""
+    return tuple(int(x * 255) for x in image_mean)
+
+
 # --------------------------------------------------------------------------------------
 # attention core shared by the ViT and LLaMA restatements
 # --------------------------------------------------------------------------------------

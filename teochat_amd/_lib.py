@@ -136,6 +136,8 @@ _SIGS = {
                                     C.c_void_p]),
     "teo_preprocess_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                         C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "teo_preprocess_frames_pad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), C.POINTER(C.c_ubyte), C.c_int, C.c_void_p]),
     "teo_gemm_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
                         + [C.c_int] * 5 + [C.c_uint, C.c_int, C.c_void_p]),
     "teo_time_skinny_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint,

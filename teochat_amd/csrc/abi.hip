@@ -386,6 +386,16 @@ int teo_preprocess_frames(const unsigned char* src, void* out, int T, int H, int
     return preprocess_frames(src, out, T, H, W, S, mean, stdv, dtype, ST(s));
 }
 
+int teo_preprocess_frames_pad(const unsigned char* src, void* out, int T, int H, int W, int S, const float* mean, const float* stdv,
+                              const unsigned char* pad_rgb, int dtype, teo_stream_t s) {
+    ENTER();
+    NEED_DT(dtype);
+    TEO_CHECK_ARG(T >= 0 && H > 0 && W > 0 && S > 0, "teo_preprocess_frames_pad: T %d H %d W %d S %d", T, H, W, S);
+    NEED(mean, "mean"); NEED(stdv, "std"); NEED(pad_rgb, "pad_rgb");
+    if (T) { NEED(src, "src"); NEED(out, "out"); }
+    return preprocess_frames(src, out, T, H, W, S, mean, stdv, dtype, ST(s), pad_rgb);
+}
+
 int teo_gemm_skinny(const void* x, const void* W, const float* w_scale, int w_fp8, const void* norm_w, float eps, const void* res,
                     void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, teo_stream_t s) {
     ENTER();

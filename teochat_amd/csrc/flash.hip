@@ -50,9 +50,22 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ql = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    // 1-D grid -> (batch*head, query block).  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2):
+    // XCD x takes the heads = x (mod 8), so every query block of a head streams that head's K / V^T through ONE L2, and
+    // inside an XCD consecutive slots walk the heads at equal query block, late (heavy, causal) query blocks first.
+    const int nqb = (a.q_len + 127) >> 7, nbh = a.heads * a.batch;
+    int bh, qidx;
+    if ((nbh & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, hpx = nbh >> 3;
+        bh = xcd + 8 * (slot % hpx);
+        qidx = slot / hpx;
+    } else {
+        bh = blockIdx.x % nbh;
+        qidx = blockIdx.x / nbh;
+    }
+    const int h = bh % a.heads, b = bh / a.heads;
     const int hk = h / (a.heads / a.kv_heads);
-    const int qb = ((int)gridDim.x - 1 - (int)blockIdx.x) * 128;       // heavy (late) query blocks are dispatched first
+    const int qb = (nqb - 1 - qidx) * 128;
     const int off = a.kv_len - a.q_len;
     const bf16_t* Q = (const bf16_t*)a.q + b * a.q_bs + h * a.q_hs;
     const bf16_t* K = (const bf16_t*)a.k + b * a.k_bs + hk * a.k_hs;
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
 }
 
 int attention_flash32(const teo_attn_args& a, hipStream_t st) {
-    dim3 grid(cdiv(a.q_len, 128), a.heads, a.batch);
+    dim3 grid(cdiv(a.q_len, 128) * a.heads * a.batch);
     const size_t lds = 2 * (size_t)(64 * a.head_dim * 2 + a.head_dim * 128);
     if (a.head_dim == 128) {
         if (a.causal) attn_flash32_kernel<128, true><<<grid, 256, lds, st>>>(a);

@@ -57,7 +57,7 @@ int gemv(const void* x, const void* W, const void* norm_w, const void* res, void
          unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
 int preprocess_frames(const unsigned char* src, void* out, int T, int H, int W, int S, const float* mean, const float* stdv,
-                      int dtype, hipStream_t st);
+                      int dtype, hipStream_t st, const unsigned char* pad_rgb = nullptr);
 int cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
                   long long ignore_index, hipStream_t st);
 int gemv_tune_set(const char* key, int value);

@@ -43,10 +43,13 @@ __device__ __forceinline__ void aa_taps(int i, int in_size, int out_size, int& x
     for (int j = 0; j < xsize; ++j) w[j] *= inv;
 }
 
-template <typename T>
+// PAD: the source is pasted at (oy, ox) into a virtual Hc x Wc canvas filled with (f0, f1, f2) -- expand2square of the
+// reference (mm_utils.py:14-25, image_aspect_ratio == 'pad') without materialising the padded image.
+template <typename T, bool PAD>
 __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __restrict__ src, T* __restrict__ out, int H,
                                                          int W, int nh, int nw, int top, int left, int S, float m0, float m1,
-                                                         float m2, float is0, float is1, float is2) {
+                                                         float m2, float is0, float is1, float is2, int Hs, int Ws, int oy,
+                                                         int ox, float f0, float f1, float f2) {
     __shared__ float wy[16][PP_MAX_TAPS], wx[16][PP_MAX_TAPS];
     __shared__ int ymin[16], ysize[16], xmin[16], xsize[16];
     const int t = blockIdx.z, ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
@@ -57,17 +60,32 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
     const int ly = tid >> 4, lx = tid & 15;
     const int y = ty0 + ly, x = tx0 + lx;
     if (y >= S || x >= S) return;
-    const unsigned char* img = src + (size_t)t * H * W * 3;
+    const unsigned char* img = src + (size_t)t * (PAD ? Hs * Ws : H * W) * 3;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const int y0 = ymin[ly], ny = ysize[ly], x0 = xmin[lx], nx = xsize[lx];
     for (int j = 0; j < ny; ++j) {
-        const unsigned char* row = img + ((size_t)(y0 + j) * W + x0) * 3;
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        for (int i = 0; i < nx; ++i) {
-            const float w = wx[lx][i];
-            r0 = fmaf(w, (float)row[3 * i], r0);
-            r1 = fmaf(w, (float)row[3 * i + 1], r1);
-            r2 = fmaf(w, (float)row[3 * i + 2], r2);
+        if (PAD) {
+            const int sy = y0 + j - oy;                                    // row of the source image, if inside it
+            const bool yin = sy >= 0 && sy < Hs;
+            const unsigned char* row = img + (size_t)(yin ? sy : 0) * Ws * 3;
+            for (int i = 0; i < nx; ++i) {
+                const float w = wx[lx][i];
+                const int sx = x0 + i - ox;
+                const bool in = yin && sx >= 0 && sx < Ws;
+                const int sxx = in ? sx : 0;
+                r0 = fmaf(w, in ? (float)row[3 * sxx] : f0, r0);
+                r1 = fmaf(w, in ? (float)row[3 * sxx + 1] : f1, r1);
+                r2 = fmaf(w, in ? (float)row[3 * sxx + 2] : f2, r2);
+            }
+        } else {
+            const unsigned char* row = img + ((size_t)(y0 + j) * W + x0) * 3;
+            for (int i = 0; i < nx; ++i) {
+                const float w = wx[lx][i];
+                r0 = fmaf(w, (float)row[3 * i], r0);
+                r1 = fmaf(w, (float)row[3 * i + 1], r1);
+                r2 = fmaf(w, (float)row[3 * i + 2], r2);
+            }
         }
         const float w = wy[ly][j];
         a0 = fmaf(w, r0, a0); a1 = fmaf(w, r1, a1); a2 = fmaf(w, r2, a2);
@@ -79,9 +97,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
     Elem<T>::st(o + (size_t)2 * S * S, (a2 * k - m2) * is2);
 }
 
-int preprocess_frames(const unsigned char* src, void* out, int T_, int H, int W, int S, const float* mean, const float* stdv,
-                      int dtype, hipStream_t st) {
+int preprocess_frames(const unsigned char* src, void* out, int T_, int Hs, int Ws, int S, const float* mean, const float* stdv,
+                      int dtype, hipStream_t st, const unsigned char* pad_rgb) {
     if (T_ == 0) return TEO_OK;
+    // pad_rgb: expand2square first -- the resize then sees a side x side canvas with the source pasted centred
+    const bool pad = pad_rgb != nullptr && Hs != Ws;
+    const int side = Hs > Ws ? Hs : Ws;
+    const int H = pad ? side : Hs, W = pad ? side : Ws;
+    const int oy = pad ? (side - Hs) / 2 : 0, ox = pad ? (side - Ws) / 2 : 0;
     // Resize(S): shorter edge -> S, the other int(S * long / short) (torchvision); CenterCrop(S): offset round((n - S) / 2)
     int nh, nw;
     if (H <= W) { nh = S; nw = (int)((long long)S * W / H); } else { nw = S; nh = (int)((long long)S * H / W); }
@@ -92,12 +115,13 @@ int preprocess_frames(const unsigned char* src, void* out, int T_, int H, int W,
     }
     const int top = (int)lrintf((nh - S) / 2.0f), left = (int)lrintf((nw - S) / 2.0f);
     const dim3 grid(cdiv(S, 16), cdiv(S, 16), T_);
-    if (dtype == TEO_F32)
-        preprocess_kernel<float><<<grid, 256, 0, st>>>(src, (float*)out, H, W, nh, nw, top, left, S, mean[0], mean[1], mean[2],
-                                                       1.0f / stdv[0], 1.0f / stdv[1], 1.0f / stdv[2]);
-    else
-        preprocess_kernel<bf16_t><<<grid, 256, 0, st>>>(src, (bf16_t*)out, H, W, nh, nw, top, left, S, mean[0], mean[1], mean[2],
-                                                        1.0f / stdv[0], 1.0f / stdv[1], 1.0f / stdv[2]);
+    const float f0 = pad ? (float)pad_rgb[0] : 0.f, f1 = pad ? (float)pad_rgb[1] : 0.f, f2 = pad ? (float)pad_rgb[2] : 0.f;
+#define TEO_PP(TT, PD)                                                                                                      \
+    preprocess_kernel<TT, PD><<<grid, 256, 0, st>>>(src, (TT*)out, H, W, nh, nw, top, left, S, mean[0], mean[1], mean[2],    \
+                                                    1.0f / stdv[0], 1.0f / stdv[1], 1.0f / stdv[2], Hs, Ws, oy, ox, f0, f1, f2)
+    if (dtype == TEO_F32) { if (pad) TEO_PP(float, true); else TEO_PP(float, false); }
+    else { if (pad) TEO_PP(bf16_t, true); else TEO_PP(bf16_t, false); }
+#undef TEO_PP
     TEO_LAUNCH_CHECK("preprocess_frames");
     return TEO_OK;
 }

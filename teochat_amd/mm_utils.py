@@ -51,7 +51,11 @@ def process_images(images, image_processor, model_cfg):
     if getattr(model_cfg, "image_aspect_ratio", None) != "pad":
         return image_processor(images, return_tensors="pt")["pixel_values"]
     fill = tuple(int(c * 255) for c in image_processor.image_mean)
-    out = [image_processor.preprocess(expand2square(im, fill), return_tensors="pt")["pixel_values"][0] for im in images]
+    if getattr(image_processor, "engine", None) is not None:
+        # the padding happens inside the device kernel (teo_preprocess_frames_pad): the square canvas is never built
+        out = [image_processor.preprocess(im, return_tensors="pt", pad_rgb=fill)["pixel_values"][0] for im in images]
+    else:
+        out = [image_processor.preprocess(expand2square(im, fill), return_tensors="pt")["pixel_values"][0] for im in images]
     if all(o.shape == out[0].shape for o in out):
         return torch.stack(out, dim=0)
     return out

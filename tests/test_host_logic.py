@@ -138,11 +138,17 @@ def test_processor_identity_at_224():
     g = torch.Generator().manual_seed(3)
     raw = torch.randint(0, 256, (224, 224, 3), generator=g, dtype=torch.uint8)
     p = TeoImageProcessor()
-    out = p.preprocess(raw.numpy(), return_tensors="pt")["pixel_values"][0]
-    assert torch.equal(out, O.preprocess_uint8(raw))
-    big = torch.randint(0, 256, (300, 448, 3), generator=g, dtype=torch.uint8)
-    assert p.preprocess(big, return_tensors="pt")["pixel_values"].shape == (1, 3, 224, 224)
     assert p.image_mean[0] == pytest.approx(0.48145466) and p.crop_size == {"height": 224, "width": 224}
+    assert p.image_mean == O.OPENAI_DATASET_MEAN and p.image_std == O.OPENAI_DATASET_STD
+    # the product has no host implementation of the transform: without an engine (= without the GPU) it refuses
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        p.preprocess(raw.numpy(), return_tensors="pt")
+    with pytest.raises(TypeError, match="uint8"):
+        p.preprocess(torch.rand(3, 224, 224))
+    with pytest.raises(ValueError):
+        p(images=None)
+    import teochat_amd.processor as P
+    assert not hasattr(P.TeoImageProcessor, "transform") and "interpolate" not in open(P.__file__).read()
 
 
 def test_library_exports_every_declared_symbol():

@@ -597,17 +597,18 @@ def test_gemm_skinny_fused_rmsnorm(MB, N, K, swiglu, fp8):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_preprocess_frames_matches_torchvision_semantics(H, W, dtype):
     """teo_preprocess_frames == ToTensor -> Resize(224, bicubic, antialias) -> CenterCrop(224) -> Normalize on the CPU
-    (teochat_amd.processor.TeoImageProcessor.transform restates processing_image.py:15-25 with torch ops)."""
+    (oracle.preprocess_image restates processing_image.py:15-25; it is pinned in tests/test_oracle_golden.py by analytic
+    cases and a PIL cross-check)."""
     import ctypes as C
-    from teochat_amd.processor import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD, TeoImageProcessor
+    from oracle import teo_oracle as O
+    from teochat_amd.processor import OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
     g = torch.Generator().manual_seed(H * 7 + W)
     T = 3
     raw = torch.randint(0, 256, (T, H, W, 3), generator=g, dtype=torch.uint8)
     # smooth content on top of the noise so that interpolation errors would show
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     raw[1] = ((torch.sin(yy / 9.0) * torch.cos(xx / 13.0) * 0.5 + 0.5) * 255).to(torch.uint8)[..., None].expand(H, W, 3)
-    proc = TeoImageProcessor()
-    want = torch.stack([proc.transform(raw[t]) for t in range(T)])
+    want = torch.stack([O.preprocess_image(raw[t]) for t in range(T)])
     src = raw.cuda()
     out = torch.empty(T, 3, 224, 224, dtype=dtype, device="cuda")
     mean, std = (C.c_float * 3)(*OPENAI_DATASET_MEAN), (C.c_float * 3)(*OPENAI_DATASET_STD)
@@ -618,6 +619,28 @@ def test_preprocess_frames_matches_torchvision_semantics(H, W, dtype):
             exact = (raw.permute(0, 3, 1, 2).float() / 255.0 - torch.tensor(OPENAI_DATASET_MEAN).view(1, 3, 1, 1)) \
                 / torch.tensor(OPENAI_DATASET_STD).view(1, 3, 1, 1)
             torch.testing.assert_close(out.cpu(), exact, atol=2e-6, rtol=0)
+    else:
+        close_bf16(out, G.bf16_round(want), ulps=1.0)
+
+
+@pytest.mark.parametrize("H,W", [(224, 224), (300, 448), (448, 300), (101, 224), (1000, 37)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_preprocess_frames_pad_mode_matches_expand2square(H, W, dtype):
+    """teo_preprocess_frames_pad == preprocess(expand2square(img, fill)) (mm_utils.py:14-36, image_aspect_ratio == 'pad'),
+    the padded canvas being virtual on the device."""
+    import ctypes as C
+    from oracle import teo_oracle as O
+    g = torch.Generator().manual_seed(H + 3 * W)
+    T = 2
+    raw = torch.randint(0, 256, (T, H, W, 3), generator=g, dtype=torch.uint8)
+    fill = O.pad_fill_from_mean(O.OPENAI_DATASET_MEAN)
+    want = torch.stack([O.preprocess_image(O.expand2square_u8(raw[t], fill)) for t in range(T)])
+    out = torch.empty(T, 3, 224, 224, dtype=dtype, device="cuda")
+    mean, std = (C.c_float * 3)(*O.OPENAI_DATASET_MEAN), (C.c_float * 3)(*O.OPENAI_DATASET_STD)
+    L.check(G.lib().teo_preprocess_frames_pad(G.p(raw.cuda()), G.p(out), T, H, W, 224, mean, std, (C.c_ubyte * 3)(*fill), G.DT[dtype],
+                                              G.stream()), "preprocess_pad")
+    if dtype == torch.float32:
+        torch.testing.assert_close(out.cpu(), want, atol=3e-5, rtol=0)
     else:
         close_bf16(out, G.bf16_round(want), ulps=1.0)
 

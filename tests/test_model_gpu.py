@@ -326,12 +326,13 @@ def test_fp8_weight_path_matches_oracle_on_dequantised_weights():
 
 
 def test_engine_bound_processor_preprocesses_on_device(tmp_path):
-    """N3: with an engine bound, uint8 frames (paths / PIL / arrays) go through teo_preprocess_frames; float inputs and
-    the engine-less processor keep the host path; both agree."""
+    """N3: uint8 frames (paths / PIL / arrays / tensors) go through teo_preprocess_frames and agree with the oracle's
+    restatement of processing_image.py:15-25; process_images' pad mode runs on the device too (mm_utils.py:28-36)."""
+    from types import SimpleNamespace
     from PIL import Image
+    from teochat_amd.mm_utils import process_images
     from teochat_amd.processor import TeoImageProcessor
     model, _ = build("tinyA", torch.float32)
-    host = TeoImageProcessor()
     dev = TeoImageProcessor(engine=model.engine)
     g = torch.Generator().manual_seed(3)
     frames = [torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8) for h, w in ((300, 260), (224, 224), (300, 260))]
@@ -340,14 +341,24 @@ def test_engine_bound_processor_preprocesses_on_device(tmp_path):
         p = tmp_path / f"f{i}.png"
         Image.fromarray(f.numpy()).save(p)
         paths.append(str(p))
-    want = host.preprocess(paths)["pixel_values"]
+    want = torch.stack([O.preprocess_image(f) for f in frames])
     got = dev.preprocess(paths)["pixel_values"]
     assert got.is_cuda and got.dtype == torch.float32 and got.shape == want.shape
     torch.testing.assert_close(got.cpu(), want, atol=3e-5, rtol=0)
     got1 = dev.preprocess(Image.open(paths[0]))["pixel_values"]
     torch.testing.assert_close(got1.cpu(), want[:1], atol=3e-5, rtol=0)
-    flt = want[0].clone()                                  # already-normalised float frames stay on the host path
-    assert not dev.preprocess(torch.rand(3, 224, 224))["pixel_values"].is_cuda
+    torch.testing.assert_close(dev.preprocess([f.numpy() for f in frames])["pixel_values"].cpu(), want, atol=3e-5, rtol=0)
+    with pytest.raises(TypeError, match="uint8"):
+        dev.preprocess(torch.rand(3, 224, 224))
+    # pad mode: expand2square inside the kernel == the reference's PIL expand2square followed by the transform
+    pils = [Image.open(p) for p in paths]
+    fill = O.pad_fill_from_mean(dev.image_mean)
+    want_pad = torch.stack([O.preprocess_image(O.expand2square_u8(f, fill)) for f in frames])
+    got_pad = process_images(pils, dev, SimpleNamespace(image_aspect_ratio="pad"))
+    assert got_pad.is_cuda and got_pad.shape == want_pad.shape
+    torch.testing.assert_close(got_pad.cpu(), want_pad, atol=3e-5, rtol=0)
+    got_nopad = process_images(pils, dev, SimpleNamespace(image_aspect_ratio=None))
+    torch.testing.assert_close(got_nopad.cpu(), want, atol=3e-5, rtol=0)
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])

@@ -238,3 +238,74 @@ def test_preallocated_kv_cache_equals_the_growing_cache():
         O.llama_forward(torch.randn(1, 3, lcfg.hidden_size), None, None, b_cache, sd, lcfg)
     sdt = O.make_state_dict_for_timing(vcfg, lcfg, mm)
     assert set(sdt) == set(sd) and all(sdt[k].shape == sd[k].shape for k in sd)
+
+
+# ---------------------------------------------------------------------------------------------- H6 / N3: preprocessing
+def test_preprocess_analytic_pins():
+    """oracle.preprocess_image (processing_image.py:15-25) against facts that hold for ANY correct implementation:
+    identity at 224x224 (ToTensor / 255 + Normalize, closed form); constants survive the resize exactly (the anti-aliased
+    bicubic weights sum to one); a linear ramp is reproduced away from the borders (the cubic kernel has linear precision);
+    the crop window is the centred one; Resize geometry = torchvision's (shorter edge -> 224, int() of the other)."""
+    g = torch.Generator().manual_seed(0)
+    raw = torch.randint(0, 256, (224, 224, 3), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(O.OPENAI_DATASET_MEAN).view(3, 1, 1)
+    std = torch.tensor(O.OPENAI_DATASET_STD).view(3, 1, 1)
+    want = (raw.permute(2, 0, 1).float() / 255.0 - mean) / std
+    assert torch.equal(O.preprocess_image(raw), want) and torch.equal(O.preprocess_uint8(raw), want)
+    for (h, w) in [(300, 448), (448, 300), (100, 150), (1000, 700)]:
+        c = torch.tensor([37, 141, 250], dtype=torch.uint8).view(1, 1, 3).expand(h, w, 3)
+        out = O.preprocess_image(c)
+        assert out.shape == (3, 224, 224)
+        ref = (torch.tensor([37, 141, 250]).float() / 255.0 - mean.view(3)) / std.view(3)
+        assert float((out - ref.view(3, 1, 1)).abs().max()) < 2e-6
+    assert O.resize_geometry(300, 448) == (224, 334, 0, 55) and O.resize_geometry(448, 300) == (334, 224, 55, 0)
+    assert O.resize_geometry(231, 517) == (224, 501, 0, 138)          # int(224 * 517 / 231) = 501; round(138.5) = 138 (half to even)
+    assert O.resize_geometry(224, 224) == (224, 224, 0, 0)
+    # linear ramp along x, down-scaled 2x: out(x) = a * (x_src) + b with x_src = (x_out + left + 0.5) * scale - 0.5
+    h, w = 448, 896
+    ramp = (torch.arange(w).float() * (255.0 / (w - 1))).round().to(torch.uint8).view(1, w, 1).expand(h, w, 3)
+    out = O.preprocess_image(ramp)
+    nh, nw, top, left = O.resize_geometry(h, w)
+    xs = (torch.arange(224).float() + left + 0.5) * (w / nw) - 0.5
+    lin = ((xs * (255.0 / (w - 1)) / 255.0) - mean[0, 0, 0]) / std[0, 0, 0]
+    assert float((out[0, 100, 8:-8] - lin[8:-8]).abs().max()) < 4e-3 / float(std[0, 0, 0])   # uint8 rounding of the ramp itself: 0.5/255
+
+
+@pytest.mark.parametrize("h,w", [(300, 448), (448, 300), (672, 672), (180, 200)])
+def test_preprocess_cross_check_against_pil_bicubic(h, w):
+    """Independent implementation of the same resampling: PIL's BICUBIC resize is the anti-aliased a = -0.5 cubic convolution
+    ATen's `_upsample_bicubic2d_aa` was written to match (PIL works on uint8 with fixed-point rounding, so the comparison is
+    to ~1.5 grey levels on smooth content)."""
+    from PIL import Image
+    yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    img = torch.stack([(torch.sin(yy / 17.0) * torch.cos(xx / 23.0) * 0.5 + 0.5) * 255, (yy / h) * 255, (xx / w) * 255], dim=-1)
+    raw = img.round().clamp(0, 255).to(torch.uint8)
+    nh, nw, top, left = O.resize_geometry(h, w)
+    pil = Image.fromarray(raw.numpy()).resize((nw, nh), Image.BICUBIC)
+    pil_t = torch.from_numpy(np.array(pil)).permute(2, 0, 1).float()[:, top:top + 224, left:left + 224]
+    mean = torch.tensor(O.OPENAI_DATASET_MEAN).view(3, 1, 1)
+    std = torch.tensor(O.OPENAI_DATASET_STD).view(3, 1, 1)
+    ours = (O.preprocess_image(raw) * std + mean) * 255.0
+    d = (ours - pil_t).abs()
+    assert float(d.max()) < 2.0 and float(d.mean()) < 0.6, (float(d.max()), float(d.mean()))
+
+
+def test_expand2square_matches_pil_paste():
+    """mm_utils.py:14-25 on arrays == the reference's PIL implementation (Image.new + paste), incl. the odd-difference offsets."""
+    from PIL import Image
+    g = torch.Generator().manual_seed(5)
+    fill = O.pad_fill_from_mean(O.OPENAI_DATASET_MEAN)
+    assert fill == (122, 116, 104)
+    for (h, w) in [(5, 8), (8, 5), (7, 7), (10, 3), (3, 10)]:
+        raw = torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8)
+        pil = Image.fromarray(raw.numpy())
+        W, H = pil.size
+        if W == H:
+            ref = pil
+        elif W > H:
+            ref = Image.new(pil.mode, (W, W), fill)
+            ref.paste(pil, (0, (W - H) // 2))
+        else:
+            ref = Image.new(pil.mode, (H, H), fill)
+            ref.paste(pil, ((H - W) // 2, 0))
+        assert torch.equal(O.expand2square_u8(raw, fill), torch.from_numpy(np.array(ref)))
