@@ -16,7 +16,8 @@
 // cycles parked, 33 % of its LDS cycles bank conflicts, 7.8 % MFMA busy).
 // LDS images (bank maths: MI355X_MICROARCH.md section LDS; ds_read_b128 is served in 16-lane groups over a 256-byte row):
 //   K   [64 keys][D] bf16, 16-byte chunk c of row r at c ^ ((r / RPB) & (CH - 1)), RPB = rows per 256 bytes  -> conflict-free
-//   V^T [D][64 keys] bf16 (128-byte rows), chunk c of row d at c ^ ((d >> 1) & 7)                                -> conflict-free
+//   V^T [D][64 keys] bf16, rows padded to 144 bytes (9 x 16: odd, so 16 rows fan out over all 16 slots of a bank row, and
+//       two neighbouring rows' 8-byte staging writes fall into different halves of the 128-byte write period) -> conflict-free
 // Arithmetic = oracle attention_core mode "flash64": 64-key tiles from key 0, running max, P = exp2(s * scale * log2e - m),
 // P rounded to bf16 per tile for the PV product, normaliser from the unrounded P, fp32 rescale (skipped, bit-identically,
 // when no row maximum of the wave moved).
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
     constexpr int KROW = D * 2;               // bytes per K row
     constexpr int RPB = 256 / KROW > 0 ? 256 / KROW : 1;
     constexpr int KT_BYTES = 64 * KROW;       // K tile
-    constexpr int VT_BYTES = D * 128;         // V^T tile: D rows x 64 keys
+    constexpr int VROW = 144;                 // V^T row: 64 keys (128 B) + 16 B pad -> reads AND the 8-byte staging writes conflict-free
+    constexpr int VT_BYTES = D * VROW;        // V^T tile: D rows x 64 keys
     constexpr int BUF = KT_BYTES + VT_BYTES;
     constexpr int NDB = D / 32;               // 32-row d-blocks of O^T
     constexpr int NKK = D / 16;               // k-steps of the score MFMA
@@ -136,10 +138,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
                     else if (2 * e + 1 >= valid) val[e] &= 0xffffu;                                               \
                 }                                                                                                 \
             }                                                                                                     \
-            const int blk = c >> 1, e = c & 1, sw = (d >> 1) & 7;                                                 \
-            unsigned char* rowp = sV_ + d * 128 + (e << 3);                                                       \
-            *reinterpret_cast<uint2*>(rowp + (((2 * blk) ^ sw) << 4)) = make_uint2(val[0], val[1]);               \
-            *reinterpret_cast<uint2*>(rowp + (((2 * blk + 1) ^ sw) << 4)) = make_uint2(val[2], val[3]);           \
+            const int blk = c >> 1, e = c & 1;                                                                    \
+            unsigned char* rowp = sV_ + d * VROW + (e << 3);                                                      \
+            *reinterpret_cast<uint2*>(rowp + ((2 * blk) << 4)) = make_uint2(val[0], val[1]);                      \
+            *reinterpret_cast<uint2*>(rowp + ((2 * blk + 1) << 4)) = make_uint2(val[2], val[3]);                  \
         }                                                                                                         \
     }
 
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     const int d = db * 32 + ql;
-                    const fa_bf16x8 vf = __builtin_bit_cast(fa_bf16x8, *reinterpret_cast<const fa_u32x4*>(sV + d * 128 + (((2 * u + hi) ^ ((d >> 1) & 7)) << 4)));
+                    const fa_bf16x8 vf = __builtin_bit_cast(fa_bf16x8, *reinterpret_cast<const fa_u32x4*>(sV + d * VROW + ((2 * u + hi) << 4)));
                     acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, acc_o[db], 0, 0, 0);
                 }
             }
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
 
 int attention_flash32(const teo_attn_args& a, hipStream_t st) {
     dim3 grid(cdiv(a.q_len, 128) * a.heads * a.batch);
-    const size_t lds = 2 * (size_t)(64 * a.head_dim * 2 + a.head_dim * 128);
+    const size_t lds = 2 * (size_t)(64 * a.head_dim * 2 + a.head_dim * 144);
     if (a.head_dim == 128) {
         if (a.causal) attn_flash32_kernel<128, true><<<grid, 256, lds, st>>>(a);
         else attn_flash32_kernel<128, false><<<grid, 256, lds, st>>>(a);

@@ -11,7 +11,7 @@ import types
 
 
 def install():
-    from . import builder, constants, conversation, eval as teo_eval, inference, metrics, mm_utils, model
+    from . import builder, constants, conversation, detection, eval as teo_eval, inference, metrics, mm_utils, model
     pkg = types.ModuleType("videollava")
     pkg.__path__ = []
     pkg.__teo_dropin__ = True
@@ -24,10 +24,11 @@ def install():
     modelpkg.LlavaConfig = LlavaConfig
     mods = {"videollava": pkg, "videollava.constants": constants, "videollava.conversation": conversation,
             "videollava.mm_utils": mm_utils, "videollava.eval": evalpkg, "videollava.eval.eval": teo_eval,
-            "videollava.eval.inference": inference, "videollava.eval.classification": metrics, "videollava.model": modelpkg,
+            "videollava.eval.inference": inference, "videollava.eval.classification": metrics, "videollava.eval.detection": detection,
+            "videollava.model": modelpkg,
             "videollava.model.builder": builder}
     sys.modules.update(mods)
     pkg.constants, pkg.conversation, pkg.mm_utils, pkg.eval, pkg.model = constants, conversation, mm_utils, evalpkg, modelpkg
-    evalpkg.eval, evalpkg.inference, evalpkg.classification = teo_eval, inference, metrics
+    evalpkg.eval, evalpkg.inference, evalpkg.classification, evalpkg.detection = teo_eval, inference, metrics, detection
     modelpkg.builder = builder
     return pkg

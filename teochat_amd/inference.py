@@ -3,6 +3,7 @@
 run_inference_single keeps the reference's positional order and defaults; `do_sample` is an extra trailing
 keyword (the reference hard-codes do_sample=True, inference.py:67) so parity runs can ask for greedy decoding.
 """
+import re
 from datetime import datetime
 
 import torch
@@ -52,15 +53,37 @@ def run_inference_single(model, processor, tokenizer, inp, image_paths, conv_mod
     return tokenizer.decode(output_ids[0, input_ids.shape[1]:]).replace("</s>", "").strip()
 
 
+_BBOX = re.compile(r"\[(\d+), (\d+), (\d+), (\d+)\]")
+_POLYGON_DATASETS = ["xbd_loc", "xbd_dmg_cls", "s2_det", "qfabric_rqa2", "qfabric_rqa5", "xbd_sre_qa_rqa", "s2_sre_qa", "s2_rqa"]
+
+
+def extract_bboxes(bbox_str):
+    """'[x1, y1, x2, y2]' groups of integers (exactly ', '-separated) -> [[x1, y1, x2, y2], ...]  (inference.py:80-85)."""
+    return [[int(v) for v in m.groups()] for m in _BBOX.finditer(bbox_str)]
+
+
 def run_inference(dataset, model, tokenizer, processor, prompt_strategy, chronological_prefix, conv_mode, temperature,
                   max_new_tokens):
-    """Dataset loop (inference.py:88-137, minus the bbox/polygon bookkeeping that belongs to the metrics code)."""
+    """Dataset loop with the bookkeeping the metrics need (inference.py:88-137): response / ground truth / task per example,
+    the example's polygon when it has one, and the integer boxes quoted in the question and in the reference answer."""
     outputs = []
     for example in dataset:
-        response = run_inference_single(model, processor, tokenizer, example["conversations"][0]["value"],
-                                        example["video"], conv_mode=conv_mode, timestamps=example["timestamp"],
-                                        prompt_strategy=prompt_strategy, chronological_prefix=chronological_prefix,
-                                        temperature=temperature, max_new_tokens=max_new_tokens)
-        outputs.append({"response": response, "ground_truth": example["conversations"][1]["value"],
-                        "task": example.get("task")})
+        question, answer = example["conversations"][0]["value"], example["conversations"][1]["value"]
+        response = run_inference_single(model, processor, tokenizer, question, example["video"], conv_mode=conv_mode,
+                                        timestamps=example["timestamp"], prompt_strategy=prompt_strategy,
+                                        chronological_prefix=chronological_prefix, temperature=temperature,
+                                        max_new_tokens=max_new_tokens)
+        record = {"response": response, "ground_truth": answer, "task": example["task"]}
+        polygon = example.get("polygon", None)
+        if polygon is not None:
+            record["polygon"] = polygon
+        elif dataset in _POLYGON_DATASETS:            # as in the reference: only a dataset passed by NAME can trip this
+            raise ValueError(f"Polygons not found for dataset {dataset}. The TEOChatlas dataset was updated to include these "
+                             "polygons on 25 Mar 2025. Please re-download the json files for these splits.")
+        boxes_in, boxes_out = extract_bboxes(question), extract_bboxes(answer)
+        if boxes_in:
+            record["input_bboxes"] = boxes_in
+        if boxes_out:
+            record["output_bboxes"] = boxes_out
+        outputs.append(record)
     return outputs

@@ -3,7 +3,7 @@
 classification_metrics follows videollava/eval/classification.py:6-41: per-task accuracy of exact matches after
 optional lower-casing / punctuation stripping; with `keywords`, a response also counts when it and the ground truth
 share one of the keywords.  As in the reference, a task without a single hit is absent from the result.
-(detection_metrics needs shapely, which is neither in this image nor on the hot path: not built.)
+The pixel-level detection metrics live in teochat_amd/detection.py.
 """
 import string
 from collections import Counter

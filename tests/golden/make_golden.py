@@ -435,10 +435,175 @@ def gen_metrics():
     print("metrics.json", {k: v["result"] for k, v in cases.items()})
 
 
+def _shapely_wkt_stub():
+    """shapely is absent from this image; the reference uses it ONLY to turn WKT text into coordinate lists (wkt.loads,
+    polygon.exterior.coords, iteration over multi-geometries; detection.py:4-5,146-147,171,206,236).  This generator-side
+    stand-in does that text parsing (independently of teochat_amd.detection.parse_wkt) so that the reference's own
+    rasterisation and metric code can run unmodified.  Geometry objects follow shapely 1.8 iteration semantics (a
+    MultiPolygon iterates over its polygons, as the reference's `iter(polygons)` expects)."""
+    import re
+    import types
+
+    class _Ring:
+        def __init__(self, coords):
+            self.coords = coords
+
+    class _Polygon:
+        def __init__(self, rings):
+            self.exterior = _Ring(rings[0])
+
+    def _coords(txt):
+        return [tuple(float(v) for v in pt.split()[:2]) for pt in txt.split(",")]
+
+    def _poly(txt):                                     # "(x y, x y, ...), (hole...)" -> exterior only
+        rings = re.findall(r"\(([^()]*)\)", txt)
+        return _Polygon([_coords(r) for r in rings])
+
+    def loads(w):
+        if not isinstance(w, str):
+            return [loads(x) for x in w]
+        w = w.strip()
+        if w.upper().startswith("MULTIPOLYGON"):
+            body = w[w.index("(") + 1:w.rindex(")")]
+            return [_poly(m) for m in re.findall(r"\((\([^()]*\)(?:\s*,\s*\([^()]*\))*)\)", body)]
+        if w.upper().startswith("POLYGON"):
+            return _poly(w[w.index("(") + 1:w.rindex(")")])
+        raise ValueError(w)
+
+    shapely = types.ModuleType("shapely")
+    wkt = types.ModuleType("shapely.wkt")
+    wkt.loads = loads
+    shapely.wkt = wkt
+    return shapely, wkt
+
+
+def detection_cases():
+    """Records in the reference's output format (eval/inference.py:112-135) for every dataset family of detection_metrics."""
+    sq = "POLYGON ((40 40, 40 120, 120 120, 120 40, 40 40))"
+    tri = "POLYGON ((10.5 200.25, 100 130, 60.75 250, 10.5 200.25))"
+    multi = "MULTIPOLYGON (((5 5, 5 30, 30 30, 30 5, 5 5)), ((200 200, 200 240, 250 240, 250 200, 200 200), (210 210, 210 220, 220 220, 220 210, 210 210)))"
+    loc = [
+        {"response": "[15, 15, 47, 47]", "ground_truth": "[16, 16, 47, 47]", "task": "change_detection_localization", "polygon": sq},
+        {"response": "[0, 50, 40, 100], [78, 78, 98, 94] and [bad, box]", "ground_truth": "[4, 51, 39, 98]", "task": "change_detection_localization", "polygon": tri},
+        {"response": "No changes.", "ground_truth": "[2, 2, 12, 12], [78, 78, 98, 94]", "task": "change_detection_localization", "polygon": multi},
+        {"response": "[10.5, 20.25, 33, 44.75]", "ground_truth": "none", "task": "change_detection_localization", "polygon": sq},
+    ]
+    dmg = [
+        {"response": "No damage.", "ground_truth": "No damage", "task": "change_detection_classification", "polygon": sq},
+        {"response": "Destroyed", "ground_truth": "Major damage", "task": "change_detection_classification", "polygon": tri},
+        {"response": "major damage", "ground_truth": "Major Damage", "task": "change_detection_classification", "polygon": multi},
+        {"response": "it is fine", "ground_truth": "Minor damage", "task": "change_detection_classification", "polygon": sq},
+        {"response": "Destroyed", "ground_truth": "unclassified", "task": "change_detection_classification", "polygon": sq},
+        {"response": "minor damage", "ground_truth": "minor damage", "task": "change_detection_classification", "polygon": tri},
+    ]
+    sre = [dict(r, task="spatial_referring_expression") for r in loc[:3]] + [
+        {"response": "Yes", "ground_truth": "yes", "task": "question_answering"},
+        {"response": "in the Top Left corner", "ground_truth": "top left", "task": "question_answering"},
+        {"response": "bottom", "ground_truth": "center", "task": "question_answering"},
+        {"response": "Major damage", "ground_truth": "major damage.", "task": "region_based_question_answering"},
+        {"response": "none", "ground_truth": "destroyed", "task": "region_based_question_answering"},
+    ]
+    s2 = [dict(r, task="change_detection_detection") for r in loc]
+    qf2 = [
+        {"response": "Residential", "ground_truth": "residential", "task": "region_based_question_answering", "polygon": sq},
+        {"response": "road", "ground_truth": "Commercial", "task": "region_based_question_answering", "polygon": tri},
+        {"response": "mega-projects", "ground_truth": "Mega projects", "task": "region_based_question_answering", "polygon": multi},
+        {"response": "a lake", "ground_truth": "industrial", "task": "region_based_question_answering", "polygon": sq},
+    ]
+    qf5 = [
+        {"response": "Land cleared", "ground_truth": "land cleared", "task": "region_based_temporal_question_answering", "polygon": sq},
+        {"response": "operational", "ground_truth": "Construction done.", "task": "region_based_temporal_question_answering", "polygon": tri},
+        {"response": "land-cleared", "ground_truth": "Greenland", "task": "region_based_temporal_question_answering", "polygon": multi},
+        {"response": "demolition", "ground_truth": "demolition", "task": "region_based_question_answering", "polygon": tri},
+    ]
+    tre = [
+        {"response": "image 2", "ground_truth": "Image 2", "task": "temporal_referring_expression"},
+        {"response": "image 1", "ground_truth": "image 3", "task": "temporal_referring_expression"},
+        {"response": "Excavation.", "ground_truth": "excavation", "task": "region_based_temporal_question_answering"},
+    ]
+    return {"xbd_loc": loc, "xbd_dmg_cls": dmg, "xbd_sre_qa_rqa": sre, "s2_det": s2,
+            "s2_sre_qa": [r for r in sre if r["task"] != "region_based_question_answering"],
+            "s2_rqa": [r for r in sre if r["task"] == "region_based_question_answering"],
+            "qfabric_rqa2": qf2, "qfabric_rqa5_rtqa5": qf5, "qfabric_tre_rtqa": tre}
+
+
+def gen_detection():
+    """N4: detection_metrics / Evaluator / create_mask / extract_bboxes / run_inference bookkeeping, produced by the
+    reference's own code (videollava/eval/detection.py, eval/inference.py:80-137)."""
+    import contextlib
+    import importlib.util
+    import io
+    import types
+    shapely, wkt = _shapely_wkt_stub()
+    sys.modules["shapely"], sys.modules["shapely.wkt"] = shapely, wkt
+    ref_import.install()
+    if "tqdm" not in sys.modules:
+        pass
+    det = importlib.import_module("videollava.eval.detection")
+    out = {"cases": {}}
+    for ds, recs in detection_cases().items():
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            res = det.detection_metrics(recs, ds)
+        out["cases"][ds] = {"outputs": recs, "result": {k: float(v) for k, v in res.items()}}
+    # all eight pixel metrics of evaluate_masks on the localisation records
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        em = det.evaluate_masks(detection_cases()["xbd_loc"], "xbd_loc")
+        cdc = det.change_detection_classification(detection_cases()["xbd_dmg_cls"], ["no damage", "minor damage", "major damage", "destroyed"],
+                                                  skip_classes=["unclassified"])
+    out["evaluate_masks_xbd_loc"] = {k: float(v) for k, v in em.items()}
+    out["change_detection_classification_xbd"] = {k: float(v) for k, v in cdc.items()}
+    # masks: pixel counts and a checksum per polygon / box list
+    masks = {}
+    for nm, w in (("sq", detection_cases()["xbd_loc"][0]["polygon"]), ("tri", detection_cases()["xbd_loc"][1]["polygon"]),
+                  ("multi", detection_cases()["xbd_loc"][2]["polygon"])):
+        m = det.create_mask(wkt.loads(w), (256, 256))
+        ys, xs = np.nonzero(m)
+        masks[nm] = {"sum": int(m.sum()), "weighted": int((ys * 257 + xs).sum()), "shape": list(m.shape)}
+    out["masks"] = masks
+    # Evaluator on a 3-class confusion matrix
+    ev = det.Evaluator(3)
+    rng = np.random.RandomState(0)
+    gt = rng.randint(0, 3, size=(32, 32))
+    pr = rng.randint(0, 3, size=(32, 32))
+    ev.add_batch(gt, pr)
+    out["evaluator3"] = {"cm": ev.confusion_matrix.tolist(), "oa": float(ev.Pixel_Accuracy()), "macc": float(ev.Pixel_Accuracy_Class()[0]),
+                         "miou": float(ev.Mean_Intersection_over_Union()), "kappa": float(ev.Kappa_coefficient()),
+                         "fwiou": float(ev.Frequency_Weighted_Intersection_over_Union()),
+                         "damage_f1": [float(v) for v in ev.Damage_F1_socore()], "cw_f1": float(ev.Class_Weighted_F1_score())}
+    out["get_classes"] = {"xbd": det.get_classes("xbd", "classification: Classify the level of damage experienced by the building at location [bbox] in the second image. Choose from: No damage, Minor Damage, Major Damage, Destroyed."),
+                          "none": det.get_classes("fmow", "x")}
+    # run_inference bookkeeping with the reference loop and a canned run_inference_single
+    lm = ref_import.import_llava_llama()  # noqa: F841  (inference.py imports the model package)
+    inf = importlib.import_module("videollava.eval.inference")
+    examples = [
+        {"conversations": [{"value": "<video> Is the building at [12, 30, 45, 60] damaged?"}, {"value": "Yes, see [10, 28, 47, 61] and [1, 2, 3, 4]."}],
+         "video": ["a.png", "b.png"], "timestamp": ["2020-01-01", "2019-01-01"], "task": "question_answering", "polygon": "POLYGON ((1 1, 1 2, 2 2, 1 1))"},
+        {"conversations": [{"value": "<video> Describe the changes."}, {"value": "Nothing [1,2,3,4] changed [5, 6, 7, 8.5]."}],
+         "video": ["c.png"], "timestamp": [], "task": "captioning"},
+    ]
+    real = inf.run_inference_single
+    calls = []
+
+    def fake_single(model, processor, tokenizer, inp, image_paths, **kw):
+        calls.append({"inp": inp, "image_paths": list(image_paths), "kw": {k: (v if not isinstance(v, list) else list(v)) for k, v in kw.items()}})
+        return f"answer {len(calls)}"
+
+    inf.run_inference_single = fake_single
+    try:
+        with contextlib.redirect_stderr(io.StringIO()):
+            outs = inf.run_inference(examples, "M", "T", "P", "interleave", True, "v1", 0.2, 64)
+    finally:
+        inf.run_inference_single = real
+    out["run_inference"] = {"examples": examples, "outputs": outs, "calls": calls,
+                            "extract": {s_: inf.extract_bboxes(s_) for s_ in ["[1, 2, 3, 4]", "[1,2,3,4]", "x [10, 20, 30, 40] y [5, 6, 7, 8]", "[1, 2, 3]", "[-1, 2, 3, 4]"]}}
+    json.dump(out, open(os.path.join(HERE, "detection.json"), "w"), indent=1)
+    print("detection.json", {k: v["result"] for k, v in out["cases"].items()})
+
+
 if __name__ == "__main__":
     assert ref_import.available(), "reference tree required"
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["host", "splice", "numeric", "train", "metrics"]
+    which = sys.argv[1:] or ["host", "splice", "numeric", "train", "metrics", "detection"]
     if "host" in which:
         gen_host()
     if "splice" in which:
@@ -450,3 +615,5 @@ if __name__ == "__main__":
             gen_train(nm)
     if "metrics" in which:
         gen_metrics()
+    if "detection" in which:
+        gen_detection()
