@@ -80,6 +80,15 @@ int teo_gemm(const void* d_A, const void* d_W, const void* d_bias, const void* d
              int N, int K, int lda, int ldc, int act, unsigned flags, int dtype, int out_dtype,
              teo_stream_t stream);
 
+/* teo_gemm with a scratch workspace (teo_gemm_workspace_bytes() bytes, 256-byte aligned): lets the library run the
+ * stream-K form of the MFMA kernel when the static 128 x 128 tiling would leave a ragged last round on the 256 CUs (e.g.
+ * M = 2168, N = 4096: 544 tiles on 512 slots).  Results are bit-identical to teo_gemm (same k-order per output element).
+ * teo_gemm_workspace_init must run once on a fresh workspace (it zeroes the hand-off flags; the kernels re-arm them). */
+size_t teo_gemm_workspace_bytes(void);
+int teo_gemm_workspace_init(void* d_workspace, teo_stream_t stream);
+int teo_gemm_ws(const void* d_A, const void* d_W, const void* d_bias, const void* d_residual, void* d_C, int M, int N, int K,
+                int lda, int ldc, int act, unsigned flags, int dtype, int out_dtype, void* d_workspace, teo_stream_t stream);
+
 /* Patch extraction for the CLIP patch-embedding conv (kernel = stride = patch, no bias):
  * cols[t*g*g + py*g + px, c*P*P + ky*P + kx] = pixels[t, c, py*P+ky, px*P+kx], zero padded to ldcols.
  * Replaces the im2col half of CLIPVisionEmbeddings.patch_embedding (used at modeling_image.py:602,645). */

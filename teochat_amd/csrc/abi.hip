@@ -95,6 +95,24 @@ int teo_gemm(const void* A, const void* W, const void* bias, const void* res, vo
     return gemm(A, W, bias, res, C, M, N, K, lda, ldc, act, flags, dtype, out_dtype, ST(s));
 }
 
+size_t teo_gemm_workspace_bytes(void) { return gemm_sk_workspace_bytes(); }
+int teo_gemm_workspace_init(void* ws, teo_stream_t s) {
+    ENTER();
+    NEED(ws, "workspace");
+    return gemm_sk_workspace_init(ws, ST(s));
+}
+int teo_gemm_ws(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                int act, unsigned flags, int dtype, int out_dtype, void* ws, teo_stream_t s) {
+    ENTER();
+    NEED_DT(dtype); NEED_DT(out_dtype);
+    TEO_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && lda >= K, "teo_gemm_ws: M %d N %d K %d lda %d", M, N, K, lda);
+    TEO_CHECK_ARG(ldc >= ((flags & TEO_GEMM_SWIGLU16) ? N / 2 : N), "teo_gemm_ws: ldc %d too small", ldc);
+    TEO_CHECK_ARG(act >= TEO_ACT_NONE && act <= TEO_ACT_QUICK_GELU, "teo_gemm_ws: act %d", act);
+    TEO_CHECK_ARG(ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "teo_gemm_ws: workspace must be 256-byte aligned");
+    if (M && N) { NEED(A, "A"); NEED(W, "W"); NEED(C, "C"); }
+    return gemm(A, W, bias, res, C, M, N, K, lda, ldc, act, flags, dtype, out_dtype, ST(s), ws);
+}
+
 int teo_im2col_patches(const void* px, void* cols, int T, int channels, int image, int patch, int ldcols, int dtype,
                        teo_stream_t s) {
     ENTER();

@@ -285,13 +285,268 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// stream-K form of the same kernel (128 x 128 x 64 tiles, same k-order, same MFMA chains)
+//
+// Static tilings quantise badly on 256 CUs x 2 resident workgroups: at M = 2168 the N = 4096 layers (o, down) have 544
+// tiles for 512 slots -- two rounds, the second 6 % full -- and qkv 1632 tiles = 3.19 rounds.  Here the grid is PERSISTENT
+// (one workgroup per slot) and the flattened (tile, k-tile) iteration space is cut into equal contiguous ranges, so every
+// workgroup does the same amount of MFMA work whatever M and N are.  A range that starts or ends inside a tile shares that
+// tile with its neighbour:
+//     tail  (range ends inside tile t): k-tiles [0, e) of t are accumulated FIRST in the workgroup's timeline, the fp32
+//           accumulators go to this workgroup's slab in the workspace, a flag is raised;
+//     full tiles: as in the plain kernel;
+//     head  (range starts inside tile t): done LAST: the neighbour's slab (raised long ago: it was the first thing that
+//           workgroup did) is loaded AS THE INITIAL ACCUMULATOR and k-tiles [b, nk) are accumulated on top of it.
+// The k-order of every output element is therefore exactly the sequential one: results are BIT-IDENTICAL to the plain kernel
+// (tests/test_kernels_gpu.py), and independent of M, N and the grid size -- the bitwise invariances the model tests rely on
+// (frame-sharded tower == unsharded, batched prefill == per-slot prefill, truncation == prefix) still hold.
+// Hand-off across workgroups (other XCDs, non-coherent L2s): slab and flag are written with relaxed agent-scope atomic
+// stores (write-through, `sc1`), every storing wave drains `vmcnt(0)`, barrier, then the flag; the reader polls the flag
+// relaxed and reads the slab with agent-scope atomic loads (`sc1`: past L1, coherent with the write-through stores).  No
+// fences.  A waiter always waits on a workgroup that produced its slab at the very start of its life.
+// ------------------------------------------------------------------------------------------------
+template <bool SWIGLU, bool OUT_F32>
+__device__ __forceinline__ void gemm_tile_epilogue(f32x4 (&acc)[4][4], const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
+                                                   int M, int N, int ldc, int act, int m0, int n0, int wm, int wn, int fr, int fg) {
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+        if (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int ng = nw + ni * 16 + fg * 4;
+                if (ng >= N) continue;
+                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_F32) {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) =
+                        make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
+                if (n + 3 < N) {
+                    if (bias) {
+                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
+                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                    }
+                    if (act != TEO_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
+                    }
+                    if (res) {
+                        const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
+                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                    }
+                    if (OUT_F32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) =
+                            make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                    }
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) {
+                        float v = o[r];
+                        if (bias) v += bf2f(bias[n + r]);
+                        v = act_apply(v, act);
+                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+constexpr int SK_SLAB_FLOATS = BM * BN;          // one 128 x 128 fp32 accumulator tile per workgroup
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
+                                                                int M, int N, int K, int lda, int ldc, int act, int tiles_m,
+                                                                int tiles_n, int per, float* slabs, int* flags, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / BK;
+    const long long total = (long long)tiles_m * tiles_n * nk;
+    const int q = xcd_remap(blockIdx.x, gridDim.x);                 // logical position: one XCD owns a contiguous run of ranges
+    const long long it0 = (long long)q * per, it1 = min(it0 + per, total);
+    if (it0 >= total) return;
+
+    const bf16_t* ag[4];
+    const bf16_t* wg[4];
+    int soff[4];
+    f32x4 acc[4][4];
+    u32x4 ra0[4], rb0[4];
+
+    // one segment: k-tiles [kb, ke) of tile `tile`, accumulated into acc (the LDS double buffer is free on entry and on exit)
+    // position s of the flattened tile sequence -> tile: the sequence is laid out in P = ceil(per / nk) interleaved runs, so
+    // that the workgroups of an XCD, which sit ~per/nk positions apart, work on NEIGHBOURING tiles at any moment (a few W
+    // panels in that XCD's L2 instead of a dozen)
+    const int ntiles_ = tiles_m * tiles_n;
+    const int P_ = (per + nk - 1) / nk, pfull_ = ntiles_ / P_, prem_ = ntiles_ % P_;
+#define TEO_SK_SETUP(POS)                                                                                         \
+    const int pr_ = (POS) % P_, pc_ = (POS) / P_;                                                                 \
+    const int tile_ = pr_ * pfull_ + min(pr_, prem_) + pc_;                                                       \
+    const int tm_ = tile_ % tiles_m, tn_ = tile_ / tiles_m;                                                       \
+    const int m0 = tm_ * BM, n0 = tn_ * BN;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        const int id = tid + 256 * i;                                                                             \
+        const int row = id >> 3, c = id & 7;                                                                      \
+        ag[i] = A + (long long)min(m0 + row, M - 1) * lda + c * 8;                                                \
+        wg[i] = W + (long long)min(n0 + row, N - 1) * K + c * 8;                                                  \
+        soff[i] = row * (BK * 2) + ((c ^ (row & 7)) << 4);                                                        \
+    }
+#define TEO_SK_GLOAD(KT)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        ra0[i] = *reinterpret_cast<const u32x4*>(ag[i] + (long long)(KT) * BK);                                   \
+        rb0[i] = *reinterpret_cast<const u32x4*>(wg[i] + (long long)(KT) * BK);                                   \
+    }
+#define TEO_SK_SWRITE(BUF)                                                                                        \
+    {                                                                                                             \
+        unsigned char* sa_ = smem + (BUF) * (2 * TILE_BYTES);                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                           \
+            *reinterpret_cast<u32x4*>(sa_ + soff[i]) = ra0[i];                                                    \
+            *reinterpret_cast<u32x4*>(sa_ + TILE_BYTES + soff[i]) = rb0[i];                                       \
+        }                                                                                                         \
+    }
+#define TEO_SK_COMPUTE(BUF)                                                                                       \
+    {                                                                                                             \
+        const unsigned char* sA = smem + (BUF) * (2 * TILE_BYTES);                                                \
+        const unsigned char* sB = sA + TILE_BYTES;                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                        \
+            bf16x8 af[4], wf[4];                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+                const int ra_ = wm * 64 + i * 16 + fr;                                                            \
+                af[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * (BK * 2) + (((ks * 4 + fg) ^ (ra_ & 7)) << 4)); \
+                const int rw_ = wn * 64 + i * 16 + fr;                                                            \
+                wf[i] = *reinterpret_cast<const bf16x8*>(sB + rw_ * (BK * 2) + (((ks * 4 + fg) ^ (rw_ & 7)) << 4)); \
+            }                                                                                                     \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                      \
+                _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);  \
+        }                                                                                                         \
+    }
+#define TEO_SK_KLOOP(KB, KE)                                                                                      \
+    {                                                                                                             \
+        TEO_SK_GLOAD(KB);                                                                                         \
+        TEO_SK_SWRITE(0);                                                                                         \
+        __syncthreads();                                                                                          \
+        for (int kt = (KB); kt < (KE); ++kt) {                                                                    \
+            const int par = (kt - (KB)) & 1;                                                                      \
+            if (kt + 1 < (KE)) TEO_SK_GLOAD(kt + 1);                                                              \
+            if (par) { TEO_SK_COMPUTE(1); } else { TEO_SK_COMPUTE(0); }                                           \
+            if (kt + 1 < (KE)) {                                                                                  \
+                if (par) { TEO_SK_SWRITE(0); } else { TEO_SK_SWRITE(1); }                                         \
+            }                                                                                                     \
+            __syncthreads();                                                                                      \
+        }                                                                                                         \
+    }
+#define TEO_SK_ZERO()                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int t_first = (int)(it0 / nk), k_first = (int)(it0 % nk);           // head: tile t_first from k-tile k_first (if > 0)
+    const int t_last = (int)((it1 - 1) / nk), k_end = (int)(it1 - (long long)t_last * nk);   // tail: tile t_last up to k_end (if < nk)
+    const bool has_head = k_first != 0;
+    // per >= nk (host): a range that starts inside a tile always reaches that tile's end, so a tile has at most two owners
+    // slabs go through buffer descriptors: 16-byte stores / loads with the sc1 bit (write-through / past L1); 8-byte agent
+    // atomics would be one fabric transaction each (measured: the hand-off then costs ~40 us per workgroup)
+    const auto my_slab = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)q * SK_SLAB_FLOATS, 0, SK_SLAB_FLOATS * 4, 0x00020000);
+
+    // ---- (1) tail first: its partial sums are what the next range's owner continues from
+    if (k_end != nk) {
+        TEO_SK_SETUP(t_last)
+        TEO_SK_ZERO()
+        TEO_SK_KLOOP(0, k_end)
+        if (!(dbg & 1))
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[ni][mi]), my_slab, ((ni * 4 + mi) * 256 + tid) * 16, 0,
+                                                       /*aux: sc1*/ 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave: write-through stores landed
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- (2) the tiles that lie entirely inside the range
+    {
+        const int tb = has_head ? t_first + 1 : t_first;
+        const int te = (k_end != nk) ? t_last : t_last + 1;
+        for (int t = tb; t < te; ++t) {
+            TEO_SK_SETUP(t)
+            TEO_SK_ZERO()
+            TEO_SK_KLOOP(0, nk)
+            gemm_tile_epilogue<SWIGLU, OUT_F32>(acc, bias, res, Cv, M, N, ldc, act, m0, n0, wm, wn, fr, fg);
+        }
+    }
+    // ---- (3) head last: continue the previous range's partial sums in the same k-order
+    if (has_head) {
+        if (tid == 0 && !(dbg & 2)) {
+            int spins = 0;
+            while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 24)) break;                              // never reached: the producer wrote its slab first thing
+            }
+            __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+        }
+        __syncthreads();
+        const auto src = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)(q - 1) * SK_SLAB_FLOATS, 0, SK_SLAB_FLOATS * 4, 0x00020000);
+        if (dbg & 4) { TEO_SK_ZERO() } else
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, ((ni * 4 + mi) * 256 + tid) * 16, 0, /*aux: sc1*/ 16));
+        TEO_SK_SETUP(t_first)
+        TEO_SK_KLOOP(k_first, nk)
+        gemm_tile_epilogue<SWIGLU, OUT_F32>(acc, bias, res, Cv, M, N, ldc, act, m0, n0, wm, wn, fr, fg);
+    }
+#undef TEO_SK_SETUP
+#undef TEO_SK_GLOAD
+#undef TEO_SK_SWRITE
+#undef TEO_SK_COMPUTE
+#undef TEO_SK_KLOOP
+#undef TEO_SK_ZERO
+}
+
+// ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
+static int g_gemm_sk_dbg = 0;  // timing diagnostics only (wrong results): 1 skip slab stores, 2 skip the flag wait, 4 skip slab loads
+static int g_gemm_sk = 1;      // 1: stream-K kernel when a workspace is given and the static tiling would leave a ragged last round
+constexpr int SK_MAX_GRID = 512;   // 256 CUs x 2 resident workgroups (64 KiB LDS, <= 256 VGPRs each)
+size_t gemm_sk_workspace_bytes() { return (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float) + SK_MAX_GRID * sizeof(int); }
+// flags live behind the slabs; they must be zero before the first stream-K launch on a workspace (the kernel re-arms them)
+int gemm_sk_workspace_init(void* ws, hipStream_t st) {
+    hipError_t e = hipMemsetAsync((unsigned char*)ws + (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float), 0, SK_MAX_GRID * sizeof(int), st);
+    return e == hipSuccess ? TEO_OK : hip_fail(e, "gemm_sk_workspace_init");
+}
 static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
 static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
 int gemm_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
     if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
+    if (!strcmp(key, "gemm_sk_dbg")) { g_gemm_sk_dbg = value; return 0; }
+    if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return 0; }          // 0 off, 1 auto, 2 forced (diagnostics)
     return -1;
 }
 
@@ -318,7 +573,7 @@ static void launch_simple(const void* A, const void* W, const void* bias, const 
 }
 
 int gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
-         int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st) {
+         int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st, void* sk_ws) {
     if (M == 0 || N == 0) return TEO_OK;
     const bool swiglu = flags & TEO_GEMM_SWIGLU16;
     if (swiglu && (bias || res || act != TEO_ACT_NONE || N % 32 != 0)) {
@@ -336,6 +591,27 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
+        // stream-K where it was measured to win: just over ONE round of tiles (544 tiles on 512 slots at M = 2168, N = 4096:
+        // o 114 -> 93 us, down 297 -> 250 us).  With several tiles per workgroup the contiguous ranges spread an XCD's
+        // concurrent tiles over three times as many W panels as the plain kernel's rolling window does and the L2 misses
+        // cost more than the idle tail of the last round saves (qkv, 3.19 rounds: 255 -> 330 us; 1.5 rounds: 118 -> 130 us).
+        if (sk_ws && g_gemm_sk && bm == 128 && nwg > SK_MAX_GRID &&
+            (g_gemm_sk == 2 || (nwg < 2 * SK_MAX_GRID && (nwg % SK_MAX_GRID) <= SK_MAX_GRID / 6))) {
+            const int nk = K / BK;
+            const long long total = (long long)nwg * nk;
+            const int per = (int)((total + SK_MAX_GRID - 1) / SK_MAX_GRID);          // >= nk because nwg > SK_MAX_GRID
+            float* slabs = (float*)sk_ws;
+            int* flg = (int*)((unsigned char*)sk_ws + (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float));
+#define TEO_SK_LAUNCH(SW, OF)                                                                                         \
+    gemm_mfma_bf16_sk_kernel<SW, OF><<<SK_MAX_GRID, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,  \
+                                                                     (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
+                                                                     tiles_n, per, slabs, flg, g_gemm_sk_dbg)
+            if (swiglu) { if (of32) TEO_SK_LAUNCH(true, true); else TEO_SK_LAUNCH(true, false); }
+            else { if (of32) TEO_SK_LAUNCH(false, true); else TEO_SK_LAUNCH(false, false); }
+#undef TEO_SK_LAUNCH
+            TEO_LAUNCH_CHECK("gemm_mfma_bf16_sk");
+            return TEO_OK;
+        }
 #define TEO_GEMM_K(SW, OF, DP, MFV)                                                                                   \
     gemm_mfma_bf16_kernel<SW, OF, DP, MFV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                   (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \

@@ -17,7 +17,7 @@ int vit_embed_ln(const void* patch, const void* cls, const void* pos, const void
 bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned flags, const void* A, const void* W,
                   const void* bias, const void* res, const void* C);
 int gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
-         int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st);
+         int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st, void* sk_ws = nullptr);
 
 int attention(const teo_attn_args* a, int dtype, hipStream_t st);
 int attention_flash32(const teo_attn_args& a, hipStream_t st);
@@ -79,6 +79,8 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
                 void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st,
                 SkinnyFuse fuse = SkinnyFuse());
 int gemm_tune_set(const char* key, int value);
+size_t gemm_sk_workspace_bytes();
+int gemm_sk_workspace_init(void* ws, hipStream_t st);
 int attn_tune_set(const char* key, int value);
 int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,
                   const float* cs, const float* sn, const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk,

@@ -30,7 +30,7 @@ struct Carver {
 // ViT
 // ------------------------------------------------------------------------------------------------
 struct VitWs {
-    void *cols, *patch, *h, *ln, *qkv, *vt, *attn, *mlp;
+    void *cols, *patch, *h, *ln, *qkv, *vt, *attn, *mlp, *sk;
     int ldv;
     size_t total;
 };
@@ -49,6 +49,7 @@ static VitWs vit_carve(const teo_vit_desc* d, int T, void* ws, size_t cap) {
     w.vt = c.take((size_t)T * D * w.ldv * e);
     w.attn = c.take((size_t)T * N * D * e);
     w.mlp = c.take((size_t)T * N * d->inter * e);
+    w.sk = c.take(gemm_sk_workspace_bytes());          // stream-K slabs + flags of the MFMA GEMMs
     w.total = c.off;
     return w;
 }
@@ -66,12 +67,13 @@ int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features,
     const int dt = d->dtype;
     const int g = d->image / d->patch, NP = g * g, N = NP + 1, D = d->hidden, H = d->heads, hd = D / H;
     const int rows = T * N;
+    TEO_TRY(gemm_sk_workspace_init(w.sk, st));
     TEO_TRY(im2col_patches(pixels, w.cols, T, d->channels, d->image, d->patch, d->k_pad, dt, st));
-    TEO_TRY(gemm(w.cols, d->patch_w, nullptr, nullptr, w.patch, T * NP, D, d->k_pad, d->k_pad, D, TEO_ACT_NONE, 0, dt, dt, st));
+    TEO_TRY(gemm(w.cols, d->patch_w, nullptr, nullptr, w.patch, T * NP, D, d->k_pad, d->k_pad, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
     TEO_TRY(vit_embed_ln(w.patch, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, w.h, T, NP, D, d->eps, dt, st));
     for (int l = 0; l < d->layers_run; ++l) {
         TEO_TRY(layernorm(w.h, d->ln1_w[l], d->ln1_b[l], w.ln, rows, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.ln, d->qkv_w[l], d->qkv_b[l], nullptr, w.qkv, rows, 3 * D, D, D, 3 * D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.ln, d->qkv_w[l], d->qkv_b[l], nullptr, w.qkv, rows, 3 * D, D, D, 3 * D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         TEO_TRY(vit_value_transpose(w.qkv, w.vt, T, N, H, hd, w.ldv, dt, st));
         teo_attn_args a;
         memset(&a, 0, sizeof(a));
@@ -93,10 +95,10 @@ int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features,
         a.causal = 0;
         a.scale = 1.0f / sqrtf((float)hd);
         TEO_TRY(attention(&a, dt, st));
-        TEO_TRY(gemm(w.attn, d->out_w[l], d->out_b[l], w.h, w.h, rows, D, D, D, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.attn, d->out_w[l], d->out_b[l], w.h, w.h, rows, D, D, D, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         TEO_TRY(layernorm(w.h, d->ln2_w[l], d->ln2_b[l], w.ln, rows, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.ln, d->fc1_w[l], d->fc1_b[l], nullptr, w.mlp, rows, d->inter, D, D, d->inter, d->act, 0, dt, dt, st));
-        TEO_TRY(gemm(w.mlp, d->fc2_w[l], d->fc2_b[l], w.h, w.h, rows, D, d->inter, d->inter, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.ln, d->fc1_w[l], d->fc1_b[l], nullptr, w.mlp, rows, d->inter, D, D, d->inter, d->act, 0, dt, dt, st, w.sk));
+        TEO_TRY(gemm(w.mlp, d->fc2_w[l], d->fc2_b[l], w.h, w.h, rows, D, d->inter, d->inter, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
     }
     if (d->keep_cls) {                                   // feature_select 'cls_patch': the whole hidden state
         hipError_t he = hipMemcpyAsync(features, w.h, (size_t)rows * D * esize(dt), hipMemcpyDeviceToDevice, st);
@@ -138,7 +140,7 @@ int projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws
 // LLaMA prefill
 // ------------------------------------------------------------------------------------------------
 struct PrefillWs {
-    void *h, *n, *qkv, *attn, *act;
+    void *h, *n, *qkv, *attn, *act, *sk;
     size_t total;
 };
 
@@ -152,6 +154,7 @@ static PrefillWs prefill_carve(const teo_llama_desc* d, int S, void* ws, size_t 
     w.qkv = c.take((size_t)S * QKV * e);
     w.attn = c.take((size_t)S * d->heads * d->head_dim * e);
     w.act = c.take((size_t)S * d->inter * e);
+    w.sk = c.take(gemm_sk_workspace_bytes());          // stream-K slabs + flags of the MFMA GEMMs
     w.total = c.off;
     return w;
 }
@@ -173,9 +176,10 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
     const int QKV = (H + 2 * Hk) * hd;
     hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
+    TEO_TRY(gemm_sk_workspace_init(w.sk, st));
     for (int l = 0; l < d->layers; ++l) {
         TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         TEO_TRY(rope_kv_append(w.qkv, QKV, positions, d->rope_cos, d->rope_sin, d->k_cache[l], d->v_cache[l],
                                d->vt_cache[l], S, past, nullptr, d->max_seq, H, Hk, hd, dt, st));
         teo_attn_args a;
@@ -190,17 +194,17 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
         a.causal = 1;
         a.scale = 1.0f / sqrtf((float)hd);
         TEO_TRY(attention(&a, dt, st));
-        TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         TEO_TRY(rmsnorm(w.h, d->post_norm_w[l], w.n, S, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st));
-        TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st, w.sk));
+        TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
     }
     if (last_only) {
         const void* hl = (const unsigned char*)w.h + (size_t)(S - 1) * D * e;
         return gemv(hl, d->lm_head, d->final_norm_w, nullptr, logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st);
     }
     TEO_TRY(rmsnorm(w.h, d->final_norm_w, w.n, S, D, d->eps, dt, st));
-    return gemm(w.n, d->lm_head, nullptr, nullptr, logits, S, d->vocab, D, D, d->vocab, TEO_ACT_NONE, 0, dt, TEO_F32, st);
+    return gemm(w.n, d->lm_head, nullptr, nullptr, logits, S, d->vocab, D, D, d->vocab, TEO_ACT_NONE, 0, dt, TEO_F32, st, w.sk);
 }
 
 // Multi-sequence prefill (batched generate): the rows of nseq new conversations are concatenated so the norms and the
@@ -226,9 +230,10 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
     const int S = total;
     hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
+    TEO_TRY(gemm_sk_workspace_init(w.sk, st));
     for (int l = 0; l < d->layers; ++l) {
         TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         int row0 = 0;
         for (int b = 0; b < nseq; ++b) {
             const int Sb = seq_lens[b];
@@ -252,10 +257,10 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
             TEO_TRY(attention(&a, dt, st));
             row0 += Sb;
         }
-        TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         TEO_TRY(rmsnorm(w.h, d->post_norm_w[l], w.n, S, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st));
-        TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st));
+        TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st, w.sk));
+        TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
     }
     int row_end = 0;
     for (int b = 0; b < nseq; ++b) {

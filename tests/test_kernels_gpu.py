@@ -889,3 +889,57 @@ def test_attn_decode_fused_combine_is_bitwise_the_two_launch_path(dtype, H, Hk, 
     finally:
         lib.teo_tune_set(b"attn_chunk", 0)
         lib.teo_tune_set(b"attn_fused_combine", 0)
+
+
+# ---------------------------------------------------------------------------------------------- stream-K GEMM
+def _gemm_ws(A, W, ws, bias=None, res=None, act=L.ACT_NONE, flags=0, out_dtype=None):
+    M, K = A.shape
+    N = W.shape[0]
+    out_dtype = out_dtype or A.dtype
+    Nc = N // 2 if flags & L.GEMM_SWIGLU16 else N
+    Cc = torch.empty(M, Nc, dtype=out_dtype, device=A.device)
+    L.check(G.lib().teo_gemm_ws(G.p(A), G.p(W), G.p(bias), G.p(res), G.p(Cc), M, N, K, A.stride(0), Nc, act, flags, G.DT[A.dtype],
+                                G.DT[out_dtype], G.p(ws), G.stream()), "gemm_ws")
+    return Cc
+
+
+@pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 4096, 4096, 0, "res"), (2168, 4096, 11008, 0, "res"), (2168, 12288, 4096, 0, ""),
+                                               (2168, 22016, 4096, L.GEMM_SWIGLU16, ""), (2056, 4096, 1024, 0, "bias_gelu"),
+                                               (4208, 4096, 4096, 0, "f32out"), (1300, 8192, 512, 0, ""), (17000, 512, 64, 0, "bias")])
+def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
+    """teo_gemm_ws (persistent stream-K grid: equal k-tile ranges per workgroup, partial tiles handed to the neighbour through
+    fp32 slabs and continued in the same k-order) against teo_gemm (one workgroup per tile): BIT-identical outputs, launch after
+    launch on the same workspace (slabs and flags are re-used: a stale or torn hand-off would show), also with a concurrent HBM
+    stream on a second HIP stream."""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g)).to(bf).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(bf).cuda()
+    Nc = N // 2 if flags else N
+    bias = (torch.randn(N, generator=g) * 0.1).to(bf).cuda() if "bias" in extra else None
+    res = (torch.randn(M, Nc, generator=g)).to(bf).cuda() if "res" in extra else None
+    act = L.ACT_GELU_ERF if "gelu" in extra else L.ACT_NONE
+    od = torch.float32 if "f32out" in extra else bf
+    lib = G.lib()
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+    side = torch.cuda.Stream()
+    big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")
+    big2 = torch.empty_like(big)
+    bad = 0
+    for it in range(8):
+        if it % 2:
+            with torch.cuda.stream(side):
+                big2.copy_(big)
+        got = _gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(got, want))
+    assert bad == 0, f"{bad}/8 launches differ from the plain kernel"
+    # without a workspace teo_gemm_ws is teo_gemm; tuning the stream-K path off gives the same bits too
+    assert torch.equal(_gemm_ws(A, W, None, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)
+    assert lib.teo_tune_set(b"gemm_sk", 0) == 0
+    try:
+        assert torch.equal(_gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)
+    finally:
+        lib.teo_tune_set(b"gemm_sk", 1)

@@ -175,14 +175,35 @@ def bench_gemv_sweep():
 
 
 def bench_gemm():
+    """MFMA GEMM at the prefill shapes: plain tiling vs the stream-K grid (teo_gemm_ws), interleaved."""
     shapes = [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
               ("down", 2168, 4096, 11008, 0), ("vit_qkv", 2056, 3072, 1024, 0), ("vit_fc1", 2056, 4096, 1024, 0),
-              ("vit_fc2", 2056, 1024, 4096, 0), ("sq4096", 4096, 4096, 4096, 0)]
+              ("vit_fc2", 2056, 1024, 4096, 0), ("sq4096", 4096, 4096, 4096, 0), ("qkv_T16", 4208, 12288, 4096, 0),
+              ("down_B8", 17344, 4096, 11008, 0)]
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    if os.environ.get("TEO_SK_DBG"):
+        lib.teo_tune_set(b"gemm_sk_dbg", int(os.environ["TEO_SK_DBG"]))
+        shapes = shapes[:2]
+    if os.environ.get("TEO_SK_FORCE"):
+        lib.teo_tune_set(b"gemm_sk", 2)
+        shapes = [("sq4096", 4096, 4096, 4096, 0), ("sq8192x4096", 8192, 4096, 4096, 0), ("3072x4096", 3072, 4096, 4096, 0)]
     for name, M, N, K, flags in shapes:
         A = torch.randn(M, K, device="cuda").to(bf)
         W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
-        us = timeit(lambda: G.gemm(A, W, flags=flags))
-        print(f"gemm {name:8s} M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
+        Nc = N // 2 if flags else N
+        Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
+
+        def run(w):
+            L.check(lib.teo_gemm_ws(G.p(A), G.p(W), None, None, G.p(Cc), M, N, K, K, Nc, 0, flags, L.TEO_BF16, L.TEO_BF16,
+                                    G.p(w) if w is not None else None, G.stream()), "gemm")
+        res = {0: [], 1: []}
+        for _ in range(3):
+            res[0].append(timeit(lambda: run(None)))
+            res[1].append(timeit(lambda: run(ws)))
+        a, b = min(res[0]), min(res[1])
+        print(f"gemm {name:8s} M={M} N={N} K={K}: plain {a:8.1f} us {2.0 * M * N * K / a / 1e6:7.1f} TFLOP/s | stream-K {b:8.1f} us "
+              f"{2.0 * M * N * K / b / 1e6:7.1f} TFLOP/s", flush=True)
 
 
 def bench_attn_prefill():
