@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8 = config C5 weight path (decode streams fp8-e4m3 weights); the headline is bf16")
+    ap.add_argument("--prefill", default="auto", choices=["auto", "bf16", "fp8"], help="prefill Linear layers: bf16 MFMA on the (dequantised) weights, or w8a8 on the fp8 MFMA (default with --weights fp8)")
     ap.add_argument("--batch", type=int, default=1, help="config C5 variant: B conversations per GPU decoded together (weights streamed once per step)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo for plumbing tests")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: every rank uses cuda:0 (needs --dist-backend gloo)")
@@ -265,6 +266,11 @@ def main():
     tok, model, _, _ = load_pretrained_model("synthetic:teochat-7b", None, "synthetic:teochat-7b", device=device,
                                              dtype=dtype, max_seq=max_seq, weight_format=("fp8" if args.weights == "fp8" else None))
     eng = model.engine
+    prefill_fp8 = args.prefill == "fp8" or (args.prefill == "auto" and args.weights == "fp8")
+    if prefill_fp8:
+        if args.weights != "fp8":
+            raise SystemExit("--prefill fp8 needs --weights fp8 (the e4m3 weight copies)")
+        L.check(eng.lib.teo_tune_set(b"prefill_fp8", 1), "teo_tune_set")
     for kv in args.tune:
         k_, v_ = kv.split("=")
         L.check(eng.lib.teo_tune_set(k_.encode(), int(v_)), "teo_tune_set")
@@ -404,7 +410,8 @@ def main():
         "metric": "end-to-end tokens/sec (prefill+decode), T=8 frames, LLaMA-2-7B",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3 decode weights", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if args.weights == "bf16" else ("bf16 activations / fp8-e4m3 weights (decode: fp8 weight stream; prefill: "
+                                                       + ("w8a8 on the fp8 MFMA)" if prefill_fp8 else "bf16 MFMA on the dequantised weights)")), "data": "synthetic",
         "config": {"workload": f"{workload_label(T, n_text, n_out, B, args.shard_frames, args.weights)}: T={T} frames 224x224 -> CLIP-ViT-L/14 (23 layers) -> mlp2x_gelu -> splice of a "
                                f"{n_text}-token prompt (L={Lseq}) -> LLaMA-2-7B prefill -> {n_out} forced greedy tokens; "
                                f"value = generated tokens / total time",

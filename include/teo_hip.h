@@ -89,6 +89,20 @@ int teo_gemm_workspace_init(void* d_workspace, teo_stream_t stream);
 int teo_gemm_ws(const void* d_A, const void* d_W, const void* d_bias, const void* d_residual, void* d_C, int M, int N, int K,
                 int lda, int ldc, int act, unsigned flags, int dtype, int out_dtype, void* d_workspace, teo_stream_t stream);
 
+/* w8a8 GEMM on the block-scaled fp8 MFMA of CDNA4 (v_mfma_scale_f32_16x16x128_f8f6f4, every block scale 2^0; config C5's "fp8
+ * weight path on CDNA4 MFMA" for the prefill phase):
+ *     C[m, n] = a_scale[m] * w_scale[n] * sum_k A8[m, k] * W8[n, k]  (+ residual[m, n]);  TEO_GEMM_SWIGLU16 as in teo_gemm.
+ * A8 [M, lda] and W8 [N, K] hold OCP e4m3 bytes, a_scale [M] / w_scale [N] fp32; C / residual bf16 (or C fp32).  K % 128 == 0,
+ * lda % 16 == 0, N % 4 == 0; TEO_ERR_UNSUPPORTED otherwise.  Same Linear layers as teo_gemm (tf LlamaAttention / LlamaMLP,
+ * reached from llava_llama.py:88-99) under a weight + activation quantisation the reference does not have (its 8-bit option is
+ * bitsandbytes, eval.py:52-53): selectable, never the default.
+ * teo_quant_rows_fp8: per-row (per-token) quantiser  q[m, :] = e4m3(f(x[m, :]) / s[m]),  s[m] = max|f(x[m, :])| / 448, with
+ * f = identity, or LlamaRMSNorm (d_norm_w != NULL: x * rsqrt(mean(x^2) + eps) * w rounded to bf16, as teo_rmsnorm).  x bf16. */
+int teo_gemm_fp8(const void* d_A8, const float* d_a_scale, const void* d_W8, const float* d_w_scale, const void* d_residual, void* d_C,
+                 int M, int N, int K, int lda, int ldc, unsigned flags, int out_dtype, teo_stream_t stream);
+int teo_quant_rows_fp8(const void* d_x, const void* d_norm_w, void* d_q, float* d_scale, int rows, int K, int ldx, float eps,
+                       teo_stream_t stream);
+
 /* Patch extraction for the CLIP patch-embedding conv (kernel = stride = patch, no bias):
  * cols[t*g*g + py*g + px, c*P*P + ky*P + kx] = pixels[t, c, py*P+ky, px*P+kx], zero padded to ldcols.
  * Replaces the im2col half of CLIPVisionEmbeddings.patch_embedding (used at modeling_image.py:602,645). */

@@ -59,7 +59,7 @@ int teo_version(void) { return TEO_ABI_VERSION; }
 const char* teo_last_error(void) { return g_err; }
 
 int teo_tune_set(const char* key, int value) {
-    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
+    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || runtime_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
     set_error("teo_tune_set: unknown key");
     return TEO_ERR_ARG;
 }
@@ -93,6 +93,22 @@ int teo_gemm(const void* A, const void* W, const void* bias, const void* res, vo
     TEO_CHECK_ARG(act >= TEO_ACT_NONE && act <= TEO_ACT_QUICK_GELU, "teo_gemm: act %d", act);
     if (M && N) { NEED(A, "A"); NEED(W, "W"); NEED(C, "C"); }
     return gemm(A, W, bias, res, C, M, N, K, lda, ldc, act, flags, dtype, out_dtype, ST(s));
+}
+
+int teo_gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,
+                 int lda, int ldc, unsigned flags, int out_dtype, teo_stream_t s) {
+    ENTER();
+    NEED_DT(out_dtype);
+    TEO_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && lda >= K, "teo_gemm_fp8: M %d N %d K %d lda %d", M, N, K, lda);
+    TEO_CHECK_ARG(ldc >= ((flags & TEO_GEMM_SWIGLU16) ? N / 2 : N), "teo_gemm_fp8: ldc %d too small", ldc);
+    if (M && N) { NEED(A8, "A8"); NEED(a_scale, "a_scale"); NEED(W8, "W8"); NEED(w_scale, "w_scale"); NEED(C, "C"); }
+    return gemm_fp8(A8, a_scale, W8, w_scale, res, C, M, N, K, lda, ldc, flags, out_dtype, ST(s));
+}
+int teo_quant_rows_fp8(const void* x, const void* norm_w, void* q, float* scale, int rows, int K, int ldx, float eps, teo_stream_t s) {
+    ENTER();
+    TEO_CHECK_ARG(rows >= 0 && K > 0 && ldx >= K, "teo_quant_rows_fp8: rows %d K %d ldx %d", rows, K, ldx);
+    if (rows) { NEED(x, "x"); NEED(q, "q"); NEED(scale, "scale"); }
+    return quant_rows_fp8(x, norm_w, q, scale, rows, K, ldx, eps, ST(s));
 }
 
 size_t teo_gemm_workspace_bytes(void) { return gemm_sk_workspace_bytes(); }

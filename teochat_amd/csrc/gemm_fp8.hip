@@ -1,0 +1,280 @@
+// w8a8 prefill GEMM on the block-scaled fp8 MFMA of CDNA4 (config C5: "fp8 weight path on CDNA4 MFMA"):
+//
+//     C[m, n] = act_scale[m] * w_scale[n] * sum_k A8[m, k] * W8[n, k]        (+ residual, or the SwiGLU pairing)
+//
+// A8 = activations quantised per TOKEN to OCP e4m3 (quant_rows_fp8 / rmsnorm_quant_fp8 below), W8 = the per-output-row e4m3
+// weights the decode path already streams (teo_llama_desc *_w8 / *_s).  The product runs on
+// v_mfma_scale_f32_16x16x128_f8f6f4 with every block scale = 2^0 (E8M0 0x7F): the instruction is used for its K = 128 depth
+// -- twice the dense rate of the bf16 MFMA and half the operand bytes -- and the two fp32 scale vectors are applied once in
+// the epilogue (they factor out of the sum).  fp8 x fp8 products are exact in fp32, so the only rounding is the fp32
+// accumulation: against the dequantised operands the kernel is exact to accumulation order.
+//
+// Same skeleton as gemm_mfma_bf16_kernel (gemm.hip): 128 x 128 workgroup tile, 4 waves of 64 x 64, K tile = 128 bytes per row
+// (the same 128-byte LDS rows, 16-byte chunks XOR-swizzled by row & 7), register-staged global loads one K tile ahead, LDS
+// double buffer, XCD-aware tile order, swapped operands (a lane owns 4 consecutive n of one m row).
+// MFMA operand layout (16 x 128 per operand): lane l holds row l & 15, bytes 32 * (l >> 4) .. + 32 of the K tile.
+// Roofline: MFMA fp8 dense (~5 PFLOP/s); algorithmic FLOPs = 2 * M * N * K.
+#include "common.h"
+#include "ops.h"
+
+namespace teo {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) float f8_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int f8_u32x4;
+
+constexpr int F8_BM = 128, F8_BN = 128, F8_BK = 128;          // BK in bytes == elements
+constexpr int F8_TILE = F8_BM * F8_BK;                        // 16 KiB per operand tile
+
+__device__ __forceinline__ int f8_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_fp8_kernel(const unsigned char* __restrict__ A, const float* __restrict__ a_scale,
+                                                            const unsigned char* __restrict__ W, const float* __restrict__ w_scale,
+                                                            const bf16_t* res, void* Cv, int M, int N, int K, int lda, int ldc,
+                                                            int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile = f8_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * F8_BM, n0 = tn * F8_BN;
+
+    const unsigned char* ag[4];
+    const unsigned char* wg[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id >> 3, c = id & 7;
+        ag[i] = A + (long long)min(m0 + row, M - 1) * lda + c * 16;
+        wg[i] = W + (long long)min(n0 + row, N - 1) * K + c * 16;
+        soff[i] = row * F8_BK + ((c ^ (row & 7)) << 4);
+    }
+    f8_u32x4 ra[4], rb[4];
+    f8_f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f8_f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / F8_BK;
+
+#define TEO_F8_GLOAD(KT)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+        ra[i] = *reinterpret_cast<const f8_u32x4*>(ag[i] + (long long)(KT) * F8_BK);         \
+        rb[i] = *reinterpret_cast<const f8_u32x4*>(wg[i] + (long long)(KT) * F8_BK);         \
+    }
+#define TEO_F8_SWRITE(BUF)                                                                   \
+    {                                                                                        \
+        unsigned char* sa_ = smem + (BUF) * (2 * F8_TILE);                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+            *reinterpret_cast<f8_u32x4*>(sa_ + soff[i]) = ra[i];                             \
+            *reinterpret_cast<f8_u32x4*>(sa_ + F8_TILE + soff[i]) = rb[i];                   \
+        }                                                                                    \
+    }
+#define TEO_F8_FRAG(BASE, ROW)                                                               \
+    ({                                                                                       \
+        const unsigned char* rp_ = (BASE) + (ROW) * F8_BK;                                   \
+        const f8_u32x4 lo_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg) ^ ((ROW) & 7)) << 4));      \
+        const f8_u32x4 hi_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg + 1) ^ ((ROW) & 7)) << 4));  \
+        i32x8 f_;                                                                            \
+        f_[0] = (int)lo_[0]; f_[1] = (int)lo_[1]; f_[2] = (int)lo_[2]; f_[3] = (int)lo_[3];  \
+        f_[4] = (int)hi_[0]; f_[5] = (int)hi_[1]; f_[6] = (int)hi_[2]; f_[7] = (int)hi_[3];  \
+        f_;                                                                                  \
+    })
+#define TEO_F8_COMPUTE(BUF)                                                                  \
+    {                                                                                        \
+        const unsigned char* sA = smem + (BUF) * (2 * F8_TILE);                              \
+        const unsigned char* sB = sA + F8_TILE;                                              \
+        i32x8 af[4], wf[4];                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+            af[i] = TEO_F8_FRAG(sA, wm * 64 + i * 16 + fr);                                  \
+            wf[i] = TEO_F8_FRAG(sB, wn * 64 + i * 16 + fr);                                  \
+        }                                                                                    \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                     \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                 \
+                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+    }
+
+    TEO_F8_GLOAD(0);
+    TEO_F8_SWRITE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) TEO_F8_GLOAD(kt + 1);
+        if (kt & 1) { TEO_F8_COMPUTE(1); } else { TEO_F8_COMPUTE(0); }
+        if (kt + 1 < nk) {
+            if (kt & 1) { TEO_F8_SWRITE(0); } else { TEO_F8_SWRITE(1); }
+        }
+        __syncthreads();
+    }
+#undef TEO_F8_GLOAD
+#undef TEO_F8_SWRITE
+#undef TEO_F8_FRAG
+#undef TEO_F8_COMPUTE
+
+    // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+        const float sa = a_scale[m];
+        if (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int ng = nw + ni * 16 + fg * 4;              // gate rows; up rows are +16 (N % 32 == 0)
+                if (ng >= N) continue;
+                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
+                const float4 sg = *reinterpret_cast<const float4*>(w_scale + ng);
+                const float4 su = *reinterpret_cast<const float4*>(w_scale + ng + 16);
+                float o[4];
+                o[0] = silu(acc[ni][mi][0] * (sa * sg.x)) * (acc[ni + 1][mi][0] * (sa * su.x));
+                o[1] = silu(acc[ni][mi][1] * (sa * sg.y)) * (acc[ni + 1][mi][1] * (sa * su.y));
+                o[2] = silu(acc[ni][mi][2] * (sa * sg.z)) * (acc[ni + 1][mi][2] * (sa * su.z));
+                o[3] = silu(acc[ni][mi][3] * (sa * sg.w)) * (acc[ni + 1][mi][3] * (sa * su.w));
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;                              // N % 4 == 0: whole group in or out
+                const float4 sw = *reinterpret_cast<const float4*>(w_scale + n);
+                float o[4] = {acc[ni][mi][0] * (sa * sw.x), acc[ni][mi][1] * (sa * sw.y), acc[ni][mi][2] * (sa * sw.z), acc[ni][mi][3] * (sa * sw.w)};
+                if (res) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                    o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
+                    o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                }
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+    }
+}
+
+bool gemm_fp8_ok(int M, int N, int K, int lda, int ldc, unsigned flags, const void* A, const void* W, const void* res, const void* C) {
+    if (M < 1 || N < 1 || K % F8_BK != 0 || lda % 16 != 0 || ldc % 4 != 0 || N % 4 != 0) return false;
+    if ((flags & TEO_GEMM_SWIGLU16) && (N % 32 != 0 || res)) return false;
+    auto al = [](const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; };
+    return al(A, 16) && al(W, 16) && al(res, 8) && al(C, 16);
+}
+
+int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,
+             int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st) {
+    if (M == 0 || N == 0) return TEO_OK;
+    if (!gemm_fp8_ok(M, N, K, lda, ldc, flags, A8, W8, res, C)) {
+        set_error("teo_gemm_fp8: needs K %% 128 == 0, lda %% 16 == 0, N %% 4 == 0 (32 with SWIGLU16, no residual) and 16-byte aligned operands "
+                  "(M %d N %d K %d lda %d ldc %d)", M, N, K, lda, ldc);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    const bool swiglu = flags & TEO_GEMM_SWIGLU16;
+    const int tiles_m = cdiv(M, F8_BM), tiles_n = cdiv(N, F8_BN);
+    const int nwg = tiles_m * tiles_n;
+    const size_t lds = 4 * F8_TILE;
+    const bool of32 = out_dtype == TEO_F32;
+#define TEO_F8_LAUNCH(SW, OF)                                                                                               \
+    gemm_mfma_fp8_kernel<SW, OF><<<nwg, 256, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, w_scale,  \
+                                                        (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n)
+    if (swiglu) { if (of32) TEO_F8_LAUNCH(true, true); else TEO_F8_LAUNCH(true, false); }
+    else { if (of32) TEO_F8_LAUNCH(false, true); else TEO_F8_LAUNCH(false, false); }
+#undef TEO_F8_LAUNCH
+    TEO_LAUNCH_CHECK("gemm_mfma_fp8");
+    return TEO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-token activation quantisation: q[m, :] = e4m3(x[m, :] / s[m]), s[m] = max|x[m, :]| / 448 (1 for an all-zero row).
+// NORM: x is first passed through LlamaRMSNorm exactly as the bf16 path does it (fp32 statistics, value rounded to bf16):
+// the quantiser sees the tensor the bf16 GEMM would have consumed.  One workgroup per row, row kept in registers.
+// ------------------------------------------------------------------------------------------------
+template <bool NORM>
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g, unsigned char* __restrict__ q,
+                                                          float* __restrict__ s, int K, int ldx, float eps) {
+    constexpr int MAXV = 6;                          // 8-element vectors per thread: K <= 256 * 8 * 6 = 12288
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* xr = x + (long long)m * ldx;
+    float v[MAXV][8];
+    const int nv = K >> 3;                           // K % 16 == 0 (host)
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+            const uint4 r = *reinterpret_cast<const uint4*>(xr + c * 8);
+            v[i][0] = __uint_as_float(r.x << 16); v[i][1] = __uint_as_float(r.x & 0xffff0000u);
+            v[i][2] = __uint_as_float(r.y << 16); v[i][3] = __uint_as_float(r.y & 0xffff0000u);
+            v[i][4] = __uint_as_float(r.z << 16); v[i][5] = __uint_as_float(r.z & 0xffff0000u);
+            v[i][6] = __uint_as_float(r.w << 16); v[i][7] = __uint_as_float(r.w & 0xffff0000u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ssq = fmaf(v[i][e], v[i][e], ssq);
+        }
+    }
+    if (NORM) {
+        const float tot = block_sum<256>(ssq, red);
+        const float inv = rsqrtf(tot / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nv) {
+                const uint4 r = *reinterpret_cast<const uint4*>(g + c * 8);
+                const float gw[8] = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                                     __uint_as_float(r.y & 0xffff0000u), __uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u),
+                                     __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = bf2f(f2bf(v[i][e] * inv * gw[e]));   // x * r * w in fp32, one rounding to bf16: as norm.hip
+            }
+        }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+        }
+    }
+    amax = wave_max(amax);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv_s = 1.0f / scale;
+    if (tid == 0) s[m] = scale;
+    unsigned char* qr = q + (long long)m * K;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv_s, v[i][1] * inv_s, w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv_s, v[i][3] * inv_s, w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][4] * inv_s, v[i][5] * inv_s, w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][6] * inv_s, v[i][7] * inv_s, w1, true);
+            *reinterpret_cast<uint2*>(qr + c * 8) = make_uint2((unsigned)w0, (unsigned)w1);
+        }
+    }
+}
+
+int quant_rows_fp8(const void* x, const void* norm_w, void* q, float* s, int M, int K, int ldx, float eps, hipStream_t st) {
+    if (M == 0) return TEO_OK;
+    if (K % 16 != 0 || K > 256 * 8 * 6 || ldx % 8 != 0) {
+        set_error("teo_quant_rows_fp8: K %d must be a multiple of 16 and <= 12288 (ldx %d a multiple of 8)", K, ldx);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    if (norm_w) quant_rows_fp8_kernel<true><<<M, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)norm_w, (unsigned char*)q, s, K, ldx, eps);
+    else quant_rows_fp8_kernel<false><<<M, 256, 0, st>>>((const bf16_t*)x, nullptr, (unsigned char*)q, s, K, ldx, eps);
+    TEO_LAUNCH_CHECK("quant_rows_fp8");
+    return TEO_OK;
+}
+
+}  // namespace teo

@@ -140,7 +140,8 @@ int projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws
 // LLaMA prefill
 // ------------------------------------------------------------------------------------------------
 struct PrefillWs {
-    void *h, *n, *qkv, *attn, *act, *sk;
+    void *h, *n, *qkv, *attn, *act, *sk, *q8;
+    float* qs;
     size_t total;
 };
 
@@ -155,8 +156,38 @@ static PrefillWs prefill_carve(const teo_llama_desc* d, int S, void* ws, size_t 
     w.attn = c.take((size_t)S * d->heads * d->head_dim * e);
     w.act = c.take((size_t)S * d->inter * e);
     w.sk = c.take(gemm_sk_workspace_bytes());          // stream-K slabs + flags of the MFMA GEMMs
+    w.q8 = c.take((size_t)S * (d->inter > d->hidden ? d->inter : d->hidden));   // w8a8 prefill: e4m3 activations of one GEMM ...
+    w.qs = (float*)c.take((size_t)S * sizeof(float));                            // ... and their per-token scales
     w.total = c.off;
     return w;
+}
+
+// prefill Linear layers on the fp8 MFMA (activations quantised per token, the decode path's e4m3 weights): tune "prefill_fp8"
+static int g_prefill_fp8 = 0;
+int runtime_tune_set(const char* key, int value) {
+    if (!strcmp(key, "prefill_fp8")) { g_prefill_fp8 = value != 0; return 0; }
+    return -1;
+}
+static bool prefill_uses_fp8(const teo_llama_desc* d) {
+    const int Hq = d->heads * d->head_dim;
+    return g_prefill_fp8 && d->dtype == TEO_BF16 && d->qkv_w8 && d->o_w8 && d->gateup_w8 && d->down_w8 && d->hidden % 128 == 0 &&
+           d->inter % 128 == 0 && Hq % 128 == 0 && d->inter <= 12288 && d->hidden <= 12288;
+}
+// one decoder layer's four Linear layers in w8a8 form; `attend` runs RoPE / KV append / attention on w.qkv -> w.attn
+template <typename F>
+static int prefill_layer_fp8(const teo_llama_desc* d, const PrefillWs& w, int l, int S, F attend, hipStream_t st) {
+    const int dt = d->dtype;
+    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, Fi = d->inter;
+    const int QKV = (H + 2 * Hk) * hd;
+    TEO_TRY(quant_rows_fp8(w.h, d->in_norm_w[l], w.q8, w.qs, S, D, D, d->eps, st));
+    TEO_TRY(gemm_fp8(w.q8, w.qs, d->qkv_w8[l], d->qkv_s[l], nullptr, w.qkv, S, QKV, D, D, QKV, 0, dt, st));
+    TEO_TRY(attend());
+    TEO_TRY(quant_rows_fp8(w.attn, nullptr, w.q8, w.qs, S, H * hd, H * hd, d->eps, st));
+    TEO_TRY(gemm_fp8(w.q8, w.qs, d->o_w8[l], d->o_s[l], w.h, w.h, S, D, H * hd, H * hd, D, 0, dt, st));
+    TEO_TRY(quant_rows_fp8(w.h, d->post_norm_w[l], w.q8, w.qs, S, D, D, d->eps, st));
+    TEO_TRY(gemm_fp8(w.q8, w.qs, d->gateup_w8[l], d->gateup_s[l], nullptr, w.act, S, 2 * Fi, D, D, Fi, TEO_GEMM_SWIGLU16, dt, st));
+    TEO_TRY(quant_rows_fp8(w.act, nullptr, w.q8, w.qs, S, Fi, Fi, d->eps, st));
+    return gemm_fp8(w.q8, w.qs, d->down_w8[l], d->down_s[l], w.h, w.h, S, D, Fi, Fi, D, 0, dt, st);
 }
 
 size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S) { return prefill_carve(d, S, nullptr, 0).total; }
@@ -177,9 +208,9 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
     hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
     TEO_TRY(gemm_sk_workspace_init(w.sk, st));
+    const bool fp8 = prefill_uses_fp8(d);
     for (int l = 0; l < d->layers; ++l) {
-        TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
+        auto attend = [&]() -> int {
         TEO_TRY(rope_kv_append(w.qkv, QKV, positions, d->rope_cos, d->rope_sin, d->k_cache[l], d->v_cache[l],
                                d->vt_cache[l], S, past, nullptr, d->max_seq, H, Hk, hd, dt, st));
         teo_attn_args a;
@@ -193,7 +224,15 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
         a.batch = 1; a.heads = H; a.kv_heads = Hk; a.head_dim = hd; a.q_len = S; a.kv_len = past + S;
         a.causal = 1;
         a.scale = 1.0f / sqrtf((float)hd);
-        TEO_TRY(attention(&a, dt, st));
+        return attention(&a, dt, st);
+        };
+        if (fp8) {
+            TEO_TRY(prefill_layer_fp8(d, w, l, S, attend, st));
+            continue;
+        }
+        TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
+        TEO_TRY(attend());
         TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         TEO_TRY(rmsnorm(w.h, d->post_norm_w[l], w.n, S, D, d->eps, dt, st));
         TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st, w.sk));
@@ -231,9 +270,9 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
     hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
     TEO_TRY(gemm_sk_workspace_init(w.sk, st));
+    const bool fp8 = prefill_uses_fp8(d);
     for (int l = 0; l < d->layers; ++l) {
-        TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
-        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
+        auto attend = [&]() -> int {
         int row0 = 0;
         for (int b = 0; b < nseq; ++b) {
             const int Sb = seq_lens[b];
@@ -257,6 +296,15 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
             TEO_TRY(attention(&a, dt, st));
             row0 += Sb;
         }
+        return TEO_OK;
+        };
+        if (fp8) {
+            TEO_TRY(prefill_layer_fp8(d, w, l, S, attend, st));
+            continue;
+        }
+        TEO_TRY(rmsnorm(w.h, d->in_norm_w[l], w.n, S, D, d->eps, dt, st));
+        TEO_TRY(gemm(w.n, d->qkv_w[l], nullptr, nullptr, w.qkv, S, QKV, D, D, QKV, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
+        TEO_TRY(attend());
         TEO_TRY(gemm(w.attn, d->o_w[l], nullptr, w.h, w.h, S, D, H * hd, H * hd, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
         TEO_TRY(rmsnorm(w.h, d->post_norm_w[l], w.n, S, D, d->eps, dt, st));
         TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st, w.sk));

@@ -181,3 +181,35 @@ def test_c5_batch8_fp8_32_layers_against_single_conversations(model_fp8):
     print(f"C5: {same_stream}/{B} batched streams identical to the single-conversation streams")
     assert same_stream >= 2          # measured 4/8: near-tie flips between the GEMV and the skinny-GEMM summation orders; the
                                      # teacher-forced check above is what guards every token
+
+
+def test_c5_w8a8_prefill_on_the_fp8_mfma(model_fp8):
+    """Config C5's "fp8 weight path on CDNA4 MFMA" for the PREFILL phase (tune prefill_fp8 = 1): every Linear layer of the 32
+    decoder layers runs as a w8a8 GEMM on v_mfma_scale_f32_16x16x128_f8f6f4 (activations quantised per token to e4m3, the
+    decode path's per-row e4m3 weights).  Against the exact path (bf16 MFMA on the dequantised weights = the same weights):
+      * per-token activation quantisation is lossy (3 mantissa bits): the logits move by a few percent of max|logit| on this
+        random-weight model -- bound below = measured + margin, reported;
+      * determinism, and the KV cache it leaves behind lets the decode loop continue (tokens are produced, finite logits);
+      * switching it off again restores the exact path bit for bit."""
+    from teochat_amd import _lib as L
+    m = model_fp8
+    lib = m.engine.lib
+    frames, ids = conversation(8, 128, seed=30)
+    exact = m(input_ids=ids, images=frames).logits[0]
+    assert lib.teo_tune_set(b"prefill_fp8", 1) == 0
+    try:
+        q1 = m(input_ids=ids, images=frames).logits[0]
+        q2 = m(input_ids=ids, images=frames).logits[0]
+        assert torch.equal(q1, q2) and bool(torch.isfinite(q1).all())
+        assert not torch.equal(q1, exact)                      # the fp8 path really ran
+        rel = float((q1 - exact).abs().max()) / float(exact.abs().max())
+        rms = float((q1 - exact).pow(2).mean().sqrt()) / float(exact.pow(2).mean().sqrt())
+        agree = float((q1.argmax(-1) == exact.argmax(-1)).float().mean())
+        print(f"w8a8 prefill vs exact: max rel-to-max {rel:.3f}, rms ratio {rms:.3f}, argmax agreement {agree:.3f}")
+        assert rms < 0.35 and rel < 0.6
+        out = m.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=8, eos_token_id=None)
+        assert out.shape[1] == 128 + 8 and m.engine.cache_len == 2168 + 7
+        assert int(out[0, 128]) == int(q1[-1].argmax())
+    finally:
+        lib.teo_tune_set(b"prefill_fp8", 0)
+    assert torch.equal(m(input_ids=ids, images=frames).logits[0], exact)

@@ -928,13 +928,17 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
     big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")
     big2 = torch.empty_like(big)
     bad = 0
-    for it in range(8):
-        if it % 2:
-            with torch.cuda.stream(side):
-                big2.copy_(big)
-        got = _gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
-        torch.cuda.synchronize()
-        bad += int(not torch.equal(got, want))
+    assert lib.teo_tune_set(b"gemm_sk", 2) == 0        # forced: the dispatch heuristic only picks it for ~1 round of tiles
+    try:
+        for it in range(8):
+            if it % 2:
+                with torch.cuda.stream(side):
+                    big2.copy_(big)
+            got = _gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(got, want))
+    finally:
+        lib.teo_tune_set(b"gemm_sk", 1)
     assert bad == 0, f"{bad}/8 launches differ from the plain kernel"
     # without a workspace teo_gemm_ws is teo_gemm; tuning the stream-K path off gives the same bits too
     assert torch.equal(_gemm_ws(A, W, None, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)
@@ -943,3 +947,92 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
         assert torch.equal(_gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)
     finally:
         lib.teo_tune_set(b"gemm_sk", 1)
+
+
+# ---------------------------------------------------------------------------------------------- w8a8 prefill GEMM (fp8 MFMA, X1)
+def _quant_ref(x):
+    """per-row e4m3 quantisation of a float tensor the way teo_quant_rows_fp8 defines it (scale = amax / 448, RNE)."""
+    amax = x.abs().amax(dim=1)
+    s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    q = (x * (1.0 / s)[:, None]).to(torch.float8_e4m3fn)
+    return q, s
+
+
+def _gemm_fp8(A8, sa, W8, sw, res=None, flags=0, out_dtype=torch.bfloat16):
+    M, K = A8.shape
+    N = W8.shape[0]
+    Nc = N // 2 if flags & L.GEMM_SWIGLU16 else N
+    Cc = torch.empty(M, Nc, dtype=out_dtype, device="cuda")
+    L.check(G.lib().teo_gemm_fp8(G.p(A8), G.p(sa), G.p(W8), G.p(sw), G.p(res), G.p(Cc), M, N, K, A8.stride(0), Nc, flags, G.DT[out_dtype],
+                                 G.stream()), "gemm_fp8")
+    return Cc
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (200, 260, 256), (2168, 4096, 4096), (333, 4096, 11008), (2168, 512, 1152)])
+def test_gemm_fp8_mfma_is_exact_against_dequantised_operands(M, N, K):
+    """teo_gemm_fp8 (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales, row scales in the epilogue) against an fp64 product
+    of the DEQUANTISED operands.  The products are exact, but the instruction adds its 128 terms in a reduced-precision
+    internal tree (measured on MI355X: up to 1.1e-5 of the row's sum |a||w|, vs 1e-7 for an fp32 FMA chain): the bound is
+    3e-5 of sum |a||w|.  Asymmetric operands (a transposed or permuted k-layout is off by O(1) and cannot pass)."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = torch.randn(M, K, generator=g) * torch.linspace(0.5, 2.0, K)[None, :]           # column structure: k order matters
+    W = torch.randn(N, K, generator=g) * 0.05 * torch.linspace(2.0, 0.25, K)[None, :]
+    qa, sa = _quant_ref(A)
+    qw, sw = _quant_ref(W)
+    A8, W8 = qa.view(torch.uint8).cuda(), qw.view(torch.uint8).cuda()
+    dsa, dsw = sa.float().cuda(), sw.float().cuda()
+    got = _gemm_fp8(A8, dsa, W8, dsw, out_dtype=torch.float32).cpu().double()
+    Ad, Wd = qa.double() * sa.double()[:, None], qw.double() * sw.double()[:, None]
+    want = Ad @ Wd.T
+    bound = (Ad.abs() @ Wd.abs().T) * 3e-5 + 1e-12
+    assert bool(((got - want).abs() <= bound).all()), float(((got - want).abs() / bound).max())
+    # bf16 output + residual: one rounding of (product + residual)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    got16 = _gemm_fp8(A8, dsa, W8, dsw, res=res.cuda(), out_dtype=torch.bfloat16)
+    close_bf16(got16, G.bf16_round((want + res.double()).float()), ulps=1.0)
+
+
+def test_gemm_fp8_swiglu_pairs_gate_and_up_rows():
+    from teochat_amd.engine import interleave_gate_up
+    M, Fd, K = 300, 704, 512
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(M, K, generator=g)
+    gate, up = torch.randn(Fd, K, generator=g) * 0.06, torch.randn(Fd, K, generator=g) * 0.06
+    qa, sa = _quant_ref(A)
+    qg, sg = _quant_ref(gate)
+    qu, su = _quant_ref(up)
+    w8 = interleave_gate_up(qg.view(torch.uint8), qu.view(torch.uint8)).cuda()
+    s8 = interleave_gate_up(sg.view(-1, 1), su.view(-1, 1)).view(-1).float().cuda()
+    got = _gemm_fp8(qa.view(torch.uint8).cuda(), sa.float().cuda(), w8, s8, flags=L.GEMM_SWIGLU16, out_dtype=torch.float32).cpu()
+    Ad = qa.double() * sa.double()[:, None]
+    gd, ud = Ad @ (qg.double() * sg.double()[:, None]).T, Ad @ (qu.double() * su.double()[:, None]).T
+    want = (F.silu(gd) * ud).float()
+    # the MFMA's internal sum is good to ~1e-5 of sum |a||w| (previous test): here ~3e-4 absolute on g and u of size ~1.4
+    torch.testing.assert_close(got, want, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("M,K,norm", [(7, 4096, False), (300, 11008, False), (300, 4096, True), (5, 1152, True)])
+def test_quant_rows_fp8_matches_the_definition(M, K, norm):
+    g = torch.Generator().manual_seed(K + M)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(-2, 1, M)[:, None]).to(torch.bfloat16)
+    x[M // 2] = 0                                                     # an all-zero row: scale 1, codes 0
+    w = (1.0 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16)
+    q = torch.empty(M, K, dtype=torch.uint8, device="cuda")
+    s = torch.empty(M, dtype=torch.float32, device="cuda")
+    dx, dw = x.cuda(), w.cuda()                                       # keep the device tensors alive across the launch
+    L.check(G.lib().teo_quant_rows_fp8(G.p(dx), G.p(dw) if norm else None, G.p(q), G.p(s), M, K, K, 1e-5, G.stream()), "quant")
+    xf = x.float()
+    if norm:
+        xf = G.bf16_round(O.rmsnorm(xf, w.float(), 1e-5))
+    qr, sr = _quant_ref(xf)
+    torch.testing.assert_close(s.cpu(), sr, rtol=2e-6, atol=0)
+    got = q.cpu().view(torch.float8_e4m3fn).float()
+    # identical codes except where x / s sits on a rounding boundary and the two divisions differ in the last fp32 bit
+    diff = (got - qr.float()).abs()
+    step = qr.float().abs().clamp_min(2 ** -6) * 0.125
+    assert bool((diff <= step + 1e-9).all())
+    assert float((diff > 0).float().mean()) < 2e-3
+    assert float(got.abs().max()) <= 448.0 and bool((got[M // 2] == 0).all()) and float(s[M // 2]) == 1.0
+    # rows that are not all zero use the full range: their largest code is exactly +-448
+    nz = [i for i in range(M) if i != M // 2]
+    assert bool((got[nz].abs().amax(dim=1) == 448.0).all())

@@ -206,6 +206,27 @@ def bench_gemm():
               f"{2.0 * M * N * K / b / 1e6:7.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm_fp8():
+    """w8a8 GEMM on the scaled fp8 MFMA vs the bf16 MFMA kernel at the prefill shapes (incl. the activation quantiser)."""
+    for name, M, N, K, flags in [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
+                                 ("down", 2168, 4096, 11008, 0), ("qkv_B8", 17344, 12288, 4096, 0)]:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+        A8 = torch.randint(0, 120, (M, K), device="cuda", dtype=torch.uint8)
+        W8 = torch.randint(0, 120, (N, K), device="cuda", dtype=torch.uint8)
+        sa, sw = torch.ones(M, device="cuda"), torch.ones(N, device="cuda")
+        Nc = N // 2 if flags else N
+        Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
+        q8 = torch.empty(M, K, dtype=torch.uint8, device="cuda")
+        t16 = timeit(lambda: G.gemm(A, W, flags=flags))
+        t8 = timeit(lambda: L.check(lib.teo_gemm_fp8(G.p(A8), G.p(sa), G.p(W8), G.p(sw), None, G.p(Cc), M, N, K, K, Nc, flags, L.TEO_BF16,
+                                                      G.stream()), "gemm_fp8"))
+        tq = timeit(lambda: L.check(lib.teo_quant_rows_fp8(G.p(A), None, G.p(q8), G.p(sa), M, K, K, 1e-5, G.stream()), "quant"))
+        fl = 2.0 * M * N * K
+        print(f"gemm_fp8 {name:8s} M={M} N={N} K={K}: bf16 {t16:8.1f} us {fl / t16 / 1e6:7.1f} TFLOP/s | fp8 {t8:8.1f} us {fl / t8 / 1e6:7.1f} "
+              f"TFLOP/s | quantiser {tq:6.1f} us ({M * K * 3 / tq / 1e3:6.1f} GB/s)", flush=True)
+
+
 def bench_attn_prefill():
     """flash32 (flash.hip) vs the round-1 kernel (attn_flash = 0), interleaved in one process."""
     for (B, H, S, d, causal) in [(1, 32, 2168, 128, True), (1, 32, 4208, 128, True), (8, 16, 257, 64, False), (1, 32, 638, 128, True)]:
@@ -259,5 +280,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
