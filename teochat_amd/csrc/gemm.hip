@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void gemm_simple_kernel(const T* __restrict__ 
 // MFMA kernel
 // ------------------------------------------------------------------------------------------------
 constexpr int BM = 128, BN = 128, BK = 64;
+constexpr double GEMM_WIDE_ROUND_COST = 0.88;  // one round of 256 wide tiles (one per CU) / one round of 512 128 x 128 tiles (two per CU):
+                                               // 62-69 us against 71-83 us at K = 4096 (tools/bench_kernels.py gemm_wide)
 constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -123,24 +125,26 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
 
     // staging: thread owns 4 chunks (16 B) of each operand tile: chunk id = tid + 256*i -> row id>>3, chunk id&7.
     // NOTE: plain arrays + fully unrolled loops only -- lambdas capturing these arrays made hipcc spill them to scratch.
-    const bf16_t* ag[MF];                      // the A tile has 32*MF rows: MF chunks per thread
-    const bf16_t* wg[4];
+    // 32-bit element offsets from the (wave-uniform) base pointers: half the address registers of per-thread pointers, which is
+    // what lets the SwiGLU variant keep two register stages without spilling (host checks M * lda and N * K < 2^31)
+    unsigned ag[MF];                           // the A tile has 32*MF rows: MF chunks per thread
+    unsigned wg[4];
     int soff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = tid + 256 * i;
         const int row = id >> 3, c = id & 7;
         const int gn = min(n0 + row, N - 1);
-        if (i < MF) ag[i] = A + (long long)min(m0 + row, M - 1) * lda + c * 8;
-        wg[i] = W + (long long)gn * K + c * 8;
+        if (i < MF) ag[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)lda + c * 8;
+        wg[i] = (unsigned)gn * (unsigned)K + c * 8;
         soff[i] = row * (BK * 2) + ((c ^ (row & 7)) << 4);
     }
     u32x4 ra0[MF], rb0[4], ra1[MF], rb1[4];   // two register stages: tiles kt+1 and kt+2 are in flight during compute(kt)
 
 #define TEO_GLOAD(RA, RB, KT)                                                   \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
-        if (i < MF) RA[i] = *reinterpret_cast<const u32x4*>(ag[i] + (long long)(KT) * BK);  \
-        RB[i] = *reinterpret_cast<const u32x4*>(wg[i] + (long long)(KT) * BK);  \
+        if (i < MF) RA[i] = *reinterpret_cast<const u32x4*>(A + (ag[i] + (unsigned)(KT) * BK));  \
+        RB[i] = *reinterpret_cast<const u32x4*>(W + (wg[i] + (unsigned)(KT) * BK));  \
     }
 #define TEO_SWRITE(RA, RB, BUF)                                                 \
     {                                                                           \
@@ -217,7 +221,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
 #undef TEO_COMPUTE
 
     // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3
-    const int mw = m0 + wm * (16 * MF), nw = n0 + wn * 64;
+    // (the tile origin goes through an empty asm so that no epilogue address can be computed -- and kept live -- ahead of the
+    // K loop: that hoisting cost the SwiGLU variant its second register stage)
+    int mw = m0 + wm * (16 * MF), nw = n0 + wn * 64;
+    asm volatile("" : "+v"(mw), "+v"(nw));
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
         const int m = mw + mi * 16 + fr;
@@ -238,6 +245,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) =
                         make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
                 }
+                // keep the 16 (gate, up) blocks in program order: hoisting all 64 expf expansions at once is what pushed this
+                // variant to 226 VGPRs (depth 1) / spills (depth 2)
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
@@ -531,6 +541,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
+static int g_gemm_wide = 1;    // wide-tile LDS-DMA kernel (gemm_wide.hip): 0 off, 1 auto, 2 forced wherever its shape constraints hold
 static int g_gemm_sk_dbg = 0;  // timing diagnostics only (wrong results): 1 skip slab stores, 2 skip the flag wait, 4 skip slab loads
 static int g_gemm_sk = 1;      // 1: stream-K kernel when a workspace is given and the static tiling would leave a ragged last round
 constexpr int SK_MAX_GRID = 512;   // 256 CUs x 2 resident workgroups (64 KiB LDS, <= 256 VGPRs each)
@@ -545,6 +556,7 @@ static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the reside
 int gemm_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
     if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
+    if (!strcmp(key, "gemm_wide")) { g_gemm_wide = value; return 0; }
     if (!strcmp(key, "gemm_sk_dbg")) { g_gemm_sk_dbg = value; return 0; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return 0; }          // 0 off, 1 auto, 2 forced (diagnostics)
     return -1;
@@ -554,10 +566,27 @@ bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned fla
                   const void* bias, const void* res, const void* C) {
     if (dtype != TEO_BF16 || (flags & TEO_GEMM_FORCE_SIMPLE)) return false;
     if (K % BK != 0 || lda % 8 != 0 || ldc % 4 != 0 || N % 4 != 0) return false;
+    if ((long long)M * lda >= (1ll << 31) || (long long)N * K >= (1ll << 31)) return false;      // 32-bit element offsets in the kernel
     if (M < 1 || N < 1) return false;
     if ((flags & TEO_GEMM_SWIGLU16) && (N % 32 != 0)) return false;
     auto al = [](const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; };
     return al(A, 16) && al(W, 16) && al(bias, 8) && al(res, 8) && al(C, 16);
+}
+
+int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                     int act, bool swiglu, bool of32, hipStream_t st);          // gemm_wide.hip
+
+// 128 x 256 tiles on 256 slots (one 8-wave workgroup per CU) against 128 x 128 tiles on 512 slots: rounds of equal-length tiles
+static bool gemm_wide_wins(int M, int N, int K, bool forced) {
+    if (K < 2 * BK) return false;
+    const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256), t_plain = (long long)cdiv(M, 128) * cdiv(N, 128);
+    if (forced) return true;
+    if (t_wide < 256) return false;                                  // not enough tiles to fill the chip once
+    // cost in rounds of the plain kernel; its ragged last round runs faster when it leaves one workgroup per CU (x 0.66, measured)
+    const long long rem = t_plain % 512;
+    const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
+    const double wide = (double)cdiv(t_wide, 256) * GEMM_WIDE_ROUND_COST;
+    return wide < plain;
 }
 
 template <typename T, typename TO>
@@ -591,6 +620,8 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
+        if (g_gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, g_gemm_wide == 2))
+            return gemm_wide_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st);
         // stream-K where it was measured to win: just over ONE round of tiles (544 tiles on 512 slots at M = 2168, N = 4096:
         // o 114 -> 93 us, down 297 -> 250 us).  With several tiles per workgroup the contiguous ranges spread an XCD's
         // concurrent tiles over three times as many W panels as the plain kernel's rolling window does and the L2 misses

@@ -1,0 +1,190 @@
+// Wide-tile form of the bf16 MFMA GEMM for the big prefill shapes: 128 (M) x 256 (N) x 64 workgroup tile, 8 waves (2 x 4) of
+// 64 x 64, operands brought in by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) into a THREE-stage
+// LDS ring (3 x 48 KB of the CU's 160 KB) with two K tiles in flight and ONE barrier per K tile:
+//
+//     for kt:   s_waitcnt vmcnt(6)      <- this wave's pieces of tile kt have landed (tile kt+1's 6 pieces may still fly)
+//               s_barrier               <- every wave's pieces of kt landed; everybody is done reading stage (kt-1) % 3
+//               issue tile kt+2 -> stage (kt+2) % 3 == (kt-1) % 3
+//               16 ds_read_b128 + 32 MFMAs per wave on stage kt % 3
+//
+// Why (ablation of the 128 x 128 register-staged kernel at M = 2168, N = 12288, K = 4096; gemm.hip): its global loads ALONE
+// take 157 us (3.4 GB per GEMM through L2 at ~22 TB/s), its LDS writes alone 91 us, its ds_read + MFMA loop alone 150 us (58 %
+// of the MFMA peak), all three together 252-278 us.  This kernel moves 25 % fewer bytes per FLOP (48 KB per 4.2 MFLOP instead
+// of 32 KB per 2.1), has no LDS write instructions at all, keeps two tiles in flight without spending registers, and M = 2168
+// still tiles without waste (17 x 128).  LDS image and fragment reads are the plain kernel's: 128-byte rows, 16-byte chunk c of
+// row r at position c ^ (r & 7) -- with LDS-DMA the swizzle is applied to the per-lane SOURCE address (the destination is
+// wave-linear: 1 KB = 8 rows per instruction), which keeps every 128-byte row a single coalesced request.
+// Same k-order per output element as the plain kernel -> bit-identical results (tests/test_kernels_gpu.py).
+#include "common.h"
+#include "ops.h"
+
+namespace teo {
+
+typedef __attribute__((ext_vector_type(8))) short gw_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float gw_f32x4;
+
+constexpr int GW_BM = 128, GW_BN = 256, GW_BK = 64;
+constexpr int GW_A_BYTES = GW_BM * GW_BK * 2;            // 16 KiB
+constexpr int GW_W_BYTES = GW_BN * GW_BK * 2;            // 32 KiB
+constexpr int GW_STAGE = GW_A_BYTES + GW_W_BYTES;        // 48 KiB
+constexpr int GW_PIECES = GW_STAGE / 1024 / 8;           // 1-KiB DMA pieces per wave per K tile = 6
+
+__device__ __forceinline__ int gw_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                  const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
+                                                                  int M, int N, int K, int lda, int ldc, int act, int tiles_m,
+                                                                  int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tile = gw_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * GW_BM, n0 = tn * GW_BN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / GW_BK;
+
+    // DMA pieces of this wave: piece g = wid * 6 + j covers 8 rows (g < 16: A rows 8g.., else W rows 8 (g - 16)..); lane l brings
+    // row (l >> 3) of the piece, logical chunk (l & 7) ^ (l >> 3), to LDS byte g * 1024 + l * 16 of the stage
+    const bf16_t* src[GW_PIECES];
+#pragma unroll
+    for (int j = 0; j < GW_PIECES; ++j) {
+        const int g = wid * GW_PIECES + j;
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        if (g < 16) src[j] = A + (long long)min(m0 + g * 8 + rl, M - 1) * lda + c * 8;
+        else src[j] = W + (long long)min(n0 + (g - 16) * 8 + rl, N - 1) * K + c * 8;
+    }
+#define TEO_GW_STAGE(KT, ST)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < GW_PIECES; ++j)                                                                 \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long long)(KT) * GW_BK), \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * GW_STAGE + (wid * GW_PIECES + j) * 1024), 16, 0, 0);
+
+    gw_f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (gw_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    TEO_GW_STAGE(0, 0)
+    if (nk > 1) TEO_GW_STAGE(1, 1)
+    int st = 0;                                          // stage of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt landed (this wave), then for everyone; the barrier also says stage (kt + 2) % 3 is no longer being read
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) {
+            const int st2 = st == 0 ? 2 : st - 1;         // (kt + 2) % 3
+            TEO_GW_STAGE(kt + 2, st2)
+        }
+        const unsigned char* sA = smem + st * GW_STAGE;
+        const unsigned char* sB = sA + GW_A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            gw_bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra_ = wm * 64 + i * 16 + fr;
+                af[i] = *reinterpret_cast<const gw_bf16x8*>(sA + ra_ * 128 + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
+                const int rw_ = wn * 64 + i * 16 + fr;
+                wf[i] = *reinterpret_cast<const gw_bf16x8*>(sB + rw_ * 128 + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+#undef TEO_GW_STAGE
+
+    // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3 (as gemm_mfma_bf16_kernel)
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+        if (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int ng = nw + ni * 16 + fg * 4;
+                if (ng >= N) continue;
+                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
+                if (n + 3 < N) {
+                    if (bias) {
+                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
+                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                    }
+                    if (act != TEO_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
+                    }
+                    if (res) {
+                        const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
+                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                    }
+                    if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) {
+                        float v = o[r];
+                        if (bias) v += bf2f(bias[n + r]);
+                        v = act_apply(v, act);
+                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                     int act, bool swiglu, bool of32, hipStream_t st) {
+    const int tiles_m = cdiv(M, GW_BM), tiles_n = cdiv(N, GW_BN);
+    const int nwg = tiles_m * tiles_n;
+    const size_t lds = 3 * GW_STAGE;
+#define TEO_GW_LAUNCH(SW, OF)                                                                                                     \
+    {                                                                                                                             \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) {                                                                                                          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_kernel<SW, OF>),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            if (e != hipSuccess) return hip_fail(e, "gemm_wide: hipFuncSetAttribute");                                            \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        gemm_mfma_bf16_wide_kernel<SW, OF><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,         \
+                                                                  (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
+    }
+    if (swiglu) { if (of32) TEO_GW_LAUNCH(true, true) else TEO_GW_LAUNCH(true, false) }
+    else { if (of32) TEO_GW_LAUNCH(false, true) else TEO_GW_LAUNCH(false, false) }
+#undef TEO_GW_LAUNCH
+    TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide");
+    return TEO_OK;
+}
+
+}  // namespace teo

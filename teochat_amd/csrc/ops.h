@@ -80,6 +80,8 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
                 SkinnyFuse fuse = SkinnyFuse());
 int gemm_tune_set(const char* key, int value);
 int runtime_tune_set(const char* key, int value);
+int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                     int act, bool swiglu, bool of32, hipStream_t st);
 size_t gemm_sk_workspace_bytes();
 // w8a8 prefill GEMM on the scaled fp8 MFMA (gemm_fp8.hip) and the per-token activation quantiser (norm_w != NULL: RMSNorm first)
 int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,

@@ -395,13 +395,16 @@ class LlavaLlamaForCausalLM:
             outs = self.generate_batch(rows, images, do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
                                        max_new_tokens=max_new_tokens, stopping_criteria=stopping_criteria,
                                        eos_token_id=eos_token_id, generator=generator, chunk=chunk)
+            # what GenerationMixin.generate returns: the input rows exactly as given (left or right padding included) followed
+            # by the new tokens of each row; rows that stopped early are filled up with pad_token_id
             pad = getattr(self.config, "pad_token_id", None)
             pad = 0 if pad is None else int(pad)
-            width = max(o.numel() for o in outs)
-            res = torch.full((B, width), pad, dtype=input_ids.dtype, device=input_ids.device)
-            for b, o in enumerate(outs):
-                res[b, :o.numel()] = o.to(res.device)
-            return res
+            news = [o[rows[b].numel():] for b, o in enumerate(outs)]
+            n_new = max(int(t.numel()) for t in news)
+            tail = torch.full((B, n_new), pad, dtype=input_ids.dtype, device=input_ids.device)
+            for b, t in enumerate(news):
+                tail[b, :t.numel()] = t.to(tail.device)
+            return torch.cat([input_ids, tail], dim=1)
         eng = self.engine
         if eos_token_id == "config":
             eos_token_id = getattr(self.config, "eos_token_id", None)

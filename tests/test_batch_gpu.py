@@ -94,9 +94,17 @@ def test_batched_generate_api_padding_eos_and_sampling(name):
         ids_p[b, :ids.numel()] = ids
         mask[b, :ids.numel()] = 1
     out = model.generate(input_ids=ids_p.to(dev), attention_mask=mask.to(dev), images=imgs, max_new_tokens=8, eos_token_id=None)
-    for b in range(3):
-        n = ref[b].numel()
-        assert out[b, :n].tolist() == ref[b].tolist() and bool((out[b, n:] == 0).all())
+    assert out.shape == (3, width + 8) and torch.equal(out[:, :width].cpu(), ids_p)      # HF: cat(input_ids, new tokens)
+    for b, (ids, _) in enumerate(convs):
+        assert out[b, width:].tolist() == ref[b][ids.numel():].tolist()
+    # left padding (what HF batched generation expects): same tokens, the pads stay where the caller put them
+    ids_l = torch.zeros(3, width, dtype=torch.long)
+    mask_l = torch.zeros(3, width, dtype=torch.long)
+    for b, (ids, _) in enumerate(convs):
+        ids_l[b, width - ids.numel():] = ids
+        mask_l[b, width - ids.numel():] = 1
+    out_l = model.generate(input_ids=ids_l.to(dev), attention_mask=mask_l.to(dev), images=imgs, max_new_tokens=8, eos_token_id=None)
+    assert torch.equal(out_l[:, :width].cpu(), ids_l) and torch.equal(out_l[:, width:], out[:, width:])
     # EOS: conversation 1 stops at its 3rd generated token, the others run on
     eos = int(ref[1][convs[1][0].numel() + 2])
     cut = model.generate_batch([ids.to(dev) for ids, _ in convs], imgs, max_new_tokens=8, eos_token_id=eos)

@@ -206,6 +206,28 @@ def bench_gemm():
               f"{2.0 * M * N * K / b / 1e6:7.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm_wide():
+    """wide-tile LDS-DMA kernel (gemm_wide = 2: forced) vs the 128 x 128 kernel (gemm_wide = 0), interleaved."""
+    shapes = [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
+              ("down", 2168, 4096, 11008, 0), ("vit_fc1", 2056, 4096, 1024, 0), ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0),
+              ("qkv_T16", 4208, 12288, 4096, 0), ("qkv_T2", 638, 12288, 4096, 0), ("gateup_B8", 17344, 22016, 4096, L.GEMM_SWIGLU16)]
+    for name, M, N, K, flags in shapes:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+        res = {0: [], 2: []}
+        outs = {}
+        for _ in range(3):
+            for mode in (2, 0):
+                lib.teo_tune_set(b"gemm_wide", mode)
+                res[mode].append(timeit(lambda: G.gemm(A, W, flags=flags)))
+                outs[mode] = G.gemm(A, W, flags=flags)
+        lib.teo_tune_set(b"gemm_wide", 1)
+        a, b_ = min(res[2]), min(res[0])
+        fl = 2.0 * M * N * K
+        print(f"gemm {name:9s} M={M} N={N} K={K}: wide {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s | 128x128 {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s"
+              f" | bit-identical: {bool(torch.equal(outs[0], outs[2]))}", flush=True)
+
+
 def bench_gemm_fp8():
     """w8a8 GEMM on the scaled fp8 MFMA vs the bf16 MFMA kernel at the prefill shapes (incl. the activation quantiser)."""
     for name, M, N, K, flags in [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
@@ -280,5 +302,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
