@@ -159,6 +159,131 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_fp8_kernel(const unsigned ch
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wide-tile form (the structure of gemm_wide.hip): 128 (M) x 256 (N) workgroup tile, 8 waves of 64 x 64, K tile = 128 fp8
+// elements = the same 128-byte LDS rows; LDS-DMA operand staging into a three-stage ring (3 x 48 KB), counted vmcnt + one raw
+// barrier per K tile.  Same k-order as gemm_mfma_fp8_kernel -> bit-identical results.
+// ------------------------------------------------------------------------------------------------
+constexpr int F8W_BM = 128, F8W_BN = 256;
+constexpr int F8W_A_BYTES = F8W_BM * F8_BK, F8W_W_BYTES = F8W_BN * F8_BK, F8W_STAGE = F8W_A_BYTES + F8W_W_BYTES;
+constexpr int F8W_PIECES = F8W_STAGE / 1024 / 8;          // 6 one-KiB DMA pieces per wave per K tile
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_mfma_fp8_wide_kernel(const unsigned char* __restrict__ A, const float* __restrict__ a_scale,
+                                                                 const unsigned char* __restrict__ W, const float* __restrict__ w_scale,
+                                                                 const bf16_t* res, void* Cv, int M, int N, int K, int lda, int ldc,
+                                                                 int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tile = f8_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * F8W_BM, n0 = tn * F8W_BN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / F8_BK;
+    const unsigned char* src[F8W_PIECES];
+#pragma unroll
+    for (int j = 0; j < F8W_PIECES; ++j) {
+        const int g = wid * F8W_PIECES + j;
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        if (g < 16) src[j] = A + (long long)min(m0 + g * 8 + rl, M - 1) * lda + c * 16;
+        else src[j] = W + (long long)min(n0 + (g - 16) * 8 + rl, N - 1) * K + c * 16;
+    }
+#define TEO_F8W_STAGE(KT, ST)                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < F8W_PIECES; ++j)                                                                  \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long long)(KT) * F8_BK), \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * F8W_STAGE + (wid * F8W_PIECES + j) * 1024), 16, 0, 0);
+#define TEO_F8W_FRAG(BASE, ROW)                                                              \
+    ({                                                                                       \
+        const unsigned char* rp_ = (BASE) + (ROW) * F8_BK;                                   \
+        const f8_u32x4 lo_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg) ^ ((ROW) & 7)) << 4));      \
+        const f8_u32x4 hi_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg + 1) ^ ((ROW) & 7)) << 4));  \
+        i32x8 f_;                                                                            \
+        f_[0] = (int)lo_[0]; f_[1] = (int)lo_[1]; f_[2] = (int)lo_[2]; f_[3] = (int)lo_[3];  \
+        f_[4] = (int)hi_[0]; f_[5] = (int)hi_[1]; f_[6] = (int)hi_[2]; f_[7] = (int)hi_[3];  \
+        f_;                                                                                  \
+    })
+    f8_f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f8_f32x4){0.f, 0.f, 0.f, 0.f};
+    TEO_F8W_STAGE(0, 0)
+    if (nk > 1) TEO_F8W_STAGE(1, 1)
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) {
+            const int st2 = st == 0 ? 2 : st - 1;
+            TEO_F8W_STAGE(kt + 2, st2)
+        }
+        const unsigned char* sA = smem + st * F8W_STAGE;
+        const unsigned char* sB = sA + F8W_A_BYTES;
+        i32x8 af[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = TEO_F8W_FRAG(sA, wm * 64 + i * 16 + fr);
+            wf[i] = TEO_F8W_FRAG(sB, wn * 64 + i * 16 + fr);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        st = st == 2 ? 0 : st + 1;
+    }
+#undef TEO_F8W_STAGE
+#undef TEO_F8W_FRAG
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+        const float sa = a_scale[m];
+        if (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int ng = nw + ni * 16 + fg * 4;
+                if (ng >= N) continue;
+                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
+                const float4 sg = *reinterpret_cast<const float4*>(w_scale + ng);
+                const float4 su = *reinterpret_cast<const float4*>(w_scale + ng + 16);
+                float o[4];
+                o[0] = silu(acc[ni][mi][0] * (sa * sg.x)) * (acc[ni + 1][mi][0] * (sa * su.x));
+                o[1] = silu(acc[ni][mi][1] * (sa * sg.y)) * (acc[ni + 1][mi][1] * (sa * su.y));
+                o[2] = silu(acc[ni][mi][2] * (sa * sg.z)) * (acc[ni + 1][mi][2] * (sa * su.z));
+                o[3] = silu(acc[ni][mi][3] * (sa * sg.w)) * (acc[ni + 1][mi][3] * (sa * su.w));
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                const float4 sw = *reinterpret_cast<const float4*>(w_scale + n);
+                float o[4] = {acc[ni][mi][0] * (sa * sw.x), acc[ni][mi][1] * (sa * sw.y), acc[ni][mi][2] * (sa * sw.z), acc[ni][mi][3] * (sa * sw.w)};
+                if (res) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                    o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
+                    o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                }
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+    }
+}
+
+static int g_fp8_wide = 1;      // 0: 128 x 128 kernel only, 1: by the rounds model, 2: wide wherever K has two tiles
+int gemm_fp8_tune_set(const char* key, int value) {
+    if (!strcmp(key, "gemm_fp8_wide")) { g_fp8_wide = value; return 0; }
+    return -1;
+}
+
 bool gemm_fp8_ok(int M, int N, int K, int lda, int ldc, unsigned flags, const void* A, const void* W, const void* res, const void* C) {
     if (M < 1 || N < 1 || K % F8_BK != 0 || lda % 16 != 0 || ldc % 4 != 0 || N % 4 != 0) return false;
     if ((flags & TEO_GEMM_SWIGLU16) && (N % 32 != 0 || res)) return false;
@@ -175,10 +300,37 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
         return TEO_ERR_UNSUPPORTED;
     }
     const bool swiglu = flags & TEO_GEMM_SWIGLU16;
+    const bool of32 = out_dtype == TEO_F32;
+    {   // wide tiles when they need fewer (cost-weighted) rounds: same model as the bf16 kernel (gemm.hip gemm_wide_wins)
+        const long long t_wide = (long long)cdiv(M, F8W_BM) * cdiv(N, F8W_BN), t_plain = (long long)cdiv(M, F8_BM) * cdiv(N, F8_BN);
+        const long long rem = t_plain % 512;
+        const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
+        const double wide = (double)cdiv(t_wide, 256) * 0.80;   // measured: a wide fp8 round costs ~0.8 of a 128 x 128 round (o: 76 vs 81 us, gate/up 219 vs 272)
+        if (K >= 2 * F8_BK && (g_fp8_wide == 2 || (g_fp8_wide == 1 && t_wide >= 256 && wide < plain))) {
+            const int tiles_m = cdiv(M, F8W_BM), tiles_n = cdiv(N, F8W_BN);
+            const size_t lds = 3 * F8W_STAGE;
+#define TEO_F8W_LAUNCH(SW, OF)                                                                                                  \
+    {                                                                                                                           \
+        static bool attr_set = false;                                                                                           \
+        if (!attr_set) {                                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_fp8_wide_kernel<SW, OF>),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            if (e != hipSuccess) return hip_fail(e, "gemm_fp8 wide: hipFuncSetAttribute");                                      \
+            attr_set = true;                                                                                                    \
+        }                                                                                                                       \
+        gemm_mfma_fp8_wide_kernel<SW, OF><<<tiles_m * tiles_n, 512, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, \
+                                                                              w_scale, (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n); \
+    }
+            if (swiglu) { if (of32) TEO_F8W_LAUNCH(true, true) else TEO_F8W_LAUNCH(true, false) }
+            else { if (of32) TEO_F8W_LAUNCH(false, true) else TEO_F8W_LAUNCH(false, false) }
+#undef TEO_F8W_LAUNCH
+            TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide");
+            return TEO_OK;
+        }
+    }
     const int tiles_m = cdiv(M, F8_BM), tiles_n = cdiv(N, F8_BN);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 4 * F8_TILE;
-    const bool of32 = out_dtype == TEO_F32;
 #define TEO_F8_LAUNCH(SW, OF)                                                                                               \
     gemm_mfma_fp8_kernel<SW, OF><<<nwg, 256, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, w_scale,  \
                                                         (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n)

@@ -80,6 +80,7 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
                 SkinnyFuse fuse = SkinnyFuse());
 int gemm_tune_set(const char* key, int value);
 int runtime_tune_set(const char* key, int value);
+int gemm_fp8_tune_set(const char* key, int value);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);
 size_t gemm_sk_workspace_bytes();

@@ -990,6 +990,16 @@ def test_gemm_fp8_mfma_is_exact_against_dequantised_operands(M, N, K):
     res = torch.randn(M, N, generator=g).to(torch.bfloat16)
     got16 = _gemm_fp8(A8, dsa, W8, dsw, res=res.cuda(), out_dtype=torch.bfloat16)
     close_bf16(got16, G.bf16_round((want + res.double()).float()), ulps=1.0)
+    # the wide-tile (LDS-DMA) and the 128 x 128 kernels add the k tiles in the same order: bit-identical
+    lib = G.lib()
+    try:
+        outs = []
+        for mode in (0, 2):
+            assert lib.teo_tune_set(b"gemm_fp8_wide", mode) == 0
+            outs.append(_gemm_fp8(A8, dsa, W8, dsw, res=res.cuda(), out_dtype=torch.bfloat16))
+        assert K < 256 or torch.equal(outs[0], outs[1])
+    finally:
+        lib.teo_tune_set(b"gemm_fp8_wide", 1)
 
 
 def test_gemm_fp8_swiglu_pairs_gate_and_up_rows():

@@ -241,12 +241,19 @@ def bench_gemm_fp8():
         Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
         q8 = torch.empty(M, K, dtype=torch.uint8, device="cuda")
         t16 = timeit(lambda: G.gemm(A, W, flags=flags))
-        t8 = timeit(lambda: L.check(lib.teo_gemm_fp8(G.p(A8), G.p(sa), G.p(W8), G.p(sw), None, G.p(Cc), M, N, K, K, Nc, flags, L.TEO_BF16,
-                                                      G.stream()), "gemm_fp8"))
+        run8 = lambda: L.check(lib.teo_gemm_fp8(G.p(A8), G.p(sa), G.p(W8), G.p(sw), None, G.p(Cc), M, N, K, K, Nc, flags, L.TEO_BF16,
+                                                 G.stream()), "gemm_fp8")
+        lib.teo_tune_set(b"gemm_fp8_wide", 0)
+        t8n = timeit(run8)
+        c0 = Cc.clone()
+        lib.teo_tune_set(b"gemm_fp8_wide", 2)
+        t8 = timeit(run8)
+        same = bool(torch.equal(c0, Cc))
+        lib.teo_tune_set(b"gemm_fp8_wide", 1)
         tq = timeit(lambda: L.check(lib.teo_quant_rows_fp8(G.p(A), None, G.p(q8), G.p(sa), M, K, K, 1e-5, G.stream()), "quant"))
         fl = 2.0 * M * N * K
-        print(f"gemm_fp8 {name:8s} M={M} N={N} K={K}: bf16 {t16:8.1f} us {fl / t16 / 1e6:7.1f} TFLOP/s | fp8 {t8:8.1f} us {fl / t8 / 1e6:7.1f} "
-              f"TFLOP/s | quantiser {tq:6.1f} us ({M * K * 3 / tq / 1e3:6.1f} GB/s)", flush=True)
+        print(f"gemm_fp8 {name:8s} M={M} N={N} K={K}: bf16 {t16:8.1f} us {fl / t16 / 1e6:7.1f} TFLOP/s | fp8 128x128 {t8n:8.1f} us {fl / t8n / 1e6:7.1f} | "
+              f"fp8 wide {t8:8.1f} us {fl / t8 / 1e6:7.1f} TFLOP/s (bit-identical {same}) | quantiser {tq:6.1f} us", flush=True)
 
 
 def bench_attn_prefill():
