@@ -575,6 +575,8 @@ bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned fla
 
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);          // gemm_wide.hip
+int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                        int act, bool of32, void* sk_ws, size_t flags_offset, hipStream_t st);
 
 // 128 x 256 tiles on 256 slots (one 8-wave workgroup per CU) against 128 x 128 tiles on 512 slots: rounds of equal-length tiles
 static bool gemm_wide_wins(int M, int N, int K, bool forced) {
@@ -620,6 +622,13 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
+        {   // just over one round of WIDE tiles (272 on 256 CUs: o / down at M = 2168): the stream-K form of the wide kernel
+            const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256);
+            if (sk_ws && g_gemm_sk && g_gemm_wide && bm == 128 && !swiglu && K >= 2 * BK && t_wide > 256 &&
+                (g_gemm_sk == 2 || t_wide <= 256 + 256 / 6))
+                return gemm_wide_sk_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, sk_ws,
+                                           (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float), st);
+        }
         if (g_gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, g_gemm_wide == 2))
             return gemm_wide_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st);
         // stream-K where it was measured to win: just over ONE round of tiles (544 tiles on 512 slots at M = 2168, N = 4096:

@@ -163,6 +163,203 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// stream-K form of the wide kernel for shapes that are just over ONE round of wide tiles (272 tiles on 256 CUs at M = 2168,
+// N = 4096: o and down).  Same scheme as gemm_mfma_bf16_sk_kernel (gemm.hip): a persistent grid of one workgroup per CU, the
+// flattened (tile, k-tile) space cut into equal contiguous ranges; a range that ends inside a tile accumulates that part FIRST
+// and hands its fp32 accumulators (128 KB) to the next range's owner, which loads them as its INITIAL accumulators and
+// continues the k-loop LAST in its own timeline -- sequential k-order per output element, bit-identical results.  Hand-off by
+// 16-byte sc1 buffer stores / loads + a relaxed agent-scope flag (no fences).  One K-loop body serves all three kinds of segment.
+// ------------------------------------------------------------------------------------------------
+constexpr int GW_SLAB_FLOATS = GW_BM * GW_BN;            // 128 KB of fp32 per workgroup
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                     const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
+                                                                     int M, int N, int K, int lda, int ldc, int act, int tiles_m,
+                                                                     int tiles_n, int per, float* slabs, int* flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / GW_BK;
+    const long long total = (long long)tiles_m * tiles_n * nk;
+    const int q = gw_xcd_remap(blockIdx.x, gridDim.x);
+    const long long it0 = (long long)q * per, it1 = min(it0 + per, total);
+    if (it0 >= total) return;
+    const int t_first = (int)(it0 / nk), k_first = (int)(it0 % nk);
+    const int t_last = (int)((it1 - 1) / nk), k_end = (int)(it1 - (long long)t_last * nk);
+    const int has_head = k_first != 0, has_tail = k_end != nk;           // per >= nk: a tile has at most two owners
+    const int t_full0 = t_first + has_head, n_full = (t_last + 1 - has_tail) - t_full0;
+    const int nseg = has_tail + n_full + has_head;
+
+    gw_f32x4 acc[4][4];
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        // order: tail (its partial sums are needed by the neighbour), the full tiles, head (the neighbour's partial sums are long there)
+        const bool is_tail = has_tail && sgi == 0;
+        const bool is_head = has_head && sgi == nseg - 1;
+        const int pos = is_tail ? t_last : (is_head ? t_first : t_full0 + (sgi - has_tail));
+        const int kb = is_head ? k_first : 0, ke = is_tail ? k_end : nk;
+        const int tm = pos % tiles_m, tn = pos / tiles_m;
+        const int m0 = tm * GW_BM, n0 = tn * GW_BN;
+        const bf16_t* src[GW_PIECES];
+#pragma unroll
+        for (int j = 0; j < GW_PIECES; ++j) {
+            const int g = wid * GW_PIECES + j;
+            const int rl = lane >> 3, c = (lane & 7) ^ rl;
+            if (g < 16) src[j] = A + (long long)min(m0 + g * 8 + rl, M - 1) * lda + c * 8;
+            else src[j] = W + (long long)min(n0 + (g - 16) * 8 + rl, N - 1) * K + c * 8;
+        }
+#define TEO_GW_STAGE(KT, ST)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < GW_PIECES; ++j)                                                                 \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long long)(KT) * GW_BK), \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * GW_STAGE + (wid * GW_PIECES + j) * 1024), 16, 0, 0);
+        if (is_head) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 24)) break;                          // never reached: the producer wrote its slab first thing
+                }
+                __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+            }
+            __builtin_amdgcn_s_barrier();
+            const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)(q - 1) * GW_SLAB_FLOATS, 0, GW_SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_bit_cast(gw_f32x4, __builtin_amdgcn_raw_buffer_load_b128(sl, ((ni * 4 + mi) * 512 + tid) * 16, 0, /*sc1*/ 16));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (gw_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // the ring is primed AFTER the slab loads were issued: vmcnt retires loads in order, so the counted waits below still
+        // mean "this wave's pieces of tile kt have landed" (the 16 slab loads of a head segment are older and retire first)
+        TEO_GW_STAGE(kb, 0)
+        if (kb + 1 < ke) TEO_GW_STAGE(kb + 1, 1)
+        int st = 0;
+        for (int kt = kb; kt < ke; ++kt) {
+            if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < ke) {
+                const int st2 = st == 0 ? 2 : st - 1;
+                TEO_GW_STAGE(kt + 2, st2)
+            }
+            const unsigned char* sA = smem + st * GW_STAGE;
+            const unsigned char* sB = sA + GW_A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                gw_bf16x8 af[4], wf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra_ = wm * 64 + i * 16 + fr;
+                    af[i] = *reinterpret_cast<const gw_bf16x8*>(sA + ra_ * 128 + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
+                    const int rw_ = wn * 64 + i * 16 + fr;
+                    wf[i] = *reinterpret_cast<const gw_bf16x8*>(sB + rw_ * 128 + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            }
+            st = st == 2 ? 0 : st + 1;
+        }
+#undef TEO_GW_STAGE
+        __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring before the next segment refills it
+        if (is_tail) {
+            const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)q * GW_SLAB_FLOATS, 0, GW_SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, acc[ni][mi]), sl,
+                                                           ((ni * 4 + mi) * 512 + tid) * 16, 0, /*sc1*/ 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave: write-through stores landed
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) __hip_atomic_store(flags + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        // epilogue (no SwiGLU in this form: it serves the N = hidden layers, o and down)
+        const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = mw + mi * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
+                if (n + 3 < N) {
+                    if (bias) {
+                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
+                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                    }
+                    if (act != TEO_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
+                    }
+                    if (res) {
+                        const uint2 qv = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                        o[0] += bf2f((bf16_t)(qv.x & 0xffff)); o[1] += bf2f((bf16_t)(qv.x >> 16));
+                        o[2] += bf2f((bf16_t)(qv.y & 0xffff)); o[3] += bf2f((bf16_t)(qv.y >> 16));
+                    }
+                    if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) {
+                        float v = o[r];
+                        if (bias) v += bf2f(bias[n + r]);
+                        v = act_apply(v, act);
+                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// slabs: 256 x 128 KB (the workspace of gemm_sk_workspace_bytes() holds 512 x 64 KB) + flags behind them
+int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                        int act, bool of32, void* sk_ws, size_t flags_offset, hipStream_t st) {
+    const int tiles_m = cdiv(M, GW_BM), tiles_n = cdiv(N, GW_BN);
+    const int nk = K / GW_BK;
+    const long long total = (long long)tiles_m * tiles_n * nk;
+    const int grid = 256;
+    const int per = (int)((total + grid - 1) / grid);                    // >= nk: the caller only comes here with more than 256 tiles
+    const size_t lds = 3 * GW_STAGE;
+    float* slabs = (float*)sk_ws;
+    int* flg = (int*)((unsigned char*)sk_ws + flags_offset);
+#define TEO_GWSK_LAUNCH(OF)                                                                                                       \
+    {                                                                                                                             \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) {                                                                                                          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_sk_kernel<OF>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            if (e != hipSuccess) return hip_fail(e, "gemm_wide_sk: hipFuncSetAttribute");                                         \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        gemm_mfma_bf16_wide_sk_kernel<OF><<<grid, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,         \
+                                                                  (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, \
+                                                                  per, slabs, flg);                                               \
+    }
+    if (of32) TEO_GWSK_LAUNCH(true) else TEO_GWSK_LAUNCH(false)
+#undef TEO_GWSK_LAUNCH
+    TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide_sk");
+    return TEO_OK;
+}
+
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st) {
     const int tiles_m = cdiv(M, GW_BM), tiles_n = cdiv(N, GW_BN);

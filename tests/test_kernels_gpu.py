@@ -903,10 +903,11 @@ def _gemm_ws(A, W, ws, bias=None, res=None, act=L.ACT_NONE, flags=0, out_dtype=N
     return Cc
 
 
+@pytest.mark.parametrize("wide", [0, 1])
 @pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 4096, 4096, 0, "res"), (2168, 4096, 11008, 0, "res"), (2168, 12288, 4096, 0, ""),
                                                (2168, 22016, 4096, L.GEMM_SWIGLU16, ""), (2056, 4096, 1024, 0, "bias_gelu"),
                                                (4208, 4096, 4096, 0, "f32out"), (1300, 8192, 512, 0, ""), (17000, 512, 64, 0, "bias")])
-def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
+def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra, wide):
     """teo_gemm_ws (persistent stream-K grid: equal k-tile ranges per workgroup, partial tiles handed to the neighbour through
     fp32 slabs and continued in the same k-order) against teo_gemm (one workgroup per tile): BIT-identical outputs, launch after
     launch on the same workspace (slabs and flags are re-used: a stale or torn hand-off would show), also with a concurrent HBM
@@ -923,12 +924,16 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
     lib = G.lib()
     ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
     L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
-    want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+    assert lib.teo_tune_set(b"gemm_wide", 0) == 0
+    want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)      # the 128 x 128 kernel, one workgroup per tile
     side = torch.cuda.Stream()
     big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")
     big2 = torch.empty_like(big)
     bad = 0
-    assert lib.teo_tune_set(b"gemm_sk", 2) == 0        # forced: the dispatch heuristic only picks it for ~1 round of tiles
+    # wide = 0: stream-K grid of the 128 x 128 kernel; wide = 1: stream-K grid of the wide-tile LDS-DMA kernel (non-SwiGLU shapes
+    # with more than 256 wide tiles; the others fall through to the 128 x 128 form).  Forced: the heuristic only picks ~1 round.
+    assert lib.teo_tune_set(b"gemm_wide", wide) == 0
+    assert lib.teo_tune_set(b"gemm_sk", 2) == 0
     try:
         for it in range(8):
             if it % 2:
@@ -939,6 +944,7 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
             bad += int(not torch.equal(got, want))
     finally:
         lib.teo_tune_set(b"gemm_sk", 1)
+        lib.teo_tune_set(b"gemm_wide", 1)
     assert bad == 0, f"{bad}/8 launches differ from the plain kernel"
     # without a workspace teo_gemm_ws is teo_gemm; tuning the stream-K path off gives the same bits too
     assert torch.equal(_gemm_ws(A, W, None, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)

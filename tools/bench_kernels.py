@@ -175,7 +175,8 @@ def bench_gemv_sweep():
 
 
 def bench_gemm():
-    """MFMA GEMM at the prefill shapes: plain tiling vs the stream-K grid (teo_gemm_ws), interleaved."""
+    """MFMA GEMM at the prefill shapes as the library dispatches it: without a workspace (wide / plain tiling) vs with one
+    (stream-K forms where the rounds model picks them), interleaved."""
     shapes = [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
               ("down", 2168, 4096, 11008, 0), ("vit_qkv", 2056, 3072, 1024, 0), ("vit_fc1", 2056, 4096, 1024, 0),
               ("vit_fc2", 2056, 1024, 4096, 0), ("sq4096", 4096, 4096, 4096, 0), ("qkv_T16", 4208, 12288, 4096, 0),
