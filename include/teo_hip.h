@@ -100,6 +100,9 @@ int teo_gemm_ws(const void* d_A, const void* d_W, const void* d_bias, const void
  * f = identity, or LlamaRMSNorm (d_norm_w != NULL: x * rsqrt(mean(x^2) + eps) * w rounded to bf16, as teo_rmsnorm).  x bf16. */
 int teo_gemm_fp8(const void* d_A8, const float* d_a_scale, const void* d_W8, const float* d_w_scale, const void* d_residual, void* d_C,
                  int M, int N, int K, int lda, int ldc, unsigned flags, int out_dtype, teo_stream_t stream);
+/* teo_gemm_fp8 with the teo_gemm_ws workspace: stream-K form of the wide fp8 kernel for the one-round-plus shapes; bit-identical. */
+int teo_gemm_fp8_ws(const void* d_A8, const float* d_a_scale, const void* d_W8, const float* d_w_scale, const void* d_residual, void* d_C,
+                    int M, int N, int K, int lda, int ldc, unsigned flags, int out_dtype, void* d_workspace, teo_stream_t stream);
 int teo_quant_rows_fp8(const void* d_x, const void* d_norm_w, void* d_q, float* d_scale, int rows, int K, int ldx, float eps,
                        teo_stream_t stream);
 

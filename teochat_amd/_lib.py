@@ -97,6 +97,7 @@ _SIGS = {
     "teo_rmsnorm": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "teo_gemm": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_uint, C.c_int, C.c_int, C.c_void_p]),
     "teo_gemm_fp8": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_uint, C.c_int, C.c_void_p]),
+    "teo_gemm_fp8_ws": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_uint, C.c_int, C.c_void_p, C.c_void_p]),
     "teo_quant_rows_fp8": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "teo_gemm_workspace_bytes": (C.c_size_t, []),
     "teo_gemm_workspace_init": (C.c_int, [C.c_void_p, C.c_void_p]),

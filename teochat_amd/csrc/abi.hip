@@ -104,6 +104,16 @@ int teo_gemm_fp8(const void* A8, const float* a_scale, const void* W8, const flo
     if (M && N) { NEED(A8, "A8"); NEED(a_scale, "a_scale"); NEED(W8, "W8"); NEED(w_scale, "w_scale"); NEED(C, "C"); }
     return gemm_fp8(A8, a_scale, W8, w_scale, res, C, M, N, K, lda, ldc, flags, out_dtype, ST(s));
 }
+int teo_gemm_fp8_ws(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N,
+                    int K, int lda, int ldc, unsigned flags, int out_dtype, void* ws, teo_stream_t s) {
+    ENTER();
+    NEED_DT(out_dtype);
+    TEO_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && lda >= K, "teo_gemm_fp8_ws: M %d N %d K %d lda %d", M, N, K, lda);
+    TEO_CHECK_ARG(ldc >= ((flags & TEO_GEMM_SWIGLU16) ? N / 2 : N), "teo_gemm_fp8_ws: ldc %d too small", ldc);
+    TEO_CHECK_ARG(ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "teo_gemm_fp8_ws: workspace must be 256-byte aligned");
+    if (M && N) { NEED(A8, "A8"); NEED(a_scale, "a_scale"); NEED(W8, "W8"); NEED(w_scale, "w_scale"); NEED(C, "C"); }
+    return gemm_fp8(A8, a_scale, W8, w_scale, res, C, M, N, K, lda, ldc, flags, out_dtype, ST(s), ws);
+}
 int teo_quant_rows_fp8(const void* x, const void* norm_w, void* q, float* scale, int rows, int K, int ldx, float eps, teo_stream_t s) {
     ENTER();
     TEO_CHECK_ARG(rows >= 0 && K > 0 && ldx >= K, "teo_quant_rows_fp8: rows %d K %d ldx %d", rows, K, ldx);

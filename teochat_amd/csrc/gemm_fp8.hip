@@ -278,6 +278,146 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_fp8_wide_kernel(const unsign
     }
 }
 
+// stream-K form of the wide fp8 kernel (one-round-plus shapes: o / down at M = 2168), the scheme of gemm_wide.hip
+constexpr int F8W_SLAB_FLOATS = F8W_BM * F8W_BN;
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm_mfma_fp8_wide_sk_kernel(const unsigned char* __restrict__ A, const float* __restrict__ a_scale,
+                                                                    const unsigned char* __restrict__ W, const float* __restrict__ w_scale,
+                                                                    const bf16_t* res, void* Cv, int M, int N, int K, int lda, int ldc,
+                                                                    int tiles_m, int tiles_n, int per, float* slabs, int* flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / F8_BK;
+    const long long total = (long long)tiles_m * tiles_n * nk;
+    const int q = f8_xcd_remap(blockIdx.x, gridDim.x);
+    const long long it0 = (long long)q * per, it1 = min(it0 + per, total);
+    if (it0 >= total) return;
+    const int t_first = (int)(it0 / nk), k_first = (int)(it0 % nk);
+    const int t_last = (int)((it1 - 1) / nk), k_end = (int)(it1 - (long long)t_last * nk);
+    const int has_head = k_first != 0, has_tail = k_end != nk;
+    const int t_full0 = t_first + has_head, n_full = (t_last + 1 - has_tail) - t_full0;
+    const int nseg = has_tail + n_full + has_head;
+    f8_f32x4 acc[4][4];
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        const bool is_tail = has_tail && sgi == 0;
+        const bool is_head = has_head && sgi == nseg - 1;
+        const int pos = is_tail ? t_last : (is_head ? t_first : t_full0 + (sgi - has_tail));
+        const int kb = is_head ? k_first : 0, ke = is_tail ? k_end : nk;
+        const int tm = pos % tiles_m, tn = pos / tiles_m;
+        const int m0 = tm * F8W_BM, n0 = tn * F8W_BN;
+        const unsigned char* src[F8W_PIECES];
+#pragma unroll
+        for (int j = 0; j < F8W_PIECES; ++j) {
+            const int g = wid * F8W_PIECES + j;
+            const int rl = lane >> 3, c = (lane & 7) ^ rl;
+            if (g < 16) src[j] = A + (long long)min(m0 + g * 8 + rl, M - 1) * lda + c * 16;
+            else src[j] = W + (long long)min(n0 + (g - 16) * 8 + rl, N - 1) * K + c * 16;
+        }
+#define TEO_F8W_STAGE(KT, ST)                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < F8W_PIECES; ++j)                                                                  \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long long)(KT) * F8_BK), \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * F8W_STAGE + (wid * F8W_PIECES + j) * 1024), 16, 0, 0);
+#define TEO_F8W_FRAG(BASE, ROW)                                                              \
+    ({                                                                                       \
+        const unsigned char* rp_ = (BASE) + (ROW) * F8_BK;                                   \
+        const f8_u32x4 lo_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg) ^ ((ROW) & 7)) << 4));      \
+        const f8_u32x4 hi_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg + 1) ^ ((ROW) & 7)) << 4));  \
+        i32x8 f_;                                                                            \
+        f_[0] = (int)lo_[0]; f_[1] = (int)lo_[1]; f_[2] = (int)lo_[2]; f_[3] = (int)lo_[3];  \
+        f_[4] = (int)hi_[0]; f_[5] = (int)hi_[1]; f_[6] = (int)hi_[2]; f_[7] = (int)hi_[3];  \
+        f_;                                                                                  \
+    })
+        if (is_head) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 24)) break;
+                }
+                __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_barrier();
+            const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)(q - 1) * F8W_SLAB_FLOATS, 0, F8W_SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_bit_cast(f8_f32x4, __builtin_amdgcn_raw_buffer_load_b128(sl, ((ni * 4 + mi) * 512 + tid) * 16, 0, 16));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f8_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        TEO_F8W_STAGE(kb, 0)
+        if (kb + 1 < ke) TEO_F8W_STAGE(kb + 1, 1)
+        int st = 0;
+        for (int kt = kb; kt < ke; ++kt) {
+            if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < ke) {
+                const int st2 = st == 0 ? 2 : st - 1;
+                TEO_F8W_STAGE(kt + 2, st2)
+            }
+            const unsigned char* sA = smem + st * F8W_STAGE;
+            const unsigned char* sB = sA + F8W_A_BYTES;
+            i32x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = TEO_F8W_FRAG(sA, wm * 64 + i * 16 + fr);
+                wf[i] = TEO_F8W_FRAG(sB, wn * 64 + i * 16 + fr);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            st = st == 2 ? 0 : st + 1;
+        }
+#undef TEO_F8W_STAGE
+#undef TEO_F8W_FRAG
+        __builtin_amdgcn_s_barrier();
+        if (is_tail) {
+            const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)q * F8W_SLAB_FLOATS, 0, F8W_SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f8_u32x4, acc[ni][mi]), sl, ((ni * 4 + mi) * 512 + tid) * 16, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) __hip_atomic_store(flags + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = mw + mi * 16 + fr;
+            if (m >= M) continue;
+            const float sa = a_scale[m];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                const float4 sw = *reinterpret_cast<const float4*>(w_scale + n);
+                float o[4] = {acc[ni][mi][0] * (sa * sw.x), acc[ni][mi][1] * (sa * sw.y), acc[ni][mi][2] * (sa * sw.z), acc[ni][mi][3] * (sa * sw.w)};
+                if (res) {
+                    const uint2 qv = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                    o[0] += bf2f((bf16_t)(qv.x & 0xffff)); o[1] += bf2f((bf16_t)(qv.x >> 16));
+                    o[2] += bf2f((bf16_t)(qv.y & 0xffff)); o[3] += bf2f((bf16_t)(qv.y >> 16));
+                }
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+    }
+}
+
 static int g_fp8_wide = 1;      // 0: 128 x 128 kernel only, 1: by the rounds model, 2: wide wherever K has two tiles
 int gemm_fp8_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_fp8_wide")) { g_fp8_wide = value; return 0; }
@@ -292,7 +432,7 @@ bool gemm_fp8_ok(int M, int N, int K, int lda, int ldc, unsigned flags, const vo
 }
 
 int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,
-             int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st) {
+             int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st, void* sk_ws) {
     if (M == 0 || N == 0) return TEO_OK;
     if (!gemm_fp8_ok(M, N, K, lda, ldc, flags, A8, W8, res, C)) {
         set_error("teo_gemm_fp8: needs K %% 128 == 0, lda %% 16 == 0, N %% 4 == 0 (32 with SWIGLU16, no residual) and 16-byte aligned operands "
@@ -306,7 +446,32 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
         const long long rem = t_plain % 512;
         const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
         const double wide = (double)cdiv(t_wide, 256) * 0.80;   // measured: a wide fp8 round costs ~0.8 of a 128 x 128 round (o: 76 vs 81 us, gate/up 219 vs 272)
-        if (K >= 2 * F8_BK && (g_fp8_wide == 2 || (g_fp8_wide == 1 && t_wide >= 256 && wide < plain))) {
+        if (sk_ws && g_fp8_wide && !swiglu && K >= 2 * F8_BK && t_wide > 256 && (g_fp8_wide == 3 || t_wide <= 256 + 256 / 6)) {
+            // just over one round of wide tiles: persistent stream-K grid (slabs: 256 x 128 KB, flags behind 32 MB as in gemm.hip)
+            const int tiles_m = cdiv(M, F8W_BM), tiles_n = cdiv(N, F8W_BN);
+            const long long total = (long long)tiles_m * tiles_n * (K / F8_BK);
+            const int per = (int)((total + 255) / 256);
+            const size_t lds = 3 * F8W_STAGE;
+            float* slabs = (float*)sk_ws;
+            int* flg = (int*)((unsigned char*)sk_ws + (size_t)512 * 16384 * sizeof(float));
+#define TEO_F8SK_LAUNCH(OF)                                                                                                     \
+    {                                                                                                                           \
+        static bool attr_set = false;                                                                                           \
+        if (!attr_set) {                                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_fp8_wide_sk_kernel<OF>),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            if (e != hipSuccess) return hip_fail(e, "gemm_fp8 wide sk: hipFuncSetAttribute");                                   \
+            attr_set = true;                                                                                                    \
+        }                                                                                                                       \
+        gemm_mfma_fp8_wide_sk_kernel<OF><<<256, 512, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, w_scale, \
+                                                               (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n, per, slabs, flg); \
+    }
+            if (of32) TEO_F8SK_LAUNCH(true) else TEO_F8SK_LAUNCH(false)
+#undef TEO_F8SK_LAUNCH
+            TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide_sk");
+            return TEO_OK;
+        }
+        if (K >= 2 * F8_BK && (g_fp8_wide >= 2 || (g_fp8_wide == 1 && t_wide >= 256 && wide < plain))) {
             const int tiles_m = cdiv(M, F8W_BM), tiles_n = cdiv(N, F8W_BN);
             const size_t lds = 3 * F8W_STAGE;
 #define TEO_F8W_LAUNCH(SW, OF)                                                                                                  \

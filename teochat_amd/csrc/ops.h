@@ -86,7 +86,7 @@ int gemm_wide_launch(const void* A, const void* W, const void* bias, const void*
 size_t gemm_sk_workspace_bytes();
 // w8a8 prefill GEMM on the scaled fp8 MFMA (gemm_fp8.hip) and the per-token activation quantiser (norm_w != NULL: RMSNorm first)
 int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,
-             int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st);
+             int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st, void* sk_ws = nullptr);
 int quant_rows_fp8(const void* x, const void* norm_w, void* q, float* s, int M, int K, int ldx, float eps, hipStream_t st);
 int gemm_sk_workspace_init(void* ws, hipStream_t st);
 int attn_tune_set(const char* key, int value);

@@ -183,11 +183,11 @@ static int prefill_layer_fp8(const teo_llama_desc* d, const PrefillWs& w, int l,
     TEO_TRY(gemm_fp8(w.q8, w.qs, d->qkv_w8[l], d->qkv_s[l], nullptr, w.qkv, S, QKV, D, D, QKV, 0, dt, st));
     TEO_TRY(attend());
     TEO_TRY(quant_rows_fp8(w.attn, nullptr, w.q8, w.qs, S, H * hd, H * hd, d->eps, st));
-    TEO_TRY(gemm_fp8(w.q8, w.qs, d->o_w8[l], d->o_s[l], w.h, w.h, S, D, H * hd, H * hd, D, 0, dt, st));
+    TEO_TRY(gemm_fp8(w.q8, w.qs, d->o_w8[l], d->o_s[l], w.h, w.h, S, D, H * hd, H * hd, D, 0, dt, st, w.sk));
     TEO_TRY(quant_rows_fp8(w.h, d->post_norm_w[l], w.q8, w.qs, S, D, D, d->eps, st));
     TEO_TRY(gemm_fp8(w.q8, w.qs, d->gateup_w8[l], d->gateup_s[l], nullptr, w.act, S, 2 * Fi, D, D, Fi, TEO_GEMM_SWIGLU16, dt, st));
     TEO_TRY(quant_rows_fp8(w.act, nullptr, w.q8, w.qs, S, Fi, Fi, d->eps, st));
-    return gemm_fp8(w.q8, w.qs, d->down_w8[l], d->down_s[l], w.h, w.h, S, D, Fi, Fi, D, 0, dt, st);
+    return gemm_fp8(w.q8, w.qs, d->down_w8[l], d->down_s[l], w.h, w.h, S, D, Fi, Fi, D, 0, dt, st, w.sk);
 }
 
 size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S) { return prefill_carve(d, S, nullptr, 0).total; }

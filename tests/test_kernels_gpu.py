@@ -1008,6 +1008,33 @@ def test_gemm_fp8_mfma_is_exact_against_dequantised_operands(M, N, K):
         lib.teo_tune_set(b"gemm_fp8_wide", 1)
 
 
+@pytest.mark.parametrize("M,N,K", [(2168, 4096, 4096), (2168, 4096, 11008), (1100, 2304, 512), (333, 768, 1024)])
+def test_gemm_fp8_stream_k_is_bit_identical(M, N, K):
+    """teo_gemm_fp8_ws (persistent stream-K grid of the wide fp8 kernel, forced with gemm_fp8_wide = 3 where the shape would not
+    pick it) against teo_gemm_fp8: same k order per output element => same bits; repeated launches share the slabs and flags."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A8 = _quant_ref(torch.randn(M, K, generator=g))[0].view(torch.uint8).cuda()
+    W8 = _quant_ref(torch.randn(N, K, generator=g) * 0.02)[0].view(torch.uint8).cuda()
+    sa = (torch.rand(M, generator=g) + 0.5).cuda()
+    sw = (torch.rand(N, generator=g) * 0.01 + 0.001).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    lib = G.lib()
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    try:
+        for od in (torch.bfloat16, torch.float32):
+            lib.teo_tune_set(b"gemm_fp8_wide", 0)
+            want = _gemm_fp8(A8, sa, W8, sw, res=res, out_dtype=od)
+            lib.teo_tune_set(b"gemm_fp8_wide", 3)
+            for _ in range(3):
+                got = torch.full((M, N), float("nan"), dtype=od, device="cuda")
+                L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(W8), G.p(sw), G.p(res), G.p(got), M, N, K, K, N, 0, G.DT[od], G.p(ws),
+                                            G.stream()), "gemm_fp8_ws")
+                assert torch.equal(got, want), (od, (got.float() - want.float()).abs().max().item())
+    finally:
+        lib.teo_tune_set(b"gemm_fp8_wide", 1)
+
+
 def test_gemm_fp8_swiglu_pairs_gate_and_up_rows():
     from teochat_amd.engine import interleave_gate_up
     M, Fd, K = 300, 704, 512

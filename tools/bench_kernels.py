@@ -251,10 +251,15 @@ def bench_gemm_fp8():
         t8 = timeit(run8)
         same = bool(torch.equal(c0, Cc))
         lib.teo_tune_set(b"gemm_fp8_wide", 1)
+        ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+        L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+        tsk = timeit(lambda: L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(W8), G.p(sw), None, G.p(Cc), M, N, K, K, Nc, flags, L.TEO_BF16,
+                                                         G.p(ws), G.stream()), "gemm_fp8_ws"))
+        same = same and bool(torch.equal(c0, Cc))
         tq = timeit(lambda: L.check(lib.teo_quant_rows_fp8(G.p(A), None, G.p(q8), G.p(sa), M, K, K, 1e-5, G.stream()), "quant"))
         fl = 2.0 * M * N * K
         print(f"gemm_fp8 {name:8s} M={M} N={N} K={K}: bf16 {t16:8.1f} us {fl / t16 / 1e6:7.1f} TFLOP/s | fp8 128x128 {t8n:8.1f} us {fl / t8n / 1e6:7.1f} | "
-              f"fp8 wide {t8:8.1f} us {fl / t8 / 1e6:7.1f} TFLOP/s (bit-identical {same}) | quantiser {tq:6.1f} us", flush=True)
+              f"fp8 wide {t8:8.1f} us {fl / t8 / 1e6:7.1f} | dispatch+ws {tsk:8.1f} us {fl / tsk / 1e6:7.1f} TFLOP/s (bit-identical {same}) | quantiser {tq:6.1f} us", flush=True)
 
 
 def bench_attn_prefill():
