@@ -216,20 +216,31 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_fp8_wide_kernel(const unsign
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) {
-            const int st2 = st == 0 ? 2 : st - 1;
-            TEO_F8W_STAGE(kt + 2, st2)
-        }
+        const int st2 = st == 0 ? 2 : st - 1;
         const unsigned char* sA = smem + st * F8W_STAGE;
         const unsigned char* sB = sA + F8W_A_BYTES;
+        // skewed halves (as gw_ktile in gemm_wide.hip): waves 4-7 issue their DMA pieces before their fragment reads, waves 0-3
+        // between their two MFMA blocks -- one wave of a SIMD multiplies while its partner loads
+        const bool late = wid < 4;
+        if (!late && kt + 2 < nk) { TEO_F8W_STAGE(kt + 2, st2) }
+        __builtin_amdgcn_sched_barrier(0);
         i32x8 af[4], wf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             af[i] = TEO_F8W_FRAG(sA, wm * 64 + i * 16 + fr);
             wf[i] = TEO_F8W_FRAG(sB, wn * 64 + i * 16 + fr);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        __builtin_amdgcn_sched_barrier(0);
+        if (late && kt + 2 < nk) { TEO_F8W_STAGE(kt + 2, st2) }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 2; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
@@ -360,20 +371,29 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_fp8_wide_sk_kernel(const uns
             if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < ke) {
-                const int st2 = st == 0 ? 2 : st - 1;
-                TEO_F8W_STAGE(kt + 2, st2)
-            }
+            const int st2 = st == 0 ? 2 : st - 1;
             const unsigned char* sA = smem + st * F8W_STAGE;
             const unsigned char* sB = sA + F8W_A_BYTES;
+            const bool late = wid < 4;                                   // skewed halves, as in the plain wide kernel
+            if (!late && kt + 2 < ke) { TEO_F8W_STAGE(kt + 2, st2) }
+            __builtin_amdgcn_sched_barrier(0);
             i32x8 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 af[i] = TEO_F8W_FRAG(sA, wm * 64 + i * 16 + fr);
                 wf[i] = TEO_F8W_FRAG(sB, wn * 64 + i * 16 + fr);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            __builtin_amdgcn_sched_barrier(0);
+            if (late && kt + 2 < ke) { TEO_F8W_STAGE(kt + 2, st2) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ni = 2; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);

@@ -29,23 +29,93 @@ constexpr int GW_W_BYTES = GW_BN * GW_BK * 2;            // 32 KiB
 constexpr int GW_STAGE = GW_A_BYTES + GW_W_BYTES;        // 48 KiB
 constexpr int GW_PIECES = GW_STAGE / 1024 / 8;           // 1-KiB DMA pieces per wave per K tile = 6
 
+static int g_wide_sched = 1, g_wide_group = 0;        // group 0: chosen from the tile grid
+int gemm_wide_tune_set(const char* key, int value) {
+    if (!strcmp(key, "gemm_wide_sched")) { g_wide_sched = value; return 0; }
+    if (!strcmp(key, "gemm_wide_group") && value >= 0) { g_wide_group = value; return 0; }
+    return -1;
+}
+
 __device__ __forceinline__ int gw_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
 }
 
-template <bool SWIGLU, bool OUT_F32>
+// One K tile of a wave: 16 fragment reads + 32 MFMAs on stage `st`, and the DMA issue of tile kt+2 (`dma()`), in the order that
+// measured best (tools/bench_kernels.py gemm_wide_sched; qkv 256 -> 225-234 us, gate/up 370 -> 345 us, bit-identical):
+//  * skewed halves: waves 4-7 (the second wave of every SIMD) issue their six DMA pieces first, waves 0-3 only after their first
+//    MFMA block -- one wave of a SIMD multiplies while its partner is in its load segment (both in lockstep: 44 % MFMA-busy;
+//    skewed: 51 %).  s_setprio on either half loses, DMA pieces interleaved one by one between MFMAs change nothing;
+//  * carried half: the second-half fragments of tile kt are multiplied right after the barrier of tile kt+1, from registers,
+//    while the first-half fragments of kt+1 are on their way from LDS -- no wave sits behind a barrier without MFMA work.
+// The MFMA chain of every output element is still k-ascending: h0(kt-1), h1(kt-1), h0(kt), ... -> results unchanged.
+// Ablation at qkv (M = 2168, N = 12288, K = 4096; us): all 234 | no DMA 196 | no MFMA 169 | no fragment reads 173 | MFMA + barrier
+// only 150 | DMA only 146 (3.4 GB / 146 us = 22 TB/s out of L2): the L2 -> LDS delivery is as long as the MFMA work.
+template <typename DMA>
+__device__ __forceinline__ void gw_ktile(const unsigned char* sA, const unsigned char* sB, int wid, int wm, int wn, int fr, int fg,
+                                         bool first, gw_f32x4 (&acc)[4][4], gw_bf16x8 (&caf)[4], gw_bf16x8 (&cwf)[4], DMA&& dma) {
+    const bool late = wid < 4;
+    if (!late) dma();
+    __builtin_amdgcn_sched_barrier(0);
+    gw_bf16x8 af[4], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra_ = wm * 64 + i * 16 + fr;
+        af[i] = *reinterpret_cast<const gw_bf16x8*>(sA + ra_ * 128 + ((fg ^ (ra_ & 7)) << 4));
+        const int rw_ = wn * 64 + i * 16 + fr;
+        wf[i] = *reinterpret_cast<const gw_bf16x8*>(sB + rw_ * 128 + ((fg ^ (rw_ & 7)) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!first) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cwf[ni], caf[mi], acc[ni][mi], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (late) dma();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra_ = wm * 64 + i * 16 + fr;
+        caf[i] = *reinterpret_cast<const gw_bf16x8*>(sA + ra_ * 128 + (((4 + fg) ^ (ra_ & 7)) << 4));
+        const int rw_ = wn * 64 + i * 16 + fr;
+        cwf[i] = *reinterpret_cast<const gw_bf16x8*>(sB + rw_ * 128 + (((4 + fg) ^ (rw_ & 7)) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+}
+// the carried second half of the last K tile of a segment
+__device__ __forceinline__ void gw_flush(gw_f32x4 (&acc)[4][4], const gw_bf16x8 (&caf)[4], const gw_bf16x8 (&cwf)[4]) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cwf[ni], caf[mi], acc[ni][mi], 0, 0, 0);
+}
+
+template <bool SWIGLU, bool OUT_F32, int SCHED>
 __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                   const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
                                                                   int M, int N, int K, int lda, int ldc, int act, int tiles_m,
-                                                                  int tiles_n) {
+                                                                  int tiles_n, int group) {
+    constexpr int sched = SCHED;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int tile = gw_xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    // tiles walk `group` N panels at a time, N fastest: the 32 workgroups an XCD runs together then cover ~(32 / group) x group
+    // tiles (8 x 4: 256 KB of distinct operand rows per K tile instead of 336 KB with whole columns) -- better L2 hit rate
+    const int gsz = group * tiles_m, sup = tile / gsz, rem = tile - sup * gsz;
+    const int gn = min(group, tiles_n - sup * group);
+    const int tm = rem / gn, tn = sup * group + rem % gn;
     const int m0 = tm * GW_BM, n0 = tn * GW_BN;
     const int fr = lane & 15, fg = lane >> 4;
     const int nk = K / GW_BK;
@@ -73,37 +143,41 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
 
     TEO_GW_STAGE(0, 0)
     if (nk > 1) TEO_GW_STAGE(1, 1)
+    gw_bf16x8 caf[4], cwf[4];                            // second-half fragments carried over the next barrier (gw_ktile)
     int st = 0;                                          // stage of tile kt
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt landed (this wave), then for everyone; the barrier also says stage (kt + 2) % 3 is no longer being read
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) {
-            const int st2 = st == 0 ? 2 : st - 1;         // (kt + 2) % 3
-            TEO_GW_STAGE(kt + 2, st2)
-        }
+        const int st2 = st == 0 ? 2 : st - 1;             // (kt + 2) % 3
         const unsigned char* sA = smem + st * GW_STAGE;
         const unsigned char* sB = sA + GW_A_BYTES;
+        if (sched == 0) {                                 // the plain order (kept for A/B: gemm_wide_sched = 0)
+            if (kt + 2 < nk) { TEO_GW_STAGE(kt + 2, st2) }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            gw_bf16x8 af[4], wf[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                gw_bf16x8 af[4], wf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra_ = wm * 64 + i * 16 + fr;
-                af[i] = *reinterpret_cast<const gw_bf16x8*>(sA + ra_ * 128 + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
-                const int rw_ = wn * 64 + i * 16 + fr;
-                wf[i] = *reinterpret_cast<const gw_bf16x8*>(sB + rw_ * 128 + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
+                for (int i = 0; i < 4; ++i) {
+                    const int ra_ = wm * 64 + i * 16 + fr;
+                    af[i] = *reinterpret_cast<const gw_bf16x8*>(sA + ra_ * 128 + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
+                    const int rw_ = wn * 64 + i * 16 + fr;
+                    wf[i] = *reinterpret_cast<const gw_bf16x8*>(sB + rw_ * 128 + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
             }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        } else {
+            gw_ktile(sA, sB, wid, wm, wn, fr, fg, kt == 0, acc, caf, cwf, [&]() { if (kt + 2 < nk) { TEO_GW_STAGE(kt + 2, st2) } });
         }
         st = st == 2 ? 0 : st + 1;
     }
 #undef TEO_GW_STAGE
+    if (sched != 0 && nk > 0) gw_flush(acc, caf, cwf);
 
     // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3 (as gemm_mfma_bf16_kernel)
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
@@ -195,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
     const int nseg = has_tail + n_full + has_head;
 
     gw_f32x4 acc[4][4];
+    gw_bf16x8 caf[4], cwf[4];
     for (int sgi = 0; sgi < nseg; ++sgi) {
         // order: tail (its partial sums are needed by the neighbour), the full tiles, head (the neighbour's partial sums are long there)
         const bool is_tail = has_tail && sgi == 0;
@@ -246,31 +321,14 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
             if (kt + 1 < ke) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < ke) {
-                const int st2 = st == 0 ? 2 : st - 1;
-                TEO_GW_STAGE(kt + 2, st2)
-            }
+            const int st2 = st == 0 ? 2 : st - 1;
             const unsigned char* sA = smem + st * GW_STAGE;
             const unsigned char* sB = sA + GW_A_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                gw_bf16x8 af[4], wf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ra_ = wm * 64 + i * 16 + fr;
-                    af[i] = *reinterpret_cast<const gw_bf16x8*>(sA + ra_ * 128 + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
-                    const int rw_ = wn * 64 + i * 16 + fr;
-                    wf[i] = *reinterpret_cast<const gw_bf16x8*>(sB + rw_ * 128 + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-            }
+            gw_ktile(sA, sB, wid, wm, wn, fr, fg, kt == kb, acc, caf, cwf, [&]() { if (kt + 2 < ke) { TEO_GW_STAGE(kt + 2, st2) } });
             st = st == 2 ? 0 : st + 1;
         }
 #undef TEO_GW_STAGE
+        if (ke > kb) gw_flush(acc, caf, cwf);
         __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring before the next segment refills it
         if (is_tail) {
             const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)q * GW_SLAB_FLOATS, 0, GW_SLAB_FLOATS * 4, 0x00020000);
@@ -365,20 +423,26 @@ int gemm_wide_launch(const void* A, const void* W, const void* bias, const void*
     const int tiles_m = cdiv(M, GW_BM), tiles_n = cdiv(N, GW_BN);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 3 * GW_STAGE;
-#define TEO_GW_LAUNCH(SW, OF)                                                                                                     \
+#define TEO_GW_LAUNCH_S(SW, OF, SC)                                                                                               \
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_kernel<SW, OF>),                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_kernel<SW, OF, SC>),            \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e != hipSuccess) return hip_fail(e, "gemm_wide: hipFuncSetAttribute");                                            \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm_mfma_bf16_wide_kernel<SW, OF><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,         \
-                                                                  (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
+        gemm_mfma_bf16_wide_kernel<SW, OF, SC><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,     \
+                                                                      (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, g_wide_group ? g_wide_group : (tiles_m >= 32 ? 4 : 1)); \
+    }
+#define TEO_GW_LAUNCH(SW, OF)                                                                                                     \
+    {                                                                                                                             \
+        if (g_wide_sched == 0) TEO_GW_LAUNCH_S(SW, OF, 0)                                                                         \
+        else TEO_GW_LAUNCH_S(SW, OF, 1)                                                                                           \
     }
     if (swiglu) { if (of32) TEO_GW_LAUNCH(true, true) else TEO_GW_LAUNCH(true, false) }
     else { if (of32) TEO_GW_LAUNCH(false, true) else TEO_GW_LAUNCH(false, false) }
+#undef TEO_GW_LAUNCH_S
 #undef TEO_GW_LAUNCH
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide");
     return TEO_OK;

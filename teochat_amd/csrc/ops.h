@@ -61,6 +61,7 @@ int preprocess_frames(const unsigned char* src, void* out, int T, int H, int W, 
 int cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
                   long long ignore_index, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
+int gemm_wide_tune_set(const char* key, int value);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
 // Producer-side RMSNorm hand-off between the GEMMs of a batched decode step.  A residual-producing GEMM (o / down

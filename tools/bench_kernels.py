@@ -229,6 +229,30 @@ def bench_gemm_wide():
               f" | bit-identical: {bool(torch.equal(outs[0], outs[2]))}", flush=True)
 
 
+def bench_gemm_wide_sched():
+    """instruction-order variants of the wide kernel's K loop (gemm_wide_sched), forced wide, plain (non-stream-K) launch."""
+    shapes = [("qkv", 2168, 12288, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("sq8192", 8192, 8192, 8192, 0),
+              ("qkv_T16", 4208, 12288, 4096, 0)]
+    lib.teo_tune_set(b"gemm_wide", 2)
+    for name, M, N, K, flags in shapes:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+        fl = 2.0 * M * N * K
+        ref = None
+        line = f"gemm {name:9s}:"
+        for sched, grp in ((0, 1), (1, 1), (1, 4)):
+            lib.teo_tune_set(b"gemm_wide_sched", sched)
+            lib.teo_tune_set(b"gemm_wide_group", grp)
+            t = min(timeit(lambda: G.gemm(A, W, flags=flags)) for _ in range(3))
+            out = G.gemm(A, W, flags=flags)
+            ref = out if ref is None else ref
+            line += f" s{sched}g{grp} {t:7.1f} us {fl / t / 1e6:7.1f} TF ({'=' if torch.equal(out, ref) else 'DIFF'}) |"
+        print(line, flush=True)
+    lib.teo_tune_set(b"gemm_wide_sched", 0)
+    lib.teo_tune_set(b"gemm_wide_group", 1)
+    lib.teo_tune_set(b"gemm_wide", 1)
+
+
 def bench_gemm_fp8():
     """w8a8 GEMM on the scaled fp8 MFMA vs the bf16 MFMA kernel at the prefill shapes (incl. the activation quantiser)."""
     for name, M, N, K, flags in [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
@@ -315,5 +339,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
