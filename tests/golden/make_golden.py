@@ -356,6 +356,18 @@ def gen_numeric(name):
         dec_logits.append(r2.logits[0, -1].numpy())
     out["greedy_tokens"] = np.array(toks, dtype=np.int64)
     out["greedy_logits"] = np.stack(dec_logits)
+    # G6b: teacher-forced decode -- the greedy streams of these tiny random models settle on one token after two steps, so the
+    # steps are ALSO driven with a prescribed varied token sequence (fresh cache from the same prefill): logits of 12 steps
+    res_f = model(input_ids=ids, images=frames, use_cache=True)
+    cache_f = res_f.past_key_values
+    forced = torch.randint(0, lcfg.vocab_size, (12,), generator=torch.Generator().manual_seed(11)).tolist()
+    forced_logits = []
+    for t in forced:
+        rf = model(input_ids=torch.tensor([[t]]), past_key_values=cache_f, use_cache=True)
+        cache_f = rf.past_key_values
+        forced_logits.append(rf.logits[0, -1].numpy())
+    out["forced_tokens"] = np.array(forced, dtype=np.int64)
+    out["forced_logits"] = np.stack(forced_logits)
     # KV snapshot (layer 0 and last), selected positions
     try:
         k0, v0 = cache.layers[0].keys, cache.layers[0].values

@@ -443,3 +443,45 @@ def test_sampling_defaults_come_from_generation_config():
     x = model.generate(input_ids=ids, do_sample=True, temperature=1.0, max_new_tokens=6, eos_token_id=None, generator=g2)
     y = model.generate(input_ids=ids, do_sample=True, temperature=1.0, max_new_tokens=6, eos_token_id=None, generator=g3)
     assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_teacher_forced_decode_steps_match_reference(name):
+    """G6b: 12 decode steps fed with the fixture's prescribed varied tokens through forward(past_key_values) -- the logits of
+    every step against the reference's own (fp32, 1e-5), then the same on the bf16 engine against the boundary oracle."""
+    g = TY.load_npz(name)
+    frames, ids = None, None
+    model, sd = build(name, torch.float32)
+    frames, ids = inputs(name, g)
+    dev = model.device
+    imgs = [f.to(dev) for f in frames]
+    out = model(input_ids=ids.to(dev), images=imgs, use_cache=True)
+    pkv = out.past_key_values
+    mask = torch.ones(1, ids.shape[1], dtype=torch.long, device=dev)
+    worst = 0.0
+    for i, t in enumerate(g["forced_tokens"].tolist()):
+        _in = model.prepare_inputs_for_generation(torch.tensor([[t]], device=dev), past_key_values=pkv, images=imgs,
+                                                  attention_mask=mask, use_cache=True)
+        out = model(**_in)
+        pkv = out.past_key_values
+        d = float((out.logits[0, -1].cpu() - torch.from_numpy(g["forced_logits"][i])).abs().max())
+        worst = max(worst, d)
+        assert d < FP32_TOL, (i, d)
+    print(f"[{name}] teacher-forced decode, 12 steps: worst max abs diff vs reference {worst:.2e}")
+    # bf16 engine, same tokens, against the oracle with bf16 rounding at the kernel boundaries
+    model16, _ = build(name, torch.bfloat16)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd16 = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    _, cache, _ = O.mm_forward(ids, frames, sd16, vcfg, lcfg, mm, rounding="bf16")
+    imgs16 = [f.to(dev, dtype=torch.bfloat16) for f in frames]
+    out = model16(input_ids=ids.to(dev), images=imgs16, use_cache=True)
+    pkv = out.past_key_values
+    emb_w = sd16["model.embed_tokens.weight"]
+    for i, t in enumerate(g["forced_tokens"].tolist()):
+        ref, cache = O.llama_forward(emb_w[torch.tensor([[t]])], None, None, cache, sd16, lcfg, "bf16", decode_kernel=True)
+        _in = model16.prepare_inputs_for_generation(torch.tensor([[t]], device=dev), past_key_values=pkv, images=imgs16,
+                                                    attention_mask=mask, use_cache=True)
+        out = model16(**_in)
+        pkv = out.past_key_values
+        rel = float((out.logits[0, -1].cpu().float() - ref[0, -1]).abs().max()) / float(ref[0, -1].abs().max())
+        assert rel < BF16_REL, (i, rel)

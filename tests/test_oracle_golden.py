@@ -309,3 +309,20 @@ def test_expand2square_matches_pil_paste():
             ref = Image.new(pil.mode, (H, H), fill)
             ref.paste(pil, ((H - W) // 2, 0))
         assert torch.equal(O.expand2square_u8(raw, fill), torch.from_numpy(np.array(ref)))
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_teacher_forced_decode_steps_match_reference(name):
+    """G6b: 12 decode steps driven with a prescribed, varied token sequence (the greedy streams of the tiny models settle on one
+    token after two steps) -- every step's logits against the reference's, so the decode path is pinned beyond step 2."""
+    g = TY.load_npz(name)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd = TY.state_dict(name)
+    frames = O.synthetic_frames(int(g["T"]), vcfg.image_size, seed=0)
+    ids = torch.from_numpy(g["input_ids"])
+    _, cache, _ = O.mm_forward(ids, frames, sd, vcfg, lcfg, mm)
+    emb_w = sd["model.embed_tokens.weight"]
+    assert len(set(g["forced_logits"].argmax(-1).tolist())) >= 4          # the stream really varies
+    for i, t in enumerate(g["forced_tokens"].tolist()):
+        logits, cache = O.llama_forward(emb_w[torch.tensor([[t]])], None, None, cache, sd, lcfg, None, decode_kernel=True)
+        np.testing.assert_allclose(logits[0, -1].numpy(), g["forced_logits"][i], atol=FP32_TOL, rtol=1e-5, err_msg=f"step {i}")
