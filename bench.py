@@ -372,6 +372,7 @@ def main():
     # the product default: generate() looks at the tokens every chunk=16 steps (one .tolist() sync per chunk); the timed
     # region above uses chunk=n_out (one look per conversation).  One untimed-region measurement of the default path:
     if B == 1:
+        model.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=n_out, eos_token_id=None)   # warm (as the timed loop is)
         torch.cuda.synchronize(); t = time.perf_counter()
         model.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=n_out, eos_token_id=None)
         torch.cuda.synchronize()
