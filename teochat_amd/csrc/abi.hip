@@ -59,7 +59,7 @@ int teo_version(void) { return TEO_ABI_VERSION; }
 const char* teo_last_error(void) { return g_err; }
 
 int teo_tune_set(const char* key, int value) {
-    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || runtime_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
+    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || gemm_big_tune_set(key, value) == 0 || runtime_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
     set_error("teo_tune_set: unknown key");
     return TEO_ERR_ARG;
 }

@@ -541,6 +541,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
+constexpr double GEMM_BIG_ROUND_COST = 1.8;
+static int g_gemm_big = 1;     // 256 x 256 LDS-DMA kernel (gemm_big.hip): 0 off, 1 auto (rounds model), 2 forced
 static int g_gemm_wide = 1;    // wide-tile LDS-DMA kernel (gemm_wide.hip): 0 off, 1 auto, 2 forced wherever its shape constraints hold
 static int g_gemm_sk_dbg = 0;  // timing diagnostics only (wrong results): 1 skip slab stores, 2 skip the flag wait, 4 skip slab loads
 static int g_gemm_sk = 1;      // 1: stream-K kernel when a workspace is given and the static tiling would leave a ragged last round
@@ -557,6 +559,7 @@ int gemm_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
     if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
     if (!strcmp(key, "gemm_wide")) { g_gemm_wide = value; return 0; }
+    if (!strcmp(key, "gemm_big")) { g_gemm_big = value; return 0; }
     if (!strcmp(key, "gemm_sk_dbg")) { g_gemm_sk_dbg = value; return 0; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return 0; }          // 0 off, 1 auto, 2 forced (diagnostics)
     return -1;
@@ -573,6 +576,8 @@ bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned fla
     return al(A, 16) && al(W, 16) && al(bias, 8) && al(res, 8) && al(C, 16);
 }
 
+int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                    int act, bool swiglu, bool of32, hipStream_t st);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);          // gemm_wide.hip
 int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
@@ -622,6 +627,13 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
+        const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = (long long)cdiv(M, 256) * cdiv(N, 256);
+        const bool sk_wide_shape = sk_ws && g_gemm_sk && g_gemm_wide && !swiglu && t_wide_ > 256 && t_wide_ <= 256 + 256 / 6;
+        // 256 x 256 tiles: a round of them costs GEMM_BIG_ROUND_COST rounds of the 128 x 256 kernel for twice the area (measured
+        // 1.45-1.7 us against 0.875 us per K tile); taken when that beats the wide kernel's round count and the chip is filled
+        if (bm == 128 && K >= 2 * BK && (g_gemm_big == 2 || (g_gemm_big == 1 && g_gemm_wide == 1 && t_big >= 224 && !sk_wide_shape &&
+                                                               cdiv(t_big, 256) * GEMM_BIG_ROUND_COST < (double)cdiv(t_wide_, 256))))
+            return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st);
         {   // just over one round of WIDE tiles (272 on 256 CUs: o / down at M = 2168): the stream-K form of the wide kernel
             const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256);
             if (sk_ws && g_gemm_sk && g_gemm_wide && bm == 128 && !swiglu && K >= 2 * BK && t_wide > 256 &&

@@ -1,0 +1,206 @@
+// 256 (M) x 256 (N) x 64 form of the bf16 MFMA GEMM: 8 waves (2 x 4) of 128 x 64, operands by LDS-DMA into a two-stage ring
+// (2 x 64 KB).  Against the 128 x 256 kernel (gemm_wide.hip) a workgroup moves 33 % fewer bytes per FLOP out of L2 (64 KB per
+// 8.4 MFLOP instead of 48 KB per 4.2) and a wave reads 25 % fewer fragment bytes per MFMA (12 ds_read_b128 per 32 MFMAs instead of
+// 8 per 16) -- the two things the ablation of the wide kernel found as long as its MFMA work.  Same LDS image (128-byte rows,
+// 16-byte chunk c of row r at c ^ (r & 7), applied through the DMA source address), same MFMA chain per output element
+// (k ascending) -> bit-identical results.  K loop as gw_ktile: skewed DMA issue between the two waves of a SIMD, second-half
+// fragments carried over the next barrier (245 VGPRs, 2 waves per SIMD).  The price is tile quantisation: 9 row tiles at
+// M = 2168 (6 % padding) and 256-column panels; the dispatch (gemm.hip) only comes here when the rounds model says it pays.
+// Measured (tools/bench_kernels.py gemm_big): 1.45-1.7 us per K tile of a workgroup (MFMA alone would be 0.94); qkv at M = 2168
+// 195 us vs 223, gate/up at M = 4208 608 vs 668, at M = 17344 2434 vs 2682, 4096^3 108 vs 118; gate/up at M = 2168 (774 tiles =
+// 3.02 rounds) loses, 371 vs 340.  Ablation (qkv): MFMA + barriers alone 159 us, DMA alone 140 (one tile in flight: a two-stage
+// ring is latency-bound at ~1.1 us per 64 KB), fragment reads alone 81.  A second barrier per K tile that frees the stage early
+// (1.5 tiles of DMA lead) makes the DMA alone faster (106 us) and the kernel slower (246 us): not kept.
+#include "common.h"
+#include "ops.h"
+
+namespace teo {
+
+typedef __attribute__((ext_vector_type(8))) short gb_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float gb_f32x4;
+
+constexpr int GB_BM = 256, GB_BN = 256, GB_BK = 64;
+constexpr int GB_A_BYTES = GB_BM * GB_BK * 2;            // 32 KiB
+constexpr int GB_STAGE = GB_A_BYTES + GB_BN * GB_BK * 2; // 64 KiB
+constexpr int GB_PIECES = 8;                             // 1-KiB DMA pieces per wave per K tile (waves 0-3: A, waves 4-7: W)
+
+__device__ __forceinline__ int gb_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                               const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M,
+                                                               int N, int K, int lda, int ldc, int act, int tiles_m, int tiles_n,
+                                                               int group) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tile = gb_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // tiles walk `group` N panels at a time, N fastest (see gemm_wide.hip): with many row tiles the 32 workgroups of an XCD would
+    // otherwise share one W panel and stream all of A (sq8192: every XCD reads the whole A once per round)
+    const int gsz = group * tiles_m, sup = tile / gsz, rem = tile - sup * gsz;
+    const int gn = min(group, tiles_n - sup * group);
+    const int tm = rem / gn, tn = sup * group + rem % gn;
+    const int m0 = tm * GB_BM, n0 = tn * GB_BN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / GB_BK;
+
+    // DMA: wave w < 4 brings A rows 64 w .. 64 w + 63 (8 pieces of 8 rows), wave w >= 4 W rows 64 (w - 4) ..; lane l carries row
+    // (l >> 3) of a piece, logical chunk (l & 7) ^ (l >> 3).  32-bit element offsets from one wave-uniform base.
+    const bool isA = wid < 4;
+    const bf16_t* base = isA ? A : W;
+    const int ld = isA ? lda : K;
+    const int row0 = isA ? m0 + wid * 64 : n0 + (wid - 4) * 64;
+    const int rmax = (isA ? M : N) - 1;
+    unsigned off[GB_PIECES];
+#pragma unroll
+    for (int j = 0; j < GB_PIECES; ++j) {
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        off[j] = (unsigned)min(row0 + j * 8 + rl, rmax) * (unsigned)ld + c * 8;
+    }
+    const int lds_piece0 = (isA ? wid * 8 : 32 + (wid - 4) * 8) * 1024;
+#define TEO_GB_STAGE(KT, ST)                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < GB_PIECES; ++j)                                                                    \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[j] + (unsigned)(KT) * GB_BK), \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * GB_STAGE + lds_piece0 + j * 1024), 16, 0, 0);
+
+    gb_f32x4 acc[4][8];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (gb_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    TEO_GB_STAGE(0, 0)
+    const bool late = wid < 4;                            // skewed DMA issue between the two waves of a SIMD (see gw_ktile)
+    gb_bf16x8 af[8], wf[4], caf[8], cwf[4];               // first-half fragments of this K tile; second half carried over the next barrier
+#define TEO_GB_READ(AF, WF, KS)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        const int rw_ = wn * 64 + i * 16 + fr;                                                                    \
+        WF[i] = *reinterpret_cast<const gb_bf16x8*>(sB + rw_ * 128 + ((((KS) * 4 + fg) ^ (rw_ & 7)) << 4));        \
+    }                                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+        const int ra_ = wm * 128 + i * 16 + fr;                                                                   \
+        AF[i] = *reinterpret_cast<const gb_bf16x8*>(sA + ra_ * 128 + ((((KS) * 4 + fg) ^ (ra_ & 7)) << 4));        \
+    }
+#define TEO_GB_MFMA(AF, WF, N0, N1)                                                                               \
+    _Pragma("unroll") for (int ni = N0; ni < N1; ++ni)                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                          \
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[ni], AF[mi], acc[ni][mi], 0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        // this wave's pieces of tile kt have landed and its fragment reads of tile kt-1 have returned; then everybody's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!late && kt + 1 < nk) { TEO_GB_STAGE(kt + 1, st ^ 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sA = smem + st * GB_STAGE;
+        const unsigned char* sB = sA + GB_A_BYTES;
+        TEO_GB_READ(af, wf, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt > 0) { TEO_GB_MFMA(caf, cwf, 0, 4) }        // second half of tile kt-1, from registers, under the reads above
+        __builtin_amdgcn_sched_barrier(0);
+        if (late && kt + 1 < nk) { TEO_GB_STAGE(kt + 1, st ^ 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        TEO_GB_READ(caf, cwf, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        TEO_GB_MFMA(af, wf, 0, 4)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nk > 0) { TEO_GB_MFMA(caf, cwf, 0, 4) }
+#undef TEO_GB_READ
+#undef TEO_GB_MFMA
+#undef TEO_GB_STAGE
+
+    // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3 (as the other MFMA kernels)
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+        if (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int ng = nw + ni * 16 + fg * 4;
+                if (ng >= N) continue;
+                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
+                if (n + 3 < N) {
+                    if (bias) {
+                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
+                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
+                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                    }
+                    if (act != TEO_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
+                    }
+                    if (res) {
+                        const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
+                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                    }
+                    if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) {
+                        float v = o[r];
+                        if (bias) v += bf2f(bias[n + r]);
+                        v = act_apply(v, act);
+                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int g_big_group = 0;      // N panels per tile group (0: from the tile grid)
+int gemm_big_tune_set(const char* key, int value) {
+    if (!strcmp(key, "gemm_big_group") && value >= 0) { g_big_group = value; return 0; }
+    return -1;
+}
+
+int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                    int act, bool swiglu, bool of32, hipStream_t st) {
+    const int tiles_m = cdiv(M, GB_BM), tiles_n = cdiv(N, GB_BN);
+    const int nwg = tiles_m * tiles_n;
+    const size_t lds = 2 * GB_STAGE;
+#define TEO_GB_LAUNCH(SW, OF)                                                                                                     \
+    {                                                                                                                             \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) {                                                                                                          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            if (e != hipSuccess) return hip_fail(e, "gemm_big: hipFuncSetAttribute");                                             \
+            attr_set = true;                                                                                                      \
+        }                                                                                                                         \
+        gemm_mfma_bf16_big_kernel<SW, OF><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,          \
+                                                                 (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, g_big_group ? g_big_group : (tiles_m >= 16 ? 4 : 1)); \
+    }
+    if (swiglu) { if (of32) TEO_GB_LAUNCH(true, true) else TEO_GB_LAUNCH(true, false) }
+    else { if (of32) TEO_GB_LAUNCH(false, true) else TEO_GB_LAUNCH(false, false) }
+#undef TEO_GB_LAUNCH
+    TEO_LAUNCH_CHECK("gemm_mfma_bf16_big");
+    return TEO_OK;
+}
+
+}  // namespace teo

@@ -62,6 +62,7 @@ int cross_entropy(const float* logits, long long ld, const long long* labels, fl
                   long long ignore_index, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
 int gemm_wide_tune_set(const char* key, int value);
+int gemm_big_tune_set(const char* key, int value);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
 // Producer-side RMSNorm hand-off between the GEMMs of a batched decode step.  A residual-producing GEMM (o / down
@@ -82,6 +83,8 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
 int gemm_tune_set(const char* key, int value);
 int runtime_tune_set(const char* key, int value);
 int gemm_fp8_tune_set(const char* key, int value);
+int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                    int act, bool swiglu, bool of32, hipStream_t st);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);
 size_t gemm_sk_workspace_bytes();

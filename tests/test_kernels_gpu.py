@@ -1106,3 +1106,32 @@ def test_gemm_wide_tile_kernel_is_bitwise_the_plain_kernel(M, N, K, flags, extra
             assert torch.equal(got, want)
     finally:
         lib.teo_tune_set(b"gemm_wide", 1)
+
+
+@pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 12288, 4096, 0, ""), (4208, 2048, 512, L.GEMM_SWIGLU16, ""), (300, 700, 192, 0, "bias_gelu"),
+                                               (129, 260, 128, 0, "res"), (1000, 1024, 2048, 0, "f32out"), (257, 512, 128, 0, ""),
+                                               (2056, 4096, 1024, 0, "bias_res"), (4096, 1024, 1024, 0, "group")])
+def test_gemm_256x256_kernel_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
+    """gemm_big.hip (256 x 256 tiles, 8 waves of 128 x 64, two-stage LDS-DMA ring, carried second half) against the 128 x 128
+    register-staged kernel: same k-order per output element -> BIT-identical, incl. ragged M / N edges, K of two tiles, every
+    epilogue, and the grouped tile walk (>= 16 row tiles)."""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    A = torch.randn(M, K, generator=g).to(bf).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(bf).cuda()
+    Nc = N // 2 if flags else N
+    bias = (torch.randn(N, generator=g) * 0.1).to(bf).cuda() if "bias" in extra else None
+    res = torch.randn(M, Nc, generator=g).to(bf).cuda() if "res" in extra else None
+    act = L.ACT_GELU_ERF if "gelu" in extra else L.ACT_NONE
+    od = torch.float32 if "f32out" in extra else bf
+    lib = G.lib()
+    try:
+        assert lib.teo_tune_set(b"gemm_big", 0) == 0 and lib.teo_tune_set(b"gemm_wide", 0) == 0
+        want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+        assert lib.teo_tune_set(b"gemm_big", 2) == 0
+        for _ in range(3):
+            got = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+            assert torch.equal(got, want)
+    finally:
+        lib.teo_tune_set(b"gemm_big", 1)
+        lib.teo_tune_set(b"gemm_wide", 1)

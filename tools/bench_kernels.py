@@ -229,6 +229,29 @@ def bench_gemm_wide():
               f" | bit-identical: {bool(torch.equal(outs[0], outs[2]))}", flush=True)
 
 
+def bench_gemm_big():
+    """256 x 256 kernel (gemm_big = 2: forced) vs the default dispatch."""
+    shapes = [("qkv", 2168, 12288, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("o", 2168, 4096, 4096, 0),
+              ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0), ("qkv_T16", 4208, 12288, 4096, 0),
+              ("gateup_T16", 4208, 22016, 4096, L.GEMM_SWIGLU16), ("qkv_2048", 2048, 12288, 4096, 0), ("gateup_B8", 17344, 22016, 4096, L.GEMM_SWIGLU16)]
+    for name, M, N, K, flags in shapes:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+        res = {0: [], 2: [], 3: []}
+        outs = {}
+        for _ in range(3):
+            for mode in (2, 3, 0):
+                lib.teo_tune_set(b"gemm_big", 2 if mode == 2 else (1 if mode == 3 else 0))
+                res[mode].append(timeit(lambda: G.gemm(A, W, flags=flags)))
+                outs[mode] = G.gemm(A, W, flags=flags)
+        lib.teo_tune_set(b"gemm_big", 1)
+        a, b_ = min(res[2]), min(res[0])
+        fl = 2.0 * M * N * K
+        tiles = -(-M // 256) * -(-N // 256)
+        print(f"gemm {name:10s} M={M} N={N} K={K}: big {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s ({tiles} tiles = {tiles / 256:.2f} rounds, {a / -(-tiles // 256) / (K // 64) * 1e3:6.0f} ns per K tile) | "
+              f"auto {min(res[3]):8.1f} us | no big {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | bit-identical: {bool(torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]))}", flush=True)
+
+
 def bench_gemm_wide_sched():
     """instruction-order variants of the wide kernel's K loop (gemm_wide_sched), forced wide, plain (non-stream-K) launch."""
     shapes = [("qkv", 2168, 12288, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("sq8192", 8192, 8192, 8192, 0),
@@ -339,5 +362,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
