@@ -12,6 +12,7 @@
 //
 // Roofline: MFMA bf16 dense (2.5 PFLOP/s); algorithmic FLOPs = 2*M*N*K.
 #include "common.h"
+#include "ops.h"
 
 namespace teo {
 
@@ -547,10 +548,12 @@ static int g_gemm_wide = 1;    // wide-tile LDS-DMA kernel (gemm_wide.hip): 0 of
 static int g_gemm_sk_dbg = 0;  // timing diagnostics only (wrong results): 1 skip slab stores, 2 skip the flag wait, 4 skip slab loads
 static int g_gemm_sk = 1;      // 1: stream-K kernel when a workspace is given and the static tiling would leave a ragged last round
 constexpr int SK_MAX_GRID = 512;   // 256 CUs x 2 resident workgroups (64 KiB LDS, <= 256 VGPRs each)
-size_t gemm_sk_workspace_bytes() { return (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float) + SK_MAX_GRID * sizeof(int); }
+// slabs of every stream-K form share the first GEMM_SK_SLAB_BYTES (512 x 64 KB here, 256 x 128 KB in gemm_wide.hip / gemm_fp8.hip,
+// 256 x 256 KB in gemm_big.hip); the hand-off flags live behind them
+size_t gemm_sk_workspace_bytes() { return GEMM_SK_SLAB_BYTES + SK_MAX_GRID * sizeof(int); }
 // flags live behind the slabs; they must be zero before the first stream-K launch on a workspace (the kernel re-arms them)
 int gemm_sk_workspace_init(void* ws, hipStream_t st) {
-    hipError_t e = hipMemsetAsync((unsigned char*)ws + (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float), 0, SK_MAX_GRID * sizeof(int), st);
+    hipError_t e = hipMemsetAsync((unsigned char*)ws + GEMM_SK_SLAB_BYTES, 0, SK_MAX_GRID * sizeof(int), st);
     return e == hipSuccess ? TEO_OK : hip_fail(e, "gemm_sk_workspace_init");
 }
 static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
@@ -577,7 +580,7 @@ bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned fla
 }
 
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st);
+                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);          // gemm_wide.hip
 int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
@@ -631,15 +634,17 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const bool sk_wide_shape = sk_ws && g_gemm_sk && g_gemm_wide && !swiglu && t_wide_ > 256 && t_wide_ <= 256 + 256 / 6;
         // 256 x 256 tiles: a round of them costs GEMM_BIG_ROUND_COST rounds of the 128 x 256 kernel for twice the area (measured
         // 1.45-1.7 us against 0.875 us per K tile); taken when that beats the wide kernel's round count and the chip is filled
+        // (with a workspace its hybrid form has no ragged last round: fractional rounds + a hand-off allowance)
+        const double big_rounds = (sk_ws && t_big > 256 && t_big % 256 != 0 && gemm_big_hybrid_fits(M, N, K)) ? (double)t_big / 256.0 + 0.12
+                                                                                                                 : (double)cdiv(t_big, 256);
         if (bm == 128 && K >= 2 * BK && (g_gemm_big == 2 || (g_gemm_big == 1 && g_gemm_wide == 1 && t_big >= 224 && !sk_wide_shape &&
-                                                               cdiv(t_big, 256) * GEMM_BIG_ROUND_COST < (double)cdiv(t_wide_, 256))))
-            return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st);
+                                                               big_rounds * GEMM_BIG_ROUND_COST < (double)cdiv(t_wide_, 256))))
+            return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st, sk_ws, GEMM_SK_SLAB_BYTES);
         {   // just over one round of WIDE tiles (272 on 256 CUs: o / down at M = 2168): the stream-K form of the wide kernel
             const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256);
             if (sk_ws && g_gemm_sk && g_gemm_wide && bm == 128 && !swiglu && K >= 2 * BK && t_wide > 256 &&
                 (g_gemm_sk == 2 || t_wide <= 256 + 256 / 6))
-                return gemm_wide_sk_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, sk_ws,
-                                           (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float), st);
+                return gemm_wide_sk_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, sk_ws, GEMM_SK_SLAB_BYTES, st);
         }
         if (g_gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, g_gemm_wide == 2))
             return gemm_wide_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st);
@@ -653,7 +658,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
             const long long total = (long long)nwg * nk;
             const int per = (int)((total + SK_MAX_GRID - 1) / SK_MAX_GRID);          // >= nk because nwg > SK_MAX_GRID
             float* slabs = (float*)sk_ws;
-            int* flg = (int*)((unsigned char*)sk_ws + (size_t)SK_MAX_GRID * SK_SLAB_FLOATS * sizeof(float));
+            int* flg = (int*)((unsigned char*)sk_ws + GEMM_SK_SLAB_BYTES);
 #define TEO_SK_LAUNCH(SW, OF)                                                                                         \
     gemm_mfma_bf16_sk_kernel<SW, OF><<<SK_MAX_GRID, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,  \
                                                                      (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \

@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(4))) float gb_f32x4;
 constexpr int GB_BM = 256, GB_BN = 256, GB_BK = 64;
 constexpr int GB_A_BYTES = GB_BM * GB_BK * 2;            // 32 KiB
 constexpr int GB_STAGE = GB_A_BYTES + GB_BN * GB_BK * 2; // 64 KiB
+constexpr int GB_SLAB_FLOATS = GB_BM * GB_BN;          // 256 KB of fp32 accumulators per workgroup
 constexpr int GB_PIECES = 8;                             // 1-KiB DMA pieces per wave per K tile (waves 0-3: A, waves 4-7: W)
 
 __device__ __forceinline__ int gb_xcd_remap(int bid, int nwg) {
@@ -30,24 +31,59 @@ __device__ __forceinline__ int gb_xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <bool SWIGLU, bool OUT_F32>
+// HYBRID = false: one workgroup per tile.  HYBRID = true: a persistent grid of 256 workgroups (one per CU); the first `dp_rounds`
+// x 256 tiles are taken whole, one per workgroup per round (all workgroups of an XCD at the same k at the same time: the L2 sharing
+// of the plain kernel), the remaining r tiles (256 <= r < 512) are cut stream-K style into 256 equal contiguous (tile, k) ranges
+// with the sequential hand-off of gemm_mfma_bf16_sk_kernel: a range that ends inside a tile runs that part FIRST and hands its fp32
+// accumulators (256 KB slab, 16-byte sc1 stores + flag) to the next range's owner, which continues from them LAST in its own
+// timeline -- k-order per output element unchanged, results bit-identical, no ragged last round.
+template <bool SWIGLU, bool OUT_F32, bool HYBRID>
 __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M,
                                                                int N, int K, int lda, int ldc, int act, int tiles_m, int tiles_n,
-                                                               int group) {
+                                                               int group, int dp_rounds, int per, float* slabs, int* flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
-    const int tile = gb_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / GB_BK;
+    const int q = gb_xcd_remap(blockIdx.x, gridDim.x);
+    // segments of this workgroup: [tail piece] [dp_rounds whole tiles] [whole tiles of its stream-K range] [head piece]
+    int t_first = 0, k_first = 0, t_last = 0, k_end = nk, has_head = 0, has_tail = 0, n_full = 0, t_full0 = 0, nseg = 1;
+    const int sk_tile0 = dp_rounds * 256;
+    if (HYBRID) {
+        const long long total = (long long)(tiles_m * tiles_n - sk_tile0) * nk;
+        const long long it0 = (long long)q * per, it1 = min(it0 + per, total);
+        if (it0 < total) {
+            t_first = (int)(it0 / nk); k_first = (int)(it0 % nk);
+            t_last = (int)((it1 - 1) / nk); k_end = (int)(it1 - (long long)t_last * nk);
+            has_head = k_first != 0; has_tail = k_end != nk;                 // per >= nk: a tile has at most two owners
+            t_full0 = t_first + has_head; n_full = (t_last + 1 - has_tail) - t_full0;
+        }
+        nseg = has_tail + dp_rounds + n_full + has_head;
+    }
+    gb_f32x4 acc[4][8];   // [ni][mi]
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+    bool is_tail = false, is_head = false;
+    int tile, kb = 0, ke = nk;
+    if (HYBRID) {
+        is_tail = has_tail && sgi == 0;
+        is_head = has_head && sgi == nseg - 1;
+        const int j = sgi - has_tail;                                        // index among the whole tiles
+        if (is_tail) { tile = sk_tile0 + t_last; ke = k_end; }
+        else if (is_head) { tile = sk_tile0 + t_first; kb = k_first; }
+        else if (j < dp_rounds) tile = j * 256 + q;
+        else tile = sk_tile0 + t_full0 + (j - dp_rounds);
+    } else {
+        tile = q;
+    }
     // tiles walk `group` N panels at a time, N fastest (see gemm_wide.hip): with many row tiles the 32 workgroups of an XCD would
     // otherwise share one W panel and stream all of A (sq8192: every XCD reads the whole A once per round)
     const int gsz = group * tiles_m, sup = tile / gsz, rem = tile - sup * gsz;
     const int gn = min(group, tiles_n - sup * group);
     const int tm = rem / gn, tn = sup * group + rem % gn;
     const int m0 = tm * GB_BM, n0 = tn * GB_BN;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int nk = K / GB_BK;
 
     // DMA: wave w < 4 brings A rows 64 w .. 64 w + 63 (8 pieces of 8 rows), wave w >= 4 W rows 64 (w - 4) ..; lane l carries row
     // (l >> 3) of a piece, logical chunk (l & 7) ^ (l >> 3).  32-bit element offsets from one wave-uniform base.
@@ -68,13 +104,31 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[j] + (unsigned)(KT) * GB_BK), \
                                          (__attribute__((address_space(3))) void*)(smem + (ST) * GB_STAGE + lds_piece0 + j * 1024), 16, 0, 0);
 
-    gb_f32x4 acc[4][8];   // [ni][mi]
+    if (HYBRID && is_head) {
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 24)) break;                              // never reached: the producer wrote its slab first thing
+            }
+            __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+        }
+        __builtin_amdgcn_s_barrier();
+        const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)(q - 1) * GB_SLAB_FLOATS, 0, GB_SLAB_FLOATS * 4, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (gb_f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mi = 0; mi < 8; ++mi)
+                acc[ni][mi] = __builtin_bit_cast(gb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(sl, ((ni * 8 + mi) * 512 + tid) * 16, 0, /*sc1*/ 16));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (gb_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
-    TEO_GB_STAGE(0, 0)
+    // (a head segment's 32 slab loads are older than the DMA pieces below: vmcnt retires in order, the waits keep their meaning)
+    TEO_GB_STAGE(kb, 0)
     const bool late = wid < 4;                            // skewed DMA issue between the two waves of a SIMD (see gw_ktile)
     gb_bf16x8 af[8], wf[4], caf[8], cwf[4];               // first-half fragments of this K tile; second half carried over the next barrier
 #define TEO_GB_READ(AF, WF, KS)                                                                                   \
@@ -90,30 +144,47 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
     _Pragma("unroll") for (int ni = N0; ni < N1; ++ni)                                                            \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                          \
             acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[ni], AF[mi], acc[ni][mi], 0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
+    for (int kt = kb; kt < ke; ++kt) {
+        const int st = (kt - kb) & 1;
         // this wave's pieces of tile kt have landed and its fragment reads of tile kt-1 have returned; then everybody's
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (!late && kt + 1 < nk) { TEO_GB_STAGE(kt + 1, st ^ 1) }
+        if (!late && kt + 1 < ke) { TEO_GB_STAGE(kt + 1, st ^ 1) }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sA = smem + st * GB_STAGE;
         const unsigned char* sB = sA + GB_A_BYTES;
         TEO_GB_READ(af, wf, 0)
         __builtin_amdgcn_sched_barrier(0);
-        if (kt > 0) { TEO_GB_MFMA(caf, cwf, 0, 4) }        // second half of tile kt-1, from registers, under the reads above
+        if (kt > kb) { TEO_GB_MFMA(caf, cwf, 0, 4) }       // second half of tile kt-1, from registers, under the reads above
         __builtin_amdgcn_sched_barrier(0);
-        if (late && kt + 1 < nk) { TEO_GB_STAGE(kt + 1, st ^ 1) }
+        if (late && kt + 1 < ke) { TEO_GB_STAGE(kt + 1, st ^ 1) }
         __builtin_amdgcn_sched_barrier(0);
         TEO_GB_READ(caf, cwf, 1)
         __builtin_amdgcn_sched_barrier(0);
         TEO_GB_MFMA(af, wf, 0, 4)
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (nk > 0) { TEO_GB_MFMA(caf, cwf, 0, 4) }
+    if (ke > kb) { TEO_GB_MFMA(caf, cwf, 0, 4) }
 #undef TEO_GB_READ
 #undef TEO_GB_MFMA
 #undef TEO_GB_STAGE
+    if (HYBRID) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring before the next segment refills it
+        if (is_tail) {
+            const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)q * GB_SLAB_FLOATS, 0, GB_SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, acc[ni][mi]), sl,
+                                                           ((ni * 8 + mi) * 512 + tid) * 16, 0, /*sc1*/ 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // every storing wave: write-through stores landed
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) __hip_atomic_store(flags + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+    }
 
     // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3 (as the other MFMA kernels)
     const int mw = m0 + wm * 128, nw = n0 + wn * 64;
@@ -171,34 +242,51 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
             }
         }
     }
+    }   // segments
 }
 
 static int g_big_group = 0;      // N panels per tile group (0: from the tile grid)
+static int g_big_hybrid = 1;     // data-parallel rounds + stream-K remainder when a workspace is given (1: if it fits MALL, 2: always)
+bool gemm_big_hybrid_fits(int M, int N, int K) { return ((long long)M + N) * K * 2 <= (160ll << 20); }
 int gemm_big_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_big_group") && value >= 0) { g_big_group = value; return 0; }
+    if (!strcmp(key, "gemm_big_hybrid")) { g_big_hybrid = value; return 0; }
     return -1;
 }
 
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st) {
+                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset) {
     const int tiles_m = cdiv(M, GB_BM), tiles_n = cdiv(N, GB_BN);
-    const int nwg = tiles_m * tiles_n;
+    const int T = tiles_m * tiles_n, nk = K / GB_BK;
     const size_t lds = 2 * GB_STAGE;
-#define TEO_GB_LAUNCH(SW, OF)                                                                                                     \
+    const int group = g_big_group ? g_big_group : (tiles_m >= 16 ? 4 : 1);
+    // hybrid form when the tile count is not a whole number of rounds -- and the operands fit the 256 MB Infinity Cache: the
+    // stream-K part has every workgroup at its own (tile, k), nothing is shared through L2, and once A + W no longer sit in MALL its
+    // K tiles take twice as long as the data-parallel ones (measured: gate/up at M = 4208, 214 MB: 712 us vs 580; at M = 2168 qkv,
+    // 118 MB: 195 vs 203; gemm_big_hybrid = 2 forces it)
+    const bool hybrid = sk_ws && g_big_hybrid && T > 256 && T % 256 != 0 && (g_big_hybrid == 2 || gemm_big_hybrid_fits(M, N, K));
+    const int dp_rounds = hybrid ? T / 256 - 1 : 0;
+    const int per = hybrid ? (int)(((long long)(T - dp_rounds * 256) * nk + 255) / 256) : 0;
+    float* slabs = (float*)sk_ws;
+    int* flg = hybrid ? (int*)((unsigned char*)sk_ws + flags_offset) : nullptr;
+#define TEO_GB_LAUNCH_H(SW, OF, HY)                                                                                               \
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF>),                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF, HY>),             \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e != hipSuccess) return hip_fail(e, "gemm_big: hipFuncSetAttribute");                                             \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm_mfma_bf16_big_kernel<SW, OF><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,          \
-                                                                 (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, g_big_group ? g_big_group : (tiles_m >= 16 ? 4 : 1)); \
+        gemm_mfma_bf16_big_kernel<SW, OF, HY><<<(HY) ? 256 : T, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+                                                                               (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m,  \
+                                                                               tiles_n, group, dp_rounds, per, slabs, flg);             \
     }
+#define TEO_GB_LAUNCH(SW, OF) { if (hybrid) TEO_GB_LAUNCH_H(SW, OF, true) else TEO_GB_LAUNCH_H(SW, OF, false) }
     if (swiglu) { if (of32) TEO_GB_LAUNCH(true, true) else TEO_GB_LAUNCH(true, false) }
     else { if (of32) TEO_GB_LAUNCH(false, true) else TEO_GB_LAUNCH(false, false) }
 #undef TEO_GB_LAUNCH
+#undef TEO_GB_LAUNCH_H
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_big");
     return TEO_OK;
 }

@@ -467,13 +467,13 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
         const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
         const double wide = (double)cdiv(t_wide, 256) * 0.80;   // measured: a wide fp8 round costs ~0.8 of a 128 x 128 round (o: 76 vs 81 us, gate/up 219 vs 272)
         if (sk_ws && g_fp8_wide && !swiglu && K >= 2 * F8_BK && t_wide > 256 && (g_fp8_wide == 3 || t_wide <= 256 + 256 / 6)) {
-            // just over one round of wide tiles: persistent stream-K grid (slabs: 256 x 128 KB, flags behind 32 MB as in gemm.hip)
+            // just over one round of wide tiles: persistent stream-K grid (slabs: 256 x 128 KB, flags behind GEMM_SK_SLAB_BYTES as in gemm.hip)
             const int tiles_m = cdiv(M, F8W_BM), tiles_n = cdiv(N, F8W_BN);
             const long long total = (long long)tiles_m * tiles_n * (K / F8_BK);
             const int per = (int)((total + 255) / 256);
             const size_t lds = 3 * F8W_STAGE;
             float* slabs = (float*)sk_ws;
-            int* flg = (int*)((unsigned char*)sk_ws + (size_t)512 * 16384 * sizeof(float));
+            int* flg = (int*)((unsigned char*)sk_ws + GEMM_SK_SLAB_BYTES);
 #define TEO_F8SK_LAUNCH(OF)                                                                                                     \
     {                                                                                                                           \
         static bool attr_set = false;                                                                                           \

@@ -63,6 +63,7 @@ int cross_entropy(const float* logits, long long ld, const long long* labels, fl
 int gemv_tune_set(const char* key, int value);
 int gemm_wide_tune_set(const char* key, int value);
 int gemm_big_tune_set(const char* key, int value);
+bool gemm_big_hybrid_fits(int M, int N, int K);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
 // Producer-side RMSNorm hand-off between the GEMMs of a batched decode step.  A residual-producing GEMM (o / down
@@ -84,9 +85,10 @@ int gemm_tune_set(const char* key, int value);
 int runtime_tune_set(const char* key, int value);
 int gemm_fp8_tune_set(const char* key, int value);
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st);
+                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);
+constexpr size_t GEMM_SK_SLAB_BYTES = (size_t)64 << 20;   // slab area of the stream-K workspaces (largest user: 256 x 256 KB)
 size_t gemm_sk_workspace_bytes();
 // w8a8 prefill GEMM on the scaled fp8 MFMA (gemm_fp8.hip) and the per-token activation quantiser (norm_w != NULL: RMSNorm first)
 int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,

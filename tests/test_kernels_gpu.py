@@ -934,6 +934,7 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra, wide):
     # with more than 256 wide tiles; the others fall through to the 128 x 128 form).  Forced: the heuristic only picks ~1 round.
     assert lib.teo_tune_set(b"gemm_wide", wide) == 0
     assert lib.teo_tune_set(b"gemm_sk", 2) == 0
+    assert lib.teo_tune_set(b"gemm_big", 0) == 0            # the 256 x 256 hybrid has its own test below
     try:
         for it in range(8):
             if it % 2:
@@ -945,6 +946,7 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra, wide):
     finally:
         lib.teo_tune_set(b"gemm_sk", 1)
         lib.teo_tune_set(b"gemm_wide", 1)
+        lib.teo_tune_set(b"gemm_big", 1)
     assert bad == 0, f"{bad}/8 launches differ from the plain kernel"
     # without a workspace teo_gemm_ws is teo_gemm; tuning the stream-K path off gives the same bits too
     assert torch.equal(_gemm_ws(A, W, None, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)
@@ -1133,5 +1135,48 @@ def test_gemm_256x256_kernel_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
             got = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
             assert torch.equal(got, want)
     finally:
+        lib.teo_tune_set(b"gemm_big", 1)
+        lib.teo_tune_set(b"gemm_wide", 1)
+
+
+@pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 12288, 4096, 0, ""), (2168, 22016, 4096, L.GEMM_SWIGLU16, ""), (4208, 12288, 512, 0, "res"),
+                                               (2100, 8192, 256, 0, "bias_gelu"), (4096, 4352, 1024, 0, "f32out"), (2168, 12288 + 256, 128, 0, "")])
+def test_gemm_256x256_hybrid_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
+    """The persistent form of gemm_big.hip behind teo_gemm_ws: whole tiles for the first rounds (one per workgroup per round), the
+    remaining 256..511 tiles cut into 256 equal (tile, k) ranges with the sequential slab hand-off -- BIT-identical to the
+    128 x 128 kernel, launch after launch on the same workspace, also next to a concurrent HBM stream.  Shapes: pure stream-K
+    (432 tiles), two whole rounds + 262 (774), K of two and four tiles (per == nk), grouped tile walk, every epilogue."""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g)).to(bf).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(bf).cuda()
+    Nc = N // 2 if flags else N
+    bias = (torch.randn(N, generator=g) * 0.1).to(bf).cuda() if "bias" in extra else None
+    res = (torch.randn(M, Nc, generator=g)).to(bf).cuda() if "res" in extra else None
+    act = L.ACT_GELU_ERF if "gelu" in extra else L.ACT_NONE
+    od = torch.float32 if "f32out" in extra else bf
+    lib = G.lib()
+    T = -(-M // 256) * -(-N // 256)
+    assert T > 256 and T % 256 != 0
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    side = torch.cuda.Stream()
+    big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")
+    big2 = torch.empty_like(big)
+    try:
+        assert lib.teo_tune_set(b"gemm_big", 0) == 0 and lib.teo_tune_set(b"gemm_wide", 0) == 0
+        want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+        assert lib.teo_tune_set(b"gemm_big", 2) == 0 and lib.teo_tune_set(b"gemm_big_hybrid", 2) == 0
+        bad = 0
+        for it in range(6):
+            if it % 2:
+                with torch.cuda.stream(side):
+                    big2.copy_(big)
+            got = _gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(got, want))
+        assert bad == 0, f"{bad}/6 launches differ from the plain kernel"
+    finally:
+        lib.teo_tune_set(b"gemm_big_hybrid", 1)
         lib.teo_tune_set(b"gemm_big", 1)
         lib.teo_tune_set(b"gemm_wide", 1)

@@ -244,12 +244,21 @@ def bench_gemm_big():
                 lib.teo_tune_set(b"gemm_big", 2 if mode == 2 else (1 if mode == 3 else 0))
                 res[mode].append(timeit(lambda: G.gemm(A, W, flags=flags)))
                 outs[mode] = G.gemm(A, W, flags=flags)
+        lib.teo_tune_set(b"gemm_big", 2)
+        ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+        L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+        Nc = N // 2 if flags else N
+        Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
+        run_ws = lambda: L.check(lib.teo_gemm_ws(G.p(A), G.p(W), None, None, G.p(Cc), M, N, K, K, Nc, 0, flags, L.TEO_BF16, L.TEO_BF16, G.p(ws), G.stream()), "gemm_ws")
+        t_h = min(timeit(run_ws) for _ in range(3))
+        same_h = bool(torch.equal(Cc, outs[0]))
         lib.teo_tune_set(b"gemm_big", 1)
+        t_auto_ws = min(timeit(run_ws) for _ in range(3))
         a, b_ = min(res[2]), min(res[0])
         fl = 2.0 * M * N * K
         tiles = -(-M // 256) * -(-N // 256)
         print(f"gemm {name:10s} M={M} N={N} K={K}: big {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s ({tiles} tiles = {tiles / 256:.2f} rounds, {a / -(-tiles // 256) / (K // 64) * 1e3:6.0f} ns per K tile) | "
-              f"auto {min(res[3]):8.1f} us | no big {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | bit-identical: {bool(torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]))}", flush=True)
+              f"hybrid {t_h:8.1f} us {fl / t_h / 1e6:7.1f} ({'=' if same_h else 'DIFF'}) | auto+ws {t_auto_ws:8.1f} | auto {min(res[3]):8.1f} us | no big {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | bit-identical: {bool(torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]))}", flush=True)
 
 
 def bench_gemm_wide_sched():
