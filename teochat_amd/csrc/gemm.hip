@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
-constexpr double GEMM_BIG_ROUND_COST = 1.8;
+constexpr double GEMM_BIG_ROUND_COST = 1.75;  // measured: 100 us per round of 256 x 256 tiles vs 58 us per round of 128 x 256 (gate/up at M = 17344; 8192^3: 195 vs 111)
 static int g_gemm_big = 1;     // 256 x 256 LDS-DMA kernel (gemm_big.hip): 0 off, 1 auto (rounds model), 2 forced
 static int g_gemm_wide = 1;    // wide-tile LDS-DMA kernel (gemm_wide.hip): 0 off, 1 auto, 2 forced wherever its shape constraints hold
 static int g_gemm_sk_dbg = 0;  // timing diagnostics only (wrong results): 1 skip slab stores, 2 skip the flag wait, 4 skip slab loads

@@ -438,8 +438,144 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_fp8_wide_sk_kernel(const uns
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 form (the geometry of gemm_big.hip: 8 waves of 128 x 64, two-stage LDS-DMA ring of 2 x 64 KB, skewed DMA issue):
+// 33 % fewer L2 -> LDS bytes and 25 % fewer fragment bytes per FLOP than the 128 x 256 kernel.  One K tile = 128 bytes = ONE scaled
+// MFMA per fragment pair, so there is no second half to carry: 24 ds_read_b128 then 32 MFMAs per wave per K tile, the MFMAs
+// ordered row-fragment-major so they start when the weight fragments and the first activation fragment have arrived.
+// Bit-identical to the other fp8 kernels (same k order per output element).
+// ------------------------------------------------------------------------------------------------
+constexpr int F8B_BM = 256, F8B_BN = 256;
+constexpr int F8B_A_BYTES = F8B_BM * F8_BK, F8B_STAGE = F8B_A_BYTES + F8B_BN * F8_BK;     // 32 KB + 32 KB
+
+template <bool SWIGLU, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_mfma_fp8_big_kernel(const unsigned char* __restrict__ A, const float* __restrict__ a_scale,
+                                                              const unsigned char* __restrict__ W, const float* __restrict__ w_scale,
+                                                              const bf16_t* res, void* Cv, int M, int N, int K, int lda, int ldc,
+                                                              int tiles_m, int tiles_n, int group) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / F8_BK;
+    const int tile = f8_xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int gsz = group * tiles_m, sup = tile / gsz, rem = tile - sup * gsz;       // grouped tile walk (gemm_big.hip)
+    const int gn = min(group, tiles_n - sup * group);
+    const int tm = rem / gn, tn = sup * group + rem % gn;
+    const int m0 = tm * F8B_BM, n0 = tn * F8B_BN;
+    // DMA: waves 0-3 bring A rows 64 w .. + 63 (8 pieces of 8 rows), waves 4-7 W rows; lane l: row l >> 3, logical chunk (l & 7) ^ (l >> 3)
+    const bool isA = wid < 4;
+    const unsigned char* base = isA ? A : W;
+    const int ld = isA ? lda : K;
+    const int row0 = isA ? m0 + wid * 64 : n0 + (wid - 4) * 64;
+    const int rmax = (isA ? M : N) - 1;
+    unsigned off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        off[j] = (unsigned)min(row0 + j * 8 + rl, rmax) * (unsigned)ld + c * 16;
+    }
+    const int lds_piece0 = (isA ? wid * 8 : 32 + (wid - 4) * 8) * 1024;
+#define TEO_F8B_STAGE(KT, ST)                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                            \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[j] + (unsigned)(KT) * F8_BK), \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * F8B_STAGE + lds_piece0 + j * 1024), 16, 0, 0);
+#define TEO_F8B_FRAG(BASE, ROW)                                                              \
+    ({                                                                                       \
+        const unsigned char* rp_ = (BASE) + (ROW) * F8_BK;                                   \
+        const f8_u32x4 lo_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg) ^ ((ROW) & 7)) << 4));      \
+        const f8_u32x4 hi_ = *reinterpret_cast<const f8_u32x4*>(rp_ + (((2 * fg + 1) ^ ((ROW) & 7)) << 4));  \
+        i32x8 f_;                                                                            \
+        f_[0] = (int)lo_[0]; f_[1] = (int)lo_[1]; f_[2] = (int)lo_[2]; f_[3] = (int)lo_[3];  \
+        f_[4] = (int)hi_[0]; f_[5] = (int)hi_[1]; f_[6] = (int)hi_[2]; f_[7] = (int)hi_[3];  \
+        f_;                                                                                  \
+    })
+    f8_f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f8_f32x4){0.f, 0.f, 0.f, 0.f};
+    TEO_F8B_STAGE(0, 0)
+    const bool late = wid < 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!late && kt + 1 < nk) { TEO_F8B_STAGE(kt + 1, st ^ 1) }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sA = smem + st * F8B_STAGE;
+        const unsigned char* sB = sA + F8B_A_BYTES;
+        i32x8 af[8], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = TEO_F8B_FRAG(sB, wn * 64 + i * 16 + fr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = TEO_F8B_FRAG(sA, wm * 128 + i * 16 + fr);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        __builtin_amdgcn_sched_barrier(0);
+        if (late && kt + 1 < nk) { TEO_F8B_STAGE(kt + 1, st ^ 1) }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 4; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], af[mi], acc[ni][mi], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef TEO_F8B_STAGE
+#undef TEO_F8B_FRAG
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+        const float sa = a_scale[m];
+        if (SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int ng = nw + ni * 16 + fg * 4;
+                if (ng >= N) continue;
+                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
+                const float4 sg = *reinterpret_cast<const float4*>(w_scale + ng);
+                const float4 su = *reinterpret_cast<const float4*>(w_scale + ng + 16);
+                float o[4];
+                o[0] = silu(acc[ni][mi][0] * (sa * sg.x)) * (acc[ni + 1][mi][0] * (sa * su.x));
+                o[1] = silu(acc[ni][mi][1] * (sa * sg.y)) * (acc[ni + 1][mi][1] * (sa * su.y));
+                o[2] = silu(acc[ni][mi][2] * (sa * sg.z)) * (acc[ni + 1][mi][2] * (sa * su.z));
+                o[3] = silu(acc[ni][mi][3] * (sa * sg.w)) * (acc[ni + 1][mi][3] * (sa * su.w));
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = nw + ni * 16 + fg * 4;
+                if (n >= N) continue;
+                const float4 sw = *reinterpret_cast<const float4*>(w_scale + n);
+                float o[4] = {acc[ni][mi][0] * (sa * sw.x), acc[ni][mi][1] * (sa * sw.y), acc[ni][mi][2] * (sa * sw.z), acc[ni][mi][3] * (sa * sw.w)};
+                if (res) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
+                    o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
+                    o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                }
+                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+        }
+    }
+}
+
+static int g_fp8_big = 1;      // 256 x 256 kernel: 0 off, 1 auto (rounds model), 2 forced
+constexpr double F8_BIG_ROUND_COST = 1.66;   // measured: 58.4 us per round of 256 x 256 tiles vs 35.3 us per round of 128 x 256 (gate/up at M = 17344)
 static int g_fp8_wide = 1;      // 0: 128 x 128 kernel only, 1: by the rounds model, 2: wide wherever K has two tiles
 int gemm_fp8_tune_set(const char* key, int value) {
+    if (!strcmp(key, "gemm_fp8_big")) { g_fp8_big = value; return 0; }
     if (!strcmp(key, "gemm_fp8_wide")) { g_fp8_wide = value; return 0; }
     return -1;
 }
@@ -466,7 +602,32 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
         const long long rem = t_plain % 512;
         const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
         const double wide = (double)cdiv(t_wide, 256) * 0.80;   // measured: a wide fp8 round costs ~0.8 of a 128 x 128 round (o: 76 vs 81 us, gate/up 219 vs 272)
-        if (sk_ws && g_fp8_wide && !swiglu && K >= 2 * F8_BK && t_wide > 256 && (g_fp8_wide == 3 || t_wide <= 256 + 256 / 6)) {
+        const bool sk_shape = sk_ws && g_fp8_wide && !swiglu && K >= 2 * F8_BK && t_wide > 256 && (g_fp8_wide == 3 || t_wide <= 256 + 256 / 6);
+        const long long t_big = (long long)cdiv(M, F8B_BM) * cdiv(N, F8B_BN);
+        if (K >= 2 * F8_BK && (g_fp8_big == 2 || (g_fp8_big == 1 && g_fp8_wide == 1 && t_big >= 224 && !sk_shape &&
+                                                  cdiv(t_big, 256) * F8_BIG_ROUND_COST < (double)cdiv(t_wide, 256)))) {
+            const int tiles_m = cdiv(M, F8B_BM), tiles_n = cdiv(N, F8B_BN);
+            const size_t lds = 2 * F8B_STAGE;
+            const int group = tiles_m >= 16 ? 4 : 1;
+#define TEO_F8B_LAUNCH(SW, OF)                                                                                                  \
+    {                                                                                                                           \
+        static bool attr_set = false;                                                                                           \
+        if (!attr_set) {                                                                                                        \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_fp8_big_kernel<SW, OF>),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            if (e != hipSuccess) return hip_fail(e, "gemm_fp8 big: hipFuncSetAttribute");                                       \
+            attr_set = true;                                                                                                    \
+        }                                                                                                                       \
+        gemm_mfma_fp8_big_kernel<SW, OF><<<tiles_m * tiles_n, 512, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, \
+                                                                             w_scale, (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n, group); \
+    }
+            if (swiglu) { if (of32) TEO_F8B_LAUNCH(true, true) else TEO_F8B_LAUNCH(true, false) }
+            else { if (of32) TEO_F8B_LAUNCH(false, true) else TEO_F8B_LAUNCH(false, false) }
+#undef TEO_F8B_LAUNCH
+            TEO_LAUNCH_CHECK("gemm_mfma_fp8_big");
+            return TEO_OK;
+        }
+        if (sk_shape) {
             // just over one round of wide tiles: persistent stream-K grid (slabs: 256 x 128 KB, flags behind GEMM_SK_SLAB_BYTES as in gemm.hip)
             const int tiles_m = cdiv(M, F8W_BM), tiles_n = cdiv(N, F8W_BN);
             const long long total = (long long)tiles_m * tiles_n * (K / F8_BK);

@@ -1180,3 +1180,29 @@ def test_gemm_256x256_hybrid_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
         lib.teo_tune_set(b"gemm_big_hybrid", 1)
         lib.teo_tune_set(b"gemm_big", 1)
         lib.teo_tune_set(b"gemm_wide", 1)
+
+
+@pytest.mark.parametrize("M,N,K,swiglu", [(2168, 12288, 4096, False), (4208, 2048, 512, True), (300, 704, 256, False), (257, 512, 128, False),
+                                          (4096, 1024, 1024, False)])
+def test_gemm_fp8_256x256_kernel_is_bitwise_the_plain_fp8_kernel(M, N, K, swiglu):
+    """gemm_mfma_fp8_big_kernel (256 x 256 tiles, two-stage LDS-DMA ring) against the 128 x 128 fp8 kernel: same k order per output
+    element -> same bits; ragged edges, K of one / two tiles, SwiGLU and residual epilogues, fp32 and bf16 outputs, grouped walk."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A8 = _quant_ref(torch.randn(M, K, generator=g))[0].view(torch.uint8).cuda()
+    W8 = _quant_ref(torch.randn(N, K, generator=g) * 0.02)[0].view(torch.uint8).cuda()
+    sa = (torch.rand(M, generator=g) + 0.5).cuda()
+    sw = (torch.rand(N, generator=g) * 0.01 + 0.001).cuda()
+    res = None if swiglu else torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    flags = L.GEMM_SWIGLU16 if swiglu else 0
+    lib = G.lib()
+    try:
+        for od in (torch.bfloat16, torch.float32):
+            lib.teo_tune_set(b"gemm_fp8_big", 0); lib.teo_tune_set(b"gemm_fp8_wide", 0)
+            want = _gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od)
+            lib.teo_tune_set(b"gemm_fp8_big", 2)
+            for _ in range(2):
+                got = _gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od)
+                assert torch.equal(got, want), (od, (got.float() - want.float()).abs().max().item())
+    finally:
+        lib.teo_tune_set(b"gemm_fp8_big", 1)
+        lib.teo_tune_set(b"gemm_fp8_wide", 1)

@@ -288,7 +288,8 @@ def bench_gemm_wide_sched():
 def bench_gemm_fp8():
     """w8a8 GEMM on the scaled fp8 MFMA vs the bf16 MFMA kernel at the prefill shapes (incl. the activation quantiser)."""
     for name, M, N, K, flags in [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
-                                 ("down", 2168, 4096, 11008, 0), ("qkv_B8", 17344, 12288, 4096, 0)]:
+                                 ("down", 2168, 4096, 11008, 0), ("qkv_B8", 17344, 12288, 4096, 0), ("gateup_B8", 17344, 22016, 4096, L.GEMM_SWIGLU16),
+                                 ("down_B8", 17344, 4096, 11008, 0), ("o_B8", 17344, 4096, 4096, 0)]:
         A = torch.randn(M, K, device="cuda").to(bf)
         W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
         A8 = torch.randint(0, 120, (M, K), device="cuda", dtype=torch.uint8)
@@ -307,6 +308,10 @@ def bench_gemm_fp8():
         t8 = timeit(run8)
         same = bool(torch.equal(c0, Cc))
         lib.teo_tune_set(b"gemm_fp8_wide", 1)
+        lib.teo_tune_set(b"gemm_fp8_big", 2)
+        t8b = timeit(run8)
+        same = same and bool(torch.equal(c0, Cc))
+        lib.teo_tune_set(b"gemm_fp8_big", 1)
         ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
         L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
         tsk = timeit(lambda: L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(W8), G.p(sw), None, G.p(Cc), M, N, K, K, Nc, flags, L.TEO_BF16,
@@ -315,7 +320,7 @@ def bench_gemm_fp8():
         tq = timeit(lambda: L.check(lib.teo_quant_rows_fp8(G.p(A), None, G.p(q8), G.p(sa), M, K, K, 1e-5, G.stream()), "quant"))
         fl = 2.0 * M * N * K
         print(f"gemm_fp8 {name:8s} M={M} N={N} K={K}: bf16 {t16:8.1f} us {fl / t16 / 1e6:7.1f} TFLOP/s | fp8 128x128 {t8n:8.1f} us {fl / t8n / 1e6:7.1f} | "
-              f"fp8 wide {t8:8.1f} us {fl / t8 / 1e6:7.1f} | dispatch+ws {tsk:8.1f} us {fl / tsk / 1e6:7.1f} TFLOP/s (bit-identical {same}) | quantiser {tq:6.1f} us", flush=True)
+              f"fp8 wide {t8:8.1f} us {fl / t8 / 1e6:7.1f} | fp8 256x256 {t8b:8.1f} us {fl / t8b / 1e6:7.1f} | dispatch+ws {tsk:8.1f} us {fl / tsk / 1e6:7.1f} TFLOP/s (bit-identical {same}) | quantiser {tq:6.1f} us", flush=True)
 
 
 def bench_attn_prefill():
