@@ -591,7 +591,7 @@ static bool gemm_wide_wins(int M, int N, int K, bool forced) {
     if (K < 2 * BK) return false;
     const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256), t_plain = (long long)cdiv(M, 128) * cdiv(N, 128);
     if (forced) return true;
-    if (t_wide < 256) return false;                                  // not enough tiles to fill the chip once
+    if (t_wide < 208) return false;                                  // not enough tiles to fill the chip once (240 at M = 638, N = 12288: 57 vs 79 us)
     // cost in rounds of the plain kernel; its ragged last round runs faster when it leaves one workgroup per CU (x 0.66, measured)
     const long long rem = t_plain % 512;
     const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
