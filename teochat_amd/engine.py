@@ -312,6 +312,12 @@ class TeoEngine:
 
         def __exit__(self, *a):
             self.ctx.__exit__(*a)
+            # Drain the engine stream BEFORE the cross-stream edge.  Measured (tools/chunk_probe.py): an event record + wait on
+            # another stream issued while hipGraph launches are still outstanding puts the not-yet-executed tail (up to ~88 decode
+            # steps) into a mode where every step takes 2.93 instead of 2.71 ms (+1.1 us per kernel); with the stream drained
+            # first every step runs at 2.71 ms, whatever the chunk size.  The host needs the results of a phase anyway.
+            if a[0] is None:
+                self.eng.stream.synchronize()
             self.cur.wait_stream(self.eng.stream)
             return False
 

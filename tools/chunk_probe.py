@@ -9,36 +9,59 @@ dev = "cuda:0"
 tok, model, _, _ = load_pretrained_model("synthetic:teochat-7b", None, "synthetic:teochat-7b", device=dev, dtype=torch.bfloat16, max_seq=2560)
 eng = model.engine
 frames, ids = synthetic_inputs(8, 128, model.config.vocab_size, seed=0, device=dev, dtype=torch.bfloat16)
-for chunk in (256, 16, 16, 32, 64):
+for chunk in (256, 256, 16, 16, 64, 256, 128, 255):
     torch.cuda.synchronize(); t = time.perf_counter()
     model.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=256, eos_token_id=None, chunk=chunk)
     torch.cuda.synchronize()
     print(f"generate chunk={chunk}: {(time.perf_counter() - t) * 1e3:.1f} ms", flush=True)
-# pieces
-model.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=2, eos_token_id=None)
+import time as _t
+from teochat_amd import _lib as L
 sync = torch.cuda.synchronize
-for rep in range(3):
-    sync(); t0 = time.perf_counter()
-    eng.decode_steps(16, use_graph=True)
-    t1 = time.perf_counter()
-    sync(); t2 = time.perf_counter()
-    got = eng.generated()
-    t3 = time.perf_counter()
-    lst = got.tolist()
-    t4 = time.perf_counter()
-    print(f"decode_steps(16) enqueue {1e3 * (t1 - t0):.2f} ms, wait {1e3 * (t2 - t1):.2f} ms, generated() {1e3 * (t3 - t2):.3f} ms, tolist {1e3 * (t4 - t3):.3f} ms", flush=True)
-for n in (1, 1, 2, 4, 8, 32):
-    sync(); t0 = time.perf_counter()
-    eng.decode_steps(n, use_graph=True)
-    t1 = time.perf_counter()
-    sync(); t2 = time.perf_counter()
-    print(f"decode_steps({n}) from idle: enqueue {1e3 * (t1 - t0):.2f} ms, total {1e3 * (t2 - t0):.2f} ms = {1e3 * (t2 - t0) / n:.3f} ms/step", flush=True)
-# per-step device timestamps inside one chunk
-evs = [torch.cuda.Event(enable_timing=True) for _ in range(17)]
-sync()
-evs[0].record()
-for i in range(16):
-    eng.decode_steps(1, use_graph=True)
-    evs[i + 1].record()
-sync()
-print("per-step device ms inside a chunk from idle:", [round(evs[i].elapsed_time(evs[i + 1]), 3) for i in range(16)], flush=True)
+def prep():
+    model.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=2, eos_token_id=None)
+    sync()
+def burst(label, groups=16, per=16, between=None, before=None):
+    prep()
+    if before:
+        before()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
+    ph = eng.phase(); st = ph.__enter__()
+    evs[0].record()
+    for i in range(groups):
+        L.check(eng.lib.teo_graph_launch(eng._graph, per, st), "launch")
+        evs[i + 1].record()
+        if between == "phase":
+            ph.__exit__(None, None, None); ph = eng.phase(); st = ph.__enter__()
+        elif between == "throttle" and i >= 2:
+            evs[i - 1].synchronize()                    # at most ~3 groups outstanding, the GPU never idles
+        elif between == "sync":
+            sync()
+        elif between == "streamsync":
+            torch.cuda.current_stream().synchronize()
+        elif between == "eventsync":
+            evs[i + 1].synchronize()
+        elif between == "sync+phase":
+            sync(); ph.__exit__(None, None, None); ph = eng.phase(); st = ph.__enter__()
+        elif between == "streamsync_every4" and i % 4 == 3:
+            torch.cuda.current_stream().synchronize()
+    if "stream-sync before leaving" in label:
+        torch.cuda.current_stream().synchronize()
+    ph.__exit__(None, None, None)
+    sync()
+    print(label, [round(evs[i].elapsed_time(evs[i + 1]) / per, 3) for i in range(groups)], flush=True)
+
+def regraph():
+    eng._drop_graph()
+    eng.decode_steps(1)
+    sync()
+for n in (256, 128, 32):
+    prep()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with eng.phase() as st:
+        e0.record()
+        L.check(eng.lib.teo_graph_launch(eng._graph, n, st), "launch")
+        e1.record()
+        torch.cuda.current_stream().synchronize()
+    sync()
+    print(f"Y1 one call of {n} launches, stream-sync before leaving the phase:", round(e0.elapsed_time(e1) / n, 3), "ms/step", flush=True)
+burst("Y2 one burst 16x16, stream-sync before leaving the phase", between=None)
