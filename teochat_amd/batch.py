@@ -194,6 +194,7 @@ class BatchDecoder:
                             "teo_llama_decode_batch_graph_create")
                     self._graph, self._graph_ws = g, ws.data_ptr()
                 L.check(self.lib.teo_graph_launch(self._graph, n, st), "teo_graph_launch")
+                eng.stream.synchronize()        # drain the replays before anything is queued behind them (engine.py _Phase.__exit__)
             else:
                 for _ in range(n):
                     L.check(self.lib.teo_llama_decode_batch_step(C.byref(self.desc), C.byref(self.state), _p(ws), ws.numel(),

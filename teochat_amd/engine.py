@@ -111,6 +111,7 @@ class TeoEngine:
             raise ValueError("weight_format='fp8' needs dtype=torch.bfloat16")
         self._keep = []                           # host pointer arrays referenced by the descriptors
         self._ws = {}
+        self._phase_depth = 0
         self._graph = None
         self._load_vit(state_dict)
         self._load_projector(state_dict)
@@ -303,6 +304,10 @@ class TeoEngine:
             self.eng = eng
 
         def __enter__(self):
+            self.nested = self.eng._phase_depth > 0          # inside an outer phase (generate()): already on the engine stream, no edges
+            self.eng._phase_depth += 1
+            if self.nested:
+                return C.c_void_p(self.eng.stream.cuda_stream)
             cur = torch.cuda.current_stream(self.eng.device)
             self.cur = cur
             self.eng.stream.wait_stream(cur)
@@ -311,6 +316,9 @@ class TeoEngine:
             return C.c_void_p(self.eng.stream.cuda_stream)
 
         def __exit__(self, *a):
+            self.eng._phase_depth -= 1
+            if self.nested:
+                return False
             self.ctx.__exit__(*a)
             # Drain the engine stream BEFORE the cross-stream edge.  Measured (tools/chunk_probe.py): an event record + wait on
             # another stream issued while hipGraph launches are still outstanding puts the not-yet-executed tail (up to ~88 decode
@@ -451,6 +459,9 @@ class TeoEngine:
                             "teo_llama_decode_graph_create")
                     self._graph, self._graph_ws = g, ws.data_ptr()
                 L.check(self.lib.teo_graph_launch(self._graph, n, st), "teo_graph_launch")
+                # drain before anything else is queued behind the replays (an event record, a D2H copy of the token buffer):
+                # replays still outstanding when such a command is enqueued run 8 % slower (see _Phase.__exit__)
+                self.stream.synchronize()
             else:
                 for _ in range(n):
                     L.check(self.lib.teo_llama_decode_step(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws),

@@ -370,9 +370,15 @@ class LlavaLlamaForCausalLM:
 
     # --- H16
     @torch.no_grad()
-    def generate(self, input_ids=None, images=None, do_sample=None, temperature=None, top_k=None, top_p=None,
-                 max_new_tokens=20, use_cache=True, stopping_criteria=None, eos_token_id="config", attention_mask=None,
-                 generator=None, chunk=16, **kwargs):
+    def generate(self, *args, **kwargs):
+        # one engine phase around the whole call: tower, projector, splice, prefill and the decode chunks run back to back on the
+        # engine stream with a single hand-over to the caller's stream at the end (no stream edges between the pieces)
+        with self.engine.phase():
+            return self._generate(*args, **kwargs)
+
+    def _generate(self, input_ids=None, images=None, do_sample=None, temperature=None, top_k=None, top_p=None,
+                  max_new_tokens=20, use_cache=True, stopping_criteria=None, eos_token_id="config", attention_mask=None,
+                  generator=None, chunk=16, **kwargs):
         """Greedy or sampled (temperature / top-k, device sampler) decoding of ONE sequence; the loop is device-resident
         and replayed from a hipGraph.
 
@@ -475,8 +481,12 @@ class LlavaLlamaForCausalLM:
         return cur
 
     @torch.no_grad()
-    def generate_batch(self, input_ids_list, images_list=None, do_sample=False, temperature=None, top_k=None, top_p=None,
-                       max_new_tokens=20, stopping_criteria=None, eos_token_id="config", generator=None, chunk=16):
+    def generate_batch(self, *args, **kwargs):
+        with self.engine.phase():
+            return self._generate_batch(*args, **kwargs)
+
+    def _generate_batch(self, input_ids_list, images_list=None, do_sample=False, temperature=None, top_k=None, top_p=None,
+                        max_new_tokens=20, stopping_criteria=None, eos_token_id="config", generator=None, chunk=16):
         """Decode B conversations together (B <= 16).  input_ids_list: B 1-D id tensors (with -200 sentinels);
         images_list: per conversation what generate() takes as `images`.  stopping_criteria: None, or one list of
         criteria per conversation.  Returns B 1-D tensors prompt + generated, each cut at its own EOS / stop keyword.
