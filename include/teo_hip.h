@@ -109,6 +109,12 @@ int teo_quant_rows_fp8(const void* d_x, const void* d_norm_w, void* d_q, float* 
 /* Patch extraction for the CLIP patch-embedding conv (kernel = stride = patch, no bias):
  * cols[t*g*g + py*g + px, c*P*P + ky*P + kx] = pixels[t, c, py*P+ky, px*P+kx], zero padded to ldcols.
  * Replaces the im2col half of CLIPVisionEmbeddings.patch_embedding (used at modeling_image.py:602,645). */
+/* Fused form of the same convolution (bf16): out[t*g*g + py*g + px, n] = sum_k W[n, k] * pixel(t, k), k = c*P*P + ky*P + kx, the
+ * patch pixels gathered straight into the LDS operand image of the MFMA tile (no im2col matrix).  W [dim, ldw] with the columns
+ * k >= channels*P*P zero (ldw % 64 == 0).  Bit-identical to teo_im2col_patches + teo_gemm.  Replaces
+ * CLIPVisionEmbeddings.patch_embedding (modeling_image.py:602,645). */
+int teo_patch_embed(const void* d_pixels, const void* d_weight, void* d_out, int T, int channels, int image, int patch, int ldw,
+                    int dim, int dtype, teo_stream_t stream);
 int teo_im2col_patches(const void* d_pixels, void* d_cols, int T, int channels, int image, int patch, int ldcols,
                        int dtype, teo_stream_t stream);
 

@@ -103,6 +103,7 @@ _SIGS = {
     "teo_gemm_workspace_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "teo_gemm_ws": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_uint, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "teo_im2col_patches": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "teo_patch_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "teo_vit_embed_ln": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "teo_attention": (C.c_int, [C.POINTER(AttnArgs), C.c_int, C.c_void_p]),
     "teo_vit_value_transpose": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),

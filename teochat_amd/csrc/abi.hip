@@ -147,6 +147,20 @@ int teo_im2col_patches(const void* px, void* cols, int T, int channels, int imag
     return im2col_patches(px, cols, T, channels, image, patch, ldcols, dtype, ST(s));
 }
 
+int teo_patch_embed(const void* px, const void* W, void* out, int T, int channels, int image, int patch, int ldw, int dim, int dtype,
+                    teo_stream_t s) {
+    ENTER();
+    NEED_DT(dtype);
+    TEO_CHECK_ARG(T >= 0 && patch > 0 && image > 0 && channels > 0 && dim > 0, "teo_patch_embed: bad sizes");
+    if (T == 0) return TEO_OK;
+    NEED(px, "pixels"); NEED(W, "weight"); NEED(out, "out");
+    if (!patch_embed_ok(channels, image, patch, ldw, dim, dtype, px, W, out)) {
+        set_error("teo_patch_embed: needs bf16, image %% patch == 0, ldw %% 64 == 0 and >= channels * patch^2, dim %% 4 == 0, 16-byte aligned weight");
+        return TEO_ERR_UNSUPPORTED;
+    }
+    return patch_embed(px, W, out, T, channels, image, patch, ldw, dim, ST(s));
+}
+
 int teo_vit_embed_ln(const void* patch, const void* cls, const void* pos, const void* w, const void* b, void* out, int T,
                      int n_patches, int dim, float eps, int dtype, teo_stream_t s) {
     ENTER();

@@ -63,6 +63,8 @@ int cross_entropy(const float* logits, long long ld, const long long* labels, fl
 int gemv_tune_set(const char* key, int value);
 int gemm_wide_tune_set(const char* key, int value);
 int gemm_big_tune_set(const char* key, int value);
+bool patch_embed_ok(int C, int img, int P, int ldw, int D, int dtype, const void* px, const void* W, const void* out);
+int patch_embed(const void* px, const void* W, void* out, int T, int C, int img, int P, int ldw, int D, hipStream_t st);
 bool gemm_big_hybrid_fits(int M, int N, int K);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);

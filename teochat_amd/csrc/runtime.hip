@@ -54,6 +54,7 @@ static VitWs vit_carve(const teo_vit_desc* d, int T, void* ws, size_t cap) {
     return w;
 }
 
+static int g_patch_fused = 1;   // tower patch embedding: fused gather + MFMA kernel (0: im2col matrix + GEMM)
 size_t vit_workspace_bytes(const teo_vit_desc* d, int T) { return vit_carve(d, T, nullptr, 0).total; }
 
 int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features, void* ws, size_t ws_bytes,
@@ -68,8 +69,13 @@ int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features,
     const int g = d->image / d->patch, NP = g * g, N = NP + 1, D = d->hidden, H = d->heads, hd = D / H;
     const int rows = T * N;
     TEO_TRY(gemm_sk_workspace_init(w.sk, st));
-    TEO_TRY(im2col_patches(pixels, w.cols, T, d->channels, d->image, d->patch, d->k_pad, dt, st));
-    TEO_TRY(gemm(w.cols, d->patch_w, nullptr, nullptr, w.patch, T * NP, D, d->k_pad, d->k_pad, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
+    if (g_patch_fused && patch_embed_ok(d->channels, d->image, d->patch, d->k_pad, D, dt, pixels, d->patch_w, w.patch)) {
+        // patch pixels gathered straight into the MFMA tile's LDS image (patch_embed.hip): no im2col matrix in HBM
+        TEO_TRY(patch_embed(pixels, d->patch_w, w.patch, T, d->channels, d->image, d->patch, d->k_pad, D, st));
+    } else {
+        TEO_TRY(im2col_patches(pixels, w.cols, T, d->channels, d->image, d->patch, d->k_pad, dt, st));
+        TEO_TRY(gemm(w.cols, d->patch_w, nullptr, nullptr, w.patch, T * NP, D, d->k_pad, d->k_pad, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
+    }
     TEO_TRY(vit_embed_ln(w.patch, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, w.h, T, NP, D, d->eps, dt, st));
     for (int l = 0; l < d->layers_run; ++l) {
         TEO_TRY(layernorm(w.h, d->ln1_w[l], d->ln1_b[l], w.ln, rows, D, d->eps, dt, st));
@@ -166,6 +172,7 @@ static PrefillWs prefill_carve(const teo_llama_desc* d, int S, void* ws, size_t 
 static int g_prefill_fp8 = 0;
 int runtime_tune_set(const char* key, int value) {
     if (!strcmp(key, "prefill_fp8")) { g_prefill_fp8 = value != 0; return 0; }
+    if (!strcmp(key, "vit_patch_fused")) { g_patch_fused = value != 0; return 0; }
     return -1;
 }
 static bool prefill_uses_fp8(const teo_llama_desc* d) {

@@ -1206,3 +1206,29 @@ def test_gemm_fp8_256x256_kernel_is_bitwise_the_plain_fp8_kernel(M, N, K, swiglu
     finally:
         lib.teo_tune_set(b"gemm_fp8_big", 1)
         lib.teo_tune_set(b"gemm_fp8_wide", 1)
+
+
+@pytest.mark.parametrize("T,img,P,D", [(2, 224, 14, 1024), (1, 56, 14, 192), (3, 64, 16, 260)])
+def test_patch_embed_fused_equals_im2col_plus_gemm_through_the_abi(T, img, P, D):
+    """teo_patch_embed against teo_im2col_patches + teo_gemm on the same padded weight: bit-identical (same k order and MFMA chain);
+    P = 14 (rows of 14 pixels never line up with the 8-element chunks), P = 16, ragged output width, several tiles of patches."""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(T + img + D)
+    Cc = 3
+    KV = Cc * P * P
+    ld = (KV + 63) // 64 * 64
+    px = torch.randn(T, Cc, img, img, generator=g).to(bf).cuda()
+    W = torch.zeros(D, ld, dtype=bf)
+    W[:, :KV] = (torch.randn(D, KV, generator=g) * 0.05).to(bf)
+    W = W.cuda()
+    npatch = (img // P) ** 2
+    cols = torch.empty(T * npatch, ld, dtype=bf, device="cuda")
+    lib = G.lib()
+    L.check(lib.teo_im2col_patches(G.p(px), G.p(cols), T, Cc, img, P, ld, L.TEO_BF16, G.stream()), "im2col")
+    want = G.gemm(cols, W)
+    got = torch.full((T * npatch, D), float("nan"), dtype=bf, device="cuda")
+    L.check(lib.teo_patch_embed(G.p(px), G.p(W), G.p(got), T, Cc, img, P, ld, D, L.TEO_BF16, G.stream()), "patch_embed")
+    assert torch.equal(got, want)
+    # and the definition: the convolution with kernel = stride = P
+    ref = torch.nn.functional.conv2d(px.float().cpu(), W[:, :KV].float().cpu().view(D, Cc, P, P), stride=P).flatten(2).transpose(1, 2).reshape(T * npatch, D)
+    close_bf16(got, G.bf16_round(ref), ulps=1.0)
