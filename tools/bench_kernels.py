@@ -261,6 +261,28 @@ def bench_gemm_big():
               f"hybrid {t_h:8.1f} us {fl / t_h / 1e6:7.1f} ({'=' if same_h else 'DIFF'}) | auto+ws {t_auto_ws:8.1f} | auto {min(res[3]):8.1f} us | no big {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | bit-identical: {bool(torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]))}", flush=True)
 
 
+def bench_gemm_cold():
+    """the prefill GEMMs with the weight matrix resident in the Infinity Cache (one W repeated) vs cold (8 matrices in rotation, as in
+    the real layer loop where every layer's weights come from HBM once)."""
+    for name, M, N, K, flags in [("qkv", 2168, 12288, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("o", 2168, 4096, 4096, 0),
+                                 ("down", 2168, 4096, 11008, 0)]:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(8)]
+        Nc = N // 2 if flags else N
+        Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
+        ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+        L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+        cnt = [0]
+        def run(rot):
+            W = Ws[cnt[0] % 8 if rot else 0]
+            cnt[0] += 1
+            L.check(lib.teo_gemm_ws(G.p(A), G.p(W), None, None, G.p(Cc), M, N, K, K, Nc, 0, flags, L.TEO_BF16, L.TEO_BF16, G.p(ws), G.stream()), "gemm_ws")
+        warm = min(timeit(lambda: run(False)) for _ in range(3))
+        cold = min(timeit(lambda: run(True)) for _ in range(3))
+        fl = 2.0 * M * N * K
+        print(f"gemm {name:7s}: W resident {warm:7.1f} us {fl / warm / 1e6:7.1f} TFLOP/s | W cold (8 in rotation) {cold:7.1f} us {fl / cold / 1e6:7.1f} TFLOP/s", flush=True)
+
+
 def bench_gemm_wide_sched():
     """instruction-order variants of the wide kernel's K loop (gemm_wide_sched), forced wide, plain (non-stream-K) launch."""
     shapes = [("qkv", 2168, 12288, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("sq8192", 8192, 8192, 8192, 0),
@@ -376,5 +398,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_cold": bench_gemm_cold, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
