@@ -283,6 +283,35 @@ def bench_gemm_cold():
         print(f"gemm {name:7s}: W resident {warm:7.1f} us {fl / warm / 1e6:7.1f} TFLOP/s | W cold (8 in rotation) {cold:7.1f} us {fl / cold / 1e6:7.1f} TFLOP/s", flush=True)
 
 
+def bench_gemm_prefetch():
+    """cold weights (8 matrices in rotation) with the NEXT matrix touched from a side stream while the current GEMM runs: does
+    pulling W into the 256 MB Infinity Cache ahead of the GEMM recover the resident-W time?"""
+    side = torch.cuda.Stream()
+    for name, M, N, K, flags in [("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("down", 2168, 4096, 11008, 0), ("o", 2168, 4096, 4096, 0),
+                                 ("qkv", 2168, 12288, 4096, 0)]:
+        A = torch.randn(M, K, device="cuda").to(bf)
+        Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(8)]
+        Nc = N // 2 if flags else N
+        Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
+        ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+        L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+        sink = torch.zeros(1, device="cuda")
+        cnt = [0]
+        def run(prefetch):
+            i = cnt[0] % 8
+            cnt[0] += 1
+            if prefetch:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    sink.add_(Ws[(i + 1) % 8].view(torch.int16)[:, ::64].sum())      # one 2-byte read per 128-byte line
+            L.check(lib.teo_gemm_ws(G.p(A), G.p(Ws[i]), None, None, G.p(Cc), M, N, K, K, Nc, 0, flags, L.TEO_BF16, L.TEO_BF16, G.p(ws), G.stream()), "gemm_ws")
+        cold = min(timeit(lambda: run(False)) for _ in range(3))
+        pf = min(timeit(lambda: run(True)) for _ in range(3))
+        torch.cuda.synchronize()
+        fl = 2.0 * M * N * K
+        print(f"gemm {name:7s}: cold {cold:7.1f} us {fl / cold / 1e6:7.1f} TFLOP/s | cold + next W touched from a side stream {pf:7.1f} us {fl / pf / 1e6:7.1f} TFLOP/s", flush=True)
+
+
 def bench_gemm_wide_sched():
     """instruction-order variants of the wide kernel's K loop (gemm_wide_sched), forced wide, plain (non-stream-K) launch."""
     shapes = [("qkv", 2168, 12288, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("sq8192", 8192, 8192, 8192, 0),
@@ -398,5 +427,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_cold": bench_gemm_cold, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_prefetch": bench_gemm_prefetch, "gemm_cold": bench_gemm_cold, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
