@@ -1232,3 +1232,87 @@ def test_patch_embed_fused_equals_im2col_plus_gemm_through_the_abi(T, img, P, D)
     # and the definition: the convolution with kernel = stride = P
     ref = torch.nn.functional.conv2d(px.float().cpu(), W[:, :KV].float().cpu().view(D, Cc, P, P), stride=P).flatten(2).transpose(1, 2).reshape(T * npatch, D)
     close_bf16(got, G.bf16_round(ref), ulps=1.0)
+
+
+def test_gemm_dispatch_fuzz_is_bitwise_the_plain_kernel():
+    """Whatever kernel the dispatch picks (128 x 128, 128 x 256, 256 x 256, their stream-K / hybrid forms behind teo_gemm_ws) for a
+    shape, the bits are those of the 128 x 128 one-workgroup-per-tile kernel: 40 random shapes incl. ragged edges, SwiGLU, residual in
+    place, fp32 output, with and without a workspace."""
+    import random
+    rnd_ = random.Random(1234)
+    bf = torch.bfloat16
+    lib = G.lib()
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    shapes = [(2168, 12288, 4096), (4208, 22016, 1024), (638, 12288, 512), (2168, 4096, 2048), (17344, 4096, 256), (300, 256, 128)]
+    while len(shapes) < 40:
+        M = rnd_.choice([1, 7, 129, 257, 638, 1000, 2056, 2168, 3000, 4208, 6000])
+        N = rnd_.choice([4, 36, 256, 260, 1024, 3072, 4096, 8192, 12288, 22016]) + rnd_.choice([0, 0, 4, 32])
+        K = 64 * rnd_.choice([1, 2, 3, 8, 16, 33, 64])
+        if M * N * K > 3.2e11:
+            continue
+        shapes.append((M, N, K))
+    for i, (M, N, K) in enumerate(shapes):
+        g = torch.Generator().manual_seed(i)
+        A = torch.randn(M, K, generator=g).to(bf).cuda()
+        W = (torch.randn(N, K, generator=g) * 0.05).to(bf).cuda()
+        swiglu = N % 32 == 0 and i % 3 == 0
+        flags = L.GEMM_SWIGLU16 if swiglu else 0
+        Nc = N // 2 if swiglu else N
+        res = None if swiglu or i % 2 else torch.randn(M, Nc, generator=g).to(bf).cuda()
+        od = torch.float32 if i % 5 == 4 else bf
+        try:
+            for k_, v_ in ((b"gemm_big", 0), (b"gemm_wide", 0), (b"gemm_sk", 0)):
+                lib.teo_tune_set(k_, v_)
+            want = G.gemm(A, W, res=res, flags=flags, out_dtype=od)
+        finally:
+            for k_ in (b"gemm_big", b"gemm_wide", b"gemm_sk"):
+                lib.teo_tune_set(k_, 1)
+        got = G.gemm(A, W, res=res, flags=flags, out_dtype=od)
+        assert torch.equal(got, want), ("teo_gemm", M, N, K, swiglu)
+        got = _gemm_ws(A, W, ws, res=res, flags=flags, out_dtype=od)
+        assert torch.equal(got, want), ("teo_gemm_ws", M, N, K, swiglu)
+        if res is not None and od == bf:                    # residual in place (C == residual), as the prefill loop calls it
+            buf = res.clone()
+            L.check(lib.teo_gemm_ws(G.p(A), G.p(W), None, G.p(buf), G.p(buf), M, N, K, K, Nc, L.ACT_NONE, flags, L.TEO_BF16, L.TEO_BF16,
+                                    G.p(ws), G.stream()), "gemm_ws in place")
+            assert torch.equal(buf, want), ("in place", M, N, K)
+
+
+def test_gemm_fp8_dispatch_fuzz_is_bitwise_the_plain_fp8_kernel():
+    """Same property for the fp8 family (128 x 128, 128 x 256, 256 x 256, stream-K form): 24 random shapes, with and without a
+    workspace, against the 128 x 128 fp8 kernel."""
+    import random
+    rnd_ = random.Random(99)
+    lib = G.lib()
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    shapes = [(2168, 12288, 4096), (2168, 4096, 4096), (4208, 22016, 512), (17344, 4096, 256)]
+    while len(shapes) < 24:
+        M = rnd_.choice([1, 33, 257, 638, 2056, 2168, 4208])
+        N = rnd_.choice([32, 256, 1024, 4096, 12288, 22016]) + rnd_.choice([0, 0, 32])
+        K = 128 * rnd_.choice([1, 2, 3, 8, 16, 32])
+        if M * N * K > 2.5e11:
+            continue
+        shapes.append((M, N, K))
+    for i, (M, N, K) in enumerate(shapes):
+        g = torch.Generator().manual_seed(1000 + i)
+        A8 = _quant_ref(torch.randn(M, K, generator=g))[0].view(torch.uint8).cuda()
+        W8 = _quant_ref(torch.randn(N, K, generator=g) * 0.02)[0].view(torch.uint8).cuda()
+        sa = (torch.rand(M, generator=g) + 0.5).cuda()
+        sw = (torch.rand(N, generator=g) * 0.01 + 0.001).cuda()
+        swiglu = i % 3 == 0
+        flags = L.GEMM_SWIGLU16 if swiglu else 0
+        Nc = N // 2 if swiglu else N
+        res = None if swiglu or i % 2 else torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+        od = torch.float32 if i % 5 == 4 else torch.bfloat16
+        try:
+            lib.teo_tune_set(b"gemm_fp8_big", 0); lib.teo_tune_set(b"gemm_fp8_wide", 0)
+            want = _gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od)
+        finally:
+            lib.teo_tune_set(b"gemm_fp8_big", 1); lib.teo_tune_set(b"gemm_fp8_wide", 1)
+        assert torch.equal(_gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od), want), ("teo_gemm_fp8", M, N, K, swiglu)
+        got = torch.full((M, Nc), float("nan"), dtype=od, device="cuda")
+        L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(W8), G.p(sw), G.p(res), G.p(got), M, N, K, K, Nc, flags, G.DT[od], G.p(ws),
+                                    G.stream()), "gemm_fp8_ws")
+        assert torch.equal(got, want), ("teo_gemm_fp8_ws", M, N, K, swiglu)
