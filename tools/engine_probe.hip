@@ -80,9 +80,19 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
                     const int slot = f % NSLOT;
                     const int need = (f / NSLOT) * FILL_PIECES;      // all earlier uses of the slot fully consumed
                     int spins = 0;
-                    while (P.mode < 2 && __hip_atomic_load(done + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1 << 20)) { fail(P.err, 1, f, done[slot], need); return; }
+                    if (P.mode < 2 && __hip_atomic_load(done + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                        // about to wait for the consumers: first publish everything of ours that is in flight (they may be waiting for it)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) {
+                            if (last3 >= 0) ready[last3 % NSLOT] = last3 + 1;
+                            if (last2 >= 0) ready[last2 % NSLOT] = last2 + 1;
+                            if (last1 >= 0) ready[last1 % NSLOT] = last1 + 1;
+                        }
+                        last1 = last2 = last3 = -1;
+                        while (__hip_atomic_load(done + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1 << 20)) { fail(P.err, 1, f, done[slot], need); return; }
+                        }
                     }
                     const int valid = min(FILL_PIECES, npieces - i * FILL_PIECES);
 #pragma unroll
