@@ -19,7 +19,7 @@ constexpr int NOP_MAX = 8;
 #endif
 constexpr int FILL_PIECES = PROBE_FILL_PIECES;          // 1-KiB pieces per fill (build with -DPROBE_FILL_PIECES=8 for 8 KB fills)
 constexpr int SLOT_BYTES = FILL_PIECES * 1024;
-constexpr int NSLOT = 114688 / SLOT_BYTES;               // 112 KB ring: 7 x 16 KB or 14 x 8 KB
+constexpr int NSLOT = 131072 / SLOT_BYTES;               // 128 KB ring: 8 x 16 KB or 16 x 8 KB
 constexpr int XIMG_BYTES = 24576;        // bf16 image of x, K <= 12288
 
 struct Op {
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
     if (wid < NLOAD) {
         // ---------------------------------------------------------------- loader
         int f = 0;                                                 // global fill index of this CU
+        int lwait = 0, lstalls = 0;
         int last1 = -1, last2 = -1, last3 = -1;                    // this wave's most recent fills (not yet published)
         for (int l = 0; l < P.layers; ++l) {
             for (int o = 0; o < P.nop; ++o) {
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
                             __builtin_amdgcn_s_sleep(1);
                             if (++spins > (1 << 20)) { fail(P.err, 1, f, done[slot], need); return; }
                         }
+                        lwait += spins; ++lstalls;
                     }
                     const int valid = min(FILL_PIECES, npieces - i * FILL_PIECES);
 #pragma unroll
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
                     // fills are retired in order: with this one issued, fill f-2 has landed
                     // this wave's fills are retired in order: with this one issued, its fill two turns back has landed
                     if (FILL_PIECES == 16) {
-                        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // two own fills of 16 loads may fly: the one before them has landed
-                        if (last2 >= 0 && lane == 0) ready[last2 % NSLOT] = last2 + 1;
-                        last2 = last1; last1 = f;
+                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // one own fill of 16 loads may fly behind this one: the one before has landed
+                        if (last1 >= 0 && lane == 0) ready[last1 % NSLOT] = last1 + 1;
+                        last1 = f;
                     } else {
                         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // three own fills of 8 loads may fly
                         if (last3 >= 0 && lane == 0) ready[last3 % NSLOT] = last3 + 1;
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
             if (last3 >= 0) ready[last3 % NSLOT] = last3 + 1;
             if (last2 >= 0) ready[last2 % NSLOT] = last2 + 1;
             if (last1 >= 0) ready[last1 % NSLOT] = last1 + 1;
+            if (cu == 0 && wid == 0) { P.err[4] = lwait; P.err[5] = lstalls; P.err[6] = f; }
         }
         return;
     }
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
     if (P.mode >= 2) return;                                       // modes 2 / 3: the loader alone, free-running over the ring
     const int cw = wid - NLOAD;
     int fbase = 0;                                                 // first fill index of the current op
+    int cwait = 0, cfills = 0;
     for (int l = 0; l < P.layers; ++l) {
         for (int o = 0; o < P.nop; ++o) {
             const Op op = P.op[o];
@@ -198,6 +202,7 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
                             __builtin_amdgcn_s_sleep(1);
                             if (++spins > (1 << 22)) { fail(P.err, 4, fill, ready[slot], cu * 8 + cw); return; }
                         }
+                        cwait += spins; ++cfills;
                     }
                     ++cur_cnt;
                     if (P.mode != 1) {
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(512) void engine_probe_kernel(EParams P) {
             fbase += nfill;
         }
     }
+    if (cu == 0 && cw == 0 && lane == 0) { P.err[7] = cwait; P.err[8] = cfills; }
 }
 
 extern "C" int engine_probe_run(const EParams* p, int blocks, void* stream) {

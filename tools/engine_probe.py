@@ -36,7 +36,7 @@ for i, (name, N, K) in enumerate(shapes):
 P.nop, P.layers = len(shapes), layers
 vecs = [torch.zeros(16384, dtype=torch.int64, device="cuda") for _ in range(2)]
 P.vec[0], P.vec[1] = vecs[0].data_ptr(), vecs[1].data_ptr()
-err = torch.zeros(4, dtype=torch.int32, device="cuda")
+err = torch.zeros(16, dtype=torch.int32, device="cuda")
 P.err = err.data_ptr()
 st = torch.cuda.current_stream().cuda_stream
 print(f"layer bytes {total / 1e6:.1f} MB x {layers} layers; ops {[s[0] for s in shapes]}", flush=True)
