@@ -247,7 +247,12 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
 
 static int g_big_group = 0;      // N panels per tile group (0: from the tile grid)
 static int g_big_hybrid = 1;     // data-parallel rounds + stream-K remainder when a workspace is given (1: if it fits MALL, 2: always)
-bool gemm_big_hybrid_fits(int M, int N, int K) { return ((long long)M + N) * K * 2 <= (160ll << 20); }
+// ... or there are at most 1.5 tiles per workgroup (a pure stream-K grid whose workgroups mostly stay on one tile: down at M = 4208,
+// 272 tiles, 183 MB: 311 us against 421 us for three ragged rounds of 128 x 256 tiles)
+bool gemm_big_hybrid_fits(int M, int N, int K) {
+    const long long T = (long long)((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
+    return ((long long)M + N) * K * 2 <= (160ll << 20) || T <= 384;
+}
 int gemm_big_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_big_group") && value >= 0) { g_big_group = value; return 0; }
     if (!strcmp(key, "gemm_big_hybrid")) { g_big_hybrid = value; return 0; }
