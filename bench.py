@@ -238,6 +238,25 @@ def cpu_baseline(T, n_text, n_out, budget_s=240.0, max_layers=None):
     return out
 
 
+def spawn_ranks(args):
+    """One child `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` (one rank per GPU, RCCL); returns its
+    exit code.  Fails loudly when the node has fewer GPUs than ranks (unless --same-gpu, the one-GPU plumbing test)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.same_gpu:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node shows {n_dev} GPU(s); refusing to report a line for fewer ranks\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,11 +276,15 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to teo_tune_set (perf knobs only)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here.  This parent has not touched the GPU (importing
+        # torch and counting devices does not initialise HIP), it never execs, and it exits with the launcher's code.
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -274,6 +297,8 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"{dist.get_world_size()} ranks joined the process group, --gpus says {args.gpus}")
     from teochat_amd import _lib as L
     from teochat_amd.builder import load_pretrained_model
     T, n_text, n_out = args.frames, args.prompt, args.new
@@ -294,11 +319,37 @@ def main():
     frames, ids = synthetic_inputs(T, n_text, model.config.vocab_size, seed=100 * rank if not args.shard_frames else 0,
                                    device=device, dtype=dtype)
 
+    # The library's own RCCL communicator (teo_ctx_create over all ranks): the data path of the frame-sharded tower, and for the
+    # data-parallel replicas a once-per-run proof that N ranks really hold one communicator over xGMI (`rccl_ranks` below) plus
+    # one checked teo_allgather_visual of a C4-sized block (2 frames x 256 x 1024 bf16 = 1 MiB per rank), outside the timed region.
+    comm, rccl_info = None, None
+    if world > 1 and args.dist_backend == "nccl":
+        from teochat_amd.parallel import TeoComm
+        try:
+            comm = TeoComm(rank, world, local_rank)
+            r_, w_, cu_, hbm_ = comm.info()
+            send = torch.full((512, 1024), float(rank + 1), dtype=dtype, device=device)
+            recv = torch.zeros(world * 512, 1024, dtype=dtype, device=device)
+            comm.all_gather_rows(send, recv); torch.cuda.synchronize()
+            t_ag = time.perf_counter()
+            for _ in range(20):
+                comm.all_gather_rows(send, recv)
+            torch.cuda.synchronize()
+            t_ag = (time.perf_counter() - t_ag) / 20
+            want = torch.arange(1, world + 1, dtype=torch.float32, device=device).repeat_interleave(512)
+            ok = bool((recv.float().amax(dim=1) == want).all()) and bool((recv.float().amin(dim=1) == want).all())
+            rccl_info = {"rccl_ranks": w_, "cu_count": cu_, "hbm_bytes": hbm_, "allgather_1MiB_per_rank_us": round(t_ag * 1e6, 1),
+                         "allgather_checked": ok}
+            if not ok:
+                raise RuntimeError("teo_allgather_visual returned wrong rows")
+        except Exception as e:  # noqa: BLE001 -- the replicas' throughput line does not depend on the collective; report, do not hide
+            if args.shard_frames:
+                raise
+            rccl_info = {"rccl_ranks": None, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+            comm = None
     if args.shard_frames:
         # C4: every rank encodes its block of frames; with the nccl backend the gather is the library's RCCL all-gather
         # (teo_allgather_visual, no torch collective on the data path); gloo only for the one-GPU plumbing test
-        from teochat_amd.parallel import TeoComm
-        comm = TeoComm(rank, world, local_rank) if (args.dist_backend == "nccl") else None
         model.get_model().image_tower.shard_frames(comm)
 
     B = args.batch
@@ -426,7 +477,7 @@ def main():
 
     result = {
         "metric": "end-to-end tokens/sec (prefill+decode), T=8 frames, LLaMA-2-7B",
-        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.weights == "bf16" else ("bf16 activations / fp8-e4m3 weights (decode: fp8 weight stream; prefill: "
                                                        + ("w8a8 on the fp8 MFMA)" if prefill_fp8 else "bf16 MFMA on the dequantised weights)")), "data": "synthetic",
@@ -441,6 +492,9 @@ def main():
         "phases": phases,
         "roofline": roofline,
     }
+    result["rccl_ranks"] = rccl_info["rccl_ranks"] if rccl_info else (1 if world == 1 else None)
+    if rccl_info:
+        result["rccl"] = rccl_info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(T, n_text, n_out)
     elif rank == 0:

@@ -339,6 +339,10 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     del sd
     image_processor = TeoImageProcessor(size=cfg.vision_config.image_size, engine=engine)     # uint8 frames -> device kernel
     model = LlavaLlamaForCausalLM(cfg, engine, image_processor)
-    load_generation_config(model, model_path)
+    # GenerationMixin's fallback knobs belong to the model object, which the LoRA / projector branches build with
+    # from_pretrained(model_base, ...) (builder.py:51,83): generation_config.json is read where the tokenizer is (tok_dir)
+    gen_dir = model_base if (model_base is not None and not model_path.startswith("synthetic:")) else model_path
+    if not load_generation_config(model, gen_dir) and gen_dir != model_path:
+        load_generation_config(model, model_path)
     context_len = getattr(cfg, "max_sequence_length", 2048)
     return tokenizer, model, {"image": image_processor, "video": None}, context_len

@@ -12,6 +12,9 @@
 // one device (llava_arch.py:194, modeling_image.py:641-643) are what is sharded here.
 #include <dlfcn.h>
 
+#include <cstdio>
+#include <mutex>
+
 #include "ops.h"
 
 namespace teo {
@@ -31,11 +34,9 @@ struct Rccl {
     bool ok = false;
 };
 
-static Rccl& rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+static char g_rccl_load_error[256] = "symbols missing";
+
+static void rccl_bind(Rccl& r) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {                       // the copy already mapped into the process first
         r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
@@ -43,14 +44,34 @@ static Rccl& rccl() {
     }
     if (!r.handle) r.handle = dlopen(nullptr, RTLD_NOW);            // symbols of an already loaded copy under another name
     if (r.handle && !dlsym(r.handle, "ncclAllGather")) r.handle = nullptr;
-    for (int i = 0; !r.handle && i < 4; ++i) r.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) return r;
+    if (!r.handle) {
+        // nothing mapped yet: load the system copy.  (A process that already holds an RCCL under a name this cannot see would
+        // end up with two; say so instead of doing it silently.)
+        for (int i = 0; !r.handle && i < 4; ++i) {
+            dlerror();
+            r.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+            if (!r.handle) {
+                const char* e = dlerror();
+                snprintf(g_rccl_load_error, sizeof(g_rccl_load_error), "%s", e ? e : "dlopen failed");
+            } else {
+                fprintf(stderr, "libteo_hip: no RCCL was mapped in this process; loaded %s\n", names[i]);
+            }
+        }
+    }
+    if (!r.handle) return;
     r.GetUniqueId = (int (*)(NcclId*))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(NcclComm*, int, NcclId, int))dlsym(r.handle, "ncclCommInitRank");
     r.CommDestroy = (int (*)(NcclComm))dlsym(r.handle, "ncclCommDestroy");
     r.AllGather = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(r.handle, "ncclAllGather");
     r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+    if (!r.ok) snprintf(g_rccl_load_error, sizeof(g_rccl_load_error), "symbols missing");
+}
+
+static Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_bind(r); });
     return r;
 }
 
@@ -62,7 +83,7 @@ static int rccl_fail(int rc, const char* what) {
 
 static int need_rccl(const char* who) {
     if (rccl().ok) return TEO_OK;
-    set_error("%s: librccl.so could not be loaded (%s)", who, dlerror() ? dlerror() : "symbols missing");
+    set_error("%s: librccl.so could not be loaded (%s)", who, g_rccl_load_error);
     return TEO_ERR_UNSUPPORTED;
 }
 

@@ -89,3 +89,46 @@ def eval(dataset_name, model_path, model_base, load_8bit=False, load_4bit=False,
     for key, value in metrics.items():
         print(f"\t{key}: {value}")
     return metrics
+
+
+def str_or_none(value):
+    """CLI helper of the reference (eval/eval.py:172-175): "" / "none" (any case) -> None."""
+    return None if value.strip().lower() in ("", "none") else value
+
+
+# The command line of the reference's driver (eval/eval.py:178-199; launched by scripts/eval_teochat.sh as
+# `python videollava/eval/eval.py --dataset_name ... --prompt_strategy interleave --chronological_prefix`): flag -> argparse
+# options.  Names and defaults are interface; every parsed value is a keyword of eval().
+_CLI = (
+    ("dataset_name", dict(type=str, required=True)),
+    ("model_path", dict(type=str, required=True)),
+    ("model_base", dict(type=str_or_none, default=None)),
+    ("load_8bit", dict(action="store_true")),
+    ("load_4bit", dict(action="store_true")),
+    ("cache_dir", dict(type=str, default=None)),
+    ("data_cache_dir", dict(type=str, default=None)),
+    ("out_name", dict(type=str, default=None)),
+    ("out_dir", dict(type=str, default=None)),
+    ("prompt_strategy", dict(type=str, default="interleave")),
+    ("chronological_prefix", dict(action="store_true")),
+    ("device", dict(type=str, default="cuda")),
+    ("force_rerun", dict(action="store_true")),
+    ("temperature", dict(type=float, default=0.2)),
+    ("max_new_tokens", dict(type=int, default=256)),
+)
+
+
+def cli_parser():
+    import argparse
+    ap = argparse.ArgumentParser(description="TEOChat dataset evaluation on the MI355X path (same flags as the reference's eval.py)")
+    for flag, opts in _CLI:
+        ap.add_argument("--" + flag, **opts)
+    return ap
+
+
+def main(argv=None):
+    return eval(**vars(cli_parser().parse_args(argv)))
+
+
+if __name__ == "__main__":
+    main()

@@ -413,7 +413,7 @@ class LlavaLlamaForCausalLM:
             return torch.cat([input_ids, tail], dim=1)
         eng = self.engine
         if eos_token_id == "config":
-            eos_token_id = getattr(self.config, "eos_token_id", None)
+            eos_token_id = self._config_eos()
         crits = list(stopping_criteria or [])
         if max_new_tokens <= 0:
             return input_ids
@@ -451,7 +451,14 @@ class LlavaLlamaForCausalLM:
         cands = [ids for c in crits for ids in getattr(c, "keyword_id_lists", []) if ids]
         if eos_token_id is not None:
             cands.append([int(eos_token_id)])
-        stop_ids = cands[0] if len(cands) == 1 else None
+        # the reference's default call stops on the keyword "</s>" AND on EOS (eval/inference.py:57-72), which are the same id
+        # sequence [2]: duplicates are folded so that this default arms the device-side stop
+        uniq = []
+        for ids in cands:
+            ids = [int(t) for t in ids]
+            if ids not in uniq:
+                uniq.append(ids)
+        stop_ids = uniq[0] if len(uniq) == 1 else None
         eng.decode_begin(first, stop_ids, do_sample=do_sample, temperature=temperature, top_k=k, seed=seed, draws_done=1, top_p=tp)
         remaining = max_new_tokens - 1
         while remaining > 0:
@@ -495,7 +502,7 @@ class LlavaLlamaForCausalLM:
         per step every weight matrix is streamed once for all conversations (teo_llama_decode_batch_step)."""
         B = len(input_ids_list)
         if eos_token_id == "config":
-            eos_token_id = getattr(self.config, "eos_token_id", None)
+            eos_token_id = self._config_eos()
         if max_new_tokens <= 0:
             return [ids.clone() for ids in input_ids_list]
         gc = self.generation_config
@@ -574,6 +581,16 @@ class LlavaLlamaForCausalLM:
                 remaining -= n
         return [torch.cat([input_ids_list[b].view(-1), torch.tensor(new_tokens[b], dtype=input_ids_list[b].dtype,
                                                                      device=input_ids_list[b].device)]) for b in range(B)]
+
+    def _config_eos(self):
+        """GenerationMixin semantics: generation_config.eos_token_id (generation_config.json of the checkpoint, or of model_base
+        on the LoRA / projector branches) wins; config.json's eos_token_id is what generation_config is seeded from."""
+        eos = getattr(self.generation_config, "eos_token_id", None)
+        if eos is None:
+            eos = getattr(self.config, "eos_token_id", None)
+        if isinstance(eos, (list, tuple)):
+            eos = eos[0] if eos else None
+        return eos
 
     def _finish(self, input_ids, new_tokens):
         tail = torch.tensor([new_tokens], dtype=input_ids.dtype, device=input_ids.device)

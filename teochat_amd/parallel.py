@@ -17,21 +17,32 @@ from . import _lib as L
 class TeoComm:
     """The RCCL communicator of this rank behind the C ABI (teo_ctx_create / teo_allgather_visual, include/teo_hip.h).
 
-    The 128-byte unique id is generated on rank 0 by the library and handed to the other ranks through the process
-    group's key-value store (control plane, host only); the data path is one ncclAllGather enqueued by the library on the
+    The 128-byte unique id is generated on rank 0 by the library and handed to the other ranks by an object broadcast of
+    the process group, or through a caller-owned key-value store (control plane, host only); the data path is one ncclAllGather enqueued by the library on the
     caller's HIP stream -- no torch collective."""
 
-    def __init__(self, rank, world_size, device_index, store=None, key="teo_comm_id"):
+    _serial = 0          # communicators created so far by this process (every rank creates them in the same order)
+
+    def __init__(self, rank, world_size, device_index, store=None, group=None, tag=None):
         self.lib = L.load()
         self.rank, self.world = int(rank), int(world_size)
+        TeoComm._serial += 1
         uid = (C.c_char * L.COMM_ID_BYTES)()
         if self.world > 1:
-            if store is None:
-                store = dist.distributed_c10d._get_default_store()
             if self.rank == 0:
                 L.check(self.lib.teo_comm_unique_id(uid), "teo_comm_unique_id")
-                store.set(key, bytes(uid.raw))
-            blob = store.get(key)
+            if store is not None:
+                # an explicit key-value store (e.g. a TCPStore the caller owns): one key per communicator, so a second
+                # communicator never reads the first one's id
+                key = f"teo_comm_id/{tag if tag is not None else TeoComm._serial}"
+                if self.rank == 0:
+                    store.set(key, bytes(uid.raw))
+                blob = bytes(store.get(key))
+            else:
+                # public API only: the 128 bytes travel as an object broadcast of the process group (control plane, host side)
+                box = [bytes(uid.raw) if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, group=group)
+                blob = box[0]
             uid = (C.c_char * L.COMM_ID_BYTES).from_buffer_copy(bytes(blob)[:L.COMM_ID_BYTES])
             id_ptr = C.cast(uid, C.c_void_p)
         else:
@@ -39,6 +50,12 @@ class TeoComm:
         h = C.c_void_p()
         L.check(self.lib.teo_ctx_create(self.rank, self.world, id_ptr, int(device_index), C.byref(h)), "teo_ctx_create")
         self.handle = h
+
+    def info(self):
+        """(rank, world_size, cu_count, hbm_bytes) as the library's context holds them (teo_ctx_info)."""
+        r, w, cu, hbm = C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+        L.check(self.lib.teo_ctx_info(self.handle, C.byref(r), C.byref(w), C.byref(cu), C.byref(hbm)), "teo_ctx_info")
+        return r.value, w.value, cu.value, hbm.value
 
     def all_gather_rows(self, send, recv):
         """send [rows, dim], recv [world * rows, dim], same dtype, contiguous, on this rank's GPU; runs on the current stream."""

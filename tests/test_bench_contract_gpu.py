@@ -48,3 +48,27 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]      # both ranks' tokens over the max time
     assert "dp2" in d["config"]["parallelism"]
+
+
+def test_bench_gpus2_without_a_launcher_starts_two_ranks_itself():
+    """VERDICT r02 missing #1: the driver calls `python bench.py --gpus N` with NO torchrun; bench.py must start the N ranks
+    itself (a child `torch.distributed.run`, the parent never touches the GPU) and rank 0 must report the ranks that joined."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--frames", "2", "--prompt", "32", "--new", "8", "--dist-backend", "gloo", "--same-gpu"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "dp2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    assert "rccl_ranks" in d and d["rccl_ranks"] is None        # gloo plumbing run: no RCCL communicator was built
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]

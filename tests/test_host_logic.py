@@ -197,3 +197,20 @@ def test_classification_metrics_match_reference_truth_table():
     g = TY.load_json("metrics")
     for name, case in g["cases"].items():
         assert classification_metrics(g["outputs"], **case["kwargs"]) == case["result"], name
+
+
+def test_eval_cli_has_the_reference_flags_and_defaults():
+    """scripts/eval_teochat.sh launches `eval.py --dataset_name .. --model_path .. --prompt_strategy interleave
+    --chronological_prefix ...` (eval/eval.py:178-199): same flag names, defaults and str_or_none semantics here."""
+    import inspect
+    from teochat_amd import eval as E
+    a = vars(E.cli_parser().parse_args(["--dataset_name", "fmow_high_res", "--model_path", "ckpt"]))
+    assert a == {"dataset_name": "fmow_high_res", "model_path": "ckpt", "model_base": None, "load_8bit": False, "load_4bit": False,
+                 "cache_dir": None, "data_cache_dir": None, "out_name": None, "out_dir": None, "prompt_strategy": "interleave",
+                 "chronological_prefix": False, "device": "cuda", "force_rerun": False, "temperature": 0.2, "max_new_tokens": 256}
+    b = vars(E.cli_parser().parse_args(["--dataset_name", "x", "--model_path", "y", "--model_base", "NONE", "--load_8bit",
+                                         "--chronological_prefix", "--temperature", "0.5"]))
+    assert b["model_base"] is None and b["load_8bit"] and b["chronological_prefix"] and b["temperature"] == 0.5
+    assert E.str_or_none("") is None and E.str_or_none("base") == "base"
+    params = inspect.signature(E.eval).parameters
+    assert all(k in params for k in a)               # every flag is a keyword of eval(), as eval(**vars(args)) needs
