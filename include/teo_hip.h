@@ -48,6 +48,10 @@ typedef enum {
 
 int teo_version(void);
 const char* teo_last_error(void);
+/* Diagnostics: which kernel family the most recent teo_gemm* / teo_attention call of this thread dispatched to
+ * ("gemm_simple", "gemm_mfma_128", "gemm_mfma_128_sk", "gemm_wide", "gemm_wide_sk", "gemm_big", "gemm_big_hybrid", "gemm_fp8_*",
+ * "attn_flash32", "attn_mfma", "attn_simple").  Lets the parity tests state which production kernel they checked. */
+const char* teo_last_kernel(void);
 /* Performance tuning knobs (never change results beyond fp32 contraction order): "gemv_variant" (-1 = default),
  * "gemv_nt", "gemv_max_blocks", "gemm_depth", "attn_chunk" (64/128/256 keys per decode workgroup), "rope_in_attn"
  * (decode RoPE + KV append: 0 = QKV-GEMV epilogue, 1 = inside the decode attention kernel, -1 = auto by weight format),
@@ -367,6 +371,15 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
 
 /* hipGraph form of the same step: capture once, replay per token. */
 typedef struct teo_graph teo_graph;
+/* Measurement aid: ONE decode step (plain launches, not a graph replay) in which every kernel launch carries its own start / stop
+ * events (hipExtLaunchKernel: the dispatch's execution timestamps -- kernel time only, what rocprofv3 --kernel-trace reports).
+ * ms_out[c] = summed kernel milliseconds of class c over the step, count_out[c] = launches of that class.  Same arithmetic and
+ * state changes as teo_llama_decode_step (it IS that step); synchronises the stream before returning. */
+enum { TEO_PROF_QKV = 0, TEO_PROF_ATTN = 1, TEO_PROF_ATTN_COMBINE = 2, TEO_PROF_O = 3, TEO_PROF_GATEUP = 4, TEO_PROF_DOWN = 5,
+       TEO_PROF_LM_HEAD = 6, TEO_PROF_TAIL = 7, TEO_PROF_CLASSES = 8 };
+int teo_llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace, size_t workspace_bytes,
+                                  float* ms_out /* [TEO_PROF_CLASSES] */, int* count_out /* [TEO_PROF_CLASSES] */,
+                                  teo_stream_t stream);
 int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace,
                                   size_t workspace_bytes, teo_stream_t stream, teo_graph** out);
 int teo_graph_launch(teo_graph* g, int n_times, teo_stream_t stream);
@@ -427,15 +440,6 @@ int teo_ctx_destroy(teo_ctx* ctx);
 int teo_ctx_info(const teo_ctx* ctx, int* rank, int* world_size, int* cu_count, size_t* hbm_bytes);
 int teo_allgather_visual(teo_ctx* ctx, const void* d_local, void* d_out, int rows_per_rank, int dim, int dtype,
                          teo_stream_t stream);
-
-/* Bench helper: run the decode gate/up GEMV (the dominant kernel by bytes) over n weight matrices
- * back to back between two HIP events on `stream`; returns the average milliseconds per launch. */
-int teo_time_gemv_chain(const void* d_x, const void* const* d_Ws, const float* const* d_scales, int n, const void* d_norm_w,
-                        void* d_y, int N, int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out,
-                        teo_stream_t stream);   /* d_scales != NULL: the matrices are fp8-e4m3 with per-row scales */
-/* The same for teo_gemm_skinny with MB activation rows (x [MB, K] bf16, y [MB, N or N/2] bf16). */
-int teo_time_skinny_chain(const void* d_x, const void* const* d_Ws, const float* const* d_scales, int n, const void* d_norm_w,
-                          void* d_y, int MB, int N, int K, unsigned flags, int reps, float* avg_ms_out, teo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -265,7 +265,9 @@ def attention_core(q, k, v, visible, scale, R, mode="exact"):
                       eager attention when R is the identity; also what the generic HIP kernel does).
     mode "flash64"  : arithmetic of the MFMA flash kernel (csrc/attention.hip attn_mfma_kernel): 64-key tiles from key
                       0, running max, P = exp2(s*scale*log2e - m_run) rounded by R per tile, fp32 rescale.
-    mode "split128" : arithmetic of the decode kernel: independent 128-key chunks (chunk max, rounded P), fp32 combine.
+    mode "splitN"   : arithmetic of the decode kernel: independent N-key chunks (chunk max, rounded P), fp32 combine
+                      ("split128" is what the model-level restatement uses; the kernel's chunk is a tuning knob, 64 by default
+                      for one conversation, and any N gives the same value up to the bf16 rounding of P).
     The bf16 parity tests use the emulating modes so that P is rounded at exactly the kernels' points.
     """
     B, H, Sq, d = q.shape
@@ -296,10 +298,11 @@ def attention_core(q, k, v, visible, scale, R, mode="exact"):
             acc = acc * alpha + R(p) @ v[:, :, j0:j1]
             m = m_new
         return acc / l
-    if mode == "split128":
+    if mode.startswith("split"):
+        chunk = int(mode[5:])                     # keys per independent chunk ("split128", "split64", ...)
         ms, ls, os_ = [], [], []
-        for j0 in range(0, Sk, 128):
-            j1 = min(Sk, j0 + 128)
+        for j0 in range(0, Sk, chunk):
+            j1 = min(Sk, j0 + chunk)
             s = (q @ k[:, :, j0:j1].transpose(-1, -2)) * scale
             if visible is not None:
                 s = s.masked_fill(~visible[..., j0:j1], neg)

@@ -91,6 +91,7 @@ class DecodeBatchState(C.Structure):
 _SIGS = {
     "teo_version": (C.c_int, []),
     "teo_last_error": (C.c_char_p, []),
+    "teo_last_kernel": (C.c_char_p, []),
     "teo_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
     "teo_gemm_uses_mfma": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "teo_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
@@ -125,6 +126,8 @@ _SIGS = {
     "teo_llama_decode_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc)]),
     "teo_llama_decode_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_decode_step_profile": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                                C.c_void_p]),
     "teo_llama_decode_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t,
                                                 C.c_void_p, C.POINTER(C.c_void_p)]),
     "teo_llama_prefill_batch": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_longlong, C.c_void_p,
@@ -147,15 +150,11 @@ _SIGS = {
                                             C.POINTER(C.c_float), C.POINTER(C.c_ubyte), C.c_int, C.c_void_p]),
     "teo_gemm_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
                         + [C.c_int] * 5 + [C.c_uint, C.c_int, C.c_void_p]),
-    "teo_time_skinny_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint,
-                                        C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "teo_comm_unique_id": (C.c_int, [C.c_void_p]),
     "teo_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "teo_ctx_destroy": (C.c_int, [C.c_void_p]),
     "teo_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "teo_allgather_visual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "teo_time_gemv_chain": (C.c_int, [C.c_void_p, PP, PP, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
-                                      C.c_uint, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS.keys())

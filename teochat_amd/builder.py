@@ -7,6 +7,8 @@ Supported sources:
   * "synthetic:<preset>" -- random weights of a named architecture (no network here for real ones):
         synthetic:teochat-7b   LLaMA-2-7B + CLIP-ViT-L/14 shapes
         synthetic:tiny         a KB-scale model for smoke tests
+        synthetic:teochat-7b-anchored   the same random stack with 8 restructured lm_head rows so that greedy decisions have
+                               margins above the bf16 noise (full-size token-stream tests; see synthetic.anchor_gains)
   * the reference's other two branches (builder.py:37-72 and :73-88):
         LoRA       model_name contains "lora" and model_base is given: base weights from model_base, then
                    non_lora_trainables.bin (prefix rules of builder.py:58-61), then the peft adapter of model_path merged
@@ -315,13 +317,16 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     if model_path.startswith("synthetic:"):
         from .synthetic import synthetic_state_dict
         preset = model_path.split(":", 1)[1]
+        anchored = preset.endswith("-anchored")          # decisive-margin variant for full-size token checks (synthetic.py)
+        if anchored:
+            preset = preset[:-len("-anchored")]
         if preset in ("teochat-7b", "teochat", "llava-7b"):
             cfg = teochat_7b_config()
         elif preset == "tiny":
             cfg = tiny_config()
         else:
             raise ValueError(f"unknown synthetic preset {preset!r}")
-        sd = synthetic_state_dict(cfg, seed=seed, std=0.02 if preset != "tiny" else 0.08, dtype=dtype, device=device)
+        sd = synthetic_state_dict(cfg, seed=seed, std=0.02 if preset != "tiny" else 0.08, dtype=dtype, device=device, anchored=anchored)
         tokenizer = ByteTokenizer()
     else:
         if "llava" not in model_name.lower() and "teochat" not in model_name.lower():

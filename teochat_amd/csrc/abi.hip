@@ -7,6 +7,9 @@ namespace teo {
 
 static thread_local char g_err[512] = "";
 
+thread_local const char* g_last_kernel = "";
+void note_kernel(const char* name) { g_last_kernel = name; }
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -30,6 +33,8 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
                         float* logits, void* ws, size_t ws_bytes, hipStream_t st);
 size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
 int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
+int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out, int* count_out,
+                              hipStream_t st);
 int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
                         teo_graph** out);
@@ -57,6 +62,7 @@ extern "C" {
 
 int teo_version(void) { return TEO_ABI_VERSION; }
 const char* teo_last_error(void) { return g_err; }
+const char* teo_last_kernel(void) { return teo::g_last_kernel; }
 
 int teo_tune_set(const char* key, int value) {
     if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || gemm_big_tune_set(key, value) == 0 || runtime_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
@@ -295,6 +301,20 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
     return llama_decode_step(d, st, ws, wsb, ST(s));
 }
 
+int teo_llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, float* ms_out, int* count_out,
+                                  teo_stream_t s) {
+    ENTER();
+    NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
+    NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
+    NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
+    if (st->do_sample) {
+        NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "teo_llama_decode_step: temperature %g", st->temperature);
+        const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc;
+    }
+    NEED(ms_out, "ms_out"); NEED(count_out, "count_out");
+    return llama_decode_step_profile(d, st, ws, wsb, ms_out, count_out, ST(s));
+}
+
 int teo_llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype); NEED(st->d_token, "d_token");
@@ -370,35 +390,6 @@ int teo_graph_destroy(teo_graph* g) {
     return TEO_OK;
 }
 
-int teo_time_gemv_chain(const void* x, const void* const* Ws, const float* const* scales, int n, const void* norm_w, void* y,
-                        int N, int K, float eps, unsigned flags, int dtype, int reps, float* avg_ms_out, teo_stream_t s) {
-    ENTER();
-    NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
-    TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_gemv_chain: n %d reps %d", n, reps);
-    hipEvent_t e0, e1;
-    hipError_t e = hipEventCreate(&e0);
-    if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
-    e = hipEventCreate(&e1);
-    if (e != hipSuccess) { (void)hipEventDestroy(e0); return hip_fail(e, "hipEventCreate"); }
-    int rc = TEO_OK;
-    for (int i = 0; i < n && rc == TEO_OK; ++i)   // warm-up pass (not timed)
-        rc = gemv_w(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
-    (void)hipEventRecord(e0, ST(s));
-    for (int r = 0; r < reps && rc == TEO_OK; ++r)
-        for (int i = 0; i < n && rc == TEO_OK; ++i)
-            rc = gemv_w(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, nullptr, y, N, K, eps, flags, dtype, dtype, ST(s));
-    (void)hipEventRecord(e1, ST(s));
-    e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (rc != TEO_OK) return rc;
-    if (e != hipSuccess) return hip_fail(e, "teo_time_gemv_chain events");
-    *avg_ms_out = ms / (float)(n * reps);
-    return TEO_OK;
-}
-
 size_t teo_attn_decode_workspace_bytes(int heads, int head_dim, int max_seq, int batch) {
     if (!(heads > 0 && head_dim > 0 && max_seq > 0 && batch > 0)) return 0;
     return attn_decode_counters_offset(heads, head_dim, max_seq, batch) + (size_t)batch * heads * sizeof(int);
@@ -462,36 +453,6 @@ int teo_gemm_skinny(const void* x, const void* W, const float* w_scale, int w_fp
     if (MB == 0 || N == 0) return TEO_OK;
     NEED(x, "x"); NEED(W, "W"); NEED(out, "out");
     return skinny_gemm(x, W, w_scale, w_fp8, norm_w, eps, res, out, MB, N, K, ldx, ldo, flags, out_dtype, ST(s));
-}
-
-int teo_time_skinny_chain(const void* x, const void* const* Ws, const float* const* scales, int n, const void* norm_w, void* y,
-                          int MB, int N, int K, unsigned flags, int reps, float* avg_ms_out, teo_stream_t s) {
-    ENTER();
-    NEED(x, "x"); NEED(Ws, "Ws"); NEED(y, "y"); NEED(avg_ms_out, "avg_ms_out");
-    TEO_CHECK_ARG(n > 0 && reps > 0, "teo_time_skinny_chain: n %d reps %d", n, reps);
-    const int ldo = (flags & (TEO_GEMM_SWIGLU16 | TEO_GEMM_SWIGLU8)) ? N / 2 : N;
-    hipEvent_t e0, e1;
-    hipError_t e = hipEventCreate(&e0);
-    if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
-    e = hipEventCreate(&e1);
-    if (e != hipSuccess) { (void)hipEventDestroy(e0); return hip_fail(e, "hipEventCreate"); }
-    int rc = TEO_OK;
-    for (int i = 0; i < n && rc == TEO_OK; ++i)   // warm-up pass (not timed)
-        rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, 1e-5f, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
-    (void)hipEventRecord(e0, ST(s));
-    for (int r = 0; r < reps && rc == TEO_OK; ++r)
-        for (int i = 0; i < n && rc == TEO_OK; ++i)
-            rc = skinny_gemm(x, Ws[i], scales ? scales[i] : nullptr, scales != nullptr, norm_w, 1e-5f, nullptr, y, MB, N, K, K, ldo, flags, TEO_BF16, ST(s));
-    (void)hipEventRecord(e1, ST(s));
-    e = hipEventSynchronize(e1);
-    float ms = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (rc != TEO_OK) return rc;
-    if (e != hipSuccess) return hip_fail(e, "teo_time_skinny_chain events");
-    *avg_ms_out = ms / (float)(n * reps);
-    return TEO_OK;
 }
 
 }  // extern "C"

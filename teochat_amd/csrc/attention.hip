@@ -272,7 +272,7 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
             if (a.causal) attn_mfma_kernel<64, true><<<grid, 256, lds, st>>>(a);
             else attn_mfma_kernel<64, false><<<grid, 256, lds, st>>>(a);
         }
-        TEO_LAUNCH_CHECK("attn_mfma");
+        note_kernel("attn_mfma"); TEO_LAUNCH_CHECK("attn_mfma");
         return TEO_OK;
     }
     TEO_CHECK_ARG(a.v != nullptr, "teo_attention: generic kernel needs row-major V");
@@ -284,7 +284,7 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
     dim3 grid(a.q_len, a.heads, a.batch);
     if (dtype == TEO_F32) attn_simple_kernel<float><<<grid, 64, lds, st>>>(a);
     else attn_simple_kernel<bf16_t><<<grid, 64, lds, st>>>(a);
-    TEO_LAUNCH_CHECK("attn_simple");
+    note_kernel("attn_simple"); TEO_LAUNCH_CHECK("attn_simple");
     return TEO_OK;
 }
 
@@ -305,7 +305,9 @@ static int g_fused_combine = 0;   // 1: the last workgroup of a head merges the 
 int g_rope_in_attn = -1;          // decode RoPE + KV append: 0 = in the QKV GEMV epilogue, 1 = inside the attention kernel,
                                    // -1 = auto (measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0,
                                    // fp8 weights 2.216 vs 2.234 in favour of 1)
+static int g_attn_fat = 1;        // decode attention for bf16 / head_dim 128: the fat-split kernel of attn_fat.hip (0: round-2 kernels)
 int attn_tune_set(const char* key, int value) {
+    if (!strcmp(key, "attn_fat")) { g_attn_fat = value != 0; return 0; }
     if (!strcmp(key, "attn_flash")) { g_attn_flash = value != 0; return 0; }
     if (!strcmp(key, "attn_chunk") && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
     if (!strcmp(key, "attn_fused_combine")) { g_fused_combine = value != 0; return 0; }
@@ -678,7 +680,7 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
                                int nsplit, int chunk, bool rope, AttnBatch bt, int* counters, hipStream_t st) {
     dim3 grid(heads, nsplit, bt.batch);
 #define TEO_PART(CH, RP)                                                                                              \
-    attn_decode_partial_kernel<T, LPR, CH, RP><<<grid, 256, 0, st>>>((const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
+    TEO_KLAUNCH((attn_decode_partial_kernel<T, LPR, CH, RP>), grid, 256, 0, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
                                                                      d_pos, S_max, heads, kv_heads, scale, nsplit, bt, \
                                                                      counters, (T*)o)
 #define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
@@ -691,8 +693,11 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
     }
 #undef TEO_PART_R
 #undef TEO_PART
-    if (!counters)
-        attn_decode_combine_kernel<T><<<dim3(heads, bt.batch), 512, 0, st>>>(part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
+    if (!counters) {
+        prof_bump(1);
+        TEO_KLAUNCH((attn_decode_combine_kernel<T>), dim3(heads, bt.batch), 512, 0, st, part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
+        prof_bump(-1);
+    }
 }
 
 // rope_cos != NULL: q is the raw qkv row; RoPE and the KV append of the new token happen inside the kernel
@@ -701,6 +706,8 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
                 hipStream_t st, AttnBatch bt, int* counters) {
     const bool rope = rope_cos != nullptr;
+    if (g_attn_fat && !g_fused_combine && bt.batch == 1 && attn_fat_ok(hd, dtype, S_max))
+        return attn_decode_fat(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, scale, st, bt, true);
     if (!g_fused_combine) counters = nullptr;
     int chunk = g_dec_chunk ? g_dec_chunk : (bt.batch > 1 ? 128 : 64);
     const int esz = dtype == TEO_F32 ? 4 : 2;

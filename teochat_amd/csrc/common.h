@@ -1,6 +1,7 @@
 // Shared device/host helpers for libteo_hip (gfx950 only: wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -14,6 +15,8 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
+// diagnostics: name of the kernel family the last dispatching entry point (GEMM / attention) chose -- teo_last_kernel()
+void note_kernel(const char* name);
 
 #define TEO_CHECK_ARG(cond, ...)                   \
     do {                                           \
@@ -27,6 +30,23 @@ int hip_fail(hipError_t e, const char* what);
     do {                                                         \
         hipError_t e__ = hipGetLastError();                      \
         if (e__ != hipSuccess) return teo::hip_fail(e__, name);  \
+    } while (0)
+
+// ---- launches of the decode path -------------------------------------------------------------
+// Every kernel of the decode step is launched through TEO_KLAUNCH so that teo_llama_decode_step_profile can time each launch
+// by its own dispatch timestamps (hipExtLaunchKernel start / stop events: kernel execution only, what rocprofv3 reports) and so
+// that launch flags (hipExtAnyOrderLaunch experiments) can be applied in one place.  Off by default: a plain <<<>>> launch.
+bool prof_take(hipEvent_t* start, hipEvent_t* stop);      // false unless a profiled step is being recorded on this thread
+void prof_class(int cls);                                 // class of the launches that follow
+void prof_bump(int delta);
+extern thread_local unsigned g_launch_flags;
+#define TEO_KLAUNCH(kern, grid, block, lds, st, ...)                                                                       \
+    do {                                                                                                                   \
+        hipEvent_t ps__ = nullptr, pe__ = nullptr;                                                                         \
+        if (teo::prof_take(&ps__, &pe__) || teo::g_launch_flags)                                                           \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)(lds), st, ps__, pe__, teo::g_launch_flags, __VA_ARGS__); \
+        else                                                                                                               \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)(lds), st, __VA_ARGS__);                             \
     } while (0)
 
 // ---- bf16 <-> f32 -----------------------------------------------------------------------------

@@ -270,7 +270,7 @@ int attention_flash32(const teo_attn_args& a, hipStream_t st) {
         if (a.causal) attn_flash32_kernel<64, true><<<grid, 256, lds, st>>>(a);
         else attn_flash32_kernel<64, false><<<grid, 256, lds, st>>>(a);
     }
-    TEO_LAUNCH_CHECK("attn_flash32");
+    note_kernel("attn_flash32"); TEO_LAUNCH_CHECK("attn_flash32");
     return TEO_OK;
 }
 

@@ -666,6 +666,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
             if (swiglu) { if (of32) TEO_SK_LAUNCH(true, true); else TEO_SK_LAUNCH(true, false); }
             else { if (of32) TEO_SK_LAUNCH(false, true); else TEO_SK_LAUNCH(false, false); }
 #undef TEO_SK_LAUNCH
+            note_kernel("gemm_mfma_128_sk");
             TEO_LAUNCH_CHECK("gemm_mfma_bf16_sk");
             return TEO_OK;
         }
@@ -681,6 +682,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         else        { if (of32) { TEO_GEMM_LAUNCH(false, true) } else { TEO_GEMM_LAUNCH(false, false) } }
 #undef TEO_GEMM_K
 #undef TEO_GEMM_LAUNCH
+        note_kernel(bm == 64 ? "gemm_mfma_64" : "gemm_mfma_128");
         TEO_LAUNCH_CHECK("gemm_mfma_bf16");
         return TEO_OK;
     }
@@ -694,6 +696,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         set_error("teo_gemm: unknown dtype %d", dtype);
         return TEO_ERR_UNSUPPORTED;
     }
+    note_kernel("gemm_simple");
     TEO_LAUNCH_CHECK("gemm_simple");
     return TEO_OK;
 }

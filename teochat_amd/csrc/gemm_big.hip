@@ -292,6 +292,7 @@ int gemm_big_launch(const void* A, const void* W, const void* bias, const void* 
     else { if (of32) TEO_GB_LAUNCH(false, true) else TEO_GB_LAUNCH(false, false) }
 #undef TEO_GB_LAUNCH
 #undef TEO_GB_LAUNCH_H
+    note_kernel(hybrid ? "gemm_big_hybrid" : "gemm_big");
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_big");
     return TEO_OK;
 }

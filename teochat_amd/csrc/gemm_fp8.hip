@@ -624,7 +624,7 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
             if (swiglu) { if (of32) TEO_F8B_LAUNCH(true, true) else TEO_F8B_LAUNCH(true, false) }
             else { if (of32) TEO_F8B_LAUNCH(false, true) else TEO_F8B_LAUNCH(false, false) }
 #undef TEO_F8B_LAUNCH
-            TEO_LAUNCH_CHECK("gemm_mfma_fp8_big");
+            note_kernel("gemm_fp8_big"); TEO_LAUNCH_CHECK("gemm_mfma_fp8_big");
             return TEO_OK;
         }
         if (sk_shape) {
@@ -649,7 +649,7 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
     }
             if (of32) TEO_F8SK_LAUNCH(true) else TEO_F8SK_LAUNCH(false)
 #undef TEO_F8SK_LAUNCH
-            TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide_sk");
+            note_kernel("gemm_fp8_wide_sk"); TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide_sk");
             return TEO_OK;
         }
         if (K >= 2 * F8_BK && (g_fp8_wide >= 2 || (g_fp8_wide == 1 && t_wide >= 256 && wide < plain))) {
@@ -670,7 +670,7 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
             if (swiglu) { if (of32) TEO_F8W_LAUNCH(true, true) else TEO_F8W_LAUNCH(true, false) }
             else { if (of32) TEO_F8W_LAUNCH(false, true) else TEO_F8W_LAUNCH(false, false) }
 #undef TEO_F8W_LAUNCH
-            TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide");
+            note_kernel("gemm_fp8_wide"); TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide");
             return TEO_OK;
         }
     }
@@ -683,7 +683,7 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
     if (swiglu) { if (of32) TEO_F8_LAUNCH(true, true); else TEO_F8_LAUNCH(true, false); }
     else { if (of32) TEO_F8_LAUNCH(false, true); else TEO_F8_LAUNCH(false, false); }
 #undef TEO_F8_LAUNCH
-    TEO_LAUNCH_CHECK("gemm_mfma_fp8");
+    note_kernel("gemm_fp8_128"); TEO_LAUNCH_CHECK("gemm_mfma_fp8");
     return TEO_OK;
 }
 

@@ -414,7 +414,7 @@ int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const vo
     }
     if (of32) TEO_GWSK_LAUNCH(true) else TEO_GWSK_LAUNCH(false)
 #undef TEO_GWSK_LAUNCH
-    TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide_sk");
+    note_kernel("gemm_wide_sk"); TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide_sk");
     return TEO_OK;
 }
 
@@ -444,7 +444,7 @@ int gemm_wide_launch(const void* A, const void* W, const void* bias, const void*
     else { if (of32) TEO_GW_LAUNCH(false, true) else TEO_GW_LAUNCH(false, false) }
 #undef TEO_GW_LAUNCH_S
 #undef TEO_GW_LAUNCH
-    TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide");
+    note_kernel("gemm_wide"); TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide");
     return TEO_OK;
 }
 

@@ -607,8 +607,8 @@ static int launch_rows(const void* x, const void* W, const float* ws, const void
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
     const size_t lds = x_image_bytes<BfImage<T, WT>::v, Vec16<WT>::N>(K);
 #define TEO_GV(NTV, SW)                                                                                              \
-    gemv_kernel<T, TO, WT, R, U, PF, NTV, SW><<<blocks, GV_THREADS, lds, st>>>((const T*)x, (const WT*)W, ws, (const T*)norm_w, \
-                                                                               (const T*)res, (TO*)y, N, K, eps)
+    TEO_KLAUNCH((gemv_kernel<T, TO, WT, R, U, PF, NTV, SW>), blocks, GV_THREADS, lds, st, (const T*)x, (const WT*)W, ws, (const T*)norm_w, \
+                (const T*)res, (TO*)y, N, K, eps)
     if (g_tune.nt) { if (swiglu) TEO_GV(true, true); else TEO_GV(true, false); }
     else           { if (swiglu) TEO_GV(false, true); else TEO_GV(false, false); }
 #undef TEO_GV
@@ -620,9 +620,9 @@ template <typename T, typename TO, typename WT, int R, int U>
 static int launch_splitk(const void* x, const void* W, const float* ws, const void* res, void* y, int N, int K, hipStream_t st) {
     const int blocks = cdiv(N, R);
     if (g_tune.nt)
-        gemv_splitk_kernel<T, TO, WT, R, U, true><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
+        TEO_KLAUNCH((gemv_splitk_kernel<T, TO, WT, R, U, true>), blocks, GV_THREADS, 0, st, (const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
     else
-        gemv_splitk_kernel<T, TO, WT, R, U, false><<<blocks, GV_THREADS, 0, st>>>((const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
+        TEO_KLAUNCH((gemv_splitk_kernel<T, TO, WT, R, U, false>), blocks, GV_THREADS, 0, st, (const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
     TEO_LAUNCH_CHECK("gemv_splitk");
     return TEO_OK;
 }
@@ -710,10 +710,10 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
     const int uu = w_fp8 ? 2 : 4;
     const bool pf = K / ve >= 64 * uu;
 #define TEO_QR(TT, WW, NTV)                                                                                             \
-    if (pf) gemv_qkv_rope_kernel<TT, WW, NTV, true, (sizeof(WW) == 1 ? 2 : 4)><<<blocks, GV_THREADS, lds, st>>>((const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+    if (pf) TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, true, (sizeof(WW) == 1 ? 2 : 4)>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
                                                                        (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
                                                                        S_max, H, Hk, hd, K, eps);                            \
-    else gemv_qkv_rope_kernel<TT, WW, NTV, false, (sizeof(WW) == 1 ? 2 : 4)><<<blocks, GV_THREADS, lds, st>>>((const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+    else TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, false, (sizeof(WW) == 1 ? 2 : 4)>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
                                                                        (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
                                                                        S_max, H, Hk, hd, K, eps)
     if (w_fp8)                 { if (g_tune.nt) { TEO_QR(bf16_t, fp8_t, true); } else { TEO_QR(bf16_t, fp8_t, false); } }

@@ -655,11 +655,11 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
                 hipStream_t st, int batch, int out_stride, const void* g0, void* hg, float* ssq, int nparts) {
     if (dtype == TEO_F32)
-        decode_tail_kernel<float><<<batch, 1024, 0, st>>>(logits, *s, (const float*)embed, (float*)h, vocab, dim, out_stride,
-                                                          (const float*)g0, (float*)hg, ssq, nparts);
+        TEO_KLAUNCH((decode_tail_kernel<float>), batch, 1024, 0, st, logits, *s, (const float*)embed, (float*)h, vocab, dim, out_stride,
+                    (const float*)g0, (float*)hg, ssq, nparts);
     else
-        decode_tail_kernel<bf16_t><<<batch, 1024, 0, st>>>(logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim, out_stride,
-                                                           (const bf16_t*)g0, (bf16_t*)hg, ssq, nparts);
+        TEO_KLAUNCH((decode_tail_kernel<bf16_t>), batch, 1024, 0, st, logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim, out_stride,
+                    (const bf16_t*)g0, (bf16_t*)hg, ssq, nparts);
     TEO_LAUNCH_CHECK("decode_tail");
     return TEO_OK;
 }

@@ -24,6 +24,23 @@ int attention_flash32(const teo_attn_args& a, hipStream_t st);
 size_t attn_decode_counters_offset(int heads, int hd, int S_max, int batch);
 bool attn_decode_fused_enabled();
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
+// "fat split" decode attention (attn_fat.hip): records of a head are merged by the consumer (o-projection GEMV prologue)
+constexpr int ATTN_FAT_MAX_SPLITS = 16;
+int attn_fat_nsplit(int S_max);
+bool attn_fat_ok(int hd, int dtype, int S_max);
+// o[d] of one head from its `nsplit` records {m, l, o[128]} (stride 130 floats), splits merged in index order
+__device__ __forceinline__ float attn_fat_merge(const float* __restrict__ pb, int nsplit, int d) {
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[s * 130]);
+    float Ls = 0.f, a = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float m = pb[s * 130];
+        const float w = (m == -INFINITY) ? 0.f : expf(m - M);
+        Ls = fmaf(w, pb[s * 130 + 1], Ls);
+        a = fmaf(w, pb[s * 130 + 2 + d], a);
+    }
+    return a / Ls;
+}
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;
     long long q_stride = 0, cache_stride = 0, o_stride = 0;
@@ -32,6 +49,8 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
                 hipStream_t st, AttnBatch bt = AttnBatch(), int* counters = nullptr);   // counters: [batch*heads] zeroed ints -> fused combine
 
+int attn_decode_fat(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o, float* part,
+                    const int* d_pos, int S_max, int heads, int kv_heads, float scale, hipStream_t st, AttnBatch bt, bool with_combine);
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                    void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,
                    hipStream_t st);

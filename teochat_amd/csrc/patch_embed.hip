@@ -123,7 +123,7 @@ int patch_embed(const void* px, const void* W, void* out, int T, int C, int img,
     const int g = img / P, M = T * g * g;
     const int tiles = cdiv(M, PE_BM) * cdiv(D, PE_BN);
     patch_embed_mfma_kernel<<<tiles, 256, 2 * PE_TILE, st>>>((const bf16_t*)px, (const bf16_t*)W, (bf16_t*)out, T, C, img, P, ldw, D);
-    TEO_LAUNCH_CHECK("patch_embed_mfma");
+    note_kernel("patch_embed_mfma"); TEO_LAUNCH_CHECK("patch_embed_mfma");
     return TEO_OK;
 }
 

@@ -368,31 +368,40 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
         if (g_rope_in_attn < 0 ? w8 : g_rope_in_attn != 0) {
             // rmsnorm + QKV projection (plain weight stream); RoPE + KV append ride inside the attention kernel
             // (position read from s->d_pos on the device)
+            prof_class(TEO_PROF_QKV);
             TEO_TRY(gemv_w(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], nullptr,
                            w.qkv, QKV, D, d->eps, 0, dt, dt, st));
+            prof_class(TEO_PROF_ATTN);
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
                                 s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, AttnBatch(), w.cnt));
         } else {
             // rmsnorm -> QKV projection -> RoPE -> KV append in the GEMV epilogue
+            prof_class(TEO_PROF_QKV);
             TEO_TRY(gemv_qkv_rope(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.qkv,
                                   d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->max_seq,
                                   H, Hk, hd, D, d->eps, dt, st));
+            prof_class(TEO_PROF_ATTN);
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], nullptr, nullptr, nullptr, w.attn, w.part, s->d_pos,
                                 d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, AttnBatch(), w.cnt));
         }
+        prof_class(TEO_PROF_O);
         TEO_TRY(gemv_w(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps,
                        0, dt, dt, st));
+        prof_class(TEO_PROF_GATEUP);
         TEO_TRY(gemv_w(w.h, w8 ? d->gateup_w8[l] : d->gateup_w[l], w8 ? d->gateup_s[l] : nullptr, w8, d->post_norm_w[l], nullptr,
                        w.act, 2 * F, D, d->eps, TEO_GEMM_SWIGLU16, dt, dt, st));
+        prof_class(TEO_PROF_DOWN);
         TEO_TRY(gemv_w(w.act, w8 ? d->down_w8[l] : d->down_w[l], w8 ? d->down_s[l] : nullptr, w8, nullptr, w.h, w.h, D, F, d->eps,
                        0, dt, dt, st));
     }
     {
         const bool h8 = d->lm_head8 != nullptr;
+        prof_class(TEO_PROF_LM_HEAD);
         TEO_TRY(gemv_w(w.h, h8 ? d->lm_head8 : d->lm_head, h8 ? d->lm_head_s : nullptr, h8, d->final_norm_w, nullptr,
                        s->d_logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st));
     }
     // argmax -> append/advance/stop test -> embedding row of the next token into w.h, one launch
+    prof_class(TEO_PROF_TAIL);
     return decode_tail(s->d_logits, s, d->embed, w.h, d->vocab, D, dt, st);
 }
 
@@ -550,6 +559,48 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
     hipError_t e = hipMemsetAsync(w.cnt, 0, (size_t)d->heads * sizeof(int), st);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiled decode step: every launch timed by its own dispatch timestamps (TEO_KLAUNCH, common.h)
+// ------------------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t start, stop; int cls; };
+static thread_local std::vector<ProfRec>* g_prof = nullptr;
+static thread_local int g_prof_cls = 0;
+thread_local unsigned g_launch_flags = 0;
+bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
+    if (!g_prof) return false;
+    ProfRec r;
+    r.cls = g_prof_cls;
+    if (hipEventCreate(&r.start) != hipSuccess) return false;
+    if (hipEventCreate(&r.stop) != hipSuccess) { (void)hipEventDestroy(r.start); return false; }
+    g_prof->push_back(r);
+    *start = r.start;
+    *stop = r.stop;
+    return true;
+}
+void prof_class(int cls) { g_prof_cls = cls; }
+void prof_bump(int delta) { g_prof_cls += delta; }
+
+int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out,
+                              int* count_out, hipStream_t st) {
+    std::vector<ProfRec> recs;
+    recs.reserve(8 * (size_t)d->layers + 8);
+    g_prof = &recs;
+    const int rc = llama_decode_step(d, s, ws, ws_bytes, st);
+    g_prof = nullptr;
+    g_prof_cls = 0;
+    hipError_t e = hipStreamSynchronize(st);
+    for (int c = 0; c < TEO_PROF_CLASSES; ++c) { ms_out[c] = 0.f; count_out[c] = 0; }
+    for (const ProfRec& r : recs) {
+        float ms = 0.f;
+        if (e == hipSuccess && rc == TEO_OK) e = hipEventElapsedTime(&ms, r.start, r.stop);
+        if (r.cls >= 0 && r.cls < TEO_PROF_CLASSES) { ms_out[r.cls] += ms; count_out[r.cls] += 1; }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    if (rc != TEO_OK) return rc;
+    return e == hipSuccess ? TEO_OK : hip_fail(e, "teo_llama_decode_step_profile");
 }
 
 // ------------------------------------------------------------------------------------------------

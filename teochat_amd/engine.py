@@ -469,6 +469,29 @@ class TeoEngine:
         self.cache_len += n
         self.steps_since_begin = getattr(self, "steps_since_begin", 0) + n
 
+    PROF_CLASSES = ("qkv_rope_gemv", "attn_decode_partial", "attn_decode_combine", "o_gemv", "gateup_gemv", "down_gemv", "lm_head_gemv",
+                    "decode_tail")
+
+    def decode_steps_profiled(self, n):
+        """n decode steps as plain launches, every kernel timed by its own dispatch timestamps (teo_llama_decode_step_profile).
+        Returns {class: (launches per step, mean microseconds per launch)}; advances the cache like decode_steps."""
+        if self.cache_len + n > self.max_seq:
+            raise ValueError(f"decode would exceed max_seq {self.max_seq}")
+        ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
+        K = len(self.PROF_CLASSES)
+        tot, cnt = [0.0] * K, [0] * K
+        ms, ct = (C.c_float * K)(), (C.c_int * K)()
+        with self.phase() as st:
+            for _ in range(n):
+                L.check(self.lib.teo_llama_decode_step_profile(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(),
+                                                               ms, ct, st), "teo_llama_decode_step_profile")
+                for k in range(K):
+                    tot[k] += ms[k]
+                    cnt[k] += ct[k]
+        self.cache_len += n
+        self.steps_since_begin = getattr(self, "steps_since_begin", 0) + n
+        return {name: (cnt[k] // n, tot[k] / cnt[k] * 1e3) for k, name in enumerate(self.PROF_CLASSES) if cnt[k]}
+
     def generated(self):
         n = int(self.d_count.item())
         return self.d_out[:n].clone()

@@ -5,7 +5,32 @@ import torch
 VIT_PREFIX = "model.image_tower.image_tower."
 
 
-def synthetic_state_dict(cfg, seed=2, std=0.02, dtype=torch.bfloat16, device="cuda:0"):
+ANCHOR_COUNT, ANCHOR_GAIN, ANCHOR_BASE_ID, ANCHOR_EMBED_STD = 16, 16.0, 1000, 0.75
+
+
+def anchor_gains(vocab, device="cpu"):
+    """Per-token gain of the "anchored" synthetic checkpoint's lm_head rows (1 for ordinary tokens).
+
+    Why: with N(0, 0.02^2) weights the 32000 logits of a position are i.i.d.-looking Gaussians, the top-2 margin is ~5 % of
+    max|logit| on average and most greedy decisions sit inside the bf16 noise of a 32-layer stack -- token-stream checks at the
+    full model size then cannot tell a correct kernel from a slightly wrong one.  The anchored checkpoint keeps every weight of
+    the stack random (same kernels, same magnitudes) and restructures ANCHOR_COUNT rows of embed_tokens and of lm_head:
+
+        embed_tokens[a_k] = ANCHOR_EMBED_STD * r_k        (r_k ~ N(0, 1): ~37 x the ordinary embedding scale)
+        lm_head[a_(k+1)]  = ANCHOR_GAIN * 0.02 * r_k      (the SUCCESSOR anchor's row points along the current anchor's embedding)
+
+    Through the residual connections the embedding of the token just fed survives to the final hidden state with a cosine of
+    ~0.07 against 32 layers of random contributions (~4.6 sigma on the successor's logit before the gain), so a greedy stream walks
+    the cycle a_0 -> a_1 -> ... with context-decided jumps where another anchor's random projection wins -- a VARIED token stream
+    whose every decision depends on the token fed at that step, on its position and on the cache, with margins far above the bf16
+    noise at ~95 % of the positions.  Gross errors (stale input token, wrong position, a broken layer) change the stream; errors at
+    the rounding level are what the logit comparisons against the oracle are for (tests/test_true_shapes_gpu.py)."""
+    g = torch.ones(vocab, dtype=torch.float32, device=device)
+    g[ANCHOR_BASE_ID:ANCHOR_BASE_ID + ANCHOR_COUNT] = ANCHOR_GAIN
+    return g
+
+
+def synthetic_state_dict(cfg, seed=2, std=0.02, dtype=torch.bfloat16, device="cuda:0", anchored=False):
     g = torch.Generator(device=device).manual_seed(seed)
     v = cfg.vision_config
 
@@ -31,6 +56,13 @@ def synthetic_state_dict(cfg, seed=2, std=0.02, dtype=torch.bfloat16, device="cu
         sd[p + "post_attention_layernorm.weight"] = near_one(D)
     sd["model.norm.weight"] = near_one(D)
     sd["lm_head.weight"] = rn(V, D)
+    if anchored:
+        if V < ANCHOR_BASE_ID + ANCHOR_COUNT:
+            raise ValueError("anchored synthetic checkpoint needs a vocabulary of at least %d" % (ANCHOR_BASE_ID + ANCHOR_COUNT))
+        r = torch.randn(ANCHOR_COUNT, D, generator=g, device=device, dtype=torch.float32)
+        ids = torch.arange(ANCHOR_BASE_ID, ANCHOR_BASE_ID + ANCHOR_COUNT, device=device)
+        sd["model.embed_tokens.weight"][ids] = (ANCHOR_EMBED_STD * r).to(dtype)
+        sd["lm_head.weight"][ids.roll(-1)] = (ANCHOR_GAIN * std * r).to(dtype)        # row of a_(k+1) <- direction of embed[a_k]
     Dv, Fv = v.hidden_size, v.intermediate_size
     sd[VIT_PREFIX + "embeddings.class_embedding"] = rn(Dv)
     sd[VIT_PREFIX + "embeddings.patch_embedding.weight"] = rn(Dv, v.num_channels, v.patch_size, v.patch_size)

@@ -1,5 +1,6 @@
 """Size-independent properties at BASELINE.json's full model size (LLaMA-2-7B + CLIP-ViT-L/14 shapes, 32 + 23 layers,
-synthetic weights): the oracle cannot run this size in seconds, these invariants can.
+synthetic weights).  The oracle itself is compared at these shapes in tests/test_true_shapes_gpu.py; the invariants below hold
+bit for bit (or within the stated noise) whatever the weights are.
 
   determinism          two runs of the same conversation give bit-identical logits and tokens
   causality            logits of a prefix do not change when the suffix changes (bit-identical: same kernels, same rows)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from oracle import teo_oracle as O
 from teochat_amd import _lib as L
+from teochat_amd.engine import rope_tables
 from tests import _gpu as G
 
 pytestmark = pytest.mark.gpu
@@ -745,6 +746,56 @@ def test_attn_decode_batched_vs_reference(dtype, H, Hk, d, S, ctx, chunk):
             torch.testing.assert_close(out[b].cpu(), ref, atol=2e-5, rtol=1e-5)
         else:
             close_bf16(out[b], G.bf16_round(ref), ulps=2.0, floor=4e-3)    # P is rounded to bf16 before the PV product
+
+
+@pytest.mark.parametrize("S,ctxs", [(2560, [2299, 2560, 2305, 320, 17, 1]), (4608, [4255, 4608, 3073, 100]), (512, [300, 512, 5])])
+@pytest.mark.parametrize("rope", [False, True])
+def test_attn_decode_fat_split_vs_reference_and_round2_kernel(S, ctxs, rope):
+    """attn_fat.hip (bf16, head_dim 128, one conversation): heads x ceil(S_max / 320) workgroups of 1024 threads, each owning an
+    equal share of the CURRENT context; against the fp64 softmax reference (P rounded to bf16 before PV: 2 ulps) and against the
+    round-2 split-64 kernels on the same inputs, for full / ragged / tiny contexts, with and without in-kernel RoPE + KV append."""
+    H, d = 32, 128
+    lib = G.lib()
+    g = torch.Generator().manual_seed(S + int(rope))
+    K = G.bf16_round(torch.randn(H, S, d, generator=g))
+    V = G.bf16_round(torch.randn(H, S, d, generator=g))
+    cs, sn = rope_tables(d, 10000.0, S)
+    d_cs, d_sn = cs.cuda(), sn.cuda()
+    part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, 1), dtype=torch.uint8, device="cuda")
+    for n in ctxs:
+        pos = n - 1
+        qkv = G.bf16_round(torch.randn(3, H, d, generator=g))                 # raw q | k | v of the new token
+        if rope:
+            c, s_ = cs[pos], sn[pos]
+            c, s_ = torch.cat([c, c]), torch.cat([s_, s_])
+            q_rot = G.bf16_round(qkv[0] * c + O.rotate_half(qkv[0]) * s_)
+            k_new = G.bf16_round(qkv[1] * c + O.rotate_half(qkv[1]) * s_)
+            Kc, Vc = K.clone(), V.clone()
+            Kc[:, pos], Vc[:, pos] = k_new, qkv[2]
+            d_q = qkv.reshape(-1).to("cuda", torch.bfloat16).contiguous()
+        else:
+            q_rot, Kc, Vc = qkv[0], K, V
+            d_q = q_rot.reshape(-1).to("cuda", torch.bfloat16).contiguous()
+        ref = G.bf16_round(_decode_attn_ref(q_rot, Kc, Vc, n))
+        outs = {}
+        for fat in (1, 0):
+            dK, dV = K.to("cuda", torch.bfloat16).contiguous(), V.to("cuda", torch.bfloat16).contiguous()
+            dVT = torch.zeros(H, d, S, dtype=torch.bfloat16, device="cuda")
+            out = torch.empty(H * d, dtype=torch.bfloat16, device="cuda")
+            d_pos = torch.tensor([pos], dtype=torch.int32, device="cuda")
+            assert lib.teo_tune_set(b"attn_fat", fat) == 0
+            try:
+                L.check(lib.teo_attn_decode(G.p(d_q), G.p(dK), G.p(dV), G.p(dVT) if rope else None, G.p(d_cs) if rope else None,
+                                            G.p(d_sn) if rope else None, G.p(out), G.p(part), G.p(d_pos), S, H, H, d, 1.0 / d ** 0.5,
+                                            L.TEO_BF16, 1, 0, 0, 0, G.stream()), "attn_decode")
+            finally:
+                lib.teo_tune_set(b"attn_fat", 1)
+            close_bf16(out, ref, ulps=2.0, floor=4e-3)
+            if rope:                                                          # the new token's K / V / V^T rows were appended
+                assert torch.equal(dK[:, pos].cpu().float(), Kc[:, pos]) and torch.equal(dV[:, pos].cpu().float(), Vc[:, pos])
+                assert torch.equal(dVT[:, :, pos].cpu().float(), Vc[:, pos])
+            outs[fat] = out.float().cpu()
+        close_bf16(outs[1], outs[0], ulps=2.0, floor=4e-3)                    # both kernels round P at their own chunk maxima
 
 
 def _hf_top_p_keep(logits, temperature, top_k, top_p):

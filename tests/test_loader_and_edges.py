@@ -226,12 +226,14 @@ def test_edge_cases_generate_and_forward():
     # stop candidate (VERDICT r02 missing #4: duplicates used to switch the device stop off)
     model.generate(input_ids=ids, images=frames, max_new_tokens=6, eos_token_id=2, stopping_criteria=[crit], chunk=4)
     assert model.engine.decode_state.n_stop_ids == 1 and int(model.engine.d_stop_ids[0]) == 2
-    crit2 = KeywordsStoppingCriteria(["</s>"], ByteTokenizer(), ids)
-    crit2.keyword_id_lists = [[ref[2]]]
-    crit2.keyword_ids = [torch.tensor([ref[2]])]
-    cut = model.generate(input_ids=ids, images=frames, max_new_tokens=6, eos_token_id=ref[2], stopping_criteria=[crit2], chunk=6)
-    assert cut[0, 5:].tolist() == ref[:ref.index(ref[2]) + 1]
-    assert int(model.engine.d_stop.item()) == 1          # the device loop itself stopped, inside the chunk
+    stop_tok = next((t for t in ref[1:] if t != ref[0]), None)       # a token the DECODE loop (not the prefill) produces first
+    if stop_tok is not None:
+        crit2 = KeywordsStoppingCriteria(["</s>"], ByteTokenizer(), ids)
+        crit2.keyword_id_lists = [[stop_tok]]
+        crit2.keyword_ids = [torch.tensor([stop_tok])]
+        cut = model.generate(input_ids=ids, images=frames, max_new_tokens=6, eos_token_id=stop_tok, stopping_criteria=[crit2], chunk=6)
+        assert cut[0, 5:].tolist() == ref[:ref.index(stop_tok) + 1]
+        assert int(model.engine.d_stop.item()) == 1      # the device-side id-suffix test fired inside the chunk
     # text-only prompt (images=None) and a prompt made only of an image
     t_ids = torch.tensor([[1, 5, 6, 7]], device=dev)
     lo, _ = O.llama_forward(sd["model.embed_tokens.weight"][t_ids.cpu()], None, None, None, sd, lcfg)

@@ -12,8 +12,11 @@ sys.path.insert(0, ROOT)
 from teochat_amd import _lib as L  # noqa: E402
 from tests import _gpu as G  # noqa: E402
 
+from tools import bench_shim  # noqa: E402
+
 bf = torch.bfloat16
 lib = L.load()
+SHIM = bench_shim.load()           # event-timed launch chains over the public C ABI (tools/bench_shim.hip)
 
 
 def timeit(fn, iters=20, warm=3):
@@ -40,7 +43,7 @@ def bench_gemv():
         y = torch.empty(N, dtype=bf, device="cuda")
         arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
         avg = C.c_float(0)
-        L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, None, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
+        L.check(SHIM.teo_bench_gemv_chain(x.data_ptr(), pp, None, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
                                         flags, L.TEO_BF16, 10, C.byref(avg), G.stream()), "chain")
         us = avg.value * 1e3
         print(f"gemv {name:8s} N={N:6d} K={K:6d}: {us:7.2f} us  {N * K * 2 / us / 1e3:7.1f} GB/s", flush=True)
@@ -61,7 +64,7 @@ def bench_gemv_mall():
             for n in (1, nrot):
                 arr, pp = L.ptr_array([w.data_ptr() for w in Ws[:n]])
                 avg = C.c_float(0)
-                L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, None, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K,
+                L.check(SHIM.teo_bench_gemv_chain(x.data_ptr(), pp, None, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K,
                                                 1e-5, flags, L.TEO_BF16, 20, C.byref(avg), G.stream()), "chain")
                 us = avg.value * 1e3
                 print(f"mall nt={nt} {name:7s} rot={n:2d} ({N * K * 2 / 1e6:6.1f} MB): {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s", flush=True)
@@ -102,7 +105,7 @@ def bench_skinny():
                         continue
                     lib.teo_tune_set(b"skinny_tiles", tiles)
                     avg = C.c_float(0)
-                    L.check(lib.teo_time_skinny_chain(x.data_ptr(), pp, pp2, n, nw.data_ptr() if norm else None, y.data_ptr(), MB, N, K, flags | tiled, 10, C.byref(avg),
+                    L.check(SHIM.teo_bench_skinny_chain(x.data_ptr(), pp, pp2, n, nw.data_ptr() if norm else None, y.data_ptr(), MB, N, K, flags | tiled, 10, C.byref(avg),
                                                       G.stream()), "chain")
                     us = avg.value * 1e3
                     line += f"  T{tiles} {us:6.1f}us {N * K * wb / us / 1e3:6.0f}GB/s"
@@ -136,7 +139,7 @@ def bench_gemv_fp8():
         arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
         arr2, pp2 = L.ptr_array([s_.data_ptr() for s_ in Ss])
         avg = C.c_float(0)
-        L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, pp2, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
+        L.check(SHIM.teo_bench_gemv_chain(x.data_ptr(), pp, pp2, n, nw.data_ptr() if norm else None, y.data_ptr(), N, K, 1e-5,
                                         flags, L.TEO_BF16, 10, C.byref(avg), G.stream()), "chain")
         us = avg.value * 1e3
         print(f"gemv fp8 {name:8s} N={N:6d} K={K:6d}: {us:7.2f} us  {N * K / us / 1e3:7.1f} GB/s", flush=True)
@@ -165,7 +168,7 @@ def bench_gemv_sweep():
                     y = torch.empty(N, dtype=bf, device="cuda")
                     arr, pp = L.ptr_array([w.data_ptr() for w in Ws])
                     avg = C.c_float(0)
-                    L.check(lib.teo_time_gemv_chain(x.data_ptr(), pp, None, len(Ws), nw.data_ptr() if norm else None, y.data_ptr(),
+                    L.check(SHIM.teo_bench_gemv_chain(x.data_ptr(), pp, None, len(Ws), nw.data_ptr() if norm else None, y.data_ptr(),
                                                     N, K, 1e-5, flags, L.TEO_BF16, 5, C.byref(avg), G.stream()), "chain")
                     us = avg.value * 1e3
                     tot += us
