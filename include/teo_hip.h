@@ -371,6 +371,16 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
 
 /* hipGraph form of the same step: capture once, replay per token. */
 typedef struct teo_graph teo_graph;
+/* Overlapped decode steps (round 3): n_steps steps of teo_llama_decode_step's arithmetic with the step's kernels launched as a CHAIN
+ * (AQL barrier bit cleared, one device-side progress word: a kernel's launch ramp and first weight block run under the tail of its
+ * predecessor; see csrc/common.h "launch chain").  Plain launches, no hipGraph: pos0 = position of the token fed by the first step
+ * (= tokens in the cache; the host knows it), step i runs at pos0 + i.  Needs bf16, head_dim 128 (teo_llama_decode_chain_supported);
+ * the workspace is teo_llama_decode_workspace_bytes(), armed by teo_llama_decode_begin.  teo_llama_decode_chain_error reads the
+ * chain's error word (a bounded wait that gave up: results invalid) after synchronising the stream: 0 = fine. */
+int teo_llama_decode_chain_supported(const teo_llama_desc* d);
+int teo_llama_decode_steps(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace, size_t workspace_bytes, int n_steps,
+                           int pos0, teo_stream_t stream);
+int teo_llama_decode_chain_error(const teo_llama_desc* d, void* d_workspace, size_t workspace_bytes, int* host_flag, teo_stream_t stream);
 /* Measurement aid: ONE decode step (plain launches, not a graph replay) in which every kernel launch carries its own start / stop
  * events (hipExtLaunchKernel: the dispatch's execution timestamps -- kernel time only, what rocprofv3 --kernel-trace reports).
  * ms_out[c] = summed kernel milliseconds of class c over the step, count_out[c] = launches of that class.  Same arithmetic and

@@ -126,6 +126,9 @@ _SIGS = {
     "teo_llama_decode_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc)]),
     "teo_llama_decode_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_decode_chain_supported": (C.c_int, [C.POINTER(LlamaDesc)]),
+    "teo_llama_decode_steps": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
+    "teo_llama_decode_chain_error": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]),
     "teo_llama_decode_step_profile": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int),
                                                 C.c_void_p]),
     "teo_llama_decode_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t,

@@ -35,6 +35,10 @@ size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
 int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out, int* count_out,
                               hipStream_t st);
+bool llama_decode_chain_ok(const teo_llama_desc* d);
+int llama_decode_chain_steps(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, int n_steps, int pos0, bool ordered,
+                             hipStream_t st);
+int llama_decode_chain_error(const teo_llama_desc* d, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
 int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
                         teo_graph** out);
@@ -299,6 +303,31 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
         const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc;
     }
     return llama_decode_step(d, st, ws, wsb, ST(s));
+}
+
+int teo_llama_decode_chain_supported(const teo_llama_desc* d) {
+    if (!d) return 0;
+    return llama_decode_chain_ok(d) ? 1 : 0;
+}
+
+int teo_llama_decode_steps(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, int n_steps, int pos0, teo_stream_t s) {
+    ENTER();
+    NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
+    NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
+    NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
+    TEO_CHECK_ARG(n_steps >= 0, "teo_llama_decode_steps: n_steps %d", n_steps);
+    if (st->do_sample) {
+        NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "teo_llama_decode_steps: temperature %g", st->temperature);
+        const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc;
+    }
+    if (!llama_decode_chain_ok(d)) { set_error("teo_llama_decode_steps: this model / dtype has no overlapped step (use teo_llama_decode_step)"); return TEO_ERR_UNSUPPORTED; }
+    return llama_decode_chain_steps(d, st, ws, wsb, n_steps, pos0, false, ST(s));
+}
+
+int teo_llama_decode_chain_error(const teo_llama_desc* d, void* ws, size_t wsb, int* host_flag, teo_stream_t s) {
+    ENTER();
+    NEED(d, "desc"); NEED(ws, "workspace"); NEED(host_flag, "host_flag");
+    return llama_decode_chain_error(d, ws, wsb, host_flag, ST(s));
 }
 
 int teo_llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, float* ms_out, int* count_out,

@@ -305,7 +305,10 @@ static int g_fused_combine = 0;   // 1: the last workgroup of a head merges the 
 int g_rope_in_attn = -1;          // decode RoPE + KV append: 0 = in the QKV GEMV epilogue, 1 = inside the attention kernel,
                                    // -1 = auto (measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0,
                                    // fp8 weights 2.216 vs 2.234 in favour of 1)
-static int g_attn_fat = 1;        // decode attention for bf16 / head_dim 128: the fat-split kernel of attn_fat.hip (0: round-2 kernels)
+static int g_attn_fat = 0;        // decode attention for bf16 / head_dim 128: 1 = the fat-split kernel of attn_fat.hip + record merge in the o-projection
+                                  // GEMV (no combine launch).  Measured on MI355X (round 3, profiles/r03_decode_attention_ab.md): a tie at
+                                  // ctx 2300 (2.713 vs 2.706 ms/token), slower at ctx 700 (2.643 vs 2.582) and 4250 (2.957 vs 2.886) -- off.
+bool attn_fat_enabled() { return g_attn_fat != 0 && g_fused_combine == 0; }
 int attn_tune_set(const char* key, int value) {
     if (!strcmp(key, "attn_fat")) { g_attn_fat = value != 0; return 0; }
     if (!strcmp(key, "attn_flash")) { g_attn_flash = value != 0; return 0; }
@@ -629,10 +632,13 @@ __global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* _
     const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys (<= 256)
     const int G = 512 / hd;                                                 // hd is a power of two <= 256
     const int g = tid / hd, d = tid % hd;
-    // the first 8 splits of this thread are requested together with the split statistics (they do not depend on them)
-    float v0[8];
+    // the first NB splits of this thread are requested together with the split statistics (they do not depend on them): ONE round
+    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split; round 2 had NB = 8 and a second, dependent
+    // batch from 33 splits on, i.e. for every C3 step)
+    constexpr int NB = 12;
+    float v0[NB];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v0[i] = pb[(long long)min(g + i * G, nact - 1) * stride + 2 + d];
+    for (int i = 0; i < NB; ++i) v0[i] = pb[(long long)min(g + i * G, nact - 1) * stride + 2 + d];
     float m0 = -INFINITY, l0 = 0.f;
     if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
     float M = wave_max(m0);
@@ -647,8 +653,8 @@ __global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* _
     const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
     float a = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a += (g + i * G < nact) ? v0[i] * w[min(g + i * G, 255)] : 0.f;
-    for (int s0 = g + 8 * G; s0 < nact; s0 += 8 * G) {
+    for (int i = 0; i < NB; ++i) a += (g + i * G < nact) ? v0[i] * w[min(g + i * G, 255)] : 0.f;
+    for (int s0 = g + NB * G; s0 < nact; s0 += 8 * G) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = pb[(long long)min(s0 + i * G, nact - 1) * stride + 2 + d];
@@ -666,7 +672,9 @@ __global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* _
 
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
     const int nsplit = cdiv(S_max, 32);      // sized for the smallest chunk
-    return (size_t)batch * heads * nsplit * (hd + 2) * sizeof(float);
+    const size_t small = (size_t)batch * heads * nsplit * (hd + 2) * sizeof(float);
+    const size_t fat = (size_t)batch * heads * ATTN_FAT_MAX_SPLITS * ATTN_FAT_REC * sizeof(float);      // attn_fat.hip records
+    return small > fat ? small : fat;
 }
 // the exported primitive (teo_attn_decode) keeps the arrival counters of the fused combine behind the partial records
 size_t attn_decode_counters_offset(int heads, int hd, int S_max, int batch) {

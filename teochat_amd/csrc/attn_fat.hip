@@ -40,20 +40,24 @@ __device__ __forceinline__ uint4 fat_pack(const float* f) {
 }
 
 constexpr int FAT_HD = 128, FAT_LPR = 16, FAT_VE = 8, FAT_RPI = 4;     // 16 lanes x 8 bf16 per key row, 4 rows per wave instruction
-constexpr int FAT_NW = 16, FAT_NI = 5;                                  // waves per workgroup, row-group loads per wave and operand
-constexpr int FAT_KPW_MAX = FAT_NI * FAT_RPI, FAT_KEYS_MAX = FAT_NW * FAT_KPW_MAX;      // 20 keys per wave, 320 per workgroup
+// waves per workgroup x row-group loads per wave and operand: 16 x 5 (1024 threads) or 8 x 10 (512 threads, <= 128 VGPRs: the form
+// of the overlapped decode step, which wants the next kernel of the chain resident beside it); 320 keys per workgroup either way
+constexpr int FAT_KEYS_MAX = 320;
 
 int attn_fat_nsplit(int S_max) { return cdiv(S_max, FAT_KEYS_MAX); }
 bool attn_fat_ok(int hd, int dtype, int S_max) { return hd == FAT_HD && dtype == TEO_BF16 && attn_fat_nsplit(S_max) <= ATTN_FAT_MAX_SPLITS; }
 
-// partial record of (head h, split sp): part[(h * NS + sp) * 130 + {0: chunk max, 1: sum of unrounded P, 2..129: sum P_bf16 * v}]
-template <bool ROPE>
-__global__ __launch_bounds__(1024) void attn_decode_fat_kernel(const bf16_t* __restrict__ q, bf16_t* __restrict__ kc,
+// partial record of (head h, split sp): part[(h * NS + sp) * ATTN_FAT_REC + {0: chunk max, 1: sum of unrounded P, 4..131: sum P_bf16 * v}]
+template <bool ROPE, int NW, int NI>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void attn_decode_fat_kernel(const bf16_t* __restrict__ q, bf16_t* __restrict__ kc,
                                                                bf16_t* __restrict__ vc, bf16_t* __restrict__ vtc,
                                                                const float* __restrict__ cs, const float* __restrict__ sn,
                                                                float* __restrict__ part, const int* __restrict__ d_pos, int S_max,
-                                                               int heads, int kv_heads, float scale, int nsplit, AttnBatch bt) {
-    constexpr int HD = FAT_HD, LPR = FAT_LPR, VE = FAT_VE, RPI = FAT_RPI, NI = FAT_NI, NW = FAT_NW;
+                                                               int heads, int kv_heads, float scale, int nsplit, AttnBatch bt,
+                                                               int pos_arg, Chain ch) {
+    constexpr int HD = FAT_HD, LPR = FAT_LPR, VE = FAT_VE, RPI = FAT_RPI;
+    constexpr int FAT_KPW_MAX = NI * RPI;
+    static_assert(NW * NI * RPI == FAT_KEYS_MAX, "320 keys per workgroup");
     {
         const long long bz = blockIdx.z;
         q += bz * bt.q_stride;
@@ -61,22 +65,25 @@ __global__ __launch_bounds__(1024) void attn_decode_fat_kernel(const bf16_t* __r
         vc += bz * bt.cache_stride;
         if (vtc) vtc += bz * bt.cache_stride;
         d_pos += bz;
-        part += bz * (long long)heads * nsplit * (HD + 2);
+        part += bz * (long long)heads * nsplit * ATTN_FAT_REC;
     }
     __shared__ float sc[FAT_KEYS_MAX];
     __shared__ float red[2 * NW];
     __shared__ float obuf[NW][HD];
     const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hk = h / (heads / kv_heads);
-    const int kv_len = *d_pos + 1;
+    const bool coh = ch.on != 0;
+    const int kv_len = (pos_arg >= 0 ? pos_arg : *d_pos) + 1;          // chained launch: the position is an argument (d_pos may still be in flight)
     // keys of this split: an equal share of the current context, a whole number of row groups per wave
     const int kpw = (int)((((long long)kv_len + nsplit - 1) / nsplit + NW - 1) / NW);   // keys per wave, <= FAT_KPW_MAX because nsplit >= S_max / 320
     const int per = kpw * NW;
     const int c0 = sp * per;
-    float* out = part + ((long long)h * nsplit + sp) * (HD + 2);
+    float* out = part + ((long long)h * nsplit + sp) * ATTN_FAT_REC;
     if (c0 >= kv_len) {                                        // short context: this split holds no key -> neutral record
-        if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
-        if (tid < HD) out[2 + tid] = 0.f;
+        chain_wait(ch);                                        // (the previous reader of the records must be done before any store)
+        if (tid == 0) { act_st4(out, 0, __float_as_uint(-INFINITY), coh); act_st4(out, 4, 0u, coh); }
+        if (tid < HD) act_st4(out, (4 + tid) * 4, 0u, coh);
+        chain_signal(ch);
         return;
     }
     const int sub = lane % LPR, grp = lane / LPR;
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(1024) void attn_decode_fat_kernel(const bf16_t* __r
         const int j = min(kw0 + min(i * RPI + grp, kpw - 1), kv_len - 1);
         vr[i] = fat_ld_nt(vb + (long long)j * HD);
     }
+    chain_wait(ch);                                            // K / V of the cached keys are in flight; q comes from the predecessor
     float qf[VE], knew[VE], vnew[VE];
     const int pos = kv_len - 1;
     if (ROPE) {
@@ -109,18 +117,18 @@ __global__ __launch_bounds__(1024) void attn_decode_fat_kernel(const bf16_t* __r
             sf[e] = s4.x; sf[e + 1] = s4.y; sf[e + 2] = s4.z; sf[e + 3] = s4.w;
         }
         float own[VE], oth[VE];
-        fat_unpack(*reinterpret_cast<const uint4*>(q + h * HD + sub * VE), own);
-        fat_unpack(*reinterpret_cast<const uint4*>(q + h * HD + psub * VE), oth);
+        fat_unpack(act_ld16(q, (unsigned)(h * HD + sub * VE) * 2u, coh), own);
+        fat_unpack(act_ld16(q, (unsigned)(h * HD + psub * VE) * 2u, coh), oth);
 #pragma unroll
         for (int e = 0; e < VE; ++e) qf[e] = Elem<bf16_t>::round(own[e] * cf[e] + sgn * oth[e] * sf[e]);
-        const bf16_t* kraw = q + (long long)(heads + hk) * HD;
-        fat_unpack(*reinterpret_cast<const uint4*>(kraw + sub * VE), own);
-        fat_unpack(*reinterpret_cast<const uint4*>(kraw + psub * VE), oth);
+        const unsigned kraw_off = (unsigned)((heads + hk) * HD) * 2u;
+        fat_unpack(act_ld16(q, kraw_off + (unsigned)(sub * VE) * 2u, coh), own);
+        fat_unpack(act_ld16(q, kraw_off + (unsigned)(psub * VE) * 2u, coh), oth);
 #pragma unroll
         for (int e = 0; e < VE; ++e) knew[e] = Elem<bf16_t>::round(own[e] * cf[e] + sgn * oth[e] * sf[e]);
-        fat_unpack(*reinterpret_cast<const uint4*>(q + (long long)(heads + kv_heads + hk) * HD + sub * VE), vnew);
+        fat_unpack(act_ld16(q, (unsigned)((heads + kv_heads + hk) * HD + sub * VE) * 2u, coh), vnew);
     } else {
-        fat_unpack(*reinterpret_cast<const uint4*>(q + h * HD + sub * VE), qf);
+        fat_unpack(act_ld16(q, (unsigned)(h * HD + sub * VE) * 2u, coh), qf);
     }
     const uint4 qpk = fat_pack(qf);                           // q is bf16-exact: packed operand of v_dot2c_f32_bf16
     // ---- scores of this wave's keys
@@ -132,13 +140,15 @@ __global__ __launch_bounds__(1024) void attn_decode_fat_kernel(const bf16_t* __r
         if (ROPE && live && j == pos) {                        // the new token's key: not in the cache yet
             kraw = fat_pack(knew);
             if (h % (heads / kv_heads) == 0) {                 // one q head per kv head appends
-                *reinterpret_cast<uint4*>(kc + ((long long)hk * S_max + pos) * HD + sub * VE) = kraw;
+                // (write-through in a chained launch: later steps read these rows with ordinary loads from lines nobody cached)
+                const unsigned row_off = (unsigned)((((long long)hk * S_max + pos) * HD + sub * VE) * 2);
+                act_st16(kc, row_off, kraw, coh);
                 const uint4 pv = fat_pack(vnew);
-                *reinterpret_cast<uint4*>(vc + ((long long)hk * S_max + pos) * HD + sub * VE) = pv;
+                act_st16(vc, row_off, pv, coh);
                 if (vtc) {
                     const bf16_t* pe = reinterpret_cast<const bf16_t*>(&pv);
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) vtc[((long long)hk * HD + sub * VE + e) * S_max + pos] = pe[e];
+                    for (int e = 0; e < VE; ++e) act_st2(vtc, (unsigned)((((long long)hk * HD + sub * VE + e) * S_max + pos) * 2), pe[e], coh);
                 }
             }
         }
@@ -151,19 +161,20 @@ __global__ __launch_bounds__(1024) void attn_decode_fat_kernel(const bf16_t* __r
     }
     __syncthreads();
     // ---- split max / exp / sum: every wave redundantly over the 320 score slots (5 per lane)
-    float sv[NI];
+    constexpr int SPL = FAT_KEYS_MAX / 64;
+    float sv[SPL];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { sv[i] = sc[lane + 64 * i]; mx = fmaxf(mx, sv[i]); }
+    for (int i = 0; i < SPL; ++i) { sv[i] = sc[lane + 64 * i]; mx = fmaxf(mx, sv[i]); }
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { sv[i] = expf(sv[i] - mx); sum += sv[i]; }      // -inf -> 0
+    for (int i = 0; i < SPL; ++i) { sv[i] = expf(sv[i] - mx); sum += sv[i]; }      // -inf -> 0
     sum = wave_sum(sum);
     __syncthreads();
     if (wid == 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) sc[lane + 64 * i] = Elem<bf16_t>::round(sv[i]);
+        for (int i = 0; i < SPL; ++i) sc[lane + 64 * i] = Elem<bf16_t>::round(sv[i]);
     }
     __syncthreads();
     // ---- PV on this wave's keys
@@ -196,35 +207,69 @@ __global__ __launch_bounds__(1024) void attn_decode_fat_kernel(const bf16_t* __r
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += obuf[w][tid];
-        out[2 + tid] = t;
+        act_st4(out, (4 + tid) * 4, __float_as_uint(t), coh);
     }
-    if (tid == 0) { out[0] = mx; out[1] = sum; }
+    if (tid == 0) { act_st4(out, 0, __float_as_uint(mx), coh); act_st4(out, 4, __float_as_uint(sum), coh); }
+    chain_signal(ch);
 }
 
 // merge of the NS records of a head (also what gemv_o_combine does in its prologue, in the same order):
 //   M = max_s m_s;  w_s = exp(m_s - M);  o[d] = (sum_s w_s * o_s[d]) / (sum_s w_s * l_s), both sums in split order
 __global__ __launch_bounds__(128) void attn_decode_fat_combine_kernel(const float* __restrict__ part, bf16_t* __restrict__ o, int nsplit,
-                                                                      long long o_stride) {
+                                                                      long long o_stride, Chain ch) {
     const int h = blockIdx.x, d = threadIdx.x;
-    part += (long long)blockIdx.y * gridDim.x * nsplit * (FAT_HD + 2);
+    const bool coh = ch.on != 0;
+    part += (long long)blockIdx.y * gridDim.x * nsplit * ATTN_FAT_REC;
     o += (long long)blockIdx.y * o_stride;
-    const float* pb = part + (long long)h * nsplit * (FAT_HD + 2);
-    o[h * FAT_HD + d] = f2bf(attn_fat_merge(pb, nsplit, d));
+    const float* pb = part + (long long)h * nsplit * ATTN_FAT_REC;
+    chain_wait(ch);
+    float v;
+    if (coh) {                                     // same chains as attn_fat_merge, records through coherent loads
+        float M = -INFINITY;
+        float m[ATTN_FAT_MAX_SPLITS], l[ATTN_FAT_MAX_SPLITS], ov[ATTN_FAT_MAX_SPLITS];
+#pragma unroll
+        for (int s2 = 0; s2 < ATTN_FAT_MAX_SPLITS; ++s2) {
+            const unsigned off = (unsigned)(min(s2, nsplit - 1) * ATTN_FAT_REC) * 4u;
+            m[s2] = __uint_as_float(act_ld4(pb, off, true));
+            l[s2] = __uint_as_float(act_ld4(pb, off + 4u, true));
+            ov[s2] = __uint_as_float(act_ld4(pb, off + (unsigned)(4 + d) * 4u, true));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < ATTN_FAT_MAX_SPLITS; ++s2) M = fmaxf(M, s2 < nsplit ? m[s2] : -INFINITY);
+        float Ls = 0.f, a = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < ATTN_FAT_MAX_SPLITS; ++s2) {
+            if (s2 < nsplit) {
+                const float w = (m[s2] == -INFINITY) ? 0.f : expf(m[s2] - M);
+                Ls = fmaf(w, l[s2], Ls);
+                a = fmaf(w, ov[s2], a);
+            }
+        }
+        v = a / Ls;
+    } else {
+        v = attn_fat_merge(pb, nsplit, d);
+    }
+    act_st2(o, (unsigned)(h * FAT_HD + d) * 2u, f2bf(v), coh);
+    chain_signal(ch);
 }
 
 int attn_decode_fat(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o, float* part,
-                    const int* d_pos, int S_max, int heads, int kv_heads, float scale, hipStream_t st, AttnBatch bt, bool with_combine) {
+                    const int* d_pos, int S_max, int heads, int kv_heads, float scale, hipStream_t st, AttnBatch bt, bool with_combine,
+                    int pos_arg, const Chain* ch_attn, const Chain* ch_combine) {
     const int ns = attn_fat_nsplit(S_max);
     dim3 grid(heads, ns, bt.batch);
-    if (rope_cos)
-        TEO_KLAUNCH((attn_decode_fat_kernel<true>), grid, 1024, 0, st, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, rope_cos,
-                    rope_sin, part, d_pos, S_max, heads, kv_heads, scale, ns, bt);
-    else
-        TEO_KLAUNCH((attn_decode_fat_kernel<false>), grid, 1024, 0, st, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, rope_cos,
-                    rope_sin, part, d_pos, S_max, heads, kv_heads, scale, ns, bt);
+    Chain off;
+    memset(&off, 0, sizeof(off));
+    const Chain c1 = ch_attn ? *ch_attn : off, c2 = ch_combine ? *ch_combine : off;
+    const bool slim = ch_attn != nullptr;          // chained step: 8 waves x 10 row groups (512 threads, half of a CU's registers)
+#define TEO_FAT(RP, NWW, NII) TEO_KLAUNCH((attn_decode_fat_kernel<RP, NWW, NII>), grid, NWW * 64, 0, st, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, \
+                                          (bf16_t*)vtc, rope_cos, rope_sin, part, d_pos, S_max, heads, kv_heads, scale, ns, bt, pos_arg, c1)
+    if (rope_cos) { if (slim) TEO_FAT(true, 8, 10); else TEO_FAT(true, 16, 5); }
+    else { if (slim) TEO_FAT(false, 8, 10); else TEO_FAT(false, 16, 5); }
+#undef TEO_FAT
     if (with_combine) {
         prof_bump(1);
-        TEO_KLAUNCH(attn_decode_fat_combine_kernel, dim3(heads, bt.batch), 128, 0, st, (const float*)part, (bf16_t*)o, ns, bt.o_stride);
+        TEO_KLAUNCH(attn_decode_fat_combine_kernel, dim3(heads, bt.batch), 128, 0, st, (const float*)part, (bf16_t*)o, ns, bt.o_stride, c2);
         prof_bump(-1);
     }
     TEO_LAUNCH_CHECK("attn_decode_fat");

@@ -28,19 +28,27 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
 constexpr int ATTN_FAT_MAX_SPLITS = 16;
 int attn_fat_nsplit(int S_max);
 bool attn_fat_ok(int hd, int dtype, int S_max);
-// o[d] of one head from its `nsplit` records {m, l, o[128]} (stride 130 floats), splits merged in index order
+// record of (head, split): ATTN_FAT_REC floats = {m, l, -, -, o[128]} (o 16-byte aligned); a head's records are contiguous.
+constexpr int ATTN_FAT_REC = 132;
+// o[d] of one head from its `nsplit` records, splits merged in index order:
+//   M = max_s m_s;  w_s = exp(m_s - M);  o[d] = (sum_s w_s * o_s[d]) / (sum_s w_s * l_s)   (fma chains in split order)
 __device__ __forceinline__ float attn_fat_merge(const float* __restrict__ pb, int nsplit, int d) {
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[s * 130]);
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[s * ATTN_FAT_REC]);
     float Ls = 0.f, a = 0.f;
     for (int s = 0; s < nsplit; ++s) {
-        const float m = pb[s * 130];
+        const float m = pb[s * ATTN_FAT_REC];
         const float w = (m == -INFINITY) ? 0.f : expf(m - M);
-        Ls = fmaf(w, pb[s * 130 + 1], Ls);
-        a = fmaf(w, pb[s * 130 + 2 + d], a);
+        Ls = fmaf(w, pb[s * ATTN_FAT_REC + 1], Ls);
+        a = fmaf(w, pb[s * ATTN_FAT_REC + 4 + d], a);
     }
     return a / Ls;
 }
+bool attn_fat_enabled();
+// o-projection GEMV whose prologue merges the fat-split records (gemv.hip): y = res + Wo . merge(records)
+bool gemv_o_merge_ok(int heads, int hd, int K, int N, int w_fp8, int dtype);
+int gemv_o_merge(const float* part, int nsplit, const void* W, const float* wscale, int w_fp8, const void* res, void* y, int N, int K,
+                 hipStream_t st);
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;
     long long q_stride = 0, cache_stride = 0, o_stride = 0;
@@ -50,7 +58,12 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
                 hipStream_t st, AttnBatch bt = AttnBatch(), int* counters = nullptr);   // counters: [batch*heads] zeroed ints -> fused combine
 
 int attn_decode_fat(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o, float* part,
-                    const int* d_pos, int S_max, int heads, int kv_heads, float scale, hipStream_t st, AttnBatch bt, bool with_combine);
+                    const int* d_pos, int S_max, int heads, int kv_heads, float scale, hipStream_t st, AttnBatch bt, bool with_combine,
+                    int pos_arg = -1, const Chain* ch_attn = nullptr, const Chain* ch_combine = nullptr);
+// GEMV of the overlapped decode step (gemv.hip): epi 0 plain (+res), 1 SwiGLU16, 2 fp32 output
+bool ck_gemv_ok(int N, int K, int w_fp8);
+int ck_gemv(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, const void* res, void* y, int N, int K,
+            float eps, int epi, int blocks, const Chain& ch, hipStream_t st);
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                    void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,
                    hipStream_t st);
@@ -67,7 +80,7 @@ int sample_topk(const float* logits, long long* tok, int vocab, float temperatur
                 unsigned long long draw, hipStream_t st);
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
                 hipStream_t st, int batch = 1, int out_stride = 0, const void* g0 = nullptr, void* hg = nullptr,
-                float* ssq = nullptr, int nparts = 0);
+                float* ssq = nullptr, int nparts = 0, const Chain* chain = nullptr);
 int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch = 1);
 int embed_token_emit(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch,
                      const void* g, void* hg, float* ssq, int nparts);

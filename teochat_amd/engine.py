@@ -449,6 +449,20 @@ class TeoEngine:
             raise ValueError(f"decode_steps: {self.steps_since_begin + n} tokens since decode_begin exceed the output buffer "
                              f"({self.max_new_cap}); call decode_begin again or build the engine with a larger max_new")
         ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
+        if use_graph and self.lib.teo_llama_decode_chain_supported(C.byref(self.llama_desc)):
+            # overlapped steps (launch chain): plain any-order launches with device-side hand-over, no hipGraph; the position of
+            # the token fed by the first step is host-known (= tokens in the cache)
+            with self.phase() as st:
+                L.check(self.lib.teo_llama_decode_steps(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(), n,
+                                                        self.cache_len, st), "teo_llama_decode_steps")
+                flag = C.c_int(0)
+                L.check(self.lib.teo_llama_decode_chain_error(C.byref(self.llama_desc), _p(ws), ws.numel(), C.byref(flag), st),
+                        "teo_llama_decode_chain_error")          # synchronises the engine stream (the host looks at the tokens next anyway)
+                if flag.value:
+                    raise RuntimeError("decode chain: a kernel gave up waiting for its predecessor (results invalid)")
+            self.cache_len += n
+            self.steps_since_begin = getattr(self, "steps_since_begin", 0) + n
+            return
         with self.phase() as st:
             if use_graph:
                 if self._graph is None or self._graph_ws != ws.data_ptr():

@@ -24,7 +24,7 @@ def anchor_gains(vocab, device="cpu"):
     the cycle a_0 -> a_1 -> ... with context-decided jumps where another anchor's random projection wins -- a VARIED token stream
     whose every decision depends on the token fed at that step, on its position and on the cache, with margins far above the bf16
     noise at ~95 % of the positions.  Gross errors (stale input token, wrong position, a broken layer) change the stream; errors at
-    the rounding level are what the logit comparisons against the oracle are for (tests/test_true_shapes_gpu.py)."""
+    the rounding level are what the logit comparisons of tests/test_true_shapes_gpu.py are for."""
     g = torch.ones(vocab, dtype=torch.float32, device=device)
     g[ANCHOR_BASE_ID:ANCHOR_BASE_ID + ANCHOR_COUNT] = ANCHOR_GAIN
     return g

@@ -792,8 +792,8 @@ def test_attn_decode_fat_split_vs_reference_and_round2_kernel(S, ctxs, rope):
                 lib.teo_tune_set(b"attn_fat", 1)
             close_bf16(out, ref, ulps=2.0, floor=4e-3)
             if rope:                                                          # the new token's K / V / V^T rows were appended
-                assert torch.equal(dK[:, pos].cpu().float(), Kc[:, pos]) and torch.equal(dV[:, pos].cpu().float(), Vc[:, pos])
-                assert torch.equal(dVT[:, :, pos].cpu().float(), Vc[:, pos])
+                close_bf16(dK[:, pos], Kc[:, pos], ulps=1.0, floor=1e-6)      # rotation: fp32 contraction order may flip a rounding
+                assert torch.equal(dV[:, pos].cpu().float(), Vc[:, pos]) and torch.equal(dVT[:, :, pos].cpu().float(), Vc[:, pos])
             outs[fat] = out.float().cpu()
         close_bf16(outs[1], outs[0], ulps=2.0, floor=4e-3)                    # both kernels round P at their own chunk maxima
 
