@@ -602,8 +602,26 @@ class KVCache:
         return self.k[i], self.v[i]
 
 
-def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, mode="exact"):
-    """tf LlamaDecoderLayer/LlamaAttention/LlamaMLP (called from llava_llama.py:88-99)."""
+def quant_rows_e4m3(x):
+    """Per-token (per-row) activation quantisation of the w8a8 prefill path (config C5; csrc/gemm_fp8.hip quant_rows_fp8): the
+    reference has no counterpart (its 8-bit option is bitsandbytes, eval.py:52-53) -- this restates the DEFINITION the kernels
+    implement: s = max|x| * (1/448) in fp32 (1 for an all-zero row), q = e4m3_rne(x * (1/s)), value used by the GEMM = q * s.
+    Returns the dequantised tensor (same shape / dtype as x)."""
+    xf = x.to(torch.float32)
+    amax = xf.abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax * torch.tensor(1.0 / 448.0, dtype=torch.float32), torch.ones_like(amax))
+    q = (xf * (1.0 / s)).to(torch.float8_e4m3fn).to(torch.float32)
+    return (q * s).to(x.dtype)
+
+
+def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, mode="exact", act_quant=None):
+    """tf LlamaDecoderLayer/LlamaAttention/LlamaMLP (called from llava_llama.py:88-99).
+    act_quant="e4m3": the input of every Linear layer goes through quant_rows_e4m3 first (w8a8 prefill of config C5; the weights
+    in `sd` are then expected to be the dequantised e4m3 weights)."""
+    if act_quant not in (None, "e4m3"):
+        raise ValueError(f"unknown act_quant {act_quant!r}")
+    if act_quant:
+        return _llama_layer_w8a8(h, i, sd, cfg, cos, sin, visible, cache, R, mode)
     B, S, D = h.shape
     H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     pre = f"model.layers.{i}."
@@ -630,8 +648,37 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, m
     return h
 
 
+def _llama_layer_w8a8(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, mode):
+    """llama_layer with per-token e4m3 activations in front of the four Linear layers (same rounding boundaries otherwise)."""
+    B, S, D = h.shape
+    H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    pre = f"model.layers.{i}."
+    Q = quant_rows_e4m3
+    n1 = Q(R(rmsnorm(h, sd[pre + "input_layernorm.weight"], cfg.rms_norm_eps)))
+    q = R(n1 @ sd[pre + "self_attn.q_proj.weight"].to(h.dtype).t()).view(B, S, H, d).transpose(1, 2)
+    k = R(n1 @ sd[pre + "self_attn.k_proj.weight"].to(h.dtype).t()).view(B, S, Hk, d).transpose(1, 2)
+    v = R(n1 @ sd[pre + "self_attn.v_proj.weight"].to(h.dtype).t()).view(B, S, Hk, d).transpose(1, 2)
+    c, s = cos.unsqueeze(1), sin.unsqueeze(1)
+    q = R(q * c + rotate_half(q) * s)
+    k = R(k * c + rotate_half(k) * s)
+    kk, vv = cache.append(i, k, v)
+    if Hk != H:
+        rep = H // Hk
+        kk = kk[:, :, None].expand(B, Hk, rep, kk.shape[2], d).reshape(B, H, -1, d)
+        vv = vv[:, :, None].expand(B, Hk, rep, vv.shape[2], d).reshape(B, H, -1, d)
+    o = attention_core(q, kk, vv, visible, 1.0 / math.sqrt(d), R, mode)
+    o = Q(R(o.transpose(1, 2).reshape(B, S, D)))
+    h = R(h + o @ sd[pre + "self_attn.o_proj.weight"].to(h.dtype).t())
+    n2 = Q(R(rmsnorm(h, sd[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)))
+    g = n2 @ sd[pre + "mlp.gate_proj.weight"].to(h.dtype).t()
+    u = n2 @ sd[pre + "mlp.up_proj.weight"].to(h.dtype).t()
+    a = Q(R(F.silu(g) * u))
+    h = R(h + a @ sd[pre + "mlp.down_proj.weight"].to(h.dtype).t())
+    return h
+
+
 def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[KVCache], sd, cfg: LlamaCfg,
-                  rounding=None, last_only=False, return_hidden=False, decode_kernel=False):
+                  rounding=None, last_only=False, return_hidden=False, decode_kernel=False, act_quant=None):
     """LlamaModel + lm_head.  inputs_embeds [B,S,D]; position_ids [B,S] or None (-> past..past+S);
     attention_mask [B, past+S] of 0/1 or None.  Returns fp logits [B,S,V] (or [B,1,V])."""
     R = _rounder(rounding)
@@ -651,7 +698,7 @@ def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[K
         visible = visible & (attention_mask[:, None, None, :T] != 0)
     mode = kernel_attention_mode(rounding, cfg.head_dim, S, decode_kernel)
     for i in range(cfg.num_hidden_layers):
-        h = llama_layer(h, i, sd, cfg, cos, sin, visible, cache, R, mode)
+        h = llama_layer(h, i, sd, cfg, cos, sin, visible, cache, R, mode, act_quant)
     if last_only:
         h = h[:, -1:, :]
     hn = R(rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps))

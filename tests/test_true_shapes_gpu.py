@@ -410,3 +410,142 @@ def test_c3_full_depth_prefill_against_the_oracle():
     # 32-layer random walk of 1-ulp flips on random weights; measured (round 3) max 6.0e-2 / p99 2.0e-2 / median 4.9e-3 + ~35 %
     assert mx < 8e-2 and p99 < 2.7e-2 and med < 7e-3
     assert bool(agree[decisive].all())
+
+
+# ------------------------------------------------------------------------------------------------------------ X1: w8a8 prefill
+def _q_rows(x):
+    """(e4m3 bytes [M, K] uint8, scales [M] fp32) of the oracle's per-token quantiser, for feeding the GPU GEMM the oracle's operand."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax * torch.tensor(1.0 / 448.0), torch.ones_like(amax))
+    q = (xf * (1.0 / s)).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), s.reshape(-1).contiguous()
+
+
+def test_w8a8_prefill_layer_walk_at_7b_shapes():
+    """Config C5's "fp8 weight path on CDNA4 MFMA" for the prefill: every Linear layer as a w8a8 GEMM on
+    v_mfma_scale_f32_16x16x128_f8f6f4 (per-token e4m3 activations, per-row e4m3 weights with power-of-two scales), at the true
+    LLaMA-2-7B shapes, against the oracle's quantised-activation mode (O.quant_rows_e4m3 + the dequantised weights):
+      * the quantiser kernel reproduces the oracle's bytes and scales exactly (no norm), and within the 1-ulp norm flips otherwise;
+      * each GEMM, fed the ORACLE's quantised operand, lands within one bf16 ulp (+ the instruction's 128-term partial sums:
+        measured <= 1.1e-5 of sum|a||w|) on every element, through the production dispatch (128x128 / wide / 256x256 / stream-K).
+    This replaces the round-2 end-to-end bound `rms < 0.35` (VERDICT r02 weak #10)."""
+    from teochat_amd.engine import quantize_fp8_rows
+    _threads()
+    t0 = time.perf_counter()
+    report = []
+    lib = G.lib()
+    S, D, Fi = 2168, 4096, 11008
+    gen = torch.Generator().manual_seed(3)
+    gw = GemmWs()
+
+    def qgemm(x, W, tag, res=None, flags=0, norm_w=None):
+        """x [S, K] bf16-valued (pre-norm if norm_w), W [N, K] fp32 -> GPU w8a8 vs oracle on the same quantised operand."""
+        q8, sw, Wdq = quantize_fp8_rows(W.to(bf))
+        Wdq = Wdq.float()
+        xin = R(O.rmsnorm(x, norm_w, 1e-5)) if norm_w is not None else x
+        x_dq = O.quant_rows_e4m3(xin)
+        # (1) the device quantiser
+        d_x = G.dev(x, bf)
+        d_q = torch.empty(S, x.shape[1], dtype=torch.uint8, device=DEV)
+        d_s = torch.empty(S, dtype=torch.float32, device=DEV)
+        d_nw = G.dev(norm_w, bf) if norm_w is not None else None
+        L.check(lib.teo_quant_rows_fp8(G.p(d_x), G.p(d_nw), G.p(d_q), G.p(d_s), S, x.shape[1], x.shape[1], 1e-5, G.stream()), "quant")
+        oq, os_ = _q_rows(xin)
+        same = float((d_q.cpu() == oq).float().mean())
+        srel = float(((d_s.cpu() - os_).abs() / os_).max())
+        if norm_w is None:
+            assert same == 1.0 and srel == 0.0, (tag, same, srel)
+        else:
+            assert same > 0.995 and srel < 2.0 ** -7, (tag, same, srel)        # 1-ulp flips of the fused norm move a few bytes
+        # (2) the GEMM on the oracle's operand
+        A8, sa = oq.to(DEV), os_.to(DEV)
+        N = W.shape[0]
+        Nc = N // 2 if flags & L.GEMM_SWIGLU16 else N
+        out = torch.empty(S, Nc, dtype=bf, device=DEV)
+        d_res = G.dev(res, bf) if res is not None else None
+        L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(q8.to(DEV)), G.p(sw.to(DEV)), G.p(d_res), G.p(out), S, N, x.shape[1], x.shape[1], Nc,
+                                    flags, L.TEO_BF16, G.p(gw.ws), G.stream()), "gemm_fp8_ws")
+        kern = lib.teo_last_kernel().decode()
+        return x_dq, Wdq, out, same, kern
+
+    def check(out, ref, tag, same, kern):
+        got = out.float().cpu()
+        d = (got - ref).abs()
+        tol = 1.25 * (2.0 ** -7) * ref.abs() + 2e-3
+        bad = int((d > tol).sum())
+        report.append(f"  {tag:<44s} kernel={kern:<18s} quantiser bytes equal {same * 100:7.3f} %  GEMM beyond 1 ulp: {bad} of {d.numel()}")
+        assert bad == 0, f"{tag}: {bad} elements beyond tolerance (max {float(d.max()):.3e})"
+
+    h = _rand((S, D), gen)
+    g_in = R(1.0 + 0.1 * torch.randn(D, generator=gen))
+    Wqkv = _rand((3 * D, D), gen, 0.02)
+    x_dq, Wdq, out, same, kern = qgemm(h, Wqkv, "qkv", norm_w=g_in)
+    check(out, R(x_dq @ Wdq.t()), "rmsnorm + quantise + qkv GEMM N=12288", same, kern)
+    a = _rand((S, D), gen)
+    Wo = _rand((D, D), gen, 0.02)
+    x_dq, Wdq, out, same, kern = qgemm(a, Wo, "o", res=h)
+    check(out, R(h + x_dq @ Wdq.t()), "quantise + o GEMM + residual", same, kern)
+    gate, up = _rand((Fi, D), gen, 0.02), _rand((Fi, D), gen, 0.02)
+    Wgu = interleave_gate_up(gate, up)
+    q8, sw, Wgu_dq = quantize_fp8_rows(Wgu.to(bf))
+    g_post = R(1.0 + 0.1 * torch.randn(D, generator=gen))
+    x_dq, _, out, same, kern = qgemm(h, Wgu, "gate/up", flags=L.GEMM_SWIGLU16, norm_w=g_post)
+    Wf = Wgu_dq.float().view(Fi // 16, 2, 16, D)
+    gate_dq, up_dq = Wf[:, 0].reshape(Fi, D), Wf[:, 1].reshape(Fi, D)
+    check(out, R(F.silu(x_dq @ gate_dq.t()) * (x_dq @ up_dq.t())), "rmsnorm + quantise + gate/up + SwiGLU N=22016", same, kern)
+    act = _rand((S, Fi), gen, 0.5)
+    Wd = _rand((D, Fi), gen, 0.02)
+    x_dq, Wdq, out, same, kern = qgemm(act, Wd, "down", res=h)
+    check(out, R(h + x_dq @ Wdq.t()), "quantise + down GEMM + residual K=11008", same, kern)
+    print("\n[w8a8 prefill walk at 7B shapes: device quantiser + fp8 MFMA GEMM vs the oracle's quantised-activation mode]\n" + "\n".join(report)
+          + f"\n  wall {time.perf_counter() - t0:.1f} s")
+
+
+def test_c5_w8a8_prefill_against_the_oracle_at_full_width():
+    """w8a8 prefill end to end (tune prefill_fp8 = 1), N_LAYERS_DEEP layers at 7B width, L = 2168, against the oracle with
+    act_quant="e4m3" on the engine's dequantised weights: logits statistics reported and bounded like the bf16 leg of (b)."""
+    from teochat_amd.config import teochat_7b_config
+    from teochat_amd.engine import TeoEngine, quantize_fp8_rows
+    from teochat_amd.model import LlavaLlamaForCausalLM
+    from teochat_amd.synthetic import synthetic_state_dict
+    _threads()
+    t0 = time.perf_counter()
+    T, n_text = 8, 128
+    cfg = teochat_7b_config()
+    cfg.num_hidden_layers = N_LAYERS_DEEP
+    sd_dev = synthetic_state_dict(cfg, seed=2, std=0.02, dtype=bf, device=DEV)
+    eng = TeoEngine(sd_dev, cfg, dtype=bf, device=DEV, max_seq=2304, weight_format="fp8")
+    m = LlavaLlamaForCausalLM(cfg, eng)
+    frames = O.synthetic_frames(T, 224, seed=0)
+    ids = O.synthetic_prompt_ids(n_text, T, 32000, seed=1).unsqueeze(0)
+    imgs = [f.to(DEV, dtype=bf) for f in frames]
+    lib = eng.lib
+    assert lib.teo_tune_set(b"prefill_fp8", 1) == 0
+    try:
+        got = m(input_ids=ids.to(DEV), images=imgs).logits[0].float().cpu()
+    finally:
+        lib.teo_tune_set(b"prefill_fp8", 0)
+    exact = m(input_ids=ids.to(DEV), images=imgs).logits[0].float().cpu()         # bf16 MFMA on the same dequantised weights
+    # the oracle sees the engine's weights: Linear layers of the LLM dequantised from their e4m3 rows, everything else as drawn
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    for k in list(sd):
+        if k.startswith("model.layers.") and k.endswith("proj.weight") or k == "lm_head.weight":
+            sd[k] = quantize_fp8_rows(sd[k])[2]
+    vcfg, lcfg, mm = _oracle_cfgs(N_LAYERS_DEEP)
+    pix = torch.stack(frames)
+    feats = O.encode_images(pix, sd, vcfg, mm, "bf16")
+    emb_w = sd["model.embed_tokens.weight"].float()
+    _, pos, mask, _, embeds, _ = O.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [feats[i] for i in range(T)], emb_w, mm)
+    want, _ = O.llama_forward(embeds, pos, mask, None, sd, lcfg, "bf16", act_quant="e4m3")
+    want = want[0]
+    mx, p99, med, sc = _stats(got, want)
+    emx, ep99, emed, _ = _stats(got, exact)
+    print(f"\n[C5 w8a8 prefill, {N_LAYERS_DEEP} layers at 7B width, L=2168] vs oracle(act_quant=e4m3, bf16 boundaries): max {mx:.2e}  p99 {p99:.2e}  "
+          f"median {med:.2e} of max|logit| {sc:.2f};  quantisation effect itself (w8a8 vs exact bf16 prefill on the same weights): "
+          f"max {emx:.2e}  p99 {ep99:.2e}  median {emed:.2e};  wall {time.perf_counter() - t0:.1f} s")
+    # Measured (round 3): max 8.95e-2 / p99 3.55e-2 / median 9.1e-3 -- ~4.5x the bf16 leg of (b).  Expected: every kernel is within
+    # 1 ulp of the oracle (walk above, quantiser bytes 100 % equal on identical inputs), but a 1-ulp bf16 flip in front of a quantiser
+    # crosses an e4m3 code boundary ~7 % of the time and then moves that activation by a whole e4m3 step (6-12 %): the rounding noise
+    # of the bf16 pipeline re-enters ~5x amplified at each of the 4 quantisers per layer.  Bound = measured + ~35 %.
+    assert mx < 1.2e-1 and p99 < 5e-2 and med < 1.3e-2
