@@ -90,6 +90,13 @@ int teo_gemm(const void* d_A, const void* d_W, const void* d_bias, const void* d
  * teo_gemm_workspace_init must run once on a fresh workspace (it zeroes the hand-off flags; the kernels re-arm them). */
 size_t teo_gemm_workspace_bytes(void);
 int teo_gemm_workspace_init(void* d_workspace, teo_stream_t stream);
+/* Contract of a workspace: ONE stream at a time (two streams running teo_gemm_ws / teo_gemm_fp8_ws / teo_vit_encode / teo_llama_prefill
+ * on the same workspace would interleave its hand-off flags and slabs).  The persistent forms are sized for the MI355X's 256 CUs; on any
+ * other CU count the workspace is ignored and the plain kernels run.  A hand-off that ever timed out (never observed; the producer of
+ * a slab is resident before its consumer by construction) sets a STICKY error word instead of continuing silently:
+ * teo_gemm_workspace_status copies it to *host_flag after synchronising the stream (0 = fine, 1 = results since the last
+ * teo_gemm_workspace_init are invalid). */
+int teo_gemm_workspace_status(const void* d_workspace, int* host_flag, teo_stream_t stream);
 int teo_gemm_ws(const void* d_A, const void* d_W, const void* d_bias, const void* d_residual, void* d_C, int M, int N, int K,
                 int lda, int ldc, int act, unsigned flags, int dtype, int out_dtype, void* d_workspace, teo_stream_t stream);
 
@@ -371,6 +378,11 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
 
 /* hipGraph form of the same step: capture once, replay per token. */
 typedef struct teo_graph teo_graph;
+/* The sticky hand-off error word (teo_gemm_workspace_status) of the GEMM workspace carved inside a teo_vit_encode /
+ * teo_llama_prefill (_batch: pass the total row count) workspace. */
+int teo_vit_workspace_status(const teo_vit_desc* d, int T, void* d_workspace, size_t workspace_bytes, int* host_flag, teo_stream_t stream);
+int teo_llama_prefill_workspace_status(const teo_llama_desc* d, int S, void* d_workspace, size_t workspace_bytes, int* host_flag,
+                                       teo_stream_t stream);
 /* Overlapped decode steps (round 3): n_steps steps of teo_llama_decode_step's arithmetic with the step's kernels launched as a CHAIN
  * (AQL barrier bit cleared, one device-side progress word: a kernel's launch ramp and first weight block run under the tail of its
  * predecessor; see csrc/common.h "launch chain").  Plain launches, no hipGraph: pos0 = position of the token fed by the first step

@@ -102,6 +102,9 @@ _SIGS = {
     "teo_quant_rows_fp8": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "teo_gemm_workspace_bytes": (C.c_size_t, []),
     "teo_gemm_workspace_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "teo_gemm_workspace_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "teo_vit_workspace_status": (C.c_int, [C.POINTER(VitDesc), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]),
+    "teo_llama_prefill_workspace_status": (C.c_int, [C.POINTER(LlamaDesc), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]),
     "teo_gemm_ws": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_uint, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "teo_im2col_patches": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "teo_patch_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),

@@ -36,6 +36,8 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
 int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out, int* count_out,
                               hipStream_t st);
 bool llama_decode_chain_ok(const teo_llama_desc* d);
+int llama_prefill_workspace_status(const teo_llama_desc* d, int S, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
+int vit_workspace_status(const teo_vit_desc* d, int T, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
 int llama_decode_chain_steps(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, int n_steps, int pos0, bool ordered,
                              hipStream_t st);
 int llama_decode_chain_error(const teo_llama_desc* d, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
@@ -136,6 +138,11 @@ int teo_gemm_workspace_init(void* ws, teo_stream_t s) {
     ENTER();
     NEED(ws, "workspace");
     return gemm_sk_workspace_init(ws, ST(s));
+}
+int teo_gemm_workspace_status(const void* ws, int* host_flag, teo_stream_t s) {
+    ENTER();
+    NEED(ws, "workspace"); NEED(host_flag, "host_flag");
+    return gemm_sk_workspace_status(ws, host_flag, ST(s));
 }
 int teo_gemm_ws(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                 int act, unsigned flags, int dtype, int out_dtype, void* ws, teo_stream_t s) {
@@ -303,6 +310,17 @@ int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, v
         const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc;
     }
     return llama_decode_step(d, st, ws, wsb, ST(s));
+}
+
+int teo_llama_prefill_workspace_status(const teo_llama_desc* d, int S, void* ws, size_t wsb, int* host_flag, teo_stream_t s) {
+    ENTER();
+    NEED(d, "desc"); NEED(ws, "workspace"); NEED(host_flag, "host_flag");
+    return llama_prefill_workspace_status(d, S, ws, wsb, host_flag, ST(s));
+}
+int teo_vit_workspace_status(const teo_vit_desc* d, int T, void* ws, size_t wsb, int* host_flag, teo_stream_t s) {
+    ENTER();
+    NEED(d, "desc"); NEED(ws, "workspace"); NEED(host_flag, "host_flag");
+    return vit_workspace_status(d, T, ws, wsb, host_flag, ST(s));
 }
 
 int teo_llama_decode_chain_supported(const teo_llama_desc* d) {

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
             int spins = 0;
             while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 24)) break;                              // never reached: the producer wrote its slab first thing
+                if (++spins > (1 << 24)) { __hip_atomic_store(flags + GEMM_SK_ERR_SLOT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never reached (the producer wrote its slab first thing); a miss is STICKY: teo_gemm_workspace_status
             }
             __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
         }
@@ -550,11 +550,28 @@ static int g_gemm_sk = 1;      // 1: stream-K kernel when a workspace is given a
 constexpr int SK_MAX_GRID = 512;   // 256 CUs x 2 resident workgroups (64 KiB LDS, <= 256 VGPRs each)
 // slabs of every stream-K form share the first GEMM_SK_SLAB_BYTES (512 x 64 KB here, 256 x 128 KB in gemm_wide.hip / gemm_fp8.hip,
 // 256 x 256 KB in gemm_big.hip); the hand-off flags live behind them
-size_t gemm_sk_workspace_bytes() { return GEMM_SK_SLAB_BYTES + SK_MAX_GRID * sizeof(int); }
+size_t gemm_sk_workspace_bytes() { return GEMM_SK_SLAB_BYTES + GEMM_SK_FLAG_INTS * sizeof(int); }
 // flags live behind the slabs; they must be zero before the first stream-K launch on a workspace (the kernel re-arms them)
 int gemm_sk_workspace_init(void* ws, hipStream_t st) {
-    hipError_t e = hipMemsetAsync((unsigned char*)ws + GEMM_SK_SLAB_BYTES, 0, SK_MAX_GRID * sizeof(int), st);
+    hipError_t e = hipMemsetAsync((unsigned char*)ws + GEMM_SK_SLAB_BYTES, 0, GEMM_SK_FLAG_INTS * sizeof(int), st);
     return e == hipSuccess ? TEO_OK : hip_fail(e, "gemm_sk_workspace_init");
+}
+// the sticky error word of a workspace (0 = every hand-off since teo_gemm_workspace_init arrived); synchronises the stream
+int gemm_sk_workspace_status(const void* ws, int* host_flag, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(host_flag, (const unsigned char*)ws + GEMM_SK_SLAB_BYTES + GEMM_SK_ERR_SLOT * sizeof(int), sizeof(int),
+                                  hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e == hipSuccess ? TEO_OK : hip_fail(e, "gemm_sk_workspace_status");
+}
+// the persistent forms assume the MI355X's 256 CUs (grids of 256 / 512 resident workgroups): elsewhere the plain kernels run
+static bool sk_grid_fits_device() {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
+    }
+    return cus == 256;
 }
 static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
 static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
@@ -614,6 +631,7 @@ static void launch_simple(const void* A, const void* W, const void* bias, const 
 int gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda,
          int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st, void* sk_ws) {
     if (M == 0 || N == 0) return TEO_OK;
+    if (sk_ws && !sk_grid_fits_device()) sk_ws = nullptr;        // stream-K / hybrid grids are sized for 256 CUs
     const bool swiglu = flags & TEO_GEMM_SWIGLU16;
     if (swiglu && (bias || res || act != TEO_ACT_NONE || N % 32 != 0)) {
         set_error("teo_gemm: SWIGLU16 needs N %% 32 == 0 and no bias/residual/act");

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_fp8_wide_sk_kernel(const uns
                 int spins = 0;
                 while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 24)) break;
+                    if (++spins > (1 << 24)) { __hip_atomic_store(flags + GEMM_SK_ERR_SLOT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never reached (the producer wrote its slab first thing); a miss is STICKY: teo_gemm_workspace_status
                 }
                 __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -590,6 +590,11 @@ bool gemm_fp8_ok(int M, int N, int K, int lda, int ldc, unsigned flags, const vo
 int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,
              int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st, void* sk_ws) {
     if (M == 0 || N == 0) return TEO_OK;
+    if (sk_ws) {                                             // the stream-K form is sized for 256 CUs
+        static int cus = -1;
+        if (cus < 0) { int dev = 0; hipDeviceProp_t p; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0; }
+        if (cus != 256) sk_ws = nullptr;
+    }
     if (!gemm_fp8_ok(M, N, K, lda, ldc, flags, A8, W8, res, C)) {
         set_error("teo_gemm_fp8: needs K %% 128 == 0, lda %% 16 == 0, N %% 4 == 0 (32 with SWIGLU16, no residual) and 16-byte aligned operands "
                   "(M %d N %d K %d lda %d ldc %d)", M, N, K, lda, ldc);

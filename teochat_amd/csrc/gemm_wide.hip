@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
                 int spins = 0;
                 while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 24)) break;                          // never reached: the producer wrote its slab first thing
+                    if (++spins > (1 << 24)) { __hip_atomic_store(flags + GEMM_SK_ERR_SLOT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never reached (the producer wrote its slab first thing); a miss is STICKY: teo_gemm_workspace_status
                 }
                 __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
             }

@@ -123,7 +123,10 @@ int gemm_big_launch(const void* A, const void* W, const void* bias, const void* 
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);
 constexpr size_t GEMM_SK_SLAB_BYTES = (size_t)64 << 20;   // slab area of the stream-K workspaces (largest user: 256 x 256 KB)
+constexpr int GEMM_SK_FLAG_INTS = 1024;          // hand-off flags (<= 512 used) + the sticky error word
+constexpr int GEMM_SK_ERR_SLOT = GEMM_SK_FLAG_INTS - 1;   // set to 1 by a hand-off that timed out (results of that GEMM are invalid)
 size_t gemm_sk_workspace_bytes();
+int gemm_sk_workspace_status(const void* ws, int* host_flag, hipStream_t st);
 // w8a8 prefill GEMM on the scaled fp8 MFMA (gemm_fp8.hip) and the per-token activation quantiser (norm_w != NULL: RMSNorm first)
 int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const void* res, void* C, int M, int N, int K,
              int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st, void* sk_ws = nullptr);

@@ -213,6 +213,17 @@ static int prefill_layer_fp8(const teo_llama_desc* d, const PrefillWs& w, int l,
 }
 
 size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S) { return prefill_carve(d, S, nullptr, 0).total; }
+// sticky hand-off error word of the GEMM workspace inside a prefill / tower workspace (0 = fine); synchronises the stream
+int llama_prefill_workspace_status(const teo_llama_desc* d, int S, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st) {
+    const PrefillWs w = prefill_carve(d, S, ws, ws_bytes);
+    if (w.total > ws_bytes) { set_error("teo_llama_prefill_workspace_status: workspace too small"); return TEO_ERR_WORKSPACE; }
+    return gemm_sk_workspace_status(w.sk, host_flag, st);
+}
+int vit_workspace_status(const teo_vit_desc* d, int T, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st) {
+    const VitWs w = vit_carve(d, T, ws, ws_bytes);
+    if (w.total > ws_bytes) { set_error("teo_vit_workspace_status: workspace too small"); return TEO_ERR_WORKSPACE; }
+    return gemm_sk_workspace_status(w.sk, host_flag, st);
+}
 
 int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
                   float* logits, void* ws, size_t ws_bytes, hipStream_t st) {

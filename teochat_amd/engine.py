@@ -346,7 +346,18 @@ class TeoEngine:
             need = self.lib.teo_vit_workspace_bytes(C.byref(self.vit_desc), T)
             ws = self._workspace("vit", need)
             L.check(self.lib.teo_vit_encode(C.byref(self.vit_desc), _p(px), T, _p(out), _p(ws), ws.numel(), st), "teo_vit_encode")
+            self._check_handoffs(lambda f: self.lib.teo_vit_workspace_status(C.byref(self.vit_desc), T, _p(ws), ws.numel(), C.byref(f), st), "teo_vit_encode")
         return out
+
+    def _check_handoffs(self, status_call, what):
+        """The persistent GEMM forms hand partial tiles over through workspace flags; a hand-off that timed out sets a sticky error word
+        instead of continuing silently.  Only looked at when this is the outermost phase (the stream is about to be drained anyway)."""
+        if self._phase_depth > 1:
+            return
+        flag = C.c_int(0)
+        L.check(status_call(flag), what + " workspace status")
+        if flag.value:
+            raise RuntimeError(f"{what}: a stream-K / hybrid GEMM hand-off timed out (results invalid)")
 
     def project(self, feats):
         """[..., Dv] -> [..., D] through the mm_projector (H12)."""
@@ -399,6 +410,8 @@ class TeoEngine:
             ws = self._workspace("prefill", need)
             L.check(self.lib.teo_llama_prefill(C.byref(self.llama_desc), _p(e), _p(pos), S, past, 1 if last_only else 0,
                                                _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill")
+            self._check_handoffs(lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(self.llama_desc), S, _p(ws), ws.numel(), C.byref(f), st),
+                                 "teo_llama_prefill")
         self.cache_len = past + S
         return logits
 
