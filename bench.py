@@ -495,12 +495,20 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
             break
+    # Two live measurements of the same kernel: (1) its dispatch timestamps inside real decode steps, (2) HIP events around 32 x 5
+    # back-to-back launches.  (2) is what `rocprofv3 --kernel-trace --stats` of this command agrees with (its per-kernel averages carry
+    # the inter-kernel gap of the replayed graph: they add up to slightly MORE than the step); `achieved` / `frac` use the LONGER of
+    # the two, so the headline fraction never exceeds what the committed rocprofv3 summary supports; both are reported.
+    avg_ms = gu_us * 1e-3 if chain_ms is None else max(gu_us * 1e-3, chain_ms)
+    achieved = gemv_bytes / (avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "gemv_kernel<bf16,bf16,R=2,U=4,NT,SWIGLU> (decode rmsnorm + gate/up + SwiGLU, N=22016 K=4096)"
                                           if args.weights == "bf16" else "gemv_kernel<fp8 weights, SWIGLU> (decode rmsnorm + gate/up + SwiGLU)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": gemv_bytes, "avg_launch_ms": round(gu_us * 1e-3, 5),
-                "measured": "in-run: per-launch dispatch timestamps over 8 decode steps x 32 layers after a real prefill (ctx %d)" % ctx_prof,
+                "algorithmic_bytes_per_launch": gemv_bytes, "avg_launch_ms": round(avg_ms, 5),
+                "measured": "the longer of: in-run per-launch dispatch timestamps over 8 decode steps x 32 layers after a real prefill (ctx %d); "
+                            "HIP events around 32 matrices x 5 back-to-back launches" % ctx_prof,
+                "in_run_avg_launch_ms": round(gu_us * 1e-3, 5), "in_run_frac": round(gemv_bytes / (gu_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "chain_microbench_avg_launch_ms": None if chain_ms is None else round(chain_ms, 5),
                 "chain_microbench_frac": None if chain_ms is None else round(gemv_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "decode_kernels_in_run": in_run,

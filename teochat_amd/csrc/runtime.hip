@@ -759,10 +759,19 @@ int llama_decode_chain_error(const teo_llama_desc* d, void* ws, size_t ws_bytes,
     return e == hipSuccess ? TEO_OK : hip_fail(e, "teo_llama_decode_chain_error");
 }
 
+// holds the stream for `ticks` of the 100 MHz wall clock: the profiled step's ~200 launches are enqueued behind it (the host needs
+// ~9 us per timestamped launch, more than the small kernels run) and then execute back to back, as a graph replay does -- a kernel
+// that starts on an idle memory system measures 2-3 % faster than the same kernel inside the real step
+__global__ void prof_hold_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out,
                               int* count_out, hipStream_t st) {
     std::vector<ProfRec> recs;
     recs.reserve(8 * (size_t)d->layers + 8);
+    prof_hold_kernel<<<1, 64, 0, st>>>(400000ull);            // 4 ms
     g_prof = &recs;
     // the overlapped step's kernels, one at a time in ordinary launch order (chain off): their own durations; position from d_pos
     int pos_now = 0;
