@@ -119,7 +119,7 @@ int gemm_tune_set(const char* key, int value);
 int runtime_tune_set(const char* key, int value);
 int gemm_fp8_tune_set(const char* key, int value);
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset);
+                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset, bool any_order = false);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);
 constexpr size_t GEMM_SK_SLAB_BYTES = (size_t)64 << 20;   // slab area of the stream-K workspaces (largest user: 256 x 256 KB)
