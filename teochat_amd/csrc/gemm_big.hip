@@ -251,7 +251,11 @@ static int g_big_hybrid = 1;     // data-parallel rounds + stream-K remainder wh
 // 272 tiles, 183 MB: 311 us against 421 us for three ragged rounds of 128 x 256 tiles)
 bool gemm_big_hybrid_fits(int M, int N, int K) {
     const long long T = (long long)((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
-    return ((long long)M + N) * K * 2 <= (160ll << 20) || T <= 384;
+    const long long bytes = ((long long)M + N) * K * 2;
+    // round 3 (tools/split_probe.py): gate/up at M = 2168 (198 MB, 774 tiles = 3.02 rounds) runs 337 / 342 us (warm / cold weights) in
+    // the hybrid form against 358 / 363 on the 128 x 256 kernel -- with only three rounds the ragged one costs more than the
+    // unshared stream-K part; at M = 4208 (214 MB, 5.7 rounds) the hybrid form loses (712 vs 580 us)
+    return bytes <= (160ll << 20) || T <= 384 || (T <= 800 && bytes <= (208ll << 20));
 }
 int gemm_big_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_big_group") && value >= 0) { g_big_group = value; return 0; }
