@@ -33,9 +33,11 @@ constexpr int SK_TP = 16 * 17;      // padded 16x16 partial tile in LDS: [b][i] 
 
 static int g_sk_tiles = 0;          // 0 = auto
 static int g_sk_nt = 1;
+static int g_sk_stream = 1;         // 0 = never, 1 = auto, 2 = whenever the streaming form is eligible
 int skinny_tune_set(const char* key, int value) {
     if (!strcmp(key, "skinny_tiles") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_sk_tiles = value; return 0; }
     if (!strcmp(key, "skinny_nt")) { g_sk_nt = value != 0; return 0; }
+    if (!strcmp(key, "skinny_stream") && value >= 0 && value <= 2) { g_sk_stream = value; return 0; }
     return -1;
 }
 
@@ -208,8 +210,6 @@ _Pragma("unroll") \
         TEO_SK_SSQ_LOAD
         TEO_SK_SSQ_REDUCE
     }
-#undef TEO_SK_SSQ_LOAD
-#undef TEO_SK_SSQ_REDUCE
 #undef TEO_SK_LOAD
 #undef TEO_SK_COMP
 
@@ -285,6 +285,229 @@ _Pragma("unroll") \
     }
 }
 
+// ---- streaming form --------------------------------------------------------------------------------------------------
+// The kernel above pays its fixed costs once per 16 weight rows: the workgroup start, the activation fragments (as many
+// bytes as the fp8 weights of the tile, twice that for 16 conversations), the drain into the LDS reduction and the
+// epilogue, during which the workgroup has no weight request in flight.  Measured on the 7B shapes the weight stream of a
+// batched step runs at 3.7-4.2 TB/s (fp8) / 5.5 TB/s (bf16, 8 rows) / 4.2 TB/s (bf16, 16 rows) against 6.4 for a plain
+// read; with the activation loads removed (probe) the 16-row case alone gains 40 %.
+//
+// Here a workgroup is PERSISTENT: 8 streaming waves own one K slice each for the whole launch and walk the row tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...:
+//   * the slice's activation fragments are loaded ONCE into registers (PER steps x 16 B [x 2 for fp8] per lane = 64
+//     VGPRs at K = 4096) -- no activation traffic after the first tile, and only weight loads in the vmcnt queue;
+//   * the weight stream is one flat double-buffered pipeline ACROSS tiles: the first loads of tile i + 1 are in flight
+//     while tile i's partial sums go to LDS;
+//   * a ninth wave does every epilogue (fixed-order reduction of the 8 partial tiles, 1/rms, fp8 scale, SwiGLU,
+//     residual, rounding, the next norm's hand-off): the streaming waves never issue another global load, so nothing
+//     they wait for sits behind the prefetched weights, and their only synchronisation is one s_barrier per tile
+//     (partial tiles double-buffered; the epilogue of tile i overlaps the stream of tile i + 1).
+// Same arithmetic as the kernel above (same K partition when K / KS is a multiple of 8, same reduction order).
+constexpr int SS_NW = 8;                       // streaming waves; wave SS_NW is the epilogue wave
+constexpr int SS_THREADS = (SS_NW + 1) * 64;
+constexpr int SS_TP = 16 * 20;                 // partial tile in LDS: [b][i] at b*20 + i (16-byte aligned rows)
+
+template <typename WT, int UNR, int SPT, bool SW8>
+__global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
+                                                                   const float* __restrict__ wscale, const bf16_t* res, void* outv,
+                                                                   int MB, int N, int K, int ldx, int ldo, int tiled, int out_f32,
+                                                                   SkinnyFuse fuse) {
+    constexpr bool F8 = sizeof(WT) == 1;
+    constexpr int KS = F8 ? 64 : 32, CH = F8 ? 16 : 8, XL = F8 ? 2 : 1;
+    constexpr int PER = UNR * SPT;                       // steps of one wave per tile
+    constexpr int TU = (SPT & 1) ? 2 : 1;                // tiles per trip of the unrolled loop (an even number of sets)
+    __shared__ __attribute__((aligned(16))) float red[2][SS_NW][SS_TP];
+    __shared__ float inv_s[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ntiles = (N + 15) / 16, nsteps = K / KS, G = gridDim.x;
+
+    if (wid < SS_NW) {
+        const int fr = lane & 15, fg = lane >> 4;
+        const int s0 = wid * PER;
+        TEO_SK_SSQ_LOAD
+        // the slice's activations, once
+        u32x4 xr[PER][XL];
+        {
+            const bf16_t* xp = x + (long long)min(fr, MB - 1) * ldx + fg * CH;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const long long sc = min(s0 + i, nsteps - 1);
+#pragma unroll
+                for (int j = 0; j < XL; ++j) xr[i][j] = *reinterpret_cast<const u32x4*>(xp + sc * KS + j * 8);
+            }
+        }
+        const long long pstep = tiled ? 64 * CH : KS;
+        const long long tstride = (long long)nsteps * (64 * CH);
+        u32x4 w[2][UNR];
+        // weight loads of set ls of tile t (t clamped: a trailing prefetch re-reads the last tile and is dropped)
+#define TEO_SS_LOADW(BUF, T, LS)                                                                               \
+        {                                                                                                      \
+            const int tc = min((T), ntiles - 1);                                                               \
+            const WT* wt = tiled ? W + (long long)tc * tstride + lane * CH                                     \
+                                 : W + (long long)min(tc * 16 + fr, N - 1) * K + fg * CH;                      \
+            _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                                    \
+                w[BUF][u] = sk_ldw<true>(wt + (long long)min(s0 + (LS) * UNR + u, nsteps - 1) * pstep);        \
+        }
+        int t = blockIdx.x;
+        TEO_SS_LOADW(0, t, 0)
+        TEO_SK_SSQ_REDUCE
+#pragma unroll
+        for (int i = 0; i < PER; ++i)                    // steps past the end of K contribute nothing
+            if (s0 + i >= nsteps) {
+#pragma unroll
+                for (int j = 0; j < XL; ++j) xr[i][j] = (u32x4){0u, 0u, 0u, 0u};
+            }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int par = 0;
+        for (; t < ntiles; t += TU * G) {
+#pragma unroll
+            for (int q = 0; q < TU * SPT; ++q) {
+                const int tq = t + (q / SPT) * G, ls = q % SPT;
+                if (q + 1 < TU * SPT) TEO_SS_LOADW((q + 1) & 1, t + ((q + 1) / SPT) * G, (q + 1) % SPT)
+                else                  TEO_SS_LOADW(0, t + TU * G, 0)
+                {
+                    // (a trailing tile past the end is computed on the clamped re-read and dropped: the loads above must
+                    // stay unconditional users, or the compiler sinks them below the previous tile's barrier)
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int i = ls * UNR + u;
+                        if (F8) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[q & 1][u].x, w[q & 1][u].y),
+                                                                          __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[q & 1][u].z, w[q & 1][u].w),
+                                                                          __builtin_bit_cast(bf16x8, xr[i][XL - 1]), acc, 0, 0, 0);
+                        } else {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[q & 1][u]),
+                                                                          __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
+                        }
+                    }
+                    if (ls == SPT - 1 && (TU == 1 || q < SPT || tq < ntiles)) {   // tile done: lane holds out[b = fr][rows fg*4 .. +3]
+                        *reinterpret_cast<f32x4*>(&red[par][wid][fr * 20 + fg * 4]) = acc;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        par ^= 1;
+                    }
+                }
+            }
+        }
+#undef TEO_SS_LOADW
+    } else {
+        // epilogue wave: lane = (conversation b, 4 consecutive rows of the tile).  The tile's scales / residual / next-norm
+        // weights are requested one tile AHEAD (a global round trip under a saturated HBM pipe is about one tile period:
+        // taken after the barrier it would make this wave the bottleneck of the workgroup)
+        const int b = lane >> 2, i4 = lane & 3;
+        const bool bok = b < MB;
+        const long long rrow = (long long)min(b, MB - 1) * ldo;
+        f32x4 sc_n = (f32x4){1.f, 1.f, 1.f, 1.f};
+        uint2 rv_n = make_uint2(0u, 0u), gv_n = make_uint2(0u, 0u);
+#define TEO_SS_PREFETCH(T)                                                                                     \
+        {                                                                                                      \
+            const int tp = min((T), ntiles - 1), np = tp * 16 + i4 * 4;                                        \
+            if (tp * 16 + 16 <= N) {                                                                           \
+                if (wscale) sc_n = *reinterpret_cast<const f32x4*>(wscale + np);                               \
+                if (!SW8 && res) rv_n = *reinterpret_cast<const uint2*>(res + rrow + np);                      \
+                if (!SW8 && fuse.xg_out) gv_n = *reinterpret_cast<const uint2*>(fuse.next_g + np);             \
+            }                                                                                                  \
+        }
+        TEO_SS_PREFETCH(blockIdx.x)
+        int par = 0;
+        for (int t = blockIdx.x; t < ntiles; t += G) {
+            __builtin_amdgcn_s_barrier();
+            const f32x4 sc = sc_n;
+            const uint2 rv = rv_n, gv = gv_n;
+            TEO_SS_PREFETCH(t + G)
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wv = 0; wv < SS_NW; ++wv) v += *reinterpret_cast<const f32x4*>(&red[par][wv][b * 20 + i4 * 4]);
+            par ^= 1;
+            const int n0 = t * 16, nb = n0 + i4 * 4;    // first weight row of the lane
+            const float inv = fuse.ssq_in ? inv_s[b] : 1.f;
+            const bool full = n0 + 16 <= N;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= inv;
+            if (wscale) {
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= wscale[min(nb + r, N - 1)];
+                }
+            }
+            if (SW8) {
+                // rows 0..7 of the tile are gate rows, 8..15 their up rows: lanes i4 < 2 pair with lane + 2
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu(v[r]) * __shfl_down(v[r], 2, 64);
+                if (bok && i4 < 2) {
+                    const long long at = (long long)b * ldo + t * 8 + i4 * 4;
+                    if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outv) + at) = o;
+                    else {
+                        uint2 pk;
+                        pk.x = pack_bf2(o[0], o[1]);
+                        pk.y = pack_bf2(o[2], o[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(outv) + at) = pk;
+                    }
+                }
+            } else {
+                const long long at = (long long)b * ldo + nb;
+                float sq = 0.f;
+                if (full) {
+                    if (res) {
+                        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+                    if (out_f32) { if (bok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outv) + at) = v; }
+                    else {
+                        uint2 pk;
+                        pk.x = pack_bf2(v[0], v[1]);
+                        pk.y = pack_bf2(v[2], v[3]);
+                        if (bok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(outv) + at) = pk;
+                        if (fuse.xg_out) {
+                            // what the NEXT layer's RMSNorm needs: bf16(h * g_next) and this tile's share of sum(h^2) per row
+                            const float h0 = __uint_as_float(pk.x << 16), h1 = __uint_as_float(pk.x & 0xffff0000u);
+                            const float h2 = __uint_as_float(pk.y << 16), h3 = __uint_as_float(pk.y & 0xffff0000u);
+                            uint2 xg;
+                            xg.x = pack_bf2(h0 * __uint_as_float(gv.x << 16), h1 * __uint_as_float(gv.x & 0xffff0000u));
+                            xg.y = pack_bf2(h2 * __uint_as_float(gv.y << 16), h3 * __uint_as_float(gv.y & 0xffff0000u));
+                            if (bok) *reinterpret_cast<uint2*>(fuse.xg_out + at) = xg;
+                            sq = h0 * h0 + h1 * h1 + h2 * h2 + h3 * h3;
+                        }
+                    }
+                } else {                                 // ragged last tile: element-wise
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = nb + r;
+                        if (col < N && bok) {
+                            float y = v[r];
+                            if (res) y += bf2f(res[at + r]);
+                            if (out_f32) reinterpret_cast<float*>(outv)[at + r] = y;
+                            else {
+                                const bf16_t hb = f2bf(y);
+                                reinterpret_cast<bf16_t*>(outv)[at + r] = hb;
+                                if (fuse.xg_out) {
+                                    const float h = bf2f(hb);
+                                    fuse.xg_out[at + r] = f2bf(h * bf2f(fuse.next_g[col]));
+                                    sq += h * h;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (fuse.xg_out) {
+                    sq += __shfl_xor(sq, 1, 64);
+                    sq += __shfl_xor(sq, 2, 64);
+                    if (i4 == 0 && bok) fuse.ssq_out[(long long)b * ntiles + t] = sq;
+                }
+            }
+        }
+#undef TEO_SS_PREFETCH
+    }
+}
+#undef TEO_SK_SSQ_LOAD
+#undef TEO_SK_SSQ_REDUCE
+
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W) {
     const int ks = w_fp8 ? 64 : 32;
     if (MB < 1 || MB > 16 || N < 1 || K < ks || K % ks != 0 || ldx % 8 != 0) return false;
@@ -317,8 +540,38 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     if (rt == 0 || fuse.xg_out) rt = 1;   // measured: one row tile per workgroup (most waves in flight) wins at every N
     const int sw8 = (flags & TEO_GEMM_SWIGLU8) ? 1 : 0;   // gate/up interleaved in blocks of 8 rows: a pair fits one tile
     if (swiglu && !sw8 && rt < 2) rt = 2; // 16-row interleave: the gate tile and its up tile meet in the epilogue
-    const int blocks = cdiv(N, 16 * rt);
     const int ldr = ldo, of = out_dtype == TEO_F32;
+    // streaming form (persistent workgroups, activations in registers): K <= 4096, one row tile per workgroup, vector
+    // epilogue accesses aligned
+    {
+        const int nsteps = K / (w_fp8 ? 64 : 32), ntiles = cdiv(N, 16);
+        const auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+        bool ok = g_sk_stream != 0 && !norm_w && !(flags & TEO_GEMM_SWIGLU16) && (g_sk_tiles == 0 || g_sk_tiles == 1) &&
+                  nsteps <= (w_fp8 ? 64 : 128) && ldo % 4 == 0 && al(out, 16) && (!res || al(res, 8)) && (!wscale || al(wscale, 16)) &&
+                  (!fuse.xg_out || (al(fuse.xg_out, 8) && al(fuse.next_g, 8)));
+        // auto: at least two tiles per workgroup, and where it measures faster (fp8 weights: -15 % at 8 rows, -25 % at 16;
+        // bf16: -10..20 % above 8 rows, a tie at 8 or fewer where the duplicate activation rows coalesce)
+        if (ok && g_sk_stream == 1) ok = ntiles >= 512 && (w_fp8 || MB > 8);
+        if (ok) {
+            static int cus = -1;
+            if (cus < 0) {
+                int dev = 0;
+                hipDeviceProp_t p;
+                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
+            }
+            const int grid = std::max(1, std::min(ntiles, cus > 0 ? cus : 256));
+#define TEO_SS(WW, UN, SP, SW)                                                                              \
+            skinny_stream_kernel<WW, UN, SP, SW><<<grid, SS_THREADS, 0, st>>>((const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
+                                                                              out, MB, N, K, ldx, ldo, tiled, of, fuse)
+            if (w_fp8) { if (sw8) TEO_SS(fp8_t, 8, 1, true); else TEO_SS(fp8_t, 8, 1, false); }
+            else       { if (sw8) TEO_SS(bf16_t, 8, 2, true); else TEO_SS(bf16_t, 8, 2, false); }
+#undef TEO_SS
+            note_kernel("skinny_stream");
+            TEO_LAUNCH_CHECK("skinny_gemm (stream)");
+            return TEO_OK;
+        }
+    }
+    const int blocks = cdiv(N, 16 * rt);
     const size_t dyn = norm_w ? (size_t)K * 2 : 0;
 #define TEO_SK(WW, NTV, SW, NM)                                                                            \
     skinny_gemm_kernel<WW, 4, NTV, SW, NM><<<blocks, SK_THREADS, dyn, st>>>(                               \
@@ -331,6 +584,7 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
 #undef TEO_SK_F
 #undef TEO_SK_N
 #undef TEO_SK
+    note_kernel("skinny_gemm");
     TEO_LAUNCH_CHECK("skinny_gemm");
     return TEO_OK;
 }

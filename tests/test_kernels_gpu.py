@@ -702,6 +702,68 @@ def test_gemm_skinny_swiglu_block8_layout(MB, fp8):
     torch.testing.assert_close(y8, y16, atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("MB", [1, 5, 8, 16])
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("N,K", [(64, 64), (300, 128), (1040, 2048), (12288, 4096), (32000, 4096)])
+def test_gemm_skinny_stream_form(MB, fp8, N, K):
+    """The persistent streaming form (activations in registers, epilogue wave) against the one-tile-per-workgroup kernel:
+    bit-identical where the K partition is the same (K / KS a multiple of 8 slices of the template's size: K = 4096),
+    fp32-summation-order close elsewhere; plain + residual, f32 and bf16 outputs, ragged last tile, row-major and tiled."""
+    from teochat_amd.engine import quantize_fp8_rows, tile_weights
+    bf = torch.bfloat16
+    x = G.bf16_round(rnd(MB, K, seed=1))
+    W = G.bf16_round(rnd(N, K, seed=2, scale=0.02 if K > 256 else 0.1))
+    dx, dr = G.dev(x, bf), G.dev(G.bf16_round(rnd(MB, N, seed=3)), bf)
+    dW, scale = G.dev(W, bf), None
+    if fp8:
+        dW, scale, _ = quantize_fp8_rows(dW)
+    same = K == 4096
+    outs = {}
+    try:
+        for mode in (0, 2):
+            assert G.lib().teo_tune_set(b"skinny_stream", mode) == 0
+            outs[mode] = (G.gemm_skinny(dx, dW, scale=scale, out_dtype=torch.float32).cpu(),
+                          G.gemm_skinny(dx, dW, scale=scale, res=dr).cpu(),
+                          G.gemm_skinny(dx, tile_weights(dW), scale=scale, res=dr, flags=L.GEMM_WTILED, N=N).cpu())
+            assert G.lib().teo_last_kernel().startswith(b"skinny_stream" if mode else b"skinny_gemm")
+    finally:
+        G.lib().teo_tune_set(b"skinny_stream", 1)
+    a, b = outs[0], outs[2]
+    assert torch.equal(b[1], b[2])                        # layouts agree within the streaming form
+    if same:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    else:
+        torch.testing.assert_close(b[0], a[0], atol=2e-4, rtol=1e-4)
+        close_bf16(b[1], a[1].float())
+
+
+@pytest.mark.parametrize("MB", [3, 8, 16])
+@pytest.mark.parametrize("fp8", [False, True])
+def test_gemm_skinny_stream_swiglu8(MB, fp8):
+    """TEO_GEMM_SWIGLU8 through the streaming form == through the tile kernel (7B gate/up shape), bf16 and f32 outputs."""
+    from teochat_amd.engine import interleave_gate_up, quantize_fp8_rows, reinterleave_gate_up, tile_weights
+    bf = torch.bfloat16
+    K, Fd = 4096, 11008
+    x = G.bf16_round(rnd(MB, K, seed=1))
+    gate, up = G.bf16_round(rnd(Fd, K, seed=2, scale=0.02)), G.bf16_round(rnd(Fd, K, seed=3, scale=0.02))
+    gu8 = reinterleave_gate_up(interleave_gate_up(gate, up).to(bf).cuda(), 8)
+    dx, scale = G.dev(x, bf), None
+    if fp8:
+        gu8, scale, _ = quantize_fp8_rows(gu8)
+    wt = tile_weights(gu8)
+    outs = {}
+    try:
+        for mode in (0, 2):
+            assert G.lib().teo_tune_set(b"skinny_stream", mode) == 0
+            outs[mode] = (G.gemm_skinny(dx, wt, scale=scale, flags=L.GEMM_SWIGLU8 | L.GEMM_WTILED, out_dtype=torch.float32, N=2 * Fd).cpu(),
+                          G.gemm_skinny(dx, wt, scale=scale, flags=L.GEMM_SWIGLU8 | L.GEMM_WTILED, N=2 * Fd).cpu())
+    finally:
+        G.lib().teo_tune_set(b"skinny_stream", 1)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    if not fp8:
+        torch.testing.assert_close(outs[2][0], F.silu(x @ gate.T) * (x @ up.T), atol=3e-4, rtol=2e-4)
+
+
 # ---------------------------------------------------------------------------------------------- decode attention
 def _decode_attn_ref(q, K, V, n):
     """q [H, d]; K, V [Hk, S, d]; n keys -> [H*d] (fp64 softmax(q K^T / sqrt(d)) V, GQA by head // (H/Hk))."""

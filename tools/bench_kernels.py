@@ -77,10 +77,13 @@ def bench_skinny():
     from teochat_amd.engine import quantize_fp8_rows
     shapes = [("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gateup", 22016, 4096, L.GEMM_SWIGLU16), ("down", 4096, 11008, 0),
               ("lm_head", 32000, 4096, 0)]
+    if os.environ.get("SK_SHAPES") == "decode":       # the shapes and flags of the batched decode step
+        shapes = [("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gateup8", 22016, 4096, L.GEMM_SWIGLU8), ("down", 4096, 11008, 0)]
     if os.environ.get("SK_SHAPES") == "gu":
         shapes = [("gateup", 22016, 4096, L.GEMM_SWIGLU16), ("gu_plain", 22016, 4096, 0)]
     tiled = L.GEMM_WTILED if int(os.environ.get("SK_TILED", "1")) else 0      # tiled and row-major cost the same to set up here
     lib.teo_tune_set(b"skinny_nt", int(os.environ.get("SK_NT", "1")))
+    lib.teo_tune_set(b"skinny_stream", int(os.environ.get("SK_STREAM", "1")))
     for fp8 in (False, True):
         for name, N, K, flags in shapes:
             wb = 1 if fp8 else 2
@@ -100,8 +103,8 @@ def bench_skinny():
                 x = torch.randn(MB, K, device="cuda").to(bf)
                 y = torch.empty(MB, N, dtype=bf, device="cuda")
                 line = f"skinny {'fp8 ' if fp8 else 'bf16'} {name:8s} MB={MB:2d}:"
-                for tiles in (1, 2, 4, 8):
-                    if tiles == 1 and flags:
+                for tiles in [int(t) for t in os.environ.get("SK_TILES", "1,2,4,8").split(",")]:
+                    if tiles == 1 and (flags & L.GEMM_SWIGLU16):
                         continue
                     lib.teo_tune_set(b"skinny_tiles", tiles)
                     avg = C.c_float(0)
