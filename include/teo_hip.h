@@ -56,7 +56,7 @@ const char* teo_last_kernel(void);
  * "gemv_nt", "gemv_max_blocks", "gemm_depth", "attn_chunk" (64/128/256 keys per decode workgroup), "rope_in_attn"
  * (decode RoPE + KV append: 0 = QKV-GEMV epilogue, 1 = inside the decode attention kernel, -1 = auto by weight format),
  * "attn_fused_combine" (1 = last-arriver merge of the KV splits inside the attention kernel; off: slower),
- * "skinny_tiles", "skinny_nt" (batched-decode GEMM geometry / load policy). */
+ * "skinny_tiles", "skinny_nt", "skinny_stream" (batched-decode GEMM geometry / load policy / persistent streaming form: 0 off, 1 auto, 2 whenever eligible). */
 int teo_tune_set(const char* key, int value);
 /* 1 when the MFMA (fast) kernel would be used for this GEMM, 0 when the generic kernel would. */
 int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags);
