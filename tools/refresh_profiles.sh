@@ -14,6 +14,7 @@ run weightsfp8 --weights fp8
 run batch8 --batch 8
 run batch8weightsfp8 --batch 8 --weights fp8
 run batch16 --batch 16
+run batch16weightsfp8 --batch 16 --weights fp8
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_bench.log 2>&1
