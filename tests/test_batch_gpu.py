@@ -17,9 +17,13 @@ from tests.test_model_gpu import BF16_REL, FP32_TOL, build
 pytestmark = pytest.mark.gpu
 
 # bf16, LLaMA-2-7B widths: first decode step through the MFMA skinny GEMMs (batched) vs through the GEMVs (single conversation),
-# both after the same prefill: different fp32 summation orders in every Linear layer.  Measured 1.42e-2 of max|logit| (round 2,
-# fp8 weights; 1.2e-2 with bf16 weights) -- bound = measured + 25 %.
-BATCH_VS_SINGLE_REL = 1.8e-2
+# both after the same prefill.  Every Linear layer sums in a different fp32 order, so its bf16 output flips by one ulp (2^-8
+# relative) on some elements; per rounded tensor that is a relative perturbation of at most a half-ulp rms (2^-9) of the
+# residual stream.  Error budget: 32 layers x 6 rounded tensors per layer (qkv, attention out, o + residual, normed copy,
+# SwiGLU product, down + residual) perturb independently and add in quadrature: sqrt(192) * 2^-9 = 2.7e-2 of the stream's
+# scale if every one of them flipped; the measured fraction that does is about half (1.2e-2 with bf16 weights, 1.42e-2 with fp8
+# weights, round 2), and the bound takes two thirds of the all-flip budget.
+BATCH_VS_SINGLE_REL = (2.0 / 3.0) * (32 * 6) ** 0.5 * 2.0 ** -9          # = 1.80e-2
 
 
 def conversations(name, n, vocab):
