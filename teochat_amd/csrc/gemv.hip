@@ -429,6 +429,9 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
     const int nchunk = K / VE;
     const int row0 = blockIdx.x * R;
     const float my_scale = (wscale && tid < R && row0 + tid < N) ? wscale[row0 + tid] : 1.f;   // ahead of the stream
+    // the residual too: read after the reduction barrier it is a dependent global round trip at the tail of EVERY workgroup
+    // (all of them are resident at once, so the whole launch ends one memory latency later); only this thread writes y[n]
+    const float my_res = (res && tid < R && row0 + tid < N) ? Elem<T>::ld(res + row0 + tid) : 0.f;
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
         if (n < N) {
             float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
             v *= my_scale;
-            if (res) v += Elem<T>::ld(res + n);
+            v += my_res;
             Elem<TO>::st(y + n, v);
         }
     }
