@@ -119,13 +119,14 @@ __device__ __forceinline__ uint4 ld16(const void* p) {
 }
 
 // Tunables (teo_tune_set): non-temporal loads on/off, workgroup cap, variant of the row-group kernel.
-struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; int ck_pf2 = 0; };
+struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; int ck_pf2 = 0; int small_k = 1; };
 static GemvTune g_tune;
 int gemv_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemv_variant")) g_tune.variant = value;
     else if (!strcmp(key, "gemv_nt")) g_tune.nt = value;
     else if (!strcmp(key, "gemv_max_blocks")) g_tune.max_blocks = value;
     else if (!strcmp(key, "ck_pf2")) g_tune.ck_pf2 = value != 0;
+    else if (!strcmp(key, "gemv_small_k")) g_tune.small_k = value != 0;
     else if (!strcmp(key, "gemv_splitk_u") && (value == 0 || value == 2 || value == 4 || value == 6)) g_tune.splitk_u = value;
     else return -1;
     return 0;
@@ -163,11 +164,13 @@ __device__ __forceinline__ float* x_image_end(float* xs, int nchunk) {
 // prologue shared by the row-group kernels: xs (fp32, LDS, xs_off layout) = f(x), f = identity or rmsnorm(x)*norm_w rounded to T.
 // `after_loads()` runs once the x / norm_w loads are in flight (the caller issues its weight prefetch there).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int VE, bool XB, typename F>
+template <typename T, int VE, bool XB, int XPT, typename F>
 __device__ __forceinline__ void stage_x(const T* __restrict__ x, const T* __restrict__ norm_w, float* xs, float* red, int K,
                                         float eps, F after_loads) {
     constexpr int VX = Vec16<T>::N;
-    constexpr int XPT = 6;                        // 16-byte x chunks a thread can hold: K <= 6*256*VX (12288 for bf16)
+    // XPT = 16-byte x chunks a thread holds in registers: K <= XPT*256*VX (6: 12288 for bf16; 2: 4096).  The kernel's VGPR
+    // allocation is the maximum over the whole kernel, and with XPT = 6 this prologue IS the maximum (fp8 row-group kernel:
+    // 128 VGPRs = 4 waves per SIMD against 61 = 8 with XPT = 2): the host picks the small form whenever K allows.
     const int tid = threadIdx.x;
     const int nx = K / VX;
     float ss = 0.f;
@@ -328,7 +331,7 @@ __device__ __forceinline__ void consume_block(const uint4 (&w)[U][R], const floa
 // ------------------------------------------------------------------------------------------------
 // Row-group kernel: a wave owns R rows (SWIGLU: R/2 (gate, up) pairs 16 apart inside 32-row blocks).
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TO, typename WT, int R, int U, bool PF, bool NT, bool SWIGLU>
+template <typename T, typename TO, typename WT, int R, int U, bool PF, bool NT, bool SWIGLU, int XPT>
 __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ x, const WT* __restrict__ W,
                                                           const float* __restrict__ wscale, const T* __restrict__ norm_w,
                                                           const T* res, TO* y, int N, int K,
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     int grp = blockIdx.x * GV_WAVES + wid;
     // PF (host guarantees nchunk >= STEP): NO branch around the prefetch -- at a control-flow merge hipcc waits vmcnt(0),
     // which would drain the weights before the prologue.  Waves past the last group prefetch a clamped (valid) row.
-    stage_x<T, VE, BfImage<T, WT>::v>(x, norm_w, xs, red, K, eps, [&]() {
+    stage_x<T, VE, BfImage<T, WT>::v, XPT>(x, norm_w, xs, red, K, eps, [&]() {
         if (PF) {
             const int gp = min(grp, ngroups - 1);
             const WT* rowp[R];
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
 //   and V^T cache[hk][:][pos].  pos (= cache slot = rotary position) is read from device memory so the launch can be
 //   replayed from a hipGraph.  Rounding points are those of the unfused path: round(linear) -> rotate in fp32 -> round.
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename WT, bool NT, bool PF, int U>
+template <typename T, typename WT, bool NT, bool PF, int U, int XPT>
 __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __restrict__ x, const WT* __restrict__ W,
                                                                    const float* __restrict__ wscale,
                                                                    const T* __restrict__ norm_w, T* __restrict__ qout,
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
 
     uint4 wa[U][R];
     const int grp0 = blockIdx.x * GV_WAVES + wid;
-    stage_x<T, VE, BfImage<T, WT>::v>(x, norm_w, xs, red, K, eps, [&]() {
+    stage_x<T, VE, BfImage<T, WT>::v, XPT>(x, norm_w, xs, red, K, eps, [&]() {
         if (PF) {                                         // branch-free (see gemv_kernel)
             long long rows[R];
             int head, i0;
@@ -601,17 +604,17 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __re
 // ------------------------------------------------------------------------------------------------
 // host dispatch  (kernels: `res` and the output may be the same buffer -- in-place residual add -- so neither is __restrict__)
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TO, typename WT, int R, int U, bool PF>
+template <typename T, typename TO, typename WT, int R, int U, bool PF, int XPT = 6>
 static int launch_rows(const void* x, const void* W, const float* ws, const void* norm_w, const void* res, void* y, int N,
                        int K, float eps, bool swiglu, hipStream_t st) {
     if (PF && K / Vec16<WT>::N < 64 * U)          // the unconditional prefetch needs one full step per row
-        return launch_rows<T, TO, WT, R, U, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+        return launch_rows<T, TO, WT, R, U, false, XPT>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
     const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
     const size_t lds = x_image_bytes<BfImage<T, WT>::v, Vec16<WT>::N>(K);
 #define TEO_GV(NTV, SW)                                                                                              \
-    TEO_KLAUNCH((gemv_kernel<T, TO, WT, R, U, PF, NTV, SW>), blocks, GV_THREADS, lds, st, (const T*)x, (const WT*)W, ws, (const T*)norm_w, \
+    TEO_KLAUNCH((gemv_kernel<T, TO, WT, R, U, PF, NTV, SW, XPT>), blocks, GV_THREADS, lds, st, (const T*)x, (const WT*)W, ws, (const T*)norm_w, \
                 (const T*)res, (TO*)y, N, K, eps)
     if (g_tune.nt) { if (swiglu) TEO_GV(true, true); else TEO_GV(true, false); }
     else           { if (swiglu) TEO_GV(false, true); else TEO_GV(false, false); }
@@ -650,6 +653,7 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
         case 2: return launch_rows<T, TO, WT, 2, 8, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
         default: break;
     }
+    const bool small_k = K / Vec16<T>::N <= 2 * GV_THREADS && g_tune.small_k;   // the x prologue fits 2 chunks per thread (stage_x)
     // >= 4 KiB contiguous per row per step streams ~7 % faster than 2 KiB; first block prefetched under the prologue.
     // fp8 rows are half as long: 4 rows per wave keep the same bytes in flight per lane
     if (sizeof(WT) == 1) {
@@ -660,9 +664,11 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
             case 13: return launch_rows<T, TO, WT, 4, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
             default: break;
         }
-        // fp8: occupancy wins (the 16-wide chunks cost registers): 2 rows x 2 chunks = 122 VGPRs, 4 waves/SIMD
+        // fp8: occupancy wins (the 16-wide chunks cost registers): 2 rows x 2 chunks
+        if (small_k) return launch_rows<T, TO, WT, 2, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
         return launch_rows<T, TO, WT, 2, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
     }
+    if (small_k) return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
     return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
 }
 
@@ -994,17 +1000,21 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
     const size_t lds = w_fp8 ? xb_lds_bytes<16>(K) : (dtype == TEO_F32 ? xs_lds_bytes<4>(K) : xs_lds_bytes<8>(K));
     const int uu = w_fp8 ? 2 : 4;
     const bool pf = K / ve >= 64 * uu;
-#define TEO_QR(TT, WW, NTV)                                                                                             \
-    if (pf) TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, true, (sizeof(WW) == 1 ? 2 : 4)>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+#define TEO_QR2(TT, WW, NTV, XP)                                                                                          \
+    if (pf) TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, true, (sizeof(WW) == 1 ? 2 : 4), XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
                                                                        (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
                                                                        S_max, H, Hk, hd, K, eps);                            \
-    else TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, false, (sizeof(WW) == 1 ? 2 : 4)>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+    else TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, false, (sizeof(WW) == 1 ? 2 : 4), XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
                                                                        (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
                                                                        S_max, H, Hk, hd, K, eps)
+    // small x prologue (2 register chunks per thread) whenever K allows: fewer VGPRs, more waves per SIMD (see stage_x)
+    const bool small_k = g_tune.small_k && K / (dtype == TEO_F32 ? 4 : 8) <= 2 * GV_THREADS;
+#define TEO_QR(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2); } else { TEO_QR2(TT, WW, NTV, 6); }
     if (w_fp8)                 { if (g_tune.nt) { TEO_QR(bf16_t, fp8_t, true); } else { TEO_QR(bf16_t, fp8_t, false); } }
     else if (dtype == TEO_F32) { if (g_tune.nt) { TEO_QR(float, float, true); } else { TEO_QR(float, float, false); } }
     else                       { if (g_tune.nt) { TEO_QR(bf16_t, bf16_t, true); } else { TEO_QR(bf16_t, bf16_t, false); } }
 #undef TEO_QR
+#undef TEO_QR2
     TEO_LAUNCH_CHECK("gemv_qkv_rope");
     return TEO_OK;
 }
