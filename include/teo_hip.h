@@ -53,7 +53,7 @@ const char* teo_last_error(void);
  * "attn_flash32", "attn_mfma", "attn_simple").  Lets the parity tests state which production kernel they checked. */
 const char* teo_last_kernel(void);
 /* Performance tuning knobs (never change results beyond fp32 contraction order): "gemv_variant" (-1 = default),
- * "gemv_nt", "gemv_max_blocks", "gemm_depth", "attn_chunk" (64/128/256 keys per decode workgroup), "rope_in_attn"
+ * "gemv_nt", "gemv_max_blocks", "gemv_small_k" (1 = the GEMV x prologue sized to K <= 4096: fewer VGPRs), "gemm_depth", "attn_chunk" (64/128/256 keys per decode workgroup), "rope_in_attn"
  * (decode RoPE + KV append: 0 = QKV-GEMV epilogue, 1 = inside the decode attention kernel, -1 = auto by weight format),
  * "attn_fused_combine" (1 = last-arriver merge of the KV splits inside the attention kernel; off: slower),
  * "skinny_tiles", "skinny_nt", "skinny_stream" (batched-decode GEMM geometry / load policy / persistent streaming form: 0 off, 1 auto, 2 whenever eligible). */
