@@ -51,10 +51,11 @@ def output_path(dataset_name, model_path, out_name=None, out_dir=None, prompt_st
 
 def eval(dataset_name, model_path, model_base, load_8bit=False, load_4bit=False, cache_dir=None, data_cache_dir=None,
          out_name=None, out_dir=None, prompt_strategy=None, chronological_prefix=True, conv_mode="v1", device="cuda",
-         force_rerun=False, temperature=0.2, max_new_tokens=256, dataset=None, model_bundle=None):
+         force_rerun=False, temperature=0.2, max_new_tokens=256, dataset=None, model_bundle=None, batch_size=1):
     """Run (or re-use) the model's answers on one TEOChatlas evaluation split and print / return its task metrics.
     Extra keywords (not in the reference): `dataset` = examples to use instead of the hub download, `model_bundle` =
-    (tokenizer, model, processor) already loaded."""
+    (tokenizer, model, processor) already loaded, `batch_size` = examples answered per generation (1 = the reference's loop;
+    up to 16 share every weight read of a decode step, inference.run_inference_batch)."""
     print("Arguments passed to eval:")
     for k, v in (("dataset_name", dataset_name), ("model_path", model_path), ("model_base", model_base), ("out_name", out_name),
                  ("out_dir", out_dir), ("prompt_strategy", prompt_strategy), ("chronological_prefix", chronological_prefix),
@@ -80,7 +81,7 @@ def eval(dataset_name, model_path, model_base, load_8bit=False, load_4bit=False,
             dataset = load_dataset("jirvin16/TEOChatlas", split=f"eval_{HF_SPLIT[dataset_name]}", cache_dir=data_cache_dir,
                                    trust_remote_code=True)
         outputs = run_inference(dataset, model, tokenizer, processor, prompt_strategy, chronological_prefix, conv_mode,
-                                temperature, max_new_tokens)
+                                temperature, max_new_tokens, **({"batch_size": batch_size} if batch_size != 1 else {}))
         print(f"Saving outputs to {out_path}")
         with open(out_path, "w") as f:
             json.dump(outputs, f, indent=4)
@@ -115,6 +116,8 @@ _CLI = (
     ("force_rerun", dict(action="store_true")),
     ("temperature", dict(type=float, default=0.2)),
     ("max_new_tokens", dict(type=int, default=256)),
+    # not in the reference: examples answered per generation (1 = its one-at-a-time loop)
+    ("batch_size", dict(type=int, default=1)),
 )
 
 

@@ -105,6 +105,33 @@ def test_run_inference_bookkeeping_matches_reference(monkeypatch):
         I.run_inference([{"conversations": [{"value": "q"}, {"value": "a"}], "video": [], "timestamp": []}], None, None, None, None, True, "v1", 0.2, 8)
 
 
+def test_run_inference_batched_loop_groups_in_order(monkeypatch):
+    """batch_size > 1: consecutive examples are answered together (run_inference_batch), records stay in dataset order with
+    the same bookkeeping; the last group may be short; out-of-range sizes are refused."""
+    r = G["run_inference"]
+    groups = []
+
+    def fake_batch(model, processor, tokenizer, inps, image_paths_list, **kw):
+        groups.append({"inps": list(inps), "paths": [list(p) for p in image_paths_list], "ts": [list(t) for t in kw["timestamps_list"]],
+                       "kw": {k: v for k, v in kw.items() if k != "timestamps_list"}})
+        base = sum(len(g["inps"]) for g in groups[:-1])
+        return [f"answer {base + i + 1}" for i in range(len(inps))]
+
+    monkeypatch.setattr(I, "run_inference_batch", fake_batch)
+    n = len(r["examples"])
+    for bs in (2, 16):
+        groups.clear()
+        outs = I.run_inference(r["examples"], "M", "T", "P", "interleave", True, "v1", 0.2, 64, batch_size=bs)
+        assert outs == r["outputs"]                       # same records as the one-at-a-time loop (fake answers are numbered alike)
+        assert [len(g["inps"]) for g in groups] == [bs] * (n // bs) + ([n % bs] if n % bs else [])
+        flat = [(q, p, t) for g in groups for q, p, t in zip(g["inps"], g["paths"], g["ts"])]
+        assert flat == [(c["inp"], c["image_paths"], c["kw"]["timestamps"]) for c in r["calls"]]
+        assert all(g["kw"] == {k: v for k, v in r["calls"][0]["kw"].items() if k != "timestamps"} for g in groups)
+    for bad in (0, 17):
+        with pytest.raises(ValueError, match="batch_size"):
+            I.run_inference(r["examples"], "M", "T", "P", "interleave", True, "v1", 0.2, 64, batch_size=bad)
+
+
 def test_eval_driver_reuses_saved_outputs_and_dispatches_metrics(tmp_path, capsys):
     from teochat_amd import eval as E
     recs = G["cases"]["xbd_dmg_cls"]["outputs"]

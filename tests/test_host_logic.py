@@ -207,7 +207,8 @@ def test_eval_cli_has_the_reference_flags_and_defaults():
     a = vars(E.cli_parser().parse_args(["--dataset_name", "fmow_high_res", "--model_path", "ckpt"]))
     assert a == {"dataset_name": "fmow_high_res", "model_path": "ckpt", "model_base": None, "load_8bit": False, "load_4bit": False,
                  "cache_dir": None, "data_cache_dir": None, "out_name": None, "out_dir": None, "prompt_strategy": "interleave",
-                 "chronological_prefix": False, "device": "cuda", "force_rerun": False, "temperature": 0.2, "max_new_tokens": 256}
+                 "chronological_prefix": False, "device": "cuda", "force_rerun": False, "temperature": 0.2, "max_new_tokens": 256,
+                 "batch_size": 1}                     # batch_size: the one flag the reference does not have (default = its loop)
     b = vars(E.cli_parser().parse_args(["--dataset_name", "x", "--model_path", "y", "--model_base", "NONE", "--load_8bit",
                                          "--chronological_prefix", "--temperature", "0.5"]))
     assert b["model_base"] is None and b["load_8bit"] and b["chronological_prefix"] and b["temperature"] == 0.5

@@ -272,6 +272,39 @@ def test_run_inference_single_end_to_end_synthetic_tiny():
     assert torch.equal(cold, greedy)                        # temperature -> 0 == greedy
 
 
+def test_run_inference_batch_equals_single_examples():
+    """The batched dataset path (run_inference_batch -> generate_batch): greedy answers of three examples with 1 / 2 / 3 frames,
+    different prompts and one with out-of-order timestamps == the one-at-a-time answers (fp32: the batched decode is bitwise the
+    single one); run_inference(batch_size=2) keeps dataset order and the reference's bookkeeping."""
+    import teochat_amd.dropin as dropin
+    dropin.install()
+    from videollava.eval.eval import load_model
+    from videollava.eval import inference as RI
+    tokenizer, model, processor = load_model("synthetic:tiny", None, device="cuda:0", dtype=torch.float32, max_seq=1024)
+    g = torch.Generator().manual_seed(3)
+    img = lambda: torch.randint(0, 256, (224, 224, 3), generator=g, dtype=torch.uint8).numpy()
+    examples = [
+        {"q": "<video>\nWhat changed?", "video": [img()], "timestamp": []},
+        {"q": "<video>\nIdentify the buildings in these images taken at times: 2019, 2017. [1, 2, 30, 40]", "video": [img(), img()],
+         "timestamp": ["2019-05-01", "2017-01-15"]},
+        {"q": "<video>\nDescribe.", "video": [img(), img(), img()], "timestamp": []},
+    ]
+    kw = dict(conv_mode="v1", prompt_strategy="interleave", chronological_prefix=True, max_new_tokens=10, do_sample=False)
+    single = [RI.run_inference_single(model, processor, tokenizer, e["q"], e["video"], timestamps=e["timestamp"], **kw) for e in examples]
+    batch = RI.run_inference_batch(model, processor, tokenizer, [e["q"] for e in examples], [e["video"] for e in examples],
+                                   timestamps_list=[e["timestamp"] for e in examples], **kw)
+    assert batch == single
+    # the dataset loop on top of it (sampling at the reference's temperature: reproducible under the global seed)
+    data = [{"conversations": [{"value": e["q"]}, {"value": "gt [5, 6, 7, 8]"}], "video": e["video"], "timestamp": e["timestamp"],
+             "task": "t", "polygon": [[0, 0]]} for e in examples]
+    torch.manual_seed(11)
+    a = RI.run_inference(data, model, tokenizer, processor, "interleave", True, "v1", 0.2, 6, batch_size=2)
+    torch.manual_seed(11)
+    b = RI.run_inference(data, model, tokenizer, processor, "interleave", True, "v1", 0.2, 6, batch_size=2)
+    assert a == b and len(a) == 3 and all(isinstance(r["response"], str) for r in a)
+    assert a[1]["input_bboxes"] == [[1, 2, 30, 40]] and a[0]["output_bboxes"] == [[5, 6, 7, 8]] and a[2]["polygon"] == [[0, 0]]
+
+
 def test_causality_and_determinism_property():
     """Size-independent properties: changing a later prompt token never changes earlier logits; two runs are bit-equal."""
     g = TY.load_npz("tinyB")
