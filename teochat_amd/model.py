@@ -498,8 +498,9 @@ class LlavaLlamaForCausalLM:
         images_list: per conversation what generate() takes as `images`.  stopping_criteria: None, or one list of
         criteria per conversation.  Returns B 1-D tensors prompt + generated, each cut at its own EOS / stop keyword.
 
-        Prefill runs one conversation after the other (MFMA GEMMs already fill the chip); the decode loop is batched:
-        per step every weight matrix is streamed once for all conversations (teo_llama_decode_batch_step)."""
+        One multimodal preparation and ONE prefill pass over the concatenated rows of all conversations (per-sequence RoPE,
+        KV append and causal attention); the decode loop is batched: per step every weight matrix is streamed once for all
+        conversations (teo_llama_decode_batch_step)."""
         B = len(input_ids_list)
         if eos_token_id == "config":
             eos_token_id = self._config_eos()
