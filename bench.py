@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="config C5 variant: B conversations per GPU decoded together (weights streamed once per step)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo for plumbing tests")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: every rank uses cuda:0 (needs --dist-backend gloo)")
+    ap.add_argument("--rccl-timeout", type=float, default=180.0, help="deadline (s) of the once-per-run RCCL communicator check")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to teo_tune_set (perf knobs only)")
     args = ap.parse_args()
 
@@ -322,31 +323,50 @@ def main():
     # The library's own RCCL communicator (teo_ctx_create over all ranks): the data path of the frame-sharded tower, and for the
     # data-parallel replicas a once-per-run proof that N ranks really hold one communicator over xGMI (`rccl_ranks` below) plus
     # one checked teo_allgather_visual of a C4-sized block (2 frames x 256 x 1024 bf16 = 1 MiB per rank), outside the timed region.
-    comm, rccl_info = None, None
+    comm, rccl_info, th = None, None, None
     if world > 1 and args.dist_backend == "nccl":
         from teochat_amd.parallel import TeoComm
-        try:
-            comm = TeoComm(rank, world, local_rank)
-            r_, w_, cu_, hbm_ = comm.info()
-            send = torch.full((512, 1024), float(rank + 1), dtype=dtype, device=device)
-            recv = torch.zeros(world * 512, 1024, dtype=dtype, device=device)
-            comm.all_gather_rows(send, recv); torch.cuda.synchronize()
-            t_ag = time.perf_counter()
-            for _ in range(20):
-                comm.all_gather_rows(send, recv)
-            torch.cuda.synchronize()
-            t_ag = (time.perf_counter() - t_ag) / 20
-            want = torch.arange(1, world + 1, dtype=torch.float32, device=device).repeat_interleave(512)
-            ok = bool((recv.float().amax(dim=1) == want).all()) and bool((recv.float().amin(dim=1) == want).all())
-            rccl_info = {"rccl_ranks": w_, "cu_count": cu_, "hbm_bytes": hbm_, "allgather_1MiB_per_rank_us": round(t_ag * 1e6, 1),
-                         "allgather_checked": ok}
-            if not ok:
-                raise RuntimeError("teo_allgather_visual returned wrong rows")
-        except Exception as e:  # noqa: BLE001 -- the replicas' throughput line does not depend on the collective; report, do not hide
+        import threading
+        box = {}
+
+        def rccl_check():
+            # runs on a helper thread with a deadline: a communicator that never forms (a rank missing, a fabric fault) must not
+            # hang the throughput line of the data-parallel replicas, which does not depend on it
+            try:
+                torch.cuda.set_device(local_rank)
+                c = TeoComm(rank, world, local_rank)
+                r_, w_, cu_, hbm_ = c.info()
+                send = torch.full((512, 1024), float(rank + 1), dtype=dtype, device=device)
+                recv = torch.zeros(world * 512, 1024, dtype=dtype, device=device)
+                c.all_gather_rows(send, recv); torch.cuda.synchronize()
+                t_ag = time.perf_counter()
+                for _ in range(20):
+                    c.all_gather_rows(send, recv)
+                torch.cuda.synchronize()
+                t_ag = (time.perf_counter() - t_ag) / 20
+                want = torch.arange(1, world + 1, dtype=torch.float32, device=device).repeat_interleave(512)
+                ok = bool((recv.float().amax(dim=1) == want).all()) and bool((recv.float().amin(dim=1) == want).all())
+                box["info"] = {"rccl_ranks": w_, "cu_count": cu_, "hbm_bytes": hbm_, "allgather_1MiB_per_rank_us": round(t_ag * 1e6, 1),
+                               "allgather_checked": ok}
+                if not ok:
+                    raise RuntimeError("teo_allgather_visual returned wrong rows")
+                box["comm"] = c
+            except Exception as e:  # noqa: BLE001 -- report, do not hide
+                box["error"] = e
+
+        th = threading.Thread(target=rccl_check, daemon=True)
+        th.start()
+        th.join(timeout=args.rccl_timeout)
+        if th.is_alive():
+            box["error"] = TimeoutError(f"the RCCL communicator check did not finish in {args.rccl_timeout:.0f} s")
+        if "error" in box:
             if args.shard_frames:
-                raise
+                raise box["error"]
+            e = box["error"]
             rccl_info = {"rccl_ranks": None, "error": f"{type(e).__name__}: {str(e)[:300]}"}
             comm = None
+        else:
+            comm, rccl_info = box["comm"], box["info"]
     if args.shard_frames:
         # C4: every rank encodes its block of frames; with the nccl backend the gather is the library's RCCL all-gather
         # (teo_allgather_visual, no torch collective on the data path); gloo only for the one-GPU plumbing test
@@ -559,6 +579,10 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        stuck = th is not None and th.is_alive()         # the communicator check never came back: do not wait for it at exit either
+        if stuck:
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
