@@ -608,7 +608,7 @@ template <typename T, typename TO, typename WT, int R, int U, bool PF, int XPT =
 static int launch_rows(const void* x, const void* W, const float* ws, const void* norm_w, const void* res, void* y, int N,
                        int K, float eps, bool swiglu, hipStream_t st) {
     if (PF && K / Vec16<WT>::N < 64 * U)          // the unconditional prefetch needs one full step per row
-        return launch_rows<T, TO, WT, R, U, false, XPT>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+        return launch_rows<T, TO, WT, R, U, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);   // (short rows: the default prologue)
     const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
@@ -665,10 +665,10 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
             default: break;
         }
         // fp8: occupancy wins (the 16-wide chunks cost registers): 2 rows x 2 chunks
-        if (small_k) return launch_rows<T, TO, WT, 2, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+        if constexpr (IsBf<T>::v) { if (small_k) return launch_rows<T, TO, WT, 2, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st); }
         return launch_rows<T, TO, WT, 2, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
     }
-    if (small_k) return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+    if constexpr (IsBf<T>::v) { if (small_k) return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st); }
     return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
 }
 
@@ -1010,10 +1010,12 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
     // small x prologue (2 register chunks per thread) whenever K allows: fewer VGPRs, more waves per SIMD (see stage_x)
     const bool small_k = g_tune.small_k && K / (dtype == TEO_F32 ? 4 : 8) <= 2 * GV_THREADS;
 #define TEO_QR(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2); } else { TEO_QR2(TT, WW, NTV, 6); }
+#define TEO_QR6(TT, WW, NTV) TEO_QR2(TT, WW, NTV, 6)
     if (w_fp8)                 { if (g_tune.nt) { TEO_QR(bf16_t, fp8_t, true); } else { TEO_QR(bf16_t, fp8_t, false); } }
-    else if (dtype == TEO_F32) { if (g_tune.nt) { TEO_QR(float, float, true); } else { TEO_QR(float, float, false); } }
+    else if (dtype == TEO_F32) { if (g_tune.nt) { TEO_QR6(float, float, true); } else { TEO_QR6(float, float, false); } }
     else                       { if (g_tune.nt) { TEO_QR(bf16_t, bf16_t, true); } else { TEO_QR(bf16_t, bf16_t, false); } }
 #undef TEO_QR
+#undef TEO_QR6
 #undef TEO_QR2
     TEO_LAUNCH_CHECK("gemv_qkv_rope");
     return TEO_OK;
