@@ -656,16 +656,26 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
     const bool small_k = K / Vec16<T>::N <= 2 * GV_THREADS && g_tune.small_k;   // the x prologue fits 2 chunks per thread (stage_x)
     // >= 4 KiB contiguous per row per step streams ~7 % faster than 2 KiB; first block prefetched under the prologue.
     // fp8 rows are half as long: 4 rows per wave keep the same bytes in flight per lane
-    if (sizeof(WT) == 1) {
+    if constexpr (sizeof(WT) == 1) {
+        // fp8 rows are half as long.  With the small prologue (61-95 VGPRs) 2 rows x 4 chunks = 8 KB per wave per step wins
+        // (gate/up 16.7 -> 15.3 us, qkv 11.3 -> 10.0, lm_head 23 -> 21.7: at the streaming floor); with the K <= 12288
+        // prologue the registers are the prologue's and 2 x 2 keeps the occupancy
+        if constexpr (IsBf<T>::v) {
+            if (small_k) {
+                switch (g_tune.variant) {
+                    case 11: return launch_rows<T, TO, WT, 4, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+                    case 12: return launch_rows<T, TO, WT, 2, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+                    case 13: return launch_rows<T, TO, WT, 4, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+                    default: return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
+                }
+            }
+        }
         switch (g_tune.variant) {
             case 10: return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
             case 11: return launch_rows<T, TO, WT, 4, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
-            case 12: return launch_rows<T, TO, WT, 2, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
             case 13: return launch_rows<T, TO, WT, 4, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
             default: break;
         }
-        // fp8: occupancy wins (the 16-wide chunks cost registers): 2 rows x 2 chunks
-        if constexpr (IsBf<T>::v) { if (small_k) return launch_rows<T, TO, WT, 2, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st); }
         return launch_rows<T, TO, WT, 2, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
     }
     if constexpr (IsBf<T>::v) { if (small_k) return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st); }
