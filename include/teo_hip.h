@@ -54,7 +54,7 @@ const char* teo_last_error(void);
 const char* teo_last_kernel(void);
 /* Performance tuning knobs (never change results beyond fp32 contraction order): "gemv_variant" (-1 = default),
  * "gemv_nt", "gemv_max_blocks", "gemv_small_k" (1 = the GEMV x prologue sized to K <= 4096: fewer VGPRs), "gemm_depth", "attn_chunk" (64/128/256 keys per decode workgroup), "rope_in_attn"
- * (decode RoPE + KV append: 0 = QKV-GEMV epilogue, 1 = inside the decode attention kernel, -1 = auto by weight format),
+ * (decode RoPE + KV append: 0 = QKV-GEMV epilogue, 1 = inside the decode attention kernel, -1 = auto = 0),
  * "attn_fused_combine" (1 = last-arriver merge of the KV splits inside the attention kernel; off: slower),
  * "skinny_tiles", "skinny_nt", "skinny_stream" (batched-decode GEMM geometry / load policy / persistent streaming form: 0 off, 1 auto, 2 whenever eligible). */
 int teo_tune_set(const char* key, int value);

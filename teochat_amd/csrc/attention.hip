@@ -303,8 +303,9 @@ static int g_fused_combine = 0;   // 1: the last workgroup of a head merges the 
                                   // agent-scope release/acquire fences cost far more than the launch they save (2.89 -> 3.51
                                   // ms/token; batch 8: 5.2 -> 13 ms/step), so it stays off -- kept as a tested experiment.
 int g_rope_in_attn = -1;          // decode RoPE + KV append: 0 = in the QKV GEMV epilogue, 1 = inside the attention kernel,
-                                   // -1 = auto (measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0,
-                                   // fp8 weights 2.216 vs 2.234 in favour of 1)
+                                   // -1 = auto = 0.  Measured end to end on one box: bf16 weights 2.926 vs 2.995 ms/token in favour of 0;
+                                   // fp8 weights were 2.216 vs 2.234 in favour of 1 until the fp8 QKV+RoPE GEMV got the small prologue
+                                   // and 4 chunks per step (round 3): now 1.815 vs 1.856 in favour of 0 as well
 static int g_attn_fat = 0;        // decode attention for bf16 / head_dim 128: 1 = the fat-split kernel of attn_fat.hip + record merge in the o-projection
                                   // GEMV (no combine launch).  Measured on MI355X (round 3, profiles/r03_decode_attention_ab.md): a tie at
                                   // ctx 2300 (2.713 vs 2.706 ms/token), slower at ctx 700 (2.643 vs 2.582) and 4250 (2.957 vs 2.886) -- off.

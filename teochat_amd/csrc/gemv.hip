@@ -1008,24 +1008,27 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
     const size_t lds = w_fp8 ? xb_lds_bytes<16>(K) : (dtype == TEO_F32 ? xs_lds_bytes<4>(K) : xs_lds_bytes<8>(K));
-    const int uu = w_fp8 ? 2 : 4;
+    // small x prologue (2 register chunks per thread) whenever K allows: fewer VGPRs, more waves per SIMD (see stage_x); fp8 rows then
+    // take 4 chunks per step like the row-group kernel (8 KB per wave in flight)
+    const bool small_k = g_tune.small_k && K / (dtype == TEO_F32 ? 4 : 8) <= 2 * GV_THREADS;
+    const int uu = (w_fp8 && !small_k) ? 2 : 4;
     const bool pf = K / ve >= 64 * uu;
-#define TEO_QR2(TT, WW, NTV, XP)                                                                                          \
-    if (pf) TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, true, (sizeof(WW) == 1 ? 2 : 4), XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+#define TEO_QR2(TT, WW, NTV, XP, UU)                                                                                      \
+    if (pf) TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, true, UU, XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
                                                                        (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
                                                                        S_max, H, Hk, hd, K, eps);                            \
-    else TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, false, (sizeof(WW) == 1 ? 2 : 4), XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
+    else TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, false, UU, XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
                                                                        (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
                                                                        S_max, H, Hk, hd, K, eps)
-    // small x prologue (2 register chunks per thread) whenever K allows: fewer VGPRs, more waves per SIMD (see stage_x)
-    const bool small_k = g_tune.small_k && K / (dtype == TEO_F32 ? 4 : 8) <= 2 * GV_THREADS;
-#define TEO_QR(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2); } else { TEO_QR2(TT, WW, NTV, 6); }
-#define TEO_QR6(TT, WW, NTV) TEO_QR2(TT, WW, NTV, 6)
-    if (w_fp8)                 { if (g_tune.nt) { TEO_QR(bf16_t, fp8_t, true); } else { TEO_QR(bf16_t, fp8_t, false); } }
+#define TEO_QR(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2, 4); } else { TEO_QR2(TT, WW, NTV, 6, 4); }
+#define TEO_QR6(TT, WW, NTV) TEO_QR2(TT, WW, NTV, 6, 4)
+#define TEO_QR8(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2, 4); } else { TEO_QR2(TT, WW, NTV, 6, 2); }
+    if (w_fp8)                 { if (g_tune.nt) { TEO_QR8(bf16_t, fp8_t, true); } else { TEO_QR8(bf16_t, fp8_t, false); } }
     else if (dtype == TEO_F32) { if (g_tune.nt) { TEO_QR6(float, float, true); } else { TEO_QR6(float, float, false); } }
     else                       { if (g_tune.nt) { TEO_QR(bf16_t, bf16_t, true); } else { TEO_QR(bf16_t, bf16_t, false); } }
 #undef TEO_QR
 #undef TEO_QR6
+#undef TEO_QR8
 #undef TEO_QR2
     TEO_LAUNCH_CHECK("gemv_qkv_rope");
     return TEO_OK;

@@ -399,7 +399,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     const int fat_ns = fat ? attn_fat_nsplit(d->max_seq) : 0;
     for (int l = 0; l < d->layers; ++l) {
         if (fat) {
-            const bool rope_in = g_rope_in_attn < 0 ? w8 : g_rope_in_attn != 0;
+            const bool rope_in = g_rope_in_attn < 0 ? false : g_rope_in_attn != 0;
             prof_class(TEO_PROF_QKV);
             if (rope_in) {
                 TEO_TRY(gemv_w(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], nullptr,
@@ -413,7 +413,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
             TEO_TRY(attn_decode_fat(w.qkv, d->k_cache[l], d->v_cache[l], rope_in ? d->vt_cache[l] : nullptr, rope_in ? d->rope_cos : nullptr,
                                     rope_in ? d->rope_sin : nullptr, w.attn, w.part, s->d_pos, d->max_seq, H, Hk, 1.0f / sqrtf((float)hd),
                                     st, AttnBatch(), !o_merge));
-        } else if (g_rope_in_attn < 0 ? w8 : g_rope_in_attn != 0) {
+        } else if (g_rope_in_attn < 0 ? false : g_rope_in_attn != 0) {
             // rmsnorm + QKV projection (plain weight stream); RoPE + KV append ride inside the attention kernel
             // (position read from s->d_pos on the device)
             prof_class(TEO_PROF_QKV);
