@@ -438,6 +438,7 @@ __global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t*
         int par = 0;
         for (int t = blockIdx.x; t < ntiles; t += G) {
             __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");               // the partial tiles are read AFTER the barrier (s_barrier alone does not order them for the compiler)
             const f32x4 sc = sc_n;
             const uint2 rv = rv_n, gv = gv_n;
             TEO_SS_PREFETCH(t + G)
