@@ -313,7 +313,7 @@ def main():
     if prefill_fp8:
         if args.weights != "fp8":
             raise SystemExit("--prefill fp8 needs --weights fp8 (the e4m3 weight copies)")
-        L.check(eng.lib.teo_tune_set(b"prefill_fp8", 1), "teo_tune_set")
+        eng.set_options(prefill_fp8=True)
     for kv in args.tune:
         k_, v_ = kv.split("=")
         L.check(eng.lib.teo_tune_set(k_.encode(), int(v_)), "teo_tune_set")
@@ -492,13 +492,19 @@ def main():
         x = torch.randn(Dh, device=device).to(dtype)
         y = torch.empty(Fi, dtype=dtype, device=device)
         avg = C.c_float(0)
-        from tools import bench_shim                  # bench-only timing shim over the public C ABI (not part of the product library)
-        shim = bench_shim.load()
-        with eng.phase() as st:
-            L.check(shim.teo_bench_gemv_chain(x.data_ptr(), pp, None, len(Ws), eng.llama_w["post_norm"][0].data_ptr(), y.data_ptr(),
-                                              2 * Fi, Dh, cfg.rms_norm_eps, L.GEMM_SWIGLU16, L.TEO_BF16, 5, C.byref(avg), st),
-                    "teo_bench_gemv_chain")
-        chain_ms = avg.value
+        # bench-only timing shim over the public C ABI (tools/libteo_bench.so, not part of the product library).  A secondary number
+        # ("reported beside the in-run timing, never instead of it"): when the shim is missing or fails the line says why and goes on
+        try:
+            from tools import bench_shim
+            shim = bench_shim.load()
+            with eng.phase() as st:
+                L.check(shim.teo_bench_gemv_chain(x.data_ptr(), pp, None, len(Ws), eng.llama_w["post_norm"][0].data_ptr(), y.data_ptr(),
+                                                  2 * Fi, Dh, cfg.rms_norm_eps, L.GEMM_SWIGLU16, L.TEO_BF16, 5, C.byref(avg), st),
+                        "teo_bench_gemv_chain")
+            chain_ms = avg.value
+        except Exception as e:  # noqa: BLE001
+            chain_ms, chain_note = None, f"chain microbenchmark skipped: {e}"
+            print(chain_note, file=sys.stderr)
     # HBM traffic comes from PMC counters, which need their own rocprofv3 --pmc passes (MI355X_MICROARCH.md section HBM:
     # FETCH_SIZE x2 on gfx950 + WRITE_SIZE); it is NOT measured inside this run: the numbers below are read from the committed
     # summary of those passes (tools/pmc_traffic.sh) and labelled with the file and the commit they were taken at.

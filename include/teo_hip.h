@@ -50,14 +50,24 @@ int teo_version(void);
 const char* teo_last_error(void);
 /* Diagnostics: which kernel family the most recent teo_gemm* / teo_attention call of this thread dispatched to
  * ("gemm_simple", "gemm_mfma_128", "gemm_mfma_128_sk", "gemm_wide", "gemm_wide_sk", "gemm_big", "gemm_big_hybrid", "gemm_fp8_*",
- * "attn_flash32", "attn_mfma", "attn_simple").  Lets the parity tests state which production kernel they checked. */
+ * "attn_flash32", "attn_simple").  Lets the parity tests state which production kernel they checked. */
 const char* teo_last_kernel(void);
-/* Performance tuning knobs (never change results beyond fp32 contraction order): "gemv_variant" (-1 = default),
- * "gemv_nt", "gemv_max_blocks", "gemv_small_k" (1 = the GEMV x prologue sized to K <= 4096: fewer VGPRs), "gemm_depth", "attn_chunk" (64/128/256 keys per decode workgroup), "rope_in_attn"
- * (decode RoPE + KV append: 0 = QKV-GEMV epilogue, 1 = inside the decode attention kernel, -1 = auto = 0),
- * "attn_fused_combine" (1 = last-arriver merge of the KV splits inside the attention kernel; off: slower),
- * "skinny_tiles", "skinny_nt", "skinny_stream" (batched-decode GEMM geometry / load policy / persistent streaming form: 0 off, 1 auto, 2 whenever eligible). */
+/* Performance tuning knobs.  PERF-ONLY: every key selects among kernels / geometries that compute the same values (bit-identical
+ * unless noted "fp32 order": the fp32 summation order of a reduction may change, nothing else).  Result- or path-selecting options
+ * are NOT here: they are fields of the descriptors (teo_llama_desc.prefill_fp8, .rope_in_attn).  The state is process-wide and meant
+ * for benchmarks and for tests that force one kernel family; the library's defaults are what ships.  Keys (value 0 / 1 unless said):
+ *   decode GEMV   : "gemv_variant" (-1 default; 0..2, 10..13: row-group geometry; fp32 order), "gemv_nt" (non-temporal weight loads),
+ *                   "gemv_max_blocks" (workgroup cap), "gemv_small_k" (x prologue sized to K <= 4096), "gemv_splitk_u" (0 auto, 2/4/6)
+ *   prefill GEMM  : "gemm_depth", "gemm_sk" (stream-K: 0 off, 1 auto, 2 force), "gemm_sk_dbg", "gemm_wide" (0 off, 1 auto, 2 force),
+ *                   "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force), "gemm_big_group", "gemm_big_hybrid"
+ *                   (0 off, 1 auto, 2 force), "gemm_fp8_wide" (0..3), "gemm_fp8_big" (0..2), "gemm_splitk" (split-K form of the
+ *                   short-N tower GEMMs: 0 off, 1 auto) -- all bit-identical families
+ *   decode attn   : "attn_chunk" (keys per decode workgroup: 0 auto, 32/64/128/256; fp32 order of the split merge), "attn_whole"
+ *                   (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto; bit-identical)
+ *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible) */
 int teo_tune_set(const char* key, int value);
+/* Every knob back to the library default (what ships). */
+int teo_tune_reset(void);
 /* 1 when the MFMA (fast) kernel would be used for this GEMM, 0 when the generic kernel would. */
 int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags);
 
@@ -329,6 +339,11 @@ typedef struct {
     const void* const* gateup_w8; const float* const* gateup_s;
     const void* const* down_w8;   const float* const* down_s;
     const void* lm_head8;         const float* lm_head_s;
+    /* Per-engine options (they select a path or change results, so they live here and not in teo_tune_set): */
+    int prefill_fp8;   /* 1: prefill Linear layers as w8a8 on the fp8 MFMA (activations quantised per token; needs the *_w8 copies,
+                        *    bf16).  Lossy beyond the weight quantisation: selectable, never a default.  0: bf16 / f32 GEMMs */
+    int rope_in_attn;  /* single-conversation decode step: 0 = RoPE + KV append in the QKV GEMV epilogue (default), 1 = inside the
+                        *    decode attention kernel (same values; the batched step always uses 1) */
 } teo_llama_desc;
 
 size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
@@ -383,16 +398,6 @@ typedef struct teo_graph teo_graph;
 int teo_vit_workspace_status(const teo_vit_desc* d, int T, void* d_workspace, size_t workspace_bytes, int* host_flag, teo_stream_t stream);
 int teo_llama_prefill_workspace_status(const teo_llama_desc* d, int S, void* d_workspace, size_t workspace_bytes, int* host_flag,
                                        teo_stream_t stream);
-/* Overlapped decode steps (round 3): n_steps steps of teo_llama_decode_step's arithmetic with the step's kernels launched as a CHAIN
- * (AQL barrier bit cleared, one device-side progress word: a kernel's launch ramp and first weight block run under the tail of its
- * predecessor; see csrc/common.h "launch chain").  Plain launches, no hipGraph: pos0 = position of the token fed by the first step
- * (= tokens in the cache; the host knows it), step i runs at pos0 + i.  Needs bf16, head_dim 128 (teo_llama_decode_chain_supported);
- * the workspace is teo_llama_decode_workspace_bytes(), armed by teo_llama_decode_begin.  teo_llama_decode_chain_error reads the
- * chain's error word (a bounded wait that gave up: results invalid) after synchronising the stream: 0 = fine. */
-int teo_llama_decode_chain_supported(const teo_llama_desc* d);
-int teo_llama_decode_steps(const teo_llama_desc* d, const teo_decode_state* st, void* d_workspace, size_t workspace_bytes, int n_steps,
-                           int pos0, teo_stream_t stream);
-int teo_llama_decode_chain_error(const teo_llama_desc* d, void* d_workspace, size_t workspace_bytes, int* host_flag, teo_stream_t stream);
 /* Measurement aid: ONE decode step (plain launches, not a graph replay) in which every kernel launch carries its own start / stop
  * events (hipExtLaunchKernel: the dispatch's execution timestamps -- kernel time only, what rocprofv3 --kernel-trace reports).
  * ms_out[c] = summed kernel milliseconds of class c over the step, count_out[c] = launches of that class.  Same arithmetic and

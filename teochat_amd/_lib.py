@@ -64,7 +64,8 @@ class LlamaDesc(C.Structure):
                 ("in_norm_w", PP), ("qkv_w", PP), ("o_w", PP), ("post_norm_w", PP), ("gateup_w", PP),
                 ("down_w", PP), ("k_cache", PP), ("v_cache", PP), ("vt_cache", PP),
                 ("qkv_w8", PP), ("qkv_s", PP), ("o_w8", PP), ("o_s", PP), ("gateup_w8", PP), ("gateup_s", PP),
-                ("down_w8", PP), ("down_s", PP), ("lm_head8", C.c_void_p), ("lm_head_s", C.c_void_p)]
+                ("down_w8", PP), ("down_s", PP), ("lm_head8", C.c_void_p), ("lm_head_s", C.c_void_p),
+                ("prefill_fp8", C.c_int), ("rope_in_attn", C.c_int)]
 
 
 class DecodeState(C.Structure):
@@ -93,6 +94,7 @@ _SIGS = {
     "teo_last_error": (C.c_char_p, []),
     "teo_last_kernel": (C.c_char_p, []),
     "teo_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "teo_tune_reset": (C.c_int, []),
     "teo_gemm_uses_mfma": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "teo_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "teo_rmsnorm": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
@@ -129,9 +131,6 @@ _SIGS = {
     "teo_llama_decode_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc)]),
     "teo_llama_decode_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "teo_llama_decode_chain_supported": (C.c_int, [C.POINTER(LlamaDesc)]),
-    "teo_llama_decode_steps": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
-    "teo_llama_decode_chain_error": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]),
     "teo_llama_decode_step_profile": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int),
                                                 C.c_void_p]),
     "teo_llama_decode_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t,

@@ -69,6 +69,16 @@ class BatchDecoder:
                 d.gateup_w, d.down_w = self._arr(tw["gateup"]), self._arr(tw["down"])
                 d.lm_head = head.data_ptr()
         self.desc = d
+        # the engine's per-engine options (TeoEngine.set_options) reach the copies made above
+        import weakref
+        me = weakref.ref(self)
+
+        def _sync_options(src):
+            o = me()
+            if o is not None:
+                for dd in o.slot_desc + [o.desc]:
+                    dd.prefill_fp8, dd.rope_in_attn = src.prefill_fp8, src.rope_in_attn
+        engine._option_hooks.append(_sync_options)
         # device state
         self.d_token = torch.zeros(B, dtype=torch.int64, device=dev)
         self.d_pos = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -114,9 +124,13 @@ class BatchDecoder:
             pos = torch.arange(past, past + S, dtype=torch.int32, device=eng.device)
             rows = 1 if last_only else S
             logits = torch.empty(rows, eng.cfg.vocab_size, dtype=torch.float32, device=eng.device)
+            eng._flush_handoff_checks("prefill")
             ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d), S))
             L.check(self.lib.teo_llama_prefill(C.byref(d), _p(e), _p(pos), S, past, 1 if last_only else 0, _p(logits), _p(ws),
                                                ws.numel(), st), "teo_llama_prefill")
+            sid = C.c_void_p(eng.stream.cuda_stream)
+            eng._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d), S, _p(ws), ws.numel(), C.byref(f), sid),
+                                "teo_llama_prefill")
         self.cache_len[slot] = past + S
         return logits
 
@@ -133,10 +147,15 @@ class BatchDecoder:
         with eng.phase() as st:
             rows = torch.cat([e.to(device=eng.device, dtype=eng.dtype) for e in embeds_list], dim=0).contiguous()
             logits = torch.empty(self.B, eng.cfg.vocab_size, dtype=torch.float32, device=eng.device)
-            ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(self.slot_desc[0]), total))
+            eng._flush_handoff_checks("prefill")
+            d0 = self.slot_desc[0]
+            ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d0), total))
             arr = (C.c_int * self.B)(*lens)
-            L.check(self.lib.teo_llama_prefill_batch(C.byref(self.slot_desc[0]), _p(rows), arr, self.B, self.k_cache.stride(1),
+            L.check(self.lib.teo_llama_prefill_batch(C.byref(d0), _p(rows), arr, self.B, self.k_cache.stride(1),
                                                      _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill_batch")
+            sid = C.c_void_p(eng.stream.cuda_stream)
+            eng._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d0), total, _p(ws), ws.numel(), C.byref(f), sid),
+                                "teo_llama_prefill_batch")
         self.cache_len = list(lens)
         return logits
 

@@ -17,6 +17,17 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int device_cu_count() {
+    static int cached[64];                      // 0 = not queried yet (a failed query is retried; a benign race writes the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
+    hipDeviceProp_t p;
+    const int cus = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 0;
+    if (dev >= 0 && dev < 64 && cus > 0) cached[dev] = cus;
+    return cus;
+}
+
 int hip_fail(hipError_t e, const char* what) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return TEO_ERR_HIP;
@@ -35,12 +46,8 @@ size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
 int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out, int* count_out,
                               hipStream_t st);
-bool llama_decode_chain_ok(const teo_llama_desc* d);
 int llama_prefill_workspace_status(const teo_llama_desc* d, int S, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
 int vit_workspace_status(const teo_vit_desc* d, int T, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
-int llama_decode_chain_steps(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, int n_steps, int pos0, bool ordered,
-                             hipStream_t st);
-int llama_decode_chain_error(const teo_llama_desc* d, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
 int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int decode_graph_create(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st,
                         teo_graph** out);
@@ -71,9 +78,15 @@ const char* teo_last_error(void) { return g_err; }
 const char* teo_last_kernel(void) { return teo::g_last_kernel; }
 
 int teo_tune_set(const char* key, int value) {
-    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || gemm_big_tune_set(key, value) == 0 || runtime_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
+    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || gemm_big_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
     set_error("teo_tune_set: unknown key");
     return TEO_ERR_ARG;
+}
+
+int teo_tune_reset(void) {
+    gemv_tune_reset(); gemm_tune_reset(); gemm_wide_tune_reset(); gemm_big_tune_reset(); gemm_fp8_tune_reset(); skinny_tune_reset();
+    attn_tune_reset();
+    return TEO_OK;
 }
 
 int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags) {
@@ -323,31 +336,6 @@ int teo_vit_workspace_status(const teo_vit_desc* d, int T, void* ws, size_t wsb,
     return vit_workspace_status(d, T, ws, wsb, host_flag, ST(s));
 }
 
-int teo_llama_decode_chain_supported(const teo_llama_desc* d) {
-    if (!d) return 0;
-    return llama_decode_chain_ok(d) ? 1 : 0;
-}
-
-int teo_llama_decode_steps(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, int n_steps, int pos0, teo_stream_t s) {
-    ENTER();
-    NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
-    NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
-    NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
-    TEO_CHECK_ARG(n_steps >= 0, "teo_llama_decode_steps: n_steps %d", n_steps);
-    if (st->do_sample) {
-        NEED(st->d_rng, "d_rng"); TEO_CHECK_ARG(st->temperature > 0.f, "teo_llama_decode_steps: temperature %g", st->temperature);
-        const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc;
-    }
-    if (!llama_decode_chain_ok(d)) { set_error("teo_llama_decode_steps: this model / dtype has no overlapped step (use teo_llama_decode_step)"); return TEO_ERR_UNSUPPORTED; }
-    return llama_decode_chain_steps(d, st, ws, wsb, n_steps, pos0, false, ST(s));
-}
-
-int teo_llama_decode_chain_error(const teo_llama_desc* d, void* ws, size_t wsb, int* host_flag, teo_stream_t s) {
-    ENTER();
-    NEED(d, "desc"); NEED(ws, "workspace"); NEED(host_flag, "host_flag");
-    return llama_decode_chain_error(d, ws, wsb, host_flag, ST(s));
-}
-
 int teo_llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, float* ms_out, int* count_out,
                                   teo_stream_t s) {
     ENTER();
@@ -439,7 +427,7 @@ int teo_graph_destroy(teo_graph* g) {
 
 size_t teo_attn_decode_workspace_bytes(int heads, int head_dim, int max_seq, int batch) {
     if (!(heads > 0 && head_dim > 0 && max_seq > 0 && batch > 0)) return 0;
-    return attn_decode_counters_offset(heads, head_dim, max_seq, batch) + (size_t)batch * heads * sizeof(int);
+    return attn_decode_ws_bytes(heads, head_dim, max_seq, batch);
 }
 
 int teo_attn_decode(const void* q, void* k_cache, void* v_cache, void* vt_cache, const float* rope_cos, const float* rope_sin,
@@ -453,14 +441,8 @@ int teo_attn_decode(const void* q, void* k_cache, void* v_cache, void* vt_cache,
     TEO_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr), "teo_attn_decode: rope_cos and rope_sin go together");
     AttnBatch bt;
     bt.batch = batch; bt.q_stride = q_stride; bt.cache_stride = cache_stride; bt.o_stride = o_stride;
-    int* counters = nullptr;
-    if (attn_decode_fused_enabled()) {                  // in-kernel merge of the KV splits: arrival counters behind the records
-        counters = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(partials) + attn_decode_counters_offset(heads, head_dim, max_seq, batch));
-        hipError_t e = hipMemsetAsync(counters, 0, (size_t)batch * heads * sizeof(int), ST(s));
-        if (e != hipSuccess) return hip_fail(e, "teo_attn_decode: hipMemsetAsync");
-    }
     return attn_decode(q, k_cache, v_cache, vt_cache, rope_cos, rope_sin, out, partials, d_pos, max_seq, heads, kv_heads, head_dim,
-                       scale, dtype, ST(s), bt, counters);
+                       scale, dtype, ST(s), bt);
 }
 
 int teo_cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,

@@ -546,10 +546,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
 // ------------------------------------------------------------------------------------------------
 constexpr double GEMM_BIG_ROUND_COST = 1.75;  // measured: 100 us per round of 256 x 256 tiles vs 58 us per round of 128 x 256 (gate/up at M = 17344; 8192^3: 195 vs 111)
 static int g_gemm_big = 1;     // 256 x 256 LDS-DMA kernel (gemm_big.hip): 0 off, 1 auto (rounds model), 2 forced
-static int g_gemm_split = 0;   // whole rounds of 256 x 256 tiles + the last column tile(s) on the 128 x 128 kernel, launched beside each other.
-                               // OFF: measured (tools/split_probe.py, profiles/r03_split_probe.txt) the two launches do overlap, but 765 tiles are
-                               // 2.99 rounds with no slack -- the 34 CUs that host a 58 us small tile first finish their three big tiles 58 us
-                               // late: 353 us against 358 (128 x 256 kernel); the pieces alone: 296 + 58.5 us.  Needs a split-K'd remainder.
 static int g_gemm_wide = 1;    // wide-tile LDS-DMA kernel (gemm_wide.hip): 0 off, 1 auto, 2 forced wherever its shape constraints hold
 static int g_gemm_sk_dbg = 0;  // timing diagnostics only (wrong results): 1 skip slab stores, 2 skip the flag wait, 4 skip slab loads
 static int g_gemm_sk = 1;      // 1: stream-K kernel when a workspace is given and the static tiling would leave a ragged last round
@@ -571,22 +567,16 @@ int gemm_sk_workspace_status(const void* ws, int* host_flag, hipStream_t st) {
 }
 // the persistent forms assume the MI355X's 256 CUs (grids of 256 / 512 resident workgroups): elsewhere the plain kernels run
 static bool sk_grid_fits_device() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
-    }
-    return cus == 256;
+    return device_cu_count() == 256;
 }
 static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
 static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
+void gemm_tune_reset() { g_gemm_big = 1; g_gemm_wide = 1; g_gemm_sk_dbg = 0; g_gemm_sk = 1; g_gemm_depth = 0; g_gemm_bm = 0; }
 int gemm_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
     if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
     if (!strcmp(key, "gemm_wide")) { g_gemm_wide = value; return 0; }
     if (!strcmp(key, "gemm_big")) { g_gemm_big = value; return 0; }
-    if (!strcmp(key, "gemm_split")) { g_gemm_split = value != 0; return 0; }
     if (!strcmp(key, "gemm_sk_dbg")) { g_gemm_sk_dbg = value; return 0; }
     if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return 0; }          // 0 off, 1 auto, 2 forced (diagnostics)
     return -1;
@@ -683,33 +673,6 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         // (with a workspace its hybrid form has no ragged last round: fractional rounds + a hand-off allowance)
         const double big_rounds = (sk_ws && t_big > 256 && t_big % 256 != 0 && gemm_big_hybrid_fits(M, N, K)) ? (double)t_big / 256.0 + 0.12
                                                                                                                  : (double)cdiv(t_big, 256);
-        // 256 x 256 tiles in WHOLE rounds + the last column tile(s) on the 128 x 128 kernel, beside each other: gate/up at M = 2168 is
-        // 9 x 86 = 774 big tiles = 3.02 rounds -- the 128 x 256 kernel took it at 5.7 rounds (1.07 PFLOP/s).  Here 85 column tiles
-        // (765 tiles: 2.99 rounds of the 1.3-1.4 PFLOP/s kernel) run as one plain launch and the last 256 columns as 34 small tiles
-        // launched FIRST; the big launch follows with the AQL barrier bit cleared (hipExtAnyOrderLaunch: disjoint outputs, same
-        // inputs), so both are on the chip together and the next ordered kernel waits for both.  Same kernels, same k-order per
-        // output element: bit-identical to every other form.
-        if (bm == 128 && g_gemm_split && g_gemm_big == 1 && g_gemm_wide == 1 && K >= 2 * BK && t_big > 256) {
-            const int tm_big = cdiv(M, 256), tn_big = cdiv(N, 256);
-            const int rounds = (int)(t_big / 256);
-            const int cols_main = std::min(tn_big - 1, (rounds * 256) / tm_big);
-            const int rem_cols = tn_big - cols_main;
-            const double split_cost = rounds * GEMM_BIG_ROUND_COST + 0.35;                     // + the shadow of the small launch
-            if (rem_cols >= 1 && rem_cols <= 2 && cols_main * tm_big > (rounds - 1) * 256 + 128 && N % 256 == 0 &&
-                split_cost < (double)cdiv(t_wide_, 256) && split_cost < big_rounds * GEMM_BIG_ROUND_COST) {
-                const int n0 = cols_main * 256;
-                const size_t eo = of32 ? 4 : 2;
-                const unsigned char* Wr = (const unsigned char*)W + (size_t)n0 * K * 2;
-                const void* bias_r = bias ? (const unsigned char*)bias + (size_t)n0 * 2 : nullptr;
-                const void* res_r = res ? (const unsigned char*)res + (size_t)n0 * 2 : nullptr;
-                void* C_r = (unsigned char*)C + (size_t)(swiglu ? n0 / 2 : n0) * eo;
-                int rc = gemm_plain_launch(A, Wr, bias_r, res_r, C_r, M, N - n0, K, lda, ldc, act, swiglu, of32, 128, st);
-                if (rc != TEO_OK) return rc;
-                rc = gemm_big_launch(A, W, bias, res, C, M, n0, K, lda, ldc, act, swiglu, of32, st, nullptr, 0, /*any_order*/ true);
-                note_kernel("gemm_big_split");
-                return rc;
-            }
-        }
         if (bm == 128 && K >= 2 * BK && (g_gemm_big == 2 || (g_gemm_big == 1 && g_gemm_wide == 1 && t_big >= 224 && !sk_wide_shape &&
                                                                big_rounds * GEMM_BIG_ROUND_COST < (double)cdiv(t_wide_, 256))))
             return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st, sk_ws, GEMM_SK_SLAB_BYTES);

@@ -257,6 +257,7 @@ bool gemm_big_hybrid_fits(int M, int N, int K) {
     // unshared stream-K part; at M = 4208 (214 MB, 5.7 rounds) the hybrid form loses (712 vs 580 us)
     return bytes <= (160ll << 20) || T <= 384 || (T <= 800 && bytes <= (208ll << 20));
 }
+void gemm_big_tune_reset() { g_big_group = 0; g_big_hybrid = 1; }
 int gemm_big_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_big_group") && value >= 0) { g_big_group = value; return 0; }
     if (!strcmp(key, "gemm_big_hybrid")) { g_big_hybrid = value; return 0; }
@@ -264,7 +265,7 @@ int gemm_big_tune_set(const char* key, int value) {
 }
 
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset, bool any_order) {
+                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset) {
     const int tiles_m = cdiv(M, GB_BM), tiles_n = cdiv(N, GB_BN);
     const int T = tiles_m * tiles_n, nk = K / GB_BK;
     const size_t lds = 2 * GB_STAGE;
@@ -287,11 +288,6 @@ int gemm_big_launch(const void* A, const void* W, const void* bias, const void* 
             if (e != hipSuccess) return hip_fail(e, "gemm_big: hipFuncSetAttribute");                                             \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        if (any_order) /* AQL barrier bit cleared: starts beside the kernel launched just before it (independent outputs) */    \
-            hipExtLaunchKernelGGL((gemm_mfma_bf16_big_kernel<SW, OF, HY>), dim3((HY) ? 256 : T), dim3(512), (uint32_t)lds, st, nullptr, nullptr, \
-                                  hipExtAnyOrderLaunch, (const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, (const bf16_t*)res, C, M, N, K, \
-                                  lda, ldc, act, tiles_m, tiles_n, group, dp_rounds, per, slabs, flg);                             \
-        else                                                                                                                      \
         gemm_mfma_bf16_big_kernel<SW, OF, HY><<<(HY) ? 256 : T, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m,  \
                                                                                tiles_n, group, dp_rounds, per, slabs, flg);             \

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_fp8_big_kernel(const unsigned c
 static int g_fp8_big = 1;      // 256 x 256 kernel: 0 off, 1 auto (rounds model), 2 forced
 constexpr double F8_BIG_ROUND_COST = 1.66;   // measured: 58.4 us per round of 256 x 256 tiles vs 35.3 us per round of 128 x 256 (gate/up at M = 17344)
 static int g_fp8_wide = 1;      // 0: 128 x 128 kernel only, 1: by the rounds model, 2: wide wherever K has two tiles
+void gemm_fp8_tune_reset() { g_fp8_big = 1; g_fp8_wide = 1; }
 int gemm_fp8_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_fp8_big")) { g_fp8_big = value; return 0; }
     if (!strcmp(key, "gemm_fp8_wide")) { g_fp8_wide = value; return 0; }
@@ -591,9 +592,7 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
              int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st, void* sk_ws) {
     if (M == 0 || N == 0) return TEO_OK;
     if (sk_ws) {                                             // the stream-K form is sized for 256 CUs
-        static int cus = -1;
-        if (cus < 0) { int dev = 0; hipDeviceProp_t p; cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0; }
-        if (cus != 256) sk_ws = nullptr;
+        if (device_cu_count() != 256) sk_ws = nullptr;
     }
     if (!gemm_fp8_ok(M, N, K, lda, ldc, flags, A8, W8, res, C)) {
         set_error("teo_gemm_fp8: needs K %% 128 == 0, lda %% 16 == 0, N %% 4 == 0 (32 with SWIGLU16, no residual) and 16-byte aligned operands "

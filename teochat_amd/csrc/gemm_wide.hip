@@ -30,6 +30,7 @@ constexpr int GW_STAGE = GW_A_BYTES + GW_W_BYTES;        // 48 KiB
 constexpr int GW_PIECES = GW_STAGE / 1024 / 8;           // 1-KiB DMA pieces per wave per K tile = 6
 
 static int g_wide_sched = 1, g_wide_group = 0;        // group 0: chosen from the tile grid
+void gemm_wide_tune_reset() { g_wide_sched = 1; g_wide_group = 0; }
 int gemm_wide_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_wide_sched")) { g_wide_sched = value; return 0; }
     if (!strcmp(key, "gemm_wide_group") && value >= 0) { g_wide_group = value; return 0; }

@@ -119,13 +119,13 @@ __device__ __forceinline__ uint4 ld16(const void* p) {
 }
 
 // Tunables (teo_tune_set): non-temporal loads on/off, workgroup cap, variant of the row-group kernel.
-struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; int ck_pf2 = 0; int small_k = 1; };
+struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; int small_k = 1; };
 static GemvTune g_tune;
+void gemv_tune_reset() { g_tune = GemvTune(); }
 int gemv_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemv_variant")) g_tune.variant = value;
     else if (!strcmp(key, "gemv_nt")) g_tune.nt = value;
     else if (!strcmp(key, "gemv_max_blocks")) g_tune.max_blocks = value;
-    else if (!strcmp(key, "ck_pf2")) g_tune.ck_pf2 = value != 0;
     else if (!strcmp(key, "gemv_small_k")) g_tune.small_k = value != 0;
     else if (!strcmp(key, "gemv_splitk_u") && (value == 0 || value == 2 || value == 4 || value == 6)) g_tune.splitk_u = value;
     else return -1;
@@ -680,287 +680,6 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
     }
     if constexpr (IsBf<T>::v) { if (small_k) return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st); }
     return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
-}
-
-// ------------------------------------------------------------------------------------------------
-// o-projection of the decode step with the merge of the fat-split attention records in its prologue (attn_fat.hip):
-//     x[h*128 + d] = bf16( (sum_s w_s o_s[d]) / (sum_s w_s l_s) ),  w_s = exp(m_s - max_s m_s)      (what the combine launch computed)
-//     y[n]         = res[n] + sum_k W[n, k] x[k]
-// One workgroup of 16 waves per 16 output rows (N / 16 = 256 workgroups for LLaMA-2-7B: one per CU), one wave per row: the wave's
-// whole row (K * sizeof(WT) = 8 KB bf16) is requested first -- 128 KB of weights in flight per CU -- then the records of all
-// heads (NS x heads x 132 floats, L2-resident: they were just written) are merged by the 1024 threads, 4 consecutive x per
-// thread, into a bf16 LDS image of x; ds_read_b128 + v_dot2c_f32_bf16 against the row, wave reduce, residual, store.
-// The combine launch of the round-2 step (4.5 us per layer, latency-bound) is gone; its loads ride under the weight stream.
-// ------------------------------------------------------------------------------------------------
-constexpr int GO_WAVES = 16, GO_THREADS = GO_WAVES * 64;
-template <typename WT, int U, bool NT, int G>          // G = groups of 8 splits (1: nsplit <= 8, everything in one round trip)
-__global__ __launch_bounds__(GO_THREADS) void gemv_o_merge_kernel(const float* __restrict__ part, int nsplit, const WT* __restrict__ W,
-                                                                  const float* __restrict__ wscale, const bf16_t* res, bf16_t* y, int N,
-                                                                  int K) {
-    constexpr int VE = Vec16<WT>::N;                      // weights per 16-byte chunk: 8 (bf16) or 16 (fp8)
-    __shared__ __attribute__((aligned(16))) bf16_t xs[4096];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int n = blockIdx.x * GO_WAVES + wid;
-    const WT* wrow = W + (long long)min(n, N - 1) * K;
-    uint4 w[U];
-    // ---- merge: thread t owns x[4t .. 4t+3] (head 4t / 128); K = 4096 = 4 * GO_THREADS.  The record loads go out FIRST (loads return
-    // in order: behind the row they would wait for all of it), the whole weight row right behind them, and the merge runs while
-    // the row is in flight.
-    {
-        const int k0 = tid * 4;
-        const int h = k0 >> 7, d = k0 & 127;
-        const float* pb = part + (long long)h * nsplit * ATTN_FAT_REC;
-        float2 ml[8 * G];
-        float4 ov[8];
-#pragma unroll
-        for (int s = 0; s < 8 * G; ++s) ml[s] = *reinterpret_cast<const float2*>(pb + min(s, nsplit - 1) * ATTN_FAT_REC);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) ov[s] = *reinterpret_cast<const float4*>(pb + min(s, nsplit - 1) * ATTN_FAT_REC + 4 + d);
-#pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = ld16<NT>(wrow + (long long)(u * 64 + lane) * VE);
-        float M = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < 8 * G; ++s) M = fmaxf(M, s < nsplit ? ml[s].x : -INFINITY);
-        float Ls = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (g > 0) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) ov[s] = *reinterpret_cast<const float4*>(pb + min(8 * g + s, nsplit - 1) * ATTN_FAT_REC + 4 + d);
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int ss = 8 * g + s;
-                const float wgt = (ss < nsplit && ml[ss].x != -INFINITY) ? expf(ml[ss].x - M) : 0.f;      // same chains as attn_fat_merge
-                if (ss < nsplit) {
-                    Ls = fmaf(wgt, ml[ss].y, Ls);
-                    a0 = fmaf(wgt, ov[s].x, a0); a1 = fmaf(wgt, ov[s].y, a1); a2 = fmaf(wgt, ov[s].z, a2); a3 = fmaf(wgt, ov[s].w, a3);
-                }
-            }
-        }
-        *reinterpret_cast<uint2*>(xs + k0) = make_uint2(pack_bf2(a0 / Ls, a1 / Ls), pack_bf2(a2 / Ls, a3 / Ls));
-    }
-    const float my_scale = wscale ? wscale[min(n, N - 1)] : 1.f;
-    __syncthreads();
-    float acc = 0.f;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        uint4 xb[VE / 8];
-#pragma unroll
-        for (int j = 0; j < VE / 8; ++j) xb[j] = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * VE + j * 8);
-        acc = dotb<WT>(w[u], xb, acc);
-    }
-    acc = wave_sum(acc);
-    if (lane == 0 && n < N) {
-        float v = acc * my_scale;
-        if (res) v += bf2f(res[n]);
-        y[n] = f2bf(v);
-    }
-}
-
-bool gemv_o_merge_ok(int heads, int hd, int K, int N, int w_fp8, int dtype) {
-    return dtype == TEO_BF16 && hd == 128 && K == heads * hd && K == 4096 && N % GO_WAVES == 0;
-}
-
-int gemv_o_merge(const float* part, int nsplit, const void* W, const float* wscale, int w_fp8, const void* res, void* y, int N, int K,
-                 hipStream_t st) {
-    TEO_CHECK_ARG(K == 4096 && N % GO_WAVES == 0 && nsplit >= 1 && nsplit <= ATTN_FAT_MAX_SPLITS, "gemv_o_merge: K %d N %d nsplit %d", K, N, nsplit);
-    const int blocks = N / GO_WAVES;
-#define TEO_GO(WTT, UU, NTT, GG) TEO_KLAUNCH((gemv_o_merge_kernel<WTT, UU, NTT, GG>), blocks, GO_THREADS, 0, st, part, nsplit, (const WTT*)W, wscale, \
-                                             (const bf16_t*)res, (bf16_t*)y, N, K)
-#define TEO_GO_G(WTT, UU, NTT) { if (nsplit <= 8) TEO_GO(WTT, UU, NTT, 1); else TEO_GO(WTT, UU, NTT, 2); }
-    if (w_fp8) { if (g_tune.nt) TEO_GO_G(fp8_t, 4, true) else TEO_GO_G(fp8_t, 4, false) }
-    else { if (g_tune.nt) TEO_GO_G(bf16_t, 8, true) else TEO_GO_G(bf16_t, 8, false) }
-#undef TEO_GO_G
-#undef TEO_GO
-    TEO_LAUNCH_CHECK("gemv_o_merge");
-    return TEO_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// GEMV of the overlapped decode step (launch chain, common.h): y = epilogue(W . f(x)) for bf16 activations.
-//   * persistent grid of CK_WAVES-wave workgroups (512 x 512 threads: two per CU, half of the CU's wave slots and, at <= 64
-//     VGPRs, half of its registers -- the next kernel of the chain fits beside it);
-//   * a wave owns R = 2 rows at a time (SWIGLU: one (gate, up) pair), U = 4 chunks per step = 4 KB contiguous per row per step;
-//   * ORDER: the wave's first weight block is requested FIRST (it depends on nothing), then the workgroup waits for its
-//     predecessor in the chain, then x is loaded with coherent loads, normalised (optional RMSNorm) and staged in LDS as the
-//     fp32 (bf16 for fp8 weights) image of the row-group kernel; outputs are stored write-through; the workgroup signals.
-//   With ch.on == 0 the same kernel is an ordinary one (plain launch order): that is how the profiled step times it.
-// ------------------------------------------------------------------------------------------------
-constexpr int CK_WAVES = 8, CK_THREADS = CK_WAVES * 64;
-enum { CK_EPI_PLAIN = 0, CK_EPI_SWIGLU = 1, CK_EPI_F32 = 2 };
-template <typename WT, int EPI, bool NT, bool PF2>
-__global__ __launch_bounds__(CK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void ck_gemv_kernel(const bf16_t* x, const WT* __restrict__ W, const float* __restrict__ wscale, const bf16_t* __restrict__ norm_w,
-                    const bf16_t* res, void* y, int N, int K, float eps, Chain ch) {
-    typedef bf16_t T;
-    constexpr int R = 2, U = 4;
-    constexpr bool SWIGLU = EPI == CK_EPI_SWIGLU;
-    constexpr bool XB = BfImage<T, WT>::v;
-    extern __shared__ __attribute__((aligned(16))) float xs[];
-    constexpr int VE = Vec16<WT>::N;
-    constexpr int STEP = 64 * U;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nchunk = K / VE;
-    float* red = x_image_end<XB, VE>(xs, nchunk);
-    const int nwaves = gridDim.x * CK_WAVES;
-    const int ngroups = SWIGLU ? N / 2 : (N + R - 1) / R;
-    const bool coh = ch.on != 0;
-    auto row_of = [&](int grp, int r) -> long long {
-        if (SWIGLU) {
-            const int j = min(grp, N / 2 - 1);
-            return (long long)((j >> 4) * 32 + (j & 15) + ((r & 1) ? 16 : 0));
-        }
-        return (long long)min(grp * R + r, N - 1);
-    };
-    uint4 wa[U][R], wb[U][R];
-    int grp = blockIdx.x * CK_WAVES + wid;
-    {   // first block(s) of the wave's first row group: unconditional, branch-free (host guarantees nchunk >= STEP, PF2: >= 2 STEP).
-        // Two blocks = 16 KB per wave = 256 KB per CU requested before the wait: ~10 us of HBM stream, more than the hand-over takes.
-        const int gp = min(grp, ngroups - 1);
-        const WT* rowp[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) rowp[r] = W + row_of(gp, r) * K;
-        issue_block<WT, R, U, NT, true>(wa, rowp, 0, lane, nchunk);
-        if (PF2) issue_block<WT, R, U, NT, true>(wb, rowp, STEP, lane, nchunk);
-    }
-    chain_wait(ch);
-    // ---- x -> LDS image of f(x)
-    {
-        const int nx = K / 8;                                  // 16-byte chunks of x
-        float ss = 0.f;
-        constexpr int XPT = 3;                                 // K <= 3 * 512 * 8 = 12288
-        uint4 xr[XPT], nr[XPT];
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int c = min(tid + i * CK_THREADS, nx - 1);
-            xr[i] = act_ld16(x, (unsigned)c * 16u, coh);
-        }
-        if (norm_w) {
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const int c = min(tid + i * CK_THREADS, nx - 1);
-                nr[i] = *reinterpret_cast<const uint4*>(norm_w + (long long)c * 8);
-            }
-        }
-        float rr = 1.f;
-        if (norm_w) {
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                if (tid + i * CK_THREADS < nx) {
-                    float f[8];
-                    Vec16<T>::cvt(xr[i], f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
-                }
-            }
-            rr = rsqrtf(block_sum<CK_THREADS>(ss, red) / K + eps);
-        }
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int c = tid + i * CK_THREADS;
-            if (c < nx) {
-                float f[8], g[8];
-                Vec16<T>::cvt(xr[i], f);
-                if (norm_w) {
-                    Vec16<T>::cvt(nr[i], g);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = Elem<T>::round(f[e] * rr * g[e]);
-                }
-                if constexpr (XB) {
-                    uint4 o = xr[i];
-                    if (norm_w) o = make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(xs) + xb_off<VE>(c * 8)) = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; e += 4)
-                        *reinterpret_cast<float4*>(xs + xs_off<VE>(c * 8 + e)) = make_float4(f[e], f[e + 1], f[e + 2], f[e + 3]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    bool have = true;
-    for (; grp < ngroups; grp += nwaves) {
-        const WT* rowp[R];
-        long long rows[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { rows[r] = row_of(grp, r); rowp[r] = W + rows[r] * K; }
-        float sc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) sc[r] = wscale ? wscale[rows[r]] : 1.f;
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        int c0 = 0;
-        if (have) {
-            consume_block<T, WT, R, U, true>(wa, xs, 0, lane, nchunk, acc);
-            c0 = STEP;
-            if (PF2) {
-                __builtin_amdgcn_sched_barrier(0);     // keep the second block's LDS reads / conversions behind the first block's FMAs
-                consume_block<T, WT, R, U, true>(wb, xs, STEP, lane, nchunk, acc);
-                c0 = 2 * STEP;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            have = false;
-        }
-        const int cfull = (nchunk / STEP) * STEP;
-        for (; c0 < cfull; c0 += STEP) {
-            issue_block<WT, R, U, NT, true>(wa, rowp, c0, lane, nchunk);
-            consume_block<T, WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
-        }
-        if (c0 < nchunk) {
-            issue_block<WT, R, U, NT, false>(wa, rowp, c0, lane, nchunk);
-            consume_block<T, WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] *= sc[r];
-            if (SWIGLU) {
-                if (grp < N / 2) act_st2(y, (unsigned)grp * 2u, f2bf(silu(acc[0]) * acc[1]), coh);
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int n = grp * R + r;
-                    if (n < N) {
-                        float v = acc[r];
-                        if (res) v += bf2f(act_ld2(res, (unsigned)n * 2u, coh));
-                        if (EPI == CK_EPI_F32) act_st4(y, (unsigned)n * 4u, __float_as_uint(v), coh);
-                        else act_st2(y, (unsigned)n * 2u, f2bf(v), coh);
-                    }
-                }
-            }
-        }
-    }
-    chain_signal(ch);
-}
-
-bool ck_gemv_ok(int N, int K, int w_fp8) {
-    const int ve = w_fp8 ? 16 : 8;
-    return K % ve == 0 && K / ve >= 64 * 4 && K <= 12288 && (size_t)(K + 1040) * 4 <= 64 * 1024;
-}
-
-// epi: CK_EPI_*; x / res / y bf16 (y fp32 for CK_EPI_F32); grid: CK grid of the chain (host chooses `blocks`)
-int ck_gemv(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, const void* res, void* y, int N, int K,
-            float eps, int epi, int blocks, const Chain& ch, hipStream_t st) {
-    TEO_CHECK_ARG(ck_gemv_ok(N, K, w_fp8), "ck_gemv: N %d K %d", N, K);
-    const size_t lds = w_fp8 ? xb_lds_bytes<16>(K) + 64 : xs_lds_bytes<8>(K) + 64;
-    const bool pf2 = g_tune.ck_pf2 && K / (w_fp8 ? 16 : 8) >= 2 * 64 * 4;
-#define TEO_CK2(WTT, EE, NTT, PP) TEO_KLAUNCH((ck_gemv_kernel<WTT, EE, NTT, PP>), blocks, CK_THREADS, lds, st, (const bf16_t*)x, (const WTT*)W, wscale, \
-                                              (const bf16_t*)norm_w, (const bf16_t*)res, y, N, K, eps, ch)
-#define TEO_CK(WTT, EE) { if (g_tune.nt) { if (pf2) TEO_CK2(WTT, EE, true, true); else TEO_CK2(WTT, EE, true, false); }   \
-                          else { if (pf2) TEO_CK2(WTT, EE, false, true); else TEO_CK2(WTT, EE, false, false); } }
-    if (w_fp8) {
-        if (epi == CK_EPI_SWIGLU) TEO_CK(fp8_t, CK_EPI_SWIGLU) else if (epi == CK_EPI_F32) TEO_CK(fp8_t, CK_EPI_F32) else TEO_CK(fp8_t, CK_EPI_PLAIN)
-    } else {
-        if (epi == CK_EPI_SWIGLU) TEO_CK(bf16_t, CK_EPI_SWIGLU) else if (epi == CK_EPI_F32) TEO_CK(bf16_t, CK_EPI_F32) else TEO_CK(bf16_t, CK_EPI_PLAIN)
-    }
-#undef TEO_CK2
-#undef TEO_CK
-    TEO_LAUNCH_CHECK("ck_gemv");
-    return TEO_OK;
 }
 
 // w_dtype: -1 = same as dtype, 2 = fp8 e4m3 with per-row fp32 scales (bf16 activations only)

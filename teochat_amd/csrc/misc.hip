@@ -549,12 +549,11 @@ int sample_topk(const float* logits, long long* tok, int vocab, float temperatur
 template <typename T>
 __device__ __forceinline__ void embed_row_emit(const T* __restrict__ embed, long long t, T* __restrict__ h, int dim,
                                                const T* __restrict__ g, T* __restrict__ hg, float* __restrict__ ssq, int nparts,
-                                               float* red16, bool coh = false) {
+                                               float* red16) {
     float sq = 0.f;
     for (int i = threadIdx.x; i < dim; i += 1024) {
         const T e = embed[t * dim + i];
-        if (coh && sizeof(T) == 2) act_st2(h, (unsigned)i * 2u, *reinterpret_cast<const unsigned short*>(&e), true);   // chained decode step: the next kernel reads h coherently
-        else h[i] = e;
+        h[i] = e;
         if (hg) {
             const float ef = Elem<T>::ld(&e);
             Elem<T>::st(hg + i, ef * Elem<T>::ld(g + i));
@@ -582,7 +581,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restrict__ logits, teo_decode_state st,
                                                            const T* __restrict__ embed, T* __restrict__ h, int vocab,
                                                            int dim, int out_stride, const T* __restrict__ g0,
-                                                           T* __restrict__ hg, float* __restrict__ ssq, int nparts, Chain ch) {
+                                                           T* __restrict__ hg, float* __restrict__ ssq, int nparts) {
     {   // conversation blockIdx.x of a batched step (out_stride = row length of d_out_tokens)
         const long long b = blockIdx.x;
         logits += b * vocab;
@@ -650,21 +649,17 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
     }
     __syncthreads();
     const long long t = s_tok;
-    embed_row_emit<T>(embed, t, h, dim, g0, hg, ssq, nparts, sv, ch.on != 0);
-    chain_signal(ch);          // chained decode step: the tail itself is an ORDERED launch (it waits for lm_head the ordinary way)
+    embed_row_emit<T>(embed, t, h, dim, g0, hg, ssq, nparts, sv);
 }
 
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
-                hipStream_t st, int batch, int out_stride, const void* g0, void* hg, float* ssq, int nparts, const Chain* chain) {
-    Chain ch;
-    memset(&ch, 0, sizeof(ch));
-    if (chain) ch = *chain;
+                hipStream_t st, int batch, int out_stride, const void* g0, void* hg, float* ssq, int nparts) {
     if (dtype == TEO_F32)
         TEO_KLAUNCH((decode_tail_kernel<float>), batch, 1024, 0, st, logits, *s, (const float*)embed, (float*)h, vocab, dim, out_stride,
-                    (const float*)g0, (float*)hg, ssq, nparts, ch);
+                    (const float*)g0, (float*)hg, ssq, nparts);
     else
         TEO_KLAUNCH((decode_tail_kernel<bf16_t>), batch, 1024, 0, st, logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim, out_stride,
-                    (const bf16_t*)g0, (bf16_t*)hg, ssq, nparts, ch);
+                    (const bf16_t*)g0, (bf16_t*)hg, ssq, nparts);
     TEO_LAUNCH_CHECK("decode_tail");
     return TEO_OK;
 }

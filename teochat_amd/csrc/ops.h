@@ -21,49 +21,15 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
 
 int attention(const teo_attn_args* a, int dtype, hipStream_t st);
 int attention_flash32(const teo_attn_args& a, hipStream_t st);
-size_t attn_decode_counters_offset(int heads, int hd, int S_max, int batch);
-bool attn_decode_fused_enabled();
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
-// "fat split" decode attention (attn_fat.hip): records of a head are merged by the consumer (o-projection GEMV prologue)
-constexpr int ATTN_FAT_MAX_SPLITS = 16;
-int attn_fat_nsplit(int S_max);
-bool attn_fat_ok(int hd, int dtype, int S_max);
-// record of (head, split): ATTN_FAT_REC floats = {m, l, -, -, o[128]} (o 16-byte aligned); a head's records are contiguous.
-constexpr int ATTN_FAT_REC = 132;
-// o[d] of one head from its `nsplit` records, splits merged in index order:
-//   M = max_s m_s;  w_s = exp(m_s - M);  o[d] = (sum_s w_s * o_s[d]) / (sum_s w_s * l_s)   (fma chains in split order)
-__device__ __forceinline__ float attn_fat_merge(const float* __restrict__ pb, int nsplit, int d) {
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[s * ATTN_FAT_REC]);
-    float Ls = 0.f, a = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float m = pb[s * ATTN_FAT_REC];
-        const float w = (m == -INFINITY) ? 0.f : expf(m - M);
-        Ls = fmaf(w, pb[s * ATTN_FAT_REC + 1], Ls);
-        a = fmaf(w, pb[s * ATTN_FAT_REC + 4 + d], a);
-    }
-    return a / Ls;
-}
-bool attn_fat_enabled();
-// o-projection GEMV whose prologue merges the fat-split records (gemv.hip): y = res + Wo . merge(records)
-bool gemv_o_merge_ok(int heads, int hd, int K, int N, int w_fp8, int dtype);
-int gemv_o_merge(const float* part, int nsplit, const void* W, const float* wscale, int w_fp8, const void* res, void* y, int N, int K,
-                 hipStream_t st);
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;
     long long q_stride = 0, cache_stride = 0, o_stride = 0;
 };
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
-                hipStream_t st, AttnBatch bt = AttnBatch(), int* counters = nullptr);   // counters: [batch*heads] zeroed ints -> fused combine
+                hipStream_t st, AttnBatch bt = AttnBatch());
 
-int attn_decode_fat(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o, float* part,
-                    const int* d_pos, int S_max, int heads, int kv_heads, float scale, hipStream_t st, AttnBatch bt, bool with_combine,
-                    int pos_arg = -1, const Chain* ch_attn = nullptr, const Chain* ch_combine = nullptr);
-// GEMV of the overlapped decode step (gemv.hip): epi 0 plain (+res), 1 SwiGLU16, 2 fp32 output
-bool ck_gemv_ok(int N, int K, int w_fp8);
-int ck_gemv(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, const void* res, void* y, int N, int K,
-            float eps, int epi, int blocks, const Chain& ch, hipStream_t st);
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
                    void* vtc, int S, int past, const int* d_past, int S_max, int heads, int kv_heads, int hd, int dtype,
                    hipStream_t st);
@@ -80,7 +46,7 @@ int sample_topk(const float* logits, long long* tok, int vocab, float temperatur
                 unsigned long long draw, hipStream_t st);
 int decode_tail(const float* logits, const teo_decode_state* s, const void* embed, void* h, int vocab, int dim, int dtype,
                 hipStream_t st, int batch = 1, int out_stride = 0, const void* g0 = nullptr, void* hg = nullptr,
-                float* ssq = nullptr, int nparts = 0, const Chain* chain = nullptr);
+                float* ssq = nullptr, int nparts = 0);
 int embed_token(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch = 1);
 int embed_token_emit(const long long* tok, const void* embed, void* h, int dim, int dtype, hipStream_t st, int batch,
                      const void* g, void* hg, float* ssq, int nparts);
@@ -93,6 +59,8 @@ int preprocess_frames(const unsigned char* src, void* out, int T, int H, int W, 
 int cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
                   long long ignore_index, hipStream_t st);
 int gemv_tune_set(const char* key, int value);
+void gemv_tune_reset(); void gemm_tune_reset(); void gemm_wide_tune_reset(); void gemm_big_tune_reset(); void gemm_fp8_tune_reset();
+void skinny_tune_reset(); void attn_tune_reset();
 int gemm_wide_tune_set(const char* key, int value);
 int gemm_big_tune_set(const char* key, int value);
 bool patch_embed_ok(int C, int img, int P, int ldw, int D, int dtype, const void* px, const void* W, const void* out);
@@ -111,15 +79,16 @@ struct SkinnyFuse {
     const float* ssq_in = nullptr;            // [MB][nparts]
     int nparts = 0;
     float eps = 0.f;
+    unsigned long long* trace = nullptr;      // probe builds only (tools/skinny_probe.hip): [workgroups][SK_TRACE_SLOTS] wall-clock marks
 };
+constexpr int SK_TRACE_SLOTS = 16;
 int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, float eps, const void* res,
                 void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st,
                 SkinnyFuse fuse = SkinnyFuse());
 int gemm_tune_set(const char* key, int value);
-int runtime_tune_set(const char* key, int value);
 int gemm_fp8_tune_set(const char* key, int value);
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset, bool any_order = false);
+                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool swiglu, bool of32, hipStream_t st);
 constexpr size_t GEMM_SK_SLAB_BYTES = (size_t)64 << 20;   // slab area of the stream-K workspaces (largest user: 256 x 256 KB)

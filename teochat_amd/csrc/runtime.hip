@@ -2,17 +2,11 @@
 // so that one host call enqueues a whole phase on the caller's stream (no per-op Python round trips) and the
 // decode step can be captured into a hipGraph and replayed once per token.
 #include <algorithm>
-#include <mutex>
-#include <unordered_map>
 #include <vector>
 
 #include "ops.h"
 
 namespace teo {
-extern int g_rope_in_attn;
-void chain_seq_reset(const void* ws);
-constexpr int CK_WAVES_HOST = 8;            // waves per workgroup of the chain GEMVs (gemv.hip CK_WAVES)
-
 struct Carver {
     unsigned char* base;
     size_t off = 0, cap;
@@ -59,7 +53,6 @@ static VitWs vit_carve(const teo_vit_desc* d, int T, void* ws, size_t cap) {
     return w;
 }
 
-static int g_patch_fused = 1;   // tower patch embedding: fused gather + MFMA kernel (0: im2col matrix + GEMM)
 size_t vit_workspace_bytes(const teo_vit_desc* d, int T) { return vit_carve(d, T, nullptr, 0).total; }
 
 int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features, void* ws, size_t ws_bytes,
@@ -74,7 +67,7 @@ int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features,
     const int g = d->image / d->patch, NP = g * g, N = NP + 1, D = d->hidden, H = d->heads, hd = D / H;
     const int rows = T * N;
     TEO_TRY(gemm_sk_workspace_init(w.sk, st));
-    if (g_patch_fused && patch_embed_ok(d->channels, d->image, d->patch, d->k_pad, D, dt, pixels, d->patch_w, w.patch)) {
+    if (patch_embed_ok(d->channels, d->image, d->patch, d->k_pad, D, dt, pixels, d->patch_w, w.patch)) {
         // patch pixels gathered straight into the MFMA tile's LDS image (patch_embed.hip): no im2col matrix in HBM
         TEO_TRY(patch_embed(pixels, d->patch_w, w.patch, T, d->channels, d->image, d->patch, d->k_pad, D, st));
     } else {
@@ -173,26 +166,11 @@ static PrefillWs prefill_carve(const teo_llama_desc* d, int S, void* ws, size_t 
     return w;
 }
 
-// prefill Linear layers on the fp8 MFMA (activations quantised per token, the decode path's e4m3 weights): tune "prefill_fp8"
-static int g_prefill_fp8 = 0;
-static int g_o_merge = 1;       // decode o-projection merges the fat-split attention records itself (0: separate merge launch)
-static int g_chain = 0;            // tune "decode_chain": 1 = overlapped steps (launch chain) where supported.  OFF by default: measured on MI355X the
-                                   // device-side hand-over (ticket + progress word + coherent reload of x: ~5 us) costs more than the ~1.7 us launch
-                                   // boundary it replaces unless >= 140 KB of weights per CU are prefetched beside the running kernel, which
-                                   // 128 VGPRs do not hold: 3.43 vs 2.74 ms per token (profiles/r03_decode_chain.txt).  Kept as a tested path.
-static int g_chain_blocks = 256;   // workgroups of the chain GEMVs (512 threads each): one per CU, half of its registers -- the next kernel fits beside it
-int runtime_tune_set(const char* key, int value) {
-    if (!strcmp(key, "attn_o_merge")) { g_o_merge = value != 0; return 0; }
-    if (!strcmp(key, "decode_chain")) { g_chain = value != 0; return 0; }
-    if (!strcmp(key, "decode_chain_blocks") && value >= 64 && value <= 4096) { g_chain_blocks = value; return 0; }
-    if (!strcmp(key, "launch_flags")) { g_launch_flags = (unsigned)value; return 0; }     // experiments only (hipExtAnyOrderLaunch = 1)
-    if (!strcmp(key, "prefill_fp8")) { g_prefill_fp8 = value != 0; return 0; }
-    if (!strcmp(key, "vit_patch_fused")) { g_patch_fused = value != 0; return 0; }
-    return -1;
-}
+// prefill Linear layers on the fp8 MFMA (activations quantised per token, the decode path's e4m3 weights): the descriptor's
+// `prefill_fp8` option -- lossy w8a8, selectable per engine, never a default
 static bool prefill_uses_fp8(const teo_llama_desc* d) {
     const int Hq = d->heads * d->head_dim;
-    return g_prefill_fp8 && d->dtype == TEO_BF16 && d->qkv_w8 && d->o_w8 && d->gateup_w8 && d->down_w8 && d->hidden % 128 == 0 &&
+    return d->prefill_fp8 && d->dtype == TEO_BF16 && d->qkv_w8 && d->o_w8 && d->gateup_w8 && d->down_w8 && d->hidden % 128 == 0 &&
            d->inter % 128 == 0 && Hq % 128 == 0 && d->inter <= 12288 && d->hidden <= 12288;
 }
 // one decoder layer's four Linear layers in w8a8 form; `attend` runs RoPE / KV append / attention on w.qkv -> w.attn
@@ -358,8 +336,6 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
 struct DecodeWs {
     void *h, *qkv, *attn, *act;
     float* part;
-    int* cnt;        // [heads] arrival counters of the fused attention combine (zeroed by decode_begin, self re-arming)
-    unsigned* chain; // launch chain of the overlapped step: [0] progress, [1] error flag, [2 ..] ticket ring (zeroed by decode_begin)
     size_t total;
 };
 
@@ -373,8 +349,6 @@ static DecodeWs decode_carve(const teo_llama_desc* d, void* ws, size_t cap) {
     w.attn = c.take((size_t)d->heads * d->head_dim * e);
     w.act = c.take((size_t)d->inter * e);
     w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq));
-    w.cnt = (int*)c.take((size_t)d->heads * sizeof(int));
-    w.chain = (unsigned*)c.take((2 + CHAIN_RING) * sizeof(unsigned));
     w.total = c.off;
     return w;
 }
@@ -392,28 +366,8 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     const int QKV = (H + 2 * Hk) * hd;
     // w.h holds the embedding of *s->d_token: written by the previous step's tail (or by teo_llama_decode_begin)
     const bool w8 = d->qkv_w8 != nullptr;              // decode streams the fp8 copies when they are present
-    // fat-split decode attention (attn_fat.hip): heads x NS records per layer, merged in the prologue of the o-projection GEMV
-    // -- no combine launch.  tune "attn_o_merge" = 0 keeps the separate merge launch (A/B).
-    const bool fat = attn_fat_enabled() && attn_fat_ok(hd, dt, d->max_seq);
-    const bool o_merge = fat && g_o_merge && gemv_o_merge_ok(H, hd, H * hd, D, w8, dt);
-    const int fat_ns = fat ? attn_fat_nsplit(d->max_seq) : 0;
     for (int l = 0; l < d->layers; ++l) {
-        if (fat) {
-            const bool rope_in = g_rope_in_attn < 0 ? false : g_rope_in_attn != 0;
-            prof_class(TEO_PROF_QKV);
-            if (rope_in) {
-                TEO_TRY(gemv_w(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], nullptr,
-                               w.qkv, QKV, D, d->eps, 0, dt, dt, st));
-            } else {
-                TEO_TRY(gemv_qkv_rope(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], w.qkv,
-                                      d->rope_cos, d->rope_sin, s->d_pos, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->max_seq,
-                                      H, Hk, hd, D, d->eps, dt, st));
-            }
-            prof_class(TEO_PROF_ATTN);
-            TEO_TRY(attn_decode_fat(w.qkv, d->k_cache[l], d->v_cache[l], rope_in ? d->vt_cache[l] : nullptr, rope_in ? d->rope_cos : nullptr,
-                                    rope_in ? d->rope_sin : nullptr, w.attn, w.part, s->d_pos, d->max_seq, H, Hk, 1.0f / sqrtf((float)hd),
-                                    st, AttnBatch(), !o_merge));
-        } else if (g_rope_in_attn < 0 ? false : g_rope_in_attn != 0) {
+        if (d->rope_in_attn) {
             // rmsnorm + QKV projection (plain weight stream); RoPE + KV append ride inside the attention kernel
             // (position read from s->d_pos on the device)
             prof_class(TEO_PROF_QKV);
@@ -421,7 +375,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
                            w.qkv, QKV, D, d->eps, 0, dt, dt, st));
             prof_class(TEO_PROF_ATTN);
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
-                                s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, AttnBatch(), w.cnt));
+                                s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
         } else {
             // rmsnorm -> QKV projection -> RoPE -> KV append in the GEMV epilogue
             prof_class(TEO_PROF_QKV);
@@ -430,15 +384,11 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
                                   H, Hk, hd, D, d->eps, dt, st));
             prof_class(TEO_PROF_ATTN);
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], nullptr, nullptr, nullptr, w.attn, w.part, s->d_pos,
-                                d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, AttnBatch(), w.cnt));
+                                d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
         }
         prof_class(TEO_PROF_O);
-        if (o_merge) {
-            TEO_TRY(gemv_o_merge(w.part, fat_ns, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, w.h, w.h, D, H * hd, st));
-        } else {
-            TEO_TRY(gemv_w(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps,
-                           0, dt, dt, st));
-        }
+        TEO_TRY(gemv_w(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps,
+                       0, dt, dt, st));
         prof_class(TEO_PROF_GATEUP);
         TEO_TRY(gemv_w(w.h, w8 ? d->gateup_w8[l] : d->gateup_w[l], w8 ? d->gateup_s[l] : nullptr, w8, d->post_norm_w[l], nullptr,
                        w.act, 2 * F, D, d->eps, TEO_GEMM_SWIGLU16, dt, dt, st));
@@ -459,126 +409,11 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
 
 
 // ------------------------------------------------------------------------------------------------
-// Overlapped decode steps (launch chain, common.h): the step's kernels are launched with the AQL barrier bit cleared
-// (hipExtAnyOrderLaunch) and hand over through one progress word, so a kernel's launch ramp and first weight block run under
-// the tail of its predecessor.  7 launches per layer-less... per layer 6: rmsnorm+QKV GEMV -> fat-split attention (RoPE + KV append
-// inside) -> record merge -> o GEMV (+res) -> rmsnorm + gate/up + SwiGLU GEMV -> down GEMV (+res); then rmsnorm + lm_head
-// and the ORDERED tail (argmax / sampler, append, stop test, next embedding row) that closes the step.  Plain launches, no hipGraph:
-// positions are arguments (host-known), the chain sequence numbers too.
-// ------------------------------------------------------------------------------------------------
-static std::mutex g_chain_mu;
-static std::unordered_map<const void*, unsigned> g_chain_seq;        // workspace -> next sequence number of its chain
-void chain_seq_reset(const void* ws) {
-    std::lock_guard<std::mutex> lk(g_chain_mu);
-    g_chain_seq[ws] = 0;
-}
-
-bool llama_decode_chain_ok(const teo_llama_desc* d) {
-    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
-    const int w8 = d->qkv_w8 != nullptr, h8 = d->lm_head8 != nullptr;
-    return g_chain && d->dtype == TEO_BF16 && attn_fat_enabled() && attn_fat_ok(hd, d->dtype, d->max_seq) && H * hd == D &&
-           ck_gemv_ok((H + 2 * Hk) * hd, D, w8) && ck_gemv_ok(D, H * hd, w8) && ck_gemv_ok(2 * F, D, w8) && ck_gemv_ok(D, F, w8) &&
-           ck_gemv_ok(d->vocab, D, h8) && (2 * F) % 32 == 0;
-}
-
-// profile != null: ONE step with ordinary launch order (chain off) and per-launch timestamps (teo_llama_decode_step_profile)
-int llama_decode_chain_steps(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, int n_steps, int pos0,
-                             bool ordered, hipStream_t st) {
-    const DecodeWs w = decode_carve(d, ws, ws_bytes);
-    if (w.total > ws_bytes) {
-        set_error("teo_llama_decode_steps: workspace %zu < %zu", ws_bytes, w.total);
-        return TEO_ERR_WORKSPACE;
-    }
-    TEO_CHECK_ARG(pos0 >= 0 && pos0 + n_steps <= d->max_seq, "teo_llama_decode_steps: positions %d..%d exceed max_seq %d", pos0, pos0 + n_steps, d->max_seq);
-    const int dt = d->dtype;
-    const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
-    const int QKV = (H + 2 * Hk) * hd;
-    const bool w8 = d->qkv_w8 != nullptr, h8 = d->lm_head8 != nullptr;
-    unsigned seq;
-    {
-        std::lock_guard<std::mutex> lk(g_chain_mu);
-        seq = g_chain_seq[ws];
-    }
-    Chain ch;
-    ch.progress = w.chain;
-    ch.err = (int*)(w.chain + 1);
-    ch.tickets = w.chain + 2;
-    ch.on = ordered ? 0u : 1u;
-    ch.seq = seq;
-    const int blocks = g_chain_blocks;
-    auto nb = [&](int groups) { return std::max(1, std::min(blocks, cdiv(groups, CK_WAVES_HOST))); };
-    int rc = TEO_OK;
-    const unsigned saved_flags = g_launch_flags;
-    bool first = true;
-    auto flags_for_next = [&]() {
-        // the first kernel of a call is an ordinary (ordered) launch: whatever came before it on the stream -- prefill, embed_token,
-        // the host's copies -- is complete and visible the ordinary way; everything after it rides the chain
-        g_launch_flags = (ordered || first) ? 0u : 1u;
-        first = false;
-    };
-    for (int step = 0; step < n_steps && rc == TEO_OK; ++step) {
-        const int pos = pos0 + step;
-        for (int l = 0; l < d->layers && rc == TEO_OK; ++l) {
-            prof_class(TEO_PROF_QKV);
-            flags_for_next();
-            rc = ck_gemv(w.h, w8 ? d->qkv_w8[l] : d->qkv_w[l], w8 ? d->qkv_s[l] : nullptr, w8, d->in_norm_w[l], nullptr, w.qkv, QKV, D,
-                         d->eps, 0, nb(QKV / 2), ch, st);
-            ch.seq++;
-            if (rc != TEO_OK) break;
-            prof_class(TEO_PROF_ATTN);
-            flags_for_next();
-            Chain c2 = ch;
-            c2.seq = ch.seq + 1;
-            rc = attn_decode_fat(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part, s->d_pos,
-                                 d->max_seq, H, Hk, 1.0f / sqrtf((float)hd), st, AttnBatch(), true, pos, &ch, &c2);
-            ch.seq += 2;
-            if (rc != TEO_OK) break;
-            prof_class(TEO_PROF_O);
-            flags_for_next();
-            rc = ck_gemv(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps, 0,
-                         nb(D / 2), ch, st);
-            ch.seq++;
-            if (rc != TEO_OK) break;
-            prof_class(TEO_PROF_GATEUP);
-            flags_for_next();
-            rc = ck_gemv(w.h, w8 ? d->gateup_w8[l] : d->gateup_w[l], w8 ? d->gateup_s[l] : nullptr, w8, d->post_norm_w[l], nullptr, w.act,
-                         2 * F, D, d->eps, 1, nb(F), ch, st);
-            ch.seq++;
-            if (rc != TEO_OK) break;
-            prof_class(TEO_PROF_DOWN);
-            flags_for_next();
-            rc = ck_gemv(w.act, w8 ? d->down_w8[l] : d->down_w[l], w8 ? d->down_s[l] : nullptr, w8, nullptr, w.h, w.h, D, F, d->eps, 0,
-                         nb(D / 2), ch, st);
-            ch.seq++;
-        }
-        if (rc != TEO_OK) break;
-        prof_class(TEO_PROF_LM_HEAD);
-        flags_for_next();
-        rc = ck_gemv(w.h, h8 ? d->lm_head8 : d->lm_head, h8 ? d->lm_head_s : nullptr, h8, d->final_norm_w, nullptr, s->d_logits, d->vocab, D,
-                     d->eps, 2, nb(d->vocab / 2), ch, st);
-        ch.seq++;
-        if (rc != TEO_OK) break;
-        prof_class(TEO_PROF_TAIL);
-        g_launch_flags = 0;                              // ORDERED: waits for the lm_head the ordinary way, drains the chain once per token
-        first = false;
-        rc = decode_tail(s->d_logits, s, d->embed, w.h, d->vocab, D, dt, st, 1, 0, nullptr, nullptr, nullptr, 0, &ch);
-        ch.seq++;
-    }
-    g_launch_flags = saved_flags;
-    if (!ordered) {
-        std::lock_guard<std::mutex> lk(g_chain_mu);
-        g_chain_seq[ws] = ch.seq;
-    }
-    return rc;
-}
-
-// ------------------------------------------------------------------------------------------------
 // batched decode: B conversations advance one token per step; every weight matrix is streamed once per step
 // ------------------------------------------------------------------------------------------------
 struct DecodeBatchWs {
     void *h, *hg, *qkv, *attn, *act;
     float *ssq, *part;
-    int* cnt;        // [B][heads] arrival counters of the fused attention combine
     int nparts;
     size_t total;
 };
@@ -596,7 +431,6 @@ static DecodeBatchWs decode_batch_carve(const teo_llama_desc* d, int B, void* ws
     w.attn = c.take((size_t)B * d->heads * d->head_dim * e);
     w.act = c.take((size_t)B * d->inter * e);
     w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq, B));
-    w.cnt = (int*)c.take((size_t)B * d->heads * sizeof(int));
     w.total = c.off;
     return w;
 }
@@ -641,8 +475,6 @@ int llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_sta
         set_error("teo_llama_decode_batch_begin: workspace %zu < %zu", ws_bytes, w.total);
         return TEO_ERR_WORKSPACE;
     }
-    hipError_t e = hipMemsetAsync(w.cnt, 0, (size_t)s->batch * d->heads * sizeof(int), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
     if (batch_uses_skinny(d, s->batch))                   // also hand layer 0's RMSNorm its inputs (SkinnyFuse)
         return embed_token_emit(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch, d->in_norm_w[0], w.hg, w.ssq, w.nparts);
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch);
@@ -685,7 +517,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
         }
         // RoPE + KV append of the B new tokens inside the attention kernel, each conversation at its own position
         TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
-                            s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt, w.cnt));
+                            s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt));
         if (skinny) {
             SkinnyFuse give;                               // h += attn Wo^T; hand post_norm its inputs
             give.next_g = (const unsigned short*)d->post_norm_w[l]; give.xg_out = (unsigned short*)w.hg; give.ssq_out = w.ssq;
@@ -722,11 +554,6 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
         set_error("teo_llama_decode_begin: workspace %zu < %zu", ws_bytes, w.total);
         return TEO_ERR_WORKSPACE;
     }
-    hipError_t e = hipMemsetAsync(w.cnt, 0, (size_t)d->heads * sizeof(int), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
-    e = hipMemsetAsync(w.chain, 0, (2 + CHAIN_RING) * sizeof(unsigned), st);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync");
-    chain_seq_reset(ws);
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st);
 }
 
@@ -736,7 +563,6 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
 struct ProfRec { hipEvent_t start, stop; int cls; };
 static thread_local std::vector<ProfRec>* g_prof = nullptr;
 static thread_local int g_prof_cls = 0;
-thread_local unsigned g_launch_flags = 0;
 bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
     if (!g_prof) return false;
     ProfRec r;
@@ -750,14 +576,6 @@ bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
 }
 void prof_class(int cls) { g_prof_cls = cls; }
 void prof_bump(int delta) { g_prof_cls += delta; }
-
-int llama_decode_chain_error(const teo_llama_desc* d, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st) {
-    const DecodeWs w = decode_carve(d, ws, ws_bytes);
-    if (w.total > ws_bytes) { set_error("teo_llama_decode_chain_error: workspace too small"); return TEO_ERR_WORKSPACE; }
-    hipError_t e = hipMemcpyAsync(host_flag, w.chain + 1, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    return e == hipSuccess ? TEO_OK : hip_fail(e, "teo_llama_decode_chain_error");
-}
 
 // holds the stream for `ticks` of the 100 MHz wall clock: the profiled step's ~200 launches are enqueued behind it (the host needs
 // ~9 us per timestamped launch, more than the small kernels run) and then execute back to back, as a graph replay does -- a kernel
@@ -773,17 +591,7 @@ int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s
     recs.reserve(8 * (size_t)d->layers + 8);
     prof_hold_kernel<<<1, 64, 0, st>>>(400000ull);            // 4 ms
     g_prof = &recs;
-    // the overlapped step's kernels, one at a time in ordinary launch order (chain off): their own durations; position from d_pos
-    int pos_now = 0;
-    int rc = TEO_OK;
-    if (llama_decode_chain_ok(d)) {
-        hipError_t pe = hipMemcpyAsync(&pos_now, s->d_pos, sizeof(int), hipMemcpyDeviceToHost, st);
-        if (pe == hipSuccess) pe = hipStreamSynchronize(st);
-        if (pe != hipSuccess) { g_prof = nullptr; return hip_fail(pe, "teo_llama_decode_step_profile: d_pos"); }
-        rc = llama_decode_chain_steps(d, s, ws, ws_bytes, 1, pos_now, true, st);
-    } else {
-        rc = llama_decode_step(d, s, ws, ws_bytes, st);
-    }
+    const int rc = llama_decode_step(d, s, ws, ws_bytes, st);
     g_prof = nullptr;
     g_prof_cls = 0;
     hipError_t e = hipStreamSynchronize(st);

@@ -34,11 +34,21 @@ constexpr int SK_TP = 16 * 17;      // padded 16x16 partial tile in LDS: [b][i] 
 static int g_sk_tiles = 0;          // 0 = auto
 static int g_sk_nt = 1;
 static int g_sk_stream = 1;         // 0 = never, 1 = auto, 2 = whenever the streaming form is eligible
+void skinny_tune_reset() { g_sk_tiles = 0; g_sk_nt = 1; g_sk_stream = 1; }
 int skinny_tune_set(const char* key, int value) {
     if (!strcmp(key, "skinny_tiles") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_sk_tiles = value; return 0; }
     if (!strcmp(key, "skinny_nt")) { g_sk_nt = value != 0; return 0; }
     if (!strcmp(key, "skinny_stream") && value >= 0 && value <= 2) { g_sk_stream = value; return 0; }
     return -1;
+}
+
+// Timeline marks of the probe build (tools/skinny_probe.hip instantiates TRACE = true; the library only TRACE = false):
+// slot s of workgroup blockIdx.x <- the 100 MHz wall clock, written by one lane.
+template <bool TRACE>
+__device__ __forceinline__ void sk_mark(const SkinnyFuse& fuse, int slot) {
+    if constexpr (TRACE) {
+        if ((threadIdx.x & 63) == 0) fuse.trace[(long long)blockIdx.x * SK_TRACE_SLOTS + slot] = wall_clock64();
+    }
 }
 
 template <bool NT>
@@ -77,7 +87,7 @@ __device__ __forceinline__ u32x4 sk_scale_frag(const u32x4& xv, const u32x4& gv,
 // per-row factor 1/rms commutes with the GEMM, so the kernel streams x once, accumulates sum(x^2) from the very
 // fragments it feeds to the matrix cores and applies inv_rms in the epilogue -- no separate norm launch, no
 // normalised copy of x.  (g is staged in LDS once per workgroup.)
-template <typename WT, int UNR, bool NT, bool SWIGLU, bool NORM>
+template <typename WT, int UNR, bool NT, bool SWIGLU, bool NORM, bool TRACE = false>
 __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
                                                                  const float* __restrict__ wscale,
                                                                  const bf16_t* __restrict__ norm_w, float eps,
@@ -94,6 +104,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // NORM: g[K] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    if (wid == 0) sk_mark<TRACE>(fuse, 0);
     if (NORM) {
         for (int i = tid; i < K / 8; i += SK_THREADS)
             reinterpret_cast<u32x4*>(sk_dyn)[i] = reinterpret_cast<const u32x4*>(norm_w)[i];
@@ -220,6 +231,7 @@ _Pragma("unroll") \
         TEO_SK_SSQ_LOAD
         TEO_SK_LOAD(wa, xa, s)
         TEO_SK_SSQ_REDUCE
+        if (wid == 0) sk_mark<TRACE>(fuse, 1);
         for (; s + 2 * UNR < s1; s += 2 * UNR) {
             TEO_SK_LOAD(wb, xb, s + UNR)
             TEO_SK_COMP(wa, xa, s)
@@ -244,7 +256,9 @@ _Pragma("unroll") \
         ssq += __shfl_xor(ssq, 32, 64);
         if (fg == 0) ssq_part[wid][fr] = ssq;
     }
+    if (wid == 0) sk_mark<TRACE>(fuse, 2);
     __syncthreads();
+    if (wid == 0) sk_mark<TRACE>(fuse, 3);
 
     const int OUTC = SWIGLU ? 8 * RT : 16 * RT;          // output columns of this workgroup
     float emit_v = 0.f;
@@ -307,6 +321,7 @@ _Pragma("unroll") \
         sq += __shfl_xor(sq, 1, 64);
         if (c == 0 && b < MB) fuse.ssq_out[(long long)b * gridDim.x + blockIdx.x] = sq;
     }
+    if (wid == 0) sk_mark<TRACE>(fuse, 4);
 }
 
 // ---- streaming form --------------------------------------------------------------------------------------------------
@@ -331,7 +346,7 @@ constexpr int SS_NW = 8;                       // streaming waves; wave SS_NW is
 constexpr int SS_THREADS = (SS_NW + 1) * 64;
 constexpr int SS_TP = 16 * 20;                 // partial tile in LDS: [b][i] at b*20 + i (16-byte aligned rows)
 
-template <typename WT, int UNR, int SPT, bool SW8>
+template <typename WT, int UNR, int SPT, bool SW8, bool TRACE = false>
 __global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
                                                                    const float* __restrict__ wscale, const bf16_t* res, void* outv,
                                                                    int MB, int N, int K, int ldx, int ldo, int tiled, int out_f32,
@@ -345,9 +360,11 @@ __global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t*
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ntiles = (N + 15) / 16, nsteps = K / KS, G = gridDim.x;
 
+    if (wid == 0 || wid == SS_NW) sk_mark<TRACE>(fuse, wid == 0 ? 0 : 8);
     if (wid < SS_NW) {
         const int fr = lane & 15, fg = lane >> 4;
         const int s0 = wid * PER;
+        int ntrace = 1;
         TEO_SK_SSQ_LOAD
         // the slice's activations, once
         u32x4 xr[PER][XL];
@@ -409,6 +426,7 @@ __global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t*
                         *reinterpret_cast<f32x4*>(&red[par][wid][fr * 20 + fg * 4]) = acc;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
+                        if (wid == 0 && ntrace < 8) sk_mark<TRACE>(fuse, ntrace++);
                         acc = (f32x4){0.f, 0.f, 0.f, 0.f};
                         par ^= 1;
                     }
@@ -435,10 +453,11 @@ __global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t*
             }                                                                                                  \
         }
         TEO_SS_PREFETCH(blockIdx.x)
-        int par = 0;
+        int par = 0, ntrace = 9;
         for (int t = blockIdx.x; t < ntiles; t += G) {
+            asm volatile("" ::: "memory");               // the previous tile's LDS reads and stores stay BEFORE this barrier ...
             __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");               // the partial tiles are read AFTER the barrier (s_barrier alone does not order them for the compiler)
+            asm volatile("" ::: "memory");               // ... and this tile's partial sums are read AFTER it (s_barrier alone does not order them for the compiler)
             const f32x4 sc = sc_n;
             const uint2 rv = rv_n, gv = gv_n;
             TEO_SS_PREFETCH(t + G)
@@ -526,6 +545,7 @@ __global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t*
                     if (i4 == 0 && bok) fuse.ssq_out[(long long)b * ntiles + t] = sq;
                 }
             }
+            if (ntrace < 16) sk_mark<TRACE>(fuse, ntrace++);
         }
 #undef TEO_SS_PREFETCH
     }
@@ -578,12 +598,7 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
         // bf16: -10..20 % above 8 rows, a tie at 8 or fewer where the duplicate activation rows coalesce)
         if (ok && g_sk_stream == 1) ok = ntiles >= 512 && (w_fp8 || MB > 8);
         if (ok) {
-            static int cus = -1;
-            if (cus < 0) {
-                int dev = 0;
-                hipDeviceProp_t p;
-                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 0;
-            }
+            const int cus = device_cu_count();
             const int grid = std::max(1, std::min(ntiles, cus > 0 ? cus : 256));
 #define TEO_SS(WW, UN, SP, SW)                                                                              \
             skinny_stream_kernel<WW, UN, SP, SW><<<grid, SS_THREADS, 0, st>>>((const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \

@@ -112,6 +112,8 @@ class TeoEngine:
         self._keep = []                           # host pointer arrays referenced by the descriptors
         self._ws = {}
         self._phase_depth = 0
+        self._pending_status = {}                 # workspace key -> deferred hand-off check (see _check_handoffs)
+        self._option_hooks = []                   # callables(desc): keep copies of the LLaMA descriptor in step with set_options
         self._graph = None
         self._load_vit(state_dict)
         self._load_projector(state_dict)
@@ -327,6 +329,10 @@ class TeoEngine:
             if a[0] is None:
                 self.eng.stream.synchronize()
             self.cur.wait_stream(self.eng.stream)
+            if a[0] is None:
+                self.eng._flush_handoff_checks()     # deferred by the nested phases of generate() / generate_batch()
+            else:
+                self.eng._pending_status.clear()
             return False
 
     def phase(self):
@@ -344,20 +350,37 @@ class TeoEngine:
             px = pixels.to(device=self.device, dtype=self.dtype).contiguous()
             out = torch.empty(T, self.vit_tokens, v.hidden_size, dtype=self.dtype, device=self.device)
             need = self.lib.teo_vit_workspace_bytes(C.byref(self.vit_desc), T)
+            self._flush_handoff_checks("vit")         # an unread status of this workspace: read it before the call re-arms the word
             ws = self._workspace("vit", need)
             L.check(self.lib.teo_vit_encode(C.byref(self.vit_desc), _p(px), T, _p(out), _p(ws), ws.numel(), st), "teo_vit_encode")
-            self._check_handoffs(lambda f: self.lib.teo_vit_workspace_status(C.byref(self.vit_desc), T, _p(ws), ws.numel(), C.byref(f), st), "teo_vit_encode")
+            sid = C.c_void_p(self.stream.cuda_stream)
+            self._check_handoffs("vit", lambda f: self.lib.teo_vit_workspace_status(C.byref(self.vit_desc), T, _p(ws), ws.numel(), C.byref(f), sid),
+                                 "teo_vit_encode")
         return out
 
-    def _check_handoffs(self, status_call, what):
-        """The persistent GEMM forms hand partial tiles over through workspace flags; a hand-off that timed out sets a sticky error word
-        instead of continuing silently.  Only looked at when this is the outermost phase (the stream is about to be drained anyway)."""
+    def _check_handoffs(self, key, status_call, what):
+        """The persistent GEMM forms hand partial tiles over through workspace flags; a hand-off that timed out sets a sticky error
+        word (cleared when the next call on that workspace re-arms it) instead of continuing silently.  Reading the word
+        synchronises the stream, so inside a nested phase (generate() / generate_batch() wrap tower, prefill and decode in one outer
+        phase) the check is DEFERRED: it runs when the outermost phase ends -- the stream is drained there anyway -- or right before
+        the same workspace is used again, whichever comes first.  A timed-out hand-off therefore always raises."""
         if self._phase_depth > 1:
+            self._pending_status[key] = (status_call, what)
             return
+        self._run_handoff_check(status_call, what)
+
+    def _run_handoff_check(self, status_call, what):
         flag = C.c_int(0)
         L.check(status_call(flag), what + " workspace status")
         if flag.value:
             raise RuntimeError(f"{what}: a stream-K / hybrid GEMM hand-off timed out (results invalid)")
+
+    def _flush_handoff_checks(self, key=None):
+        keys = [key] if key is not None else list(self._pending_status)
+        for k in keys:
+            item = self._pending_status.pop(k, None)
+            if item is not None:
+                self._run_handoff_check(*item)
 
     def project(self, feats):
         """[..., Dv] -> [..., D] through the mm_projector (H12)."""
@@ -407,11 +430,13 @@ class TeoEngine:
             rows = 1 if last_only else S
             logits = torch.empty(rows, self.cfg.vocab_size, dtype=torch.float32, device=self.device)
             need = self.lib.teo_llama_prefill_workspace_bytes(C.byref(self.llama_desc), S)
+            self._flush_handoff_checks("prefill")
             ws = self._workspace("prefill", need)
             L.check(self.lib.teo_llama_prefill(C.byref(self.llama_desc), _p(e), _p(pos), S, past, 1 if last_only else 0,
                                                _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill")
-            self._check_handoffs(lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(self.llama_desc), S, _p(ws), ws.numel(), C.byref(f), st),
-                                 "teo_llama_prefill")
+            sid = C.c_void_p(self.stream.cuda_stream)
+            self._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(self.llama_desc), S, _p(ws), ws.numel(),
+                                                                                                  C.byref(f), sid), "teo_llama_prefill")
         self.cache_len = past + S
         return logits
 
@@ -449,6 +474,21 @@ class TeoEngine:
             L.check(self.lib.teo_llama_decode_begin(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(),
                                                     st), "teo_llama_decode_begin")
 
+    def set_options(self, prefill_fp8=None, rope_in_attn=None):
+        """Per-engine options of the LLaMA descriptor (include/teo_hip.h teo_llama_desc): `prefill_fp8` = w8a8 prefill on the fp8
+        MFMA (lossy, needs weight_format='fp8'), `rope_in_attn` = RoPE + KV append inside the decode attention kernel instead of
+        the QKV GEMV epilogue (same values).  Not process-global: two engines in one process can differ."""
+        d = self.llama_desc
+        if prefill_fp8 is not None:
+            if prefill_fp8 and self.llama_w8 is None:
+                raise ValueError("prefill_fp8 needs weight_format='fp8' (the e4m3 weight copies)")
+            d.prefill_fp8 = 1 if prefill_fp8 else 0
+        if rope_in_attn is not None and int(bool(rope_in_attn)) != d.rope_in_attn:
+            d.rope_in_attn = 1 if rope_in_attn else 0
+            self._drop_graph()                    # the placement is baked into the captured decode step
+        for hook in getattr(self, "_option_hooks", []):
+            hook(d)
+
     def _drop_graph(self):
         if self._graph is not None:
             self.lib.teo_graph_destroy(self._graph)
@@ -462,20 +502,6 @@ class TeoEngine:
             raise ValueError(f"decode_steps: {self.steps_since_begin + n} tokens since decode_begin exceed the output buffer "
                              f"({self.max_new_cap}); call decode_begin again or build the engine with a larger max_new")
         ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
-        if use_graph and self.lib.teo_llama_decode_chain_supported(C.byref(self.llama_desc)):
-            # overlapped steps (launch chain): plain any-order launches with device-side hand-over, no hipGraph; the position of
-            # the token fed by the first step is host-known (= tokens in the cache)
-            with self.phase() as st:
-                L.check(self.lib.teo_llama_decode_steps(C.byref(self.llama_desc), C.byref(self.decode_state), _p(ws), ws.numel(), n,
-                                                        self.cache_len, st), "teo_llama_decode_steps")
-                flag = C.c_int(0)
-                L.check(self.lib.teo_llama_decode_chain_error(C.byref(self.llama_desc), _p(ws), ws.numel(), C.byref(flag), st),
-                        "teo_llama_decode_chain_error")          # synchronises the engine stream (the host looks at the tokens next anyway)
-                if flag.value:
-                    raise RuntimeError("decode chain: a kernel gave up waiting for its predecessor (results invalid)")
-            self.cache_len += n
-            self.steps_since_begin = getattr(self, "steps_since_begin", 0) + n
-            return
         with self.phase() as st:
             if use_graph:
                 if self._graph is None or self._graph_ws != ws.data_ptr():
@@ -504,6 +530,9 @@ class TeoEngine:
         Returns {class: (launches per step, mean microseconds per launch)}; advances the cache like decode_steps."""
         if self.cache_len + n > self.max_seq:
             raise ValueError(f"decode would exceed max_seq {self.max_seq}")
+        if getattr(self, "steps_since_begin", 0) + n > self.max_new_cap:
+            raise ValueError(f"decode_steps_profiled: {self.steps_since_begin + n} tokens since decode_begin exceed the output buffer "
+                             f"({self.max_new_cap})")
         ws = self._workspace("decode", self.lib.teo_llama_decode_workspace_bytes(C.byref(self.llama_desc)))
         K = len(self.PROF_CLASSES)
         tot, cnt = [0.0] * K, [0] * K

@@ -33,3 +33,12 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _tune_defaults_after_each_gpu_test(request):
+    """The library's tuning knobs are process-wide: whatever a test forced, the NEXT test runs on the shipped defaults."""
+    yield
+    if "gpu" in request.keywords and _has_gpu():
+        from teochat_amd import _lib
+        _lib.load().teo_tune_reset()

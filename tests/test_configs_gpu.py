@@ -225,7 +225,7 @@ def test_c5_batch8_fp8_32_layers_against_single_conversations(model_fp8):
 
 
 def test_c5_w8a8_prefill_on_the_fp8_mfma(model_fp8):
-    """Config C5's "fp8 weight path on CDNA4 MFMA" for the PREFILL phase (tune prefill_fp8 = 1): every Linear layer of the 32
+    """Config C5's "fp8 weight path on CDNA4 MFMA" for the PREFILL phase (engine option prefill_fp8): every Linear layer of the 32
     decoder layers runs as a w8a8 GEMM on v_mfma_scale_f32_16x16x128_f8f6f4 (activations quantised per token to e4m3, the
     decode path's per-row e4m3 weights).  Against the exact path (bf16 MFMA on the dequantised weights = the same weights):
       * per-token activation quantisation is lossy (3 mantissa bits): the logits move by a few percent of max|logit| on this
@@ -237,7 +237,7 @@ def test_c5_w8a8_prefill_on_the_fp8_mfma(model_fp8):
     lib = m.engine.lib
     frames, ids = conversation(8, 128, seed=30)
     exact = m(input_ids=ids, images=frames).logits[0]
-    assert lib.teo_tune_set(b"prefill_fp8", 1) == 0
+    m.engine.set_options(prefill_fp8=True)
     try:
         q1 = m(input_ids=ids, images=frames).logits[0]
         q2 = m(input_ids=ids, images=frames).logits[0]
@@ -252,5 +252,5 @@ def test_c5_w8a8_prefill_on_the_fp8_mfma(model_fp8):
         assert out.shape[1] == 128 + 8 and m.engine.cache_len == 2168 + 7
         assert int(out[0, 128]) == int(q1[-1].argmax())
     finally:
-        lib.teo_tune_set(b"prefill_fp8", 0)
+        m.engine.set_options(prefill_fp8=False)
     assert torch.equal(m(input_ids=ids, images=frames).logits[0], exact)

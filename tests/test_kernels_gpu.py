@@ -810,56 +810,6 @@ def test_attn_decode_batched_vs_reference(dtype, H, Hk, d, S, ctx, chunk):
             close_bf16(out[b], G.bf16_round(ref), ulps=2.0, floor=4e-3)    # P is rounded to bf16 before the PV product
 
 
-@pytest.mark.parametrize("S,ctxs", [(2560, [2299, 2560, 2305, 320, 17, 1]), (4608, [4255, 4608, 3073, 100]), (512, [300, 512, 5])])
-@pytest.mark.parametrize("rope", [False, True])
-def test_attn_decode_fat_split_vs_reference_and_round2_kernel(S, ctxs, rope):
-    """attn_fat.hip (bf16, head_dim 128, one conversation): heads x ceil(S_max / 320) workgroups of 1024 threads, each owning an
-    equal share of the CURRENT context; against the fp64 softmax reference (P rounded to bf16 before PV: 2 ulps) and against the
-    round-2 split-64 kernels on the same inputs, for full / ragged / tiny contexts, with and without in-kernel RoPE + KV append."""
-    H, d = 32, 128
-    lib = G.lib()
-    g = torch.Generator().manual_seed(S + int(rope))
-    K = G.bf16_round(torch.randn(H, S, d, generator=g))
-    V = G.bf16_round(torch.randn(H, S, d, generator=g))
-    cs, sn = rope_tables(d, 10000.0, S)
-    d_cs, d_sn = cs.cuda(), sn.cuda()
-    part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, 1), dtype=torch.uint8, device="cuda")
-    for n in ctxs:
-        pos = n - 1
-        qkv = G.bf16_round(torch.randn(3, H, d, generator=g))                 # raw q | k | v of the new token
-        if rope:
-            c, s_ = cs[pos], sn[pos]
-            c, s_ = torch.cat([c, c]), torch.cat([s_, s_])
-            q_rot = G.bf16_round(qkv[0] * c + O.rotate_half(qkv[0]) * s_)
-            k_new = G.bf16_round(qkv[1] * c + O.rotate_half(qkv[1]) * s_)
-            Kc, Vc = K.clone(), V.clone()
-            Kc[:, pos], Vc[:, pos] = k_new, qkv[2]
-            d_q = qkv.reshape(-1).to("cuda", torch.bfloat16).contiguous()
-        else:
-            q_rot, Kc, Vc = qkv[0], K, V
-            d_q = q_rot.reshape(-1).to("cuda", torch.bfloat16).contiguous()
-        ref = G.bf16_round(_decode_attn_ref(q_rot, Kc, Vc, n))
-        outs = {}
-        for fat in (1, 0):
-            dK, dV = K.to("cuda", torch.bfloat16).contiguous(), V.to("cuda", torch.bfloat16).contiguous()
-            dVT = torch.zeros(H, d, S, dtype=torch.bfloat16, device="cuda")
-            out = torch.empty(H * d, dtype=torch.bfloat16, device="cuda")
-            d_pos = torch.tensor([pos], dtype=torch.int32, device="cuda")
-            assert lib.teo_tune_set(b"attn_fat", fat) == 0
-            try:
-                L.check(lib.teo_attn_decode(G.p(d_q), G.p(dK), G.p(dV), G.p(dVT) if rope else None, G.p(d_cs) if rope else None,
-                                            G.p(d_sn) if rope else None, G.p(out), G.p(part), G.p(d_pos), S, H, H, d, 1.0 / d ** 0.5,
-                                            L.TEO_BF16, 1, 0, 0, 0, G.stream()), "attn_decode")
-            finally:
-                lib.teo_tune_set(b"attn_fat", 1)
-            close_bf16(out, ref, ulps=2.0, floor=4e-3)
-            if rope:                                                          # the new token's K / V / V^T rows were appended
-                close_bf16(dK[:, pos], Kc[:, pos], ulps=1.0, floor=1e-6)      # rotation: fp32 contraction order may flip a rounding
-                assert torch.equal(dV[:, pos].cpu().float(), Vc[:, pos]) and torch.equal(dVT[:, :, pos].cpu().float(), Vc[:, pos])
-            outs[fat] = out.float().cpu()
-        close_bf16(outs[1], outs[0], ulps=2.0, floor=4e-3)                    # both kernels round P at their own chunk maxima
-
-
 def _hf_top_p_keep(logits, temperature, top_k, top_p):
     """HF order: temperature -> TopKLogitsWarper -> TopPLogitsWarper (ascending sort, cumulative <= 1 - top_p removed,
     at least one token kept).  Returns (kept index set, renormalised probabilities)."""
@@ -937,71 +887,6 @@ def test_sampler_rejects_what_it_cannot_do_exactly():
     assert G.lib().teo_sample_topk(G.p(lg), G.p(tok), 32000, 1.0, 0, 0.9, 1, 0, G.stream()) == -2
     assert b"top_p" in G.lib().teo_last_error()
     assert G.lib().teo_sample_topk(G.p(lg), G.p(tok), 32000, 1.0, 50, 0.9, 1, 0, G.stream()) == 0
-
-
-@pytest.mark.parametrize("dtype,H,Hk,d,S", [(torch.bfloat16, 32, 32, 128, 2560), (torch.bfloat16, 8, 2, 64, 1024),
-                                            (torch.float32, 4, 2, 32, 512)])
-@pytest.mark.parametrize("chunk", [0, 128])
-def test_attn_decode_fused_combine_is_bitwise_the_two_launch_path(dtype, H, Hk, d, S, chunk):
-    """The in-kernel merge of the KV splits (last-arriving workgroup of a head; write-through sc1 records + relaxed ticket, no
-    fences) against the separate combine launch: same arithmetic in the same order -> BIT-identical outputs.  The records
-    and counters are re-used launch after launch with changing positions, alone and under a concurrent HBM stream on another
-    HIP stream (uneven load), consumer lines warm from the previous launch: any stale read shows up as a mismatch."""
-    B = 3
-    g = torch.Generator().manual_seed(5)
-    q = torch.randn(B, H, d, generator=g)
-    K = torch.randn(B, Hk, S, d, generator=g)
-    V = torch.randn(B, Hk, S, d, generator=g)
-    dq, dK, dV = q.to("cuda", dtype).contiguous(), K.to("cuda", dtype).contiguous(), V.to("cuda", dtype).contiguous()
-    lib = G.lib()
-    part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, B), dtype=torch.uint8, device="cuda")
-    part2 = torch.empty_like(part)
-    pos = torch.zeros(B, dtype=torch.int32, device="cuda")
-    out_f = torch.empty(B, H * d, dtype=dtype, device="cuda")
-    out_u = torch.empty_like(out_f)
-    assert lib.teo_tune_set(b"attn_chunk", chunk) == 0
-    side = torch.cuda.Stream()
-    big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")       # 256 MB: copies stream through HBM
-    big2 = torch.empty_like(big)
-
-    def run(fused, out, ws):
-        assert lib.teo_tune_set(b"attn_fused_combine", 1 if fused else 0) == 0
-        L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), None, None, None, G.p(out), G.p(ws), G.p(pos), S, H, Hk, d,
-                                    1.0 / d ** 0.5, G.DT[dtype], B, H * d, Hk * S * d, H * d, G.stream()), "attn_decode")
-
-    try:
-        rng = torch.Generator().manual_seed(9)
-        n_mismatch = 0
-        for it in range(60):
-            ctx = torch.randint(1, S + 1, (B,), generator=rng)
-            if it % 7 == 0:
-                ctx[0] = S                                                       # every split active
-            if it % 11 == 0:
-                ctx[1] = 1                                                       # a single key
-            pos.copy_((ctx - 1).to(torch.int32))
-            if it % 2:
-                with torch.cuda.stream(side):                                    # load on the memory system while the hand-offs run
-                    for _ in range(3):
-                        big2.copy_(big)
-            run(True, out_f, part)
-            run(False, out_u, part2)
-            torch.cuda.synchronize()
-            n_mismatch += int(not torch.equal(out_f, out_u))
-            # and the fused path again on the SAME records right away (previous launch's lines still cached)
-            run(True, out_u, part)
-            torch.cuda.synchronize()
-            n_mismatch += int(not torch.equal(out_f, out_u))
-        assert n_mismatch == 0, f"{n_mismatch} of 120 comparisons differ"
-        ref = _decode_attn_ref(q[0] if dtype == torch.float32 else G.bf16_round(q[0]),
-                               K[0] if dtype == torch.float32 else G.bf16_round(K[0]),
-                               V[0] if dtype == torch.float32 else G.bf16_round(V[0]), int(pos[0]) + 1)
-        if dtype == torch.float32:
-            torch.testing.assert_close(out_f[0].cpu(), ref, atol=2e-5, rtol=1e-5)
-        else:
-            close_bf16(out_f[0], G.bf16_round(ref), ulps=2.0, floor=4e-3)
-    finally:
-        lib.teo_tune_set(b"attn_chunk", 0)
-        lib.teo_tune_set(b"attn_fused_combine", 0)
 
 
 # ---------------------------------------------------------------------------------------------- stream-K GEMM

@@ -95,7 +95,7 @@ def test_fp32_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])
-@pytest.mark.parametrize("placement", [0, 1, 2])
+@pytest.mark.parametrize("placement", [0, 1])
 def test_decode_rope_placements_match_reference_golden(name, placement):
     """Both decode RoPE/KV-append placements (QKV-GEMV epilogue, decode-attention kernel) reproduce the reference's
     greedy tokens, KV snapshots and last-step logits (fp32), eager and through the hipGraph."""
@@ -106,9 +106,7 @@ def test_decode_rope_placements_match_reference_golden(name, placement):
     frames, ids = inputs(name, g)
     dev = model.device
     imgs = [f.to(dev) for f in frames]
-    # placement 2 = RoPE in the attention kernel + the (off by default) last-arriver fused combine
-    assert lib.teo_tune_set(b"rope_in_attn", min(placement, 1)) == 0
-    assert lib.teo_tune_set(b"attn_fused_combine", 1 if placement == 2 else 0) == 0
+    model.engine.set_options(rope_in_attn=bool(placement))
     try:
         n_new = len(g["greedy_tokens"])
         gen = model.generate(input_ids=ids.to(dev), images=imgs, do_sample=False, max_new_tokens=n_new, eos_token_id=None)
@@ -138,8 +136,7 @@ def test_decode_rope_placements_match_reference_golden(name, placement):
         check_state()
         assert torch.equal(lg_graph, eng.d_logits)
     finally:
-        lib.teo_tune_set(b"rope_in_attn", -1)
-        lib.teo_tune_set(b"attn_fused_combine", 0)
+        model.engine.set_options(rope_in_attn=False)
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])
@@ -518,28 +515,3 @@ def test_teacher_forced_decode_steps_match_reference(name):
         pkv = out.past_key_values
         rel = float((out.logits[0, -1].cpu().float() - ref[0, -1]).abs().max()) / float(ref[0, -1].abs().max())
         assert rel < BF16_REL, (i, rel)
-
-
-@pytest.mark.parametrize("T", [1, 3])
-def test_fused_patch_embed_is_bitwise_im2col_plus_gemm(T):
-    """patch_embed.hip (patch pixels gathered straight into the MFMA tile's LDS image) against the im2col matrix + GEMM path it
-    replaces: same k order, same zero padding, same MFMA chain -> the tower's features are bit-identical; real ViT-L/14 geometry
-    (224 / 14, K = 588 padded to 640) so the 14-pixel rows never line up with the 8-element operand chunks."""
-    from teochat_amd.config import LlavaConfig, VisionConfig
-    from teochat_amd.engine import TeoEngine
-    from teochat_amd.synthetic import synthetic_state_dict
-    cfg = LlavaConfig(hidden_size=256, num_attention_heads=2, num_key_value_heads=2, intermediate_size=512, num_hidden_layers=1,
-                      vocab_size=512, mm_hidden_size=1024, max_position_embeddings=1024,
-                      vision_config=VisionConfig(hidden_act="gelu", num_hidden_layers=3))
-    sd = synthetic_state_dict(cfg, seed=3, device="cuda:0")
-    eng = TeoEngine(sd, cfg, dtype=torch.bfloat16, device="cuda:0", max_seq=128)
-    px = torch.randn(T, 3, 224, 224, generator=torch.Generator().manual_seed(T)).to(torch.bfloat16).cuda()
-    lib = eng.lib
-    try:
-        assert lib.teo_tune_set(b"vit_patch_fused", 0) == 0
-        want = eng.vit_features(px).clone()
-        assert lib.teo_tune_set(b"vit_patch_fused", 1) == 0
-        got = eng.vit_features(px)
-        assert torch.equal(got, want)
-    finally:
-        lib.teo_tune_set(b"vit_patch_fused", 1)

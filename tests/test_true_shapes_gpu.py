@@ -503,7 +503,7 @@ def test_w8a8_prefill_layer_walk_at_7b_shapes():
 
 
 def test_c5_w8a8_prefill_against_the_oracle_at_full_width():
-    """w8a8 prefill end to end (tune prefill_fp8 = 1), N_LAYERS_DEEP layers at 7B width, L = 2168, against the oracle with
+    """w8a8 prefill end to end (engine option prefill_fp8), N_LAYERS_DEEP layers at 7B width, L = 2168, against the oracle with
     act_quant="e4m3" on the engine's dequantised weights: logits statistics reported and bounded like the bf16 leg of (b)."""
     from teochat_amd.config import teochat_7b_config
     from teochat_amd.engine import TeoEngine, quantize_fp8_rows
@@ -521,11 +521,11 @@ def test_c5_w8a8_prefill_against_the_oracle_at_full_width():
     ids = O.synthetic_prompt_ids(n_text, T, 32000, seed=1).unsqueeze(0)
     imgs = [f.to(DEV, dtype=bf) for f in frames]
     lib = eng.lib
-    assert lib.teo_tune_set(b"prefill_fp8", 1) == 0
+    eng.set_options(prefill_fp8=True)
     try:
         got = m(input_ids=ids.to(DEV), images=imgs).logits[0].float().cpu()
     finally:
-        lib.teo_tune_set(b"prefill_fp8", 0)
+        eng.set_options(prefill_fp8=False)
     exact = m(input_ids=ids.to(DEV), images=imgs).logits[0].float().cpu()         # bf16 MFMA on the same dequantised weights
     # the oracle sees the engine's weights: Linear layers of the LLM dequantised from their e4m3 rows, everything else as drawn
     sd = {k: v.cpu() for k, v in sd_dev.items()}
