@@ -96,6 +96,30 @@ def _rounder(rounding):
     raise ValueError(f"unknown rounding {rounding!r}")
 
 
+# fp32 summation order of the Linear layers (test infrastructure for the bf16 noise-floor control, tests/test_noise_floor.py):
+# None = one matmul over the whole K; (n, descending) = K cut into n equal chunks whose partial products are added in
+# ascending or descending chunk order.  Nothing else changes -- same weights, same rounding points.
+K_ORDER = None
+
+
+def _lin(x, w):
+    """x [..., K] . w[N, K]^T -- every nn.Linear of the path (bias added by the caller)."""
+    wt = w.to(x.dtype).t()
+    if K_ORDER is None:
+        return x @ wt
+    n, descending = K_ORDER
+    K = x.shape[-1]
+    step = -(-K // n)
+    starts = list(range(0, K, step))
+    if descending:
+        starts.reverse()
+    acc = None
+    for k0 in starts:
+        part = x[..., k0:k0 + step] @ wt[k0:k0 + step]
+        acc = part if acc is None else acc + part
+    return acc
+
+
 # --------------------------------------------------------------------------------------
 # H2/H3: prompt construction
 # --------------------------------------------------------------------------------------
@@ -351,7 +375,7 @@ def vit_embeddings(pixels: torch.Tensor, sd, cfg: VitCfg, R) -> torch.Tensor:
     g = cfg.image_size // P
     # [B,3,g,P,g,P] -> [B,g,g,3,P,P] -> [B*g*g, 3*P*P]
     cols = pixels.view(B, cfg.num_channels, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, -1)
-    patches = R(cols @ w.reshape(D, -1).t()).view(B, g * g, D)
+    patches = R(_lin(cols, w.reshape(D, -1))).view(B, g * g, D)
     cls = sd[VIT_PREFIX + "embeddings.class_embedding"].to(pixels.dtype).view(1, 1, D).expand(B, 1, D)
     pos = sd[VIT_PREFIX + "embeddings.position_embedding.weight"].to(pixels.dtype)
     return R(torch.cat([cls, patches], dim=1) + pos.unsqueeze(0))
@@ -369,7 +393,7 @@ def vit_attention(x, sd, pre, cfg: VitCfg, R, mode="exact"):
     d = D // H
 
     def lin(name):
-        return R(x @ sd[pre + name + ".weight"].to(x.dtype).t() + sd[pre + name + ".bias"].to(x.dtype))
+        return R(_lin(x, sd[pre + name + ".weight"]) + sd[pre + name + ".bias"].to(x.dtype))
 
     q = lin("self_attn.q_proj").view(B, N, H, d).transpose(1, 2)
     k = lin("self_attn.k_proj").view(B, N, H, d).transpose(1, 2)
@@ -384,10 +408,10 @@ def vit_layer(h, sd, i, cfg: VitCfg, R, mode="exact"):
     pre = VIT_PREFIX + f"encoder.layers.{i}."
     a = R(_layernorm(h, sd[pre + "layer_norm1.weight"], sd[pre + "layer_norm1.bias"], cfg.layer_norm_eps))
     a = vit_attention(a, sd, pre, cfg, R, mode)
-    h = R(h + a @ sd[pre + "self_attn.out_proj.weight"].to(h.dtype).t() + sd[pre + "self_attn.out_proj.bias"].to(h.dtype))
+    h = R(h + _lin(a, sd[pre + "self_attn.out_proj.weight"]) + sd[pre + "self_attn.out_proj.bias"].to(h.dtype))
     m = R(_layernorm(h, sd[pre + "layer_norm2.weight"], sd[pre + "layer_norm2.bias"], cfg.layer_norm_eps))
-    m = R(_act(cfg.hidden_act)(m @ sd[pre + "mlp.fc1.weight"].to(h.dtype).t() + sd[pre + "mlp.fc1.bias"].to(h.dtype)))
-    h = R(h + m @ sd[pre + "mlp.fc2.weight"].to(h.dtype).t() + sd[pre + "mlp.fc2.bias"].to(h.dtype))
+    m = R(_act(cfg.hidden_act)(_lin(m, sd[pre + "mlp.fc1.weight"]) + sd[pre + "mlp.fc1.bias"].to(h.dtype)))
+    h = R(h + _lin(m, sd[pre + "mlp.fc2.weight"]) + sd[pre + "mlp.fc2.bias"].to(h.dtype))
     return h
 
 
@@ -432,15 +456,15 @@ def projector(x, sd, projector_type="mlp2x_gelu", rounding=None):
     if projector_type == "identity":
         return x
     if projector_type == "linear":
-        return R(x @ sd[pre + "weight"].to(x.dtype).t() + sd[pre + "bias"].to(x.dtype))
+        return R(_lin(x, sd[pre + "weight"]) + sd[pre + "bias"].to(x.dtype))
     m = re.match(r"^mlp(\d+)x_gelu$", projector_type)
     if not m:
         raise ValueError(f"Unknown projector type: {projector_type}")
     depth = int(m.group(1))
-    h = x @ sd[pre + "0.weight"].to(x.dtype).t() + sd[pre + "0.bias"].to(x.dtype)
+    h = _lin(x, sd[pre + "0.weight"]) + sd[pre + "0.bias"].to(x.dtype)
     for j in range(1, depth):
         h = R(F.gelu(h))
-        h = h @ sd[pre + f"{2 * j}.weight"].to(x.dtype).t() + sd[pre + f"{2 * j}.bias"].to(x.dtype)
+        h = _lin(h, sd[pre + f"{2 * j}.weight"]) + sd[pre + f"{2 * j}.bias"].to(x.dtype)
     return R(h)
 
 
@@ -626,9 +650,9 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, m
     H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     pre = f"model.layers.{i}."
     n1 = R(rmsnorm(h, sd[pre + "input_layernorm.weight"], cfg.rms_norm_eps))
-    q = R(n1 @ sd[pre + "self_attn.q_proj.weight"].to(h.dtype).t()).view(B, S, H, d).transpose(1, 2)
-    k = R(n1 @ sd[pre + "self_attn.k_proj.weight"].to(h.dtype).t()).view(B, S, Hk, d).transpose(1, 2)
-    v = R(n1 @ sd[pre + "self_attn.v_proj.weight"].to(h.dtype).t()).view(B, S, Hk, d).transpose(1, 2)
+    q = R(_lin(n1, sd[pre + "self_attn.q_proj.weight"])).view(B, S, H, d).transpose(1, 2)
+    k = R(_lin(n1, sd[pre + "self_attn.k_proj.weight"])).view(B, S, Hk, d).transpose(1, 2)
+    v = R(_lin(n1, sd[pre + "self_attn.v_proj.weight"])).view(B, S, Hk, d).transpose(1, 2)
     c, s = cos.unsqueeze(1), sin.unsqueeze(1)
     q = R(q * c + rotate_half(q) * s)
     k = R(k * c + rotate_half(k) * s)
@@ -639,12 +663,12 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, m
         vv = vv[:, :, None].expand(B, Hk, rep, vv.shape[2], d).reshape(B, H, -1, d)
     o = attention_core(q, kk, vv, visible, 1.0 / math.sqrt(d), R, mode)
     o = R(o.transpose(1, 2).reshape(B, S, D))
-    h = R(h + o @ sd[pre + "self_attn.o_proj.weight"].to(h.dtype).t())
+    h = R(h + _lin(o, sd[pre + "self_attn.o_proj.weight"]))
     n2 = R(rmsnorm(h, sd[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
-    g = n2 @ sd[pre + "mlp.gate_proj.weight"].to(h.dtype).t()
-    u = n2 @ sd[pre + "mlp.up_proj.weight"].to(h.dtype).t()
+    g = _lin(n2, sd[pre + "mlp.gate_proj.weight"])
+    u = _lin(n2, sd[pre + "mlp.up_proj.weight"])
     a = R(F.silu(g) * u)
-    h = R(h + a @ sd[pre + "mlp.down_proj.weight"].to(h.dtype).t())
+    h = R(h + _lin(a, sd[pre + "mlp.down_proj.weight"]))
     return h
 
 
@@ -655,9 +679,9 @@ def _llama_layer_w8a8(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache
     pre = f"model.layers.{i}."
     Q = quant_rows_e4m3
     n1 = Q(R(rmsnorm(h, sd[pre + "input_layernorm.weight"], cfg.rms_norm_eps)))
-    q = R(n1 @ sd[pre + "self_attn.q_proj.weight"].to(h.dtype).t()).view(B, S, H, d).transpose(1, 2)
-    k = R(n1 @ sd[pre + "self_attn.k_proj.weight"].to(h.dtype).t()).view(B, S, Hk, d).transpose(1, 2)
-    v = R(n1 @ sd[pre + "self_attn.v_proj.weight"].to(h.dtype).t()).view(B, S, Hk, d).transpose(1, 2)
+    q = R(_lin(n1, sd[pre + "self_attn.q_proj.weight"])).view(B, S, H, d).transpose(1, 2)
+    k = R(_lin(n1, sd[pre + "self_attn.k_proj.weight"])).view(B, S, Hk, d).transpose(1, 2)
+    v = R(_lin(n1, sd[pre + "self_attn.v_proj.weight"])).view(B, S, Hk, d).transpose(1, 2)
     c, s = cos.unsqueeze(1), sin.unsqueeze(1)
     q = R(q * c + rotate_half(q) * s)
     k = R(k * c + rotate_half(k) * s)
@@ -668,12 +692,12 @@ def _llama_layer_w8a8(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache
         vv = vv[:, :, None].expand(B, Hk, rep, vv.shape[2], d).reshape(B, H, -1, d)
     o = attention_core(q, kk, vv, visible, 1.0 / math.sqrt(d), R, mode)
     o = Q(R(o.transpose(1, 2).reshape(B, S, D)))
-    h = R(h + o @ sd[pre + "self_attn.o_proj.weight"].to(h.dtype).t())
+    h = R(h + _lin(o, sd[pre + "self_attn.o_proj.weight"]))
     n2 = Q(R(rmsnorm(h, sd[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)))
-    g = n2 @ sd[pre + "mlp.gate_proj.weight"].to(h.dtype).t()
-    u = n2 @ sd[pre + "mlp.up_proj.weight"].to(h.dtype).t()
+    g = _lin(n2, sd[pre + "mlp.gate_proj.weight"])
+    u = _lin(n2, sd[pre + "mlp.up_proj.weight"])
     a = Q(R(F.silu(g) * u))
-    h = R(h + a @ sd[pre + "mlp.down_proj.weight"].to(h.dtype).t())
+    h = R(h + _lin(a, sd[pre + "mlp.down_proj.weight"]))
     return h
 
 
@@ -702,7 +726,7 @@ def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[K
     if last_only:
         h = h[:, -1:, :]
     hn = R(rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps))
-    logits = hn @ sd["lm_head.weight"].to(h.dtype).t()
+    logits = _lin(hn, sd["lm_head.weight"])
     if return_hidden:
         return logits, cache, hn
     return logits, cache

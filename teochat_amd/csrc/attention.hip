@@ -100,8 +100,11 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 static int g_dec_chunk = 0;       // keys per workgroup (32 / 64 / 128 / 256); 0 = auto: 64 for one conversation (2.83 vs 2.86 ms/token
                                   // at 128, 2.87 at 32, 2.94 at 256), 128 for a batched step (4.74 vs 4.79 ms/step at 64)
-void attn_tune_reset() { g_dec_chunk = 0; }
+static int g_attn_whole = 1;      // batched steps: whole-context kernel (one workgroup per (conversation, head), no combine launch): 0 off, 1 auto
+                                  // (batch * heads >= half the CUs), 2 whenever the shape allows.  Bit-identical to the split + combine pair.
+void attn_tune_reset() { g_dec_chunk = 0; g_attn_whole = 1; }
 int attn_tune_set(const char* key, int value) {
+    if (!strcmp(key, "attn_whole") && value >= 0 && value <= 2) { g_attn_whole = value; return 0; }
     if (!strcmp(key, "attn_chunk") && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
     return -1;
 }
@@ -317,28 +320,20 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     if (tid == 0) { out[0] = mx; out[1] = sum; }
 }
 
-// one workgroup (512 threads) per head.  Split weights: one thread per split (parallel loads).  Output: thread =
-// (column d, split group g); a thread owns every G-th split (G = 512 / hd) and keeps 8 loads in flight, the G partial
-// sums of a column meet in LDS -- one or two L2 round trips instead of a dependent chain over all splits.
+// Merge of one head's split records (m, l, o[hd]) by 512 threads: shared by the combine launch (records in global memory)
+// and the whole-context kernel (records in LDS) so both evaluate the same expressions in the same order.
+// Split weights: one thread per split (parallel loads).  Output: thread = (column d, split group g); a thread owns every G-th
+// split (G = 512 / hd) and keeps its loads in flight, the G partial sums of a column meet in LDS -- one or two round trips
+// instead of a dependent chain over all splits.  pb: records of this head, `stride` floats apart; nact <= 256 splits hold keys.
 template <typename T>
-__global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
-                                                                  const int* __restrict__ d_pos, int hd, int nsplit, int chunk,
-                                                                  long long o_stride) {
-    __shared__ float w[256];
-    __shared__ float red[16];
-    __shared__ float accs[512];
-    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int stride = hd + 2;
-    part += (long long)blockIdx.y * gridDim.x * nsplit * stride;
-    o += (long long)blockIdx.y * o_stride;
-    d_pos += blockIdx.y;
-    const float* pb = part + (long long)h * nsplit * stride;
-    const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys (<= 256)
+__device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb, int stride, int nact, int hd, T* __restrict__ o_row,
+                                                   float* w /* [256] */, float* red /* [16] */, float* accs /* [512] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool on = tid < 512;                                              // a larger workgroup: the other waves only join the barriers
     const int G = 512 / hd;                                                 // hd is a power of two <= 256
-    const int g = tid / hd, d = tid % hd;
+    const int g = on ? tid / hd : 0, d = tid % hd;
     // the first NB splits of this thread are requested together with the split statistics (they do not depend on them): ONE round
-    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split; round 2 had NB = 8 and a second, dependent
-    // batch from 33 splits on, i.e. for every C3 step)
+    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split)
     constexpr int NB = 12;
     float v0[NB];
 #pragma unroll
@@ -346,13 +341,13 @@ __global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* _
     float m0 = -INFINITY, l0 = 0.f;
     if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
     float M = wave_max(m0);
-    if (lane == 0) red[wid] = M;
+    if (lane == 0 && on) red[wid] = M;
     __syncthreads();
     M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));               // splits live in threads 0..255 = waves 0..3
     const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
     if (tid < 256) w[tid] = w0;
     float L = wave_sum(l0 * w0);
-    if (lane == 0) red[8 + wid] = L;
+    if (lane == 0 && on) red[8 + wid] = L;
     __syncthreads();
     const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
     float a = 0.f;
@@ -365,13 +360,261 @@ __global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * w[min(s0 + i * G, 255)] : 0.f;
     }
-    accs[tid] = a;
+    if (on) accs[tid] = a;
     __syncthreads();
-    if (g == 0) {
+    if (on && g == 0) {
         float t = 0.f;
         for (int k = 0; k < G; ++k) t += accs[d + k * hd];
-        Elem<T>::st(o + h * hd + d, t * inv);
+        Elem<T>::st(o_row + d, t * inv);
     }
+}
+
+// one workgroup (512 threads) per head
+template <typename T>
+__global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
+                                                                  const int* __restrict__ d_pos, int hd, int nsplit, int chunk,
+                                                                  long long o_stride) {
+    __shared__ float w[256];
+    __shared__ float red[16];
+    __shared__ float accs[512];
+    const int h = blockIdx.x;
+    const int stride = hd + 2;
+    part += (long long)blockIdx.y * gridDim.x * nsplit * stride;
+    o += (long long)blockIdx.y * o_stride;
+    d_pos += blockIdx.y;
+    const float* pb = part + (long long)h * nsplit * stride;
+    const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys (<= 256)
+    attn_merge_records<T>(pb, stride, nact, hd, o + h * hd, w, red, accs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole-context form for BATCHED steps: one workgroup (8 waves) per (conversation, head) walks the conversation's whole
+// context -- with batch x heads >= the CU count every CU streams ONE long K/V range instead of ~20 short launches' worth of
+// 64 KB workgroups, and the split records never leave the CU: no partial-record traffic, no combine launch (4.9 us per layer
+// of a batched step, pure latency).
+//   * a WAVE owns a chunk of DEC_CHUNK keys at a time (chunks wid, wid + 8, ...), processed as the four quarter-chunks the
+//     four waves of the split kernel take: same score expression, same chunk max / exp / sum, same four partial PV sums added in
+//     the same order -> the chunk record (m, l, o[hd]) is bit-identical to attn_decode_partial_kernel's;
+//   * no workgroup barrier in the stream: scores go through a per-wave LDS strip; the loads run as a 4-slot register ring
+//     (K0 K1 K2 K3 V0 V1 V2 V3 K0' ...: a slot is refilled with the next quarter as soon as it is consumed) so every wave keeps
+//     3-4 quarters (24-32 KB) in flight across chunk boundaries;
+//   * the records stay in LDS and are merged by the same code as the combine launch (attn_merge_records) -> the output is
+//     bit-identical to the two-launch path with the same chunk size (tested).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LPR, int DEC_CHUNK, bool ROPE, int AW_WAVES, bool PROBE = false>   // PROBE (tools/attn_probe.hip only): loads without the arithmetic
+__global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const T* __restrict__ q, T* __restrict__ kc, T* __restrict__ vc,
+                                                                          T* __restrict__ vtc, const float* __restrict__ cs,
+                                                                          const float* __restrict__ sn, T* __restrict__ o,
+                                                                          const int* __restrict__ d_pos, int S_max, int heads, int kv_heads,
+                                                                          float scale, AttnBatch bt) {
+    constexpr int VE = Cvt16<T>::N;
+    constexpr int HD = LPR * VE;
+    constexpr int RPI = 64 / LPR;                       // keys per wave-wide load instruction
+    constexpr int KPQ = DEC_CHUNK / 4;                  // keys per quarter-chunk (= keys per wave of the split kernel)
+    constexpr int NI = KPQ / RPI;                       // load instructions per quarter
+    constexpr int SPL = (DEC_CHUNK + 63) / 64;
+    constexpr int STRIDE = HD + 2;
+    extern __shared__ __attribute__((aligned(16))) float aw_lds[];
+    float* sc = aw_lds + (threadIdx.x >> 6) * DEC_CHUNK;               // this wave's score strip
+    float* rec = aw_lds + AW_WAVES * DEC_CHUNK;                         // [nact][HD + 2]
+    {
+        const long long bz = blockIdx.y;
+        q += bz * bt.q_stride;
+        kc += bz * bt.cache_stride;
+        vc += bz * bt.cache_stride;
+        if (vtc) vtc += bz * bt.cache_stride;
+        d_pos += bz;
+        o += bz * bt.o_stride;
+    }
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int hk = h / (heads / kv_heads);
+    const int kv_len = *d_pos + 1;
+    const int nact = (kv_len + DEC_CHUNK - 1) / DEC_CHUNK;
+    const int sub = lane % LPR, grp = lane / LPR;
+    // uniform head bases + 32-bit byte offsets (one head's cache is far below 4 GB): SGPR-base addressing, no 64-bit address per load
+    const char* kb = reinterpret_cast<const char*>(kc + (long long)hk * S_max * HD);
+    const char* vb = reinterpret_cast<const char*>(vc + (long long)hk * S_max * HD);
+    const unsigned lane_off = (unsigned)(sub * VE * sizeof(T));
+
+    // quarter `qt` of chunk `c` into a ring slot.  Unconditional: a wave without a next chunk re-reads row 0 of the head (cached)
+    uint4 r0[NI], r1[NI], r2[NI], r3[NI];
+#define TEO_AW_ISSUE(SLOT, BASE, C, QT, LIVE)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                   \
+        const int j = (LIVE) ? min((C) * DEC_CHUNK + (QT) * KPQ + i * RPI + grp, kv_len - 1) : 0;                      \
+        SLOT[i] = ld_kv((BASE) + ((unsigned)j * (unsigned)(HD * sizeof(T)) + lane_off));                               \
+    }
+    int c = wid;
+    {
+        const bool live = c < nact;
+        TEO_AW_ISSUE(r0, kb, c, 0, live)
+        TEO_AW_ISSUE(r1, kb, c, 1, live)
+        TEO_AW_ISSUE(r2, kb, c, 2, live)
+        TEO_AW_ISSUE(r3, kb, c, 3, live)
+    }
+    float qf[VE];
+    uint4 knew_pk = make_uint4(0, 0, 0, 0), vnew_pk = make_uint4(0, 0, 0, 0);     // the new token's rotated key / value, in the storage type
+    const int pos = kv_len - 1;
+    if (ROPE) {
+        constexpr int HL = LPR / 2;
+        const int psub = sub ^ HL, ci = (sub % HL) * VE;
+        const float sgn = (sub < HL) ? -1.f : 1.f;
+        float cf[VE], sf[VE];
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) {
+            const float4 c4 = *reinterpret_cast<const float4*>(cs + (long long)pos * (HD / 2) + ci + e);
+            const float4 s4 = *reinterpret_cast<const float4*>(sn + (long long)pos * (HD / 2) + ci + e);
+            cf[e] = c4.x; cf[e + 1] = c4.y; cf[e + 2] = c4.z; cf[e + 3] = c4.w;
+            sf[e] = s4.x; sf[e + 1] = s4.y; sf[e + 2] = s4.z; sf[e + 3] = s4.w;
+        }
+        float own[VE], oth[VE];
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(q + h * HD + sub * VE), own);
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(q + h * HD + psub * VE), oth);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) qf[e] = Elem<T>::round(own[e] * cf[e] + sgn * oth[e] * sf[e]);
+        const T* kraw = q + (long long)(heads + hk) * HD;
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(kraw + sub * VE), own);
+        Cvt16<T>::cvt(*reinterpret_cast<const uint4*>(kraw + psub * VE), oth);
+        float knew[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) knew[e] = Elem<T>::round(own[e] * cf[e] + sgn * oth[e] * sf[e]);
+        knew_pk = Cvt16<T>::pack(knew);                    // exact: the values are already rounded to T
+        vnew_pk = *reinterpret_cast<const uint4*>(q + (long long)(heads + kv_heads + hk) * HD + sub * VE);
+        // KV append of the new token, once per kv head (the stream below never reads row `pos`: it substitutes these registers)
+        if (wid == 0 && grp == 0 && h % (heads / kv_heads) == 0) {
+            *reinterpret_cast<uint4*>(kc + ((long long)hk * S_max + pos) * HD + sub * VE) = knew_pk;
+            *reinterpret_cast<uint4*>(vc + ((long long)hk * S_max + pos) * HD + sub * VE) = vnew_pk;
+            if (vtc) {
+                const uint4 pv = vnew_pk;
+                const T* pe = reinterpret_cast<const T*>(&pv);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) vtc[((long long)hk * HD + sub * VE + e) * S_max + pos] = pe[e];
+            }
+        }
+    } else {
+        const uint4 qraw = *reinterpret_cast<const uint4*>(q + h * HD + sub * VE);
+        Cvt16<T>::cvt(qraw, qf);
+    }
+    constexpr bool DOT2 = sizeof(T) == 2;
+    uint4 qpk = make_uint4(0, 0, 0, 0);
+    if (DOT2) qpk = Cvt16<T>::pack(qf);
+
+    // scores of quarter QT (keys c0 + QT*KPQ ..) from ring slot SLOT into the wave's strip
+#define TEO_AW_SCORES(SLOT, QT)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                   \
+        const int j = c0 + (QT) * KPQ + i * RPI + grp;                                                                 \
+        const bool isnew = ROPE && j == pos;               /* the new token's key: registers, not the cache row */     \
+        uint4 kraw = SLOT[i];                                                                                          \
+        kraw.x = isnew ? knew_pk.x : kraw.x; kraw.y = isnew ? knew_pk.y : kraw.y;                                      \
+        kraw.z = isnew ? knew_pk.z : kraw.z; kraw.w = isnew ? knew_pk.w : kraw.w;                                      \
+        float s = 0.f;                                                                                                 \
+        if (DOT2) {                                                                                                    \
+            s = attn_dot2(kraw.x, qpk.x, s); s = attn_dot2(kraw.y, qpk.y, s);                                          \
+            s = attn_dot2(kraw.z, qpk.z, s); s = attn_dot2(kraw.w, qpk.w, s);                                          \
+        } else {                                                                                                       \
+            float kf[VE];                                                                                              \
+            Cvt16<T>::cvt(kraw, kf);                                                                                   \
+            _Pragma("unroll") for (int e = 0; e < VE; ++e) s = fmaf(qf[e], kf[e], s);                                  \
+        }                                                                                                              \
+        _Pragma("unroll") for (int o_ = LPR >> 1; o_ > 0; o_ >>= 1) s += __shfl_xor(s, o_, 64);                        \
+        if (sub == 0) sc[j - c0] = (j < kv_len) ? s * scale : -INFINITY;                                               \
+    }
+    // PV of quarter QT from ring slot SLOT: the split kernel's per-wave partial sum, reduced over the key groups
+#define TEO_AW_PV(SLOT, QT, OUT)                                                                                       \
+    {                                                                                                                  \
+        float acc[VE];                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] = 0.f;                                                   \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                               \
+            const float p = sc[(QT) * KPQ + i * RPI + grp];                                                            \
+            const bool isnew = ROPE && c0 + (QT) * KPQ + i * RPI + grp == pos;                                         \
+            uint4 vraw = SLOT[i];                                                                                      \
+            vraw.x = isnew ? vnew_pk.x : vraw.x; vraw.y = isnew ? vnew_pk.y : vraw.y;                                  \
+            vraw.z = isnew ? vnew_pk.z : vraw.z; vraw.w = isnew ? vnew_pk.w : vraw.w;                                  \
+            float vf[VE];                                                                                              \
+            Cvt16<T>::cvt(vraw, vf);                                                                                   \
+            _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);                            \
+        }                                                                                                              \
+        _Pragma("unroll") for (int o_ = LPR; o_ < 64; o_ <<= 1) {                                                      \
+            _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] += __shfl_xor(acc[e], o_, 64);                       \
+        }                                                                                                              \
+        if ((QT) == 0) { _Pragma("unroll") for (int e = 0; e < VE; ++e) OUT[e] = acc[e]; }                             \
+        else           { _Pragma("unroll") for (int e = 0; e < VE; ++e) OUT[e] = OUT[e] + acc[e]; }                    \
+    }
+
+    unsigned probe_acc = 0;
+#define TEO_AW_TOUCH(SLOT) _Pragma("unroll") for (int i = 0; i < NI; ++i) probe_acc ^= SLOT[i].x ^ SLOT[i].y ^ SLOT[i].z ^ SLOT[i].w;
+    if constexpr (PROBE) {
+        for (; c < nact; c += AW_WAVES) {
+            const int cn = c + AW_WAVES;
+            const bool nlive = cn < nact;
+            TEO_AW_TOUCH(r0) TEO_AW_ISSUE(r0, vb, c, 0, true)
+            TEO_AW_TOUCH(r1) TEO_AW_ISSUE(r1, vb, c, 1, true)
+            TEO_AW_TOUCH(r2) TEO_AW_ISSUE(r2, vb, c, 2, true)
+            TEO_AW_TOUCH(r3) TEO_AW_ISSUE(r3, vb, c, 3, true)
+            TEO_AW_TOUCH(r0) TEO_AW_ISSUE(r0, kb, cn, 0, nlive)
+            TEO_AW_TOUCH(r1) TEO_AW_ISSUE(r1, kb, cn, 1, nlive)
+            TEO_AW_TOUCH(r2) TEO_AW_ISSUE(r2, kb, cn, 2, nlive)
+            TEO_AW_TOUCH(r3) TEO_AW_ISSUE(r3, kb, cn, 3, nlive)
+        }
+        if (probe_acc == 0x12345678u) o[h * HD + (tid & (HD - 1))] = T(0);
+        return;
+    }
+#undef TEO_AW_TOUCH
+    for (; c < nact; c += AW_WAVES) {
+        const int c0 = c * DEC_CHUNK;
+        const int cn = c + AW_WAVES;
+        const bool nlive = cn < nact;
+        // ---- scores, quarter by quarter; each consumed K slot is refilled with the same quarter of V
+        TEO_AW_SCORES(r0, 0)
+        TEO_AW_ISSUE(r0, vb, c, 0, true)
+        TEO_AW_SCORES(r1, 1)
+        TEO_AW_ISSUE(r1, vb, c, 1, true)
+        TEO_AW_SCORES(r2, 2)
+        TEO_AW_ISSUE(r2, vb, c, 2, true)
+        TEO_AW_SCORES(r3, 3)
+        TEO_AW_ISSUE(r3, vb, c, 3, true)
+        __builtin_amdgcn_wave_barrier();
+        // ---- chunk max / exp / sum: the split kernel's expressions over the same strip
+        float sv[SPL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+            sv[i] = (DEC_CHUNK >= 64 || lane + 64 * i < DEC_CHUNK) ? sc[(lane + 64 * i) % DEC_CHUNK] : -INFINITY;
+            mx = fmaxf(mx, sv[i]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) { sv[i] = expf(sv[i] - mx); sum += sv[i]; }      // -inf -> 0
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < SPL; ++i)
+            if (DEC_CHUNK >= 64 || lane + 64 * i < DEC_CHUNK) sc[lane + 64 * i] = Elem<T>::round(sv[i]);
+        __builtin_amdgcn_wave_barrier();
+        // ---- PV, quarter by quarter; each consumed V slot is refilled with the next chunk's K quarter
+        float ot[VE];                                      // ((q0 + q1) + q2) + q3, the order the split kernel adds its four waves
+        TEO_AW_PV(r0, 0, ot)
+        TEO_AW_ISSUE(r0, kb, cn, 0, nlive)
+        TEO_AW_PV(r1, 1, ot)
+        TEO_AW_ISSUE(r1, kb, cn, 1, nlive)
+        TEO_AW_PV(r2, 2, ot)
+        TEO_AW_ISSUE(r2, kb, cn, 2, nlive)
+        TEO_AW_PV(r3, 3, ot)
+        TEO_AW_ISSUE(r3, kb, cn, 3, nlive)
+        __builtin_amdgcn_wave_barrier();                   // the strip is rewritten by the next chunk's scores
+        float* rc = rec + (long long)c * STRIDE;
+        if (grp == 0) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) rc[2 + sub * VE + e] = ot[e];
+        }
+        if (lane == 0) { rc[0] = mx; rc[1] = sum; }
+    }
+#undef TEO_AW_ISSUE
+#undef TEO_AW_SCORES
+#undef TEO_AW_PV
+    __syncthreads();
+    float* w = rec + (long long)nact * STRIDE;             // merge scratch behind the records: w[256], red[16], accs[512]
+    attn_merge_records<T>(rec, STRIDE, nact, HD, o + h * HD, w, w + 256, w + 272);
 }
 
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
@@ -402,6 +645,47 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
     prof_bump(-1);
 }
 
+template <typename T, int LPR, int NW>
+static int attn_whole_launch_t(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o, const int* d_pos,
+                               int S_max, int heads, int kv_heads, float scale, int chunk, bool rope, AttnBatch bt, size_t lds, hipStream_t st) {
+    constexpr int RPI = 64 / LPR;
+    dim3 grid(heads, bt.batch);
+#define TEO_AW(CH, RP)                                                                                                          \
+    {                                                                                                                           \
+        static bool attr_set = false;                                                                                           \
+        if (!attr_set && lds > 48 * 1024) {                                                                                     \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_whole_kernel<T, LPR, CH, RP, NW>),    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                          \
+            if (e != hipSuccess) return hip_fail(e, "attn_decode_whole: hipFuncSetAttribute");                                  \
+            attr_set = true;                                                                                                    \
+        }                                                                                                                       \
+        TEO_KLAUNCH((attn_decode_whole_kernel<T, LPR, CH, RP, NW>), grid, NW * 64, lds, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, \
+                    (T*)o, d_pos, S_max, heads, kv_heads, scale, bt);                                                           \
+    }
+#define TEO_AW_R(CH) { if (rope) TEO_AW(CH, true) else TEO_AW(CH, false) }
+    // quarter-chunks of 1..8 load instructions: chunk / 4 / RPI in [1, 8]
+    if (chunk == 128) { if constexpr (128 / 4 / RPI >= 1 && 128 / 4 / RPI <= 8) TEO_AW_R(128) else return TEO_ERR_UNSUPPORTED; }
+    else if (chunk == 64) { if constexpr (64 / 4 / RPI >= 1 && 64 / 4 / RPI <= 8) TEO_AW_R(64) else return TEO_ERR_UNSUPPORTED; }
+    else if (chunk == 32) { if constexpr (32 / 4 / RPI >= 1 && 32 / 4 / RPI <= 8) TEO_AW_R(32) else return TEO_ERR_UNSUPPORTED; }
+    else return TEO_ERR_UNSUPPORTED;
+#undef TEO_AW_R
+#undef TEO_AW
+    note_kernel("attn_decode_whole");
+    TEO_LAUNCH_CHECK("attn_decode_whole");
+    return TEO_OK;
+}
+
+static int attn_whole_launch(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o, const int* d_pos, int S_max,
+                             int heads, int kv_heads, int hd, float scale, int chunk, int lpr, int dtype, AttnBatch bt, size_t lds, hipStream_t st) {
+    const bool rope = cs != nullptr;
+#define TEO_AWL(TT, LL) return attn_whole_launch_t<TT, LL, 8>(q, kc, vc, vtc, cs, sn, o, d_pos, S_max, heads, kv_heads, scale, chunk, rope, bt, lds, st)
+    if (dtype == TEO_F32) {
+        switch (lpr) { case 4: TEO_AWL(float, 4); case 8: TEO_AWL(float, 8); case 16: TEO_AWL(float, 16); case 32: TEO_AWL(float, 32); default: return TEO_ERR_UNSUPPORTED; }
+    }
+    switch (lpr) { case 4: TEO_AWL(bf16_t, 4); case 8: TEO_AWL(bf16_t, 8); case 16: TEO_AWL(bf16_t, 16); case 32: TEO_AWL(bf16_t, 32); default: return TEO_ERR_UNSUPPORTED; }
+#undef TEO_AWL
+}
+
 // rope_cos != NULL: q is the raw qkv row; RoPE and the KV append of the new token happen inside the kernel
 // bt: batched step (bt.batch conversations: q/o rows, caches, positions and partial slabs strided per conversation)
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
@@ -418,6 +702,22 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
     if (nsplit > 256 || (hd * esz) % 16 != 0 || (lpr != 2 && lpr != 4 && lpr != 8 && lpr != 16 && lpr != 32)) {
         set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
         return TEO_ERR_UNSUPPORTED;
+    }
+    // whole-context form (batched steps).  Its default chunk is 64 keys (quarter-chunks of 4 load instructions: a 4-slot ring of 64
+    // VGPRs; with 128-key chunks the bf16 / head_dim 128 kernel needs more than 256 registers), "attn_chunk" forces another.
+    {
+        int cw = g_dec_chunk ? g_dec_chunk : 64;
+        if (cw / 4 < 64 / lpr) cw = 4 * (64 / lpr);
+        while (cw < 128 && cdiv(S_max, cw) > 256) cw *= 2;
+        const int nsw = cdiv(S_max, cw);
+        const int ni = cw / 4 / (64 / lpr);
+        const size_t lds = ((size_t)8 * cw + (size_t)nsw * (hd + 2) + 784) * sizeof(float);
+        const int cus = device_cu_count();
+        const bool fits = ni >= 1 && ni <= 8 && (hd & (hd - 1)) == 0 && hd <= 256 && lds <= 96 * 1024 && nsw <= 256 && (cw == 32 || cw == 64 || cw == 128);
+        if (fits && (g_attn_whole == 2 || (g_attn_whole == 1 && bt.batch > 1 && 2 * bt.batch * heads >= (cus > 0 ? cus : 256)))) {
+            const int rcw = attn_whole_launch(q, kc, vc, vtc, rope_cos, rope_sin, o, d_pos, S_max, heads, kv_heads, hd, scale, cw, lpr, dtype, bt, lds, st);
+            if (rcw != TEO_ERR_UNSUPPORTED) return rcw;
+        }
     }
 #define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, st)
     if (dtype == TEO_F32) {

@@ -28,6 +28,19 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def ulp16(ref, mant_bits=8):
+    """Exact unit in the last place of a 16-bit float format at |ref| (bf16: 8 significand bits incl. the hidden one; fp16: 11):
+    x = m * 2^e with m in [0.5, 1) (torch.frexp) sits in the binade [2^(e-1), 2^e) whose spacing is 2^(e - mant_bits).
+    Below 2^-14 the spacing of that binade is used (a floor far below anything the path produces, not a tolerance knob)."""
+    _, e = torch.frexp(ref.float().abs().clamp_min(2.0 ** -14))
+    return torch.ldexp(torch.ones_like(ref, dtype=torch.float32), e - mant_bits)
+
+
+def ulps_off(got, ref, mant_bits=8):
+    """|got - ref| in exact ulps of ref (fp32 tensors, same shape)."""
+    return (got.float() - ref.float()).abs() / ulp16(ref, mant_bits)
+
+
 def layernorm(x, w, b, eps):
     y = torch.empty_like(x)
     L.check(lib().teo_layernorm(p(x), p(w), p(b), p(y), x.shape[0], x.shape[1], eps, DT[x.dtype], stream()), "layernorm")

@@ -810,6 +810,77 @@ def test_attn_decode_batched_vs_reference(dtype, H, Hk, d, S, ctx, chunk):
             close_bf16(out[b], G.bf16_round(ref), ulps=2.0, floor=4e-3)    # P is rounded to bf16 before the PV product
 
 
+@pytest.mark.parametrize("dtype,H,Hk,d,S,ctx", [(torch.bfloat16, 32, 32, 128, 2560, [2299, 64, 1, 2560, 129, 2305, 640, 2048]),
+                                                (torch.bfloat16, 32, 32, 128, 4608, [4255, 4608, 100]),
+                                                (torch.bfloat16, 8, 2, 64, 512, [300, 512, 5]),
+                                                (torch.float32, 4, 2, 32, 512, [17, 200, 512])])
+@pytest.mark.parametrize("chunk", [0, 32, 64, 128])
+@pytest.mark.parametrize("rope", [False, True])
+def test_attn_decode_whole_context_is_bitwise_the_split_pair(dtype, H, Hk, d, S, ctx, chunk, rope):
+    """attn_decode_whole_kernel (one workgroup per (conversation, head) walks the whole context; the split records stay in LDS)
+    against attn_decode_partial + attn_decode_combine at the SAME chunk size: same chunk records, same merge code -> BIT-identical
+    outputs, with and without the in-kernel RoPE + KV append (appended rows compared too), ragged / full / one-key contexts;
+    and against the fp64 softmax reference."""
+    from teochat_amd.engine import rope_tables
+    B = len(ctx)
+    lib = G.lib()
+    g = torch.Generator().manual_seed(31 + chunk + int(rope))
+    K = torch.randn(B, Hk, S, d, generator=g)
+    V = torch.randn(B, Hk, S, d, generator=g)
+    qkv = torch.randn(B, H + 2 * Hk, d, generator=g)                           # raw q | k | v rows of the new tokens
+    if dtype == torch.bfloat16:
+        K, V, qkv = G.bf16_round(K), G.bf16_round(V), G.bf16_round(qkv)
+    cs, sn = rope_tables(d, 10000.0, S)
+    d_cs, d_sn = cs.cuda(), sn.cuda()
+    pos = torch.tensor([n - 1 for n in ctx], dtype=torch.int32, device="cuda")
+    cw = chunk if chunk else 64                                                 # the whole-context kernel's default chunk
+    rpi = 64 // (d * (4 if dtype == torch.float32 else 2) // 16)
+    if cw // 4 < rpi:
+        cw = 4 * rpi
+    if cw // 4 // rpi > 8:
+        pytest.skip("quarter-chunk above 8 load instructions: the whole-context form does not take this shape")
+    outs, caches = {}, {}
+    part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, B), dtype=torch.uint8, device="cuda")
+    for whole in (2, 0):
+        dK, dV = K.to("cuda", dtype).contiguous(), V.to("cuda", dtype).contiguous()
+        dVT = torch.zeros(B, Hk, d, S, dtype=dtype, device="cuda")
+        out = torch.zeros(B, H * d, dtype=dtype, device="cuda")
+        if rope:
+            dq = qkv.reshape(B, -1).to("cuda", dtype).contiguous()
+            qs = (H + 2 * Hk) * d
+        else:
+            dq = qkv[:, :H].reshape(B, -1).to("cuda", dtype).contiguous()
+            qs = H * d
+        assert lib.teo_tune_set(b"attn_whole", whole) == 0 and lib.teo_tune_set(b"attn_chunk", cw) == 0
+        L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), G.p(dVT) if rope else None, G.p(d_cs) if rope else None,
+                                    G.p(d_sn) if rope else None, G.p(out), G.p(part), G.p(pos), S, H, Hk, d, 1.0 / d ** 0.5,
+                                    G.DT[dtype], B, qs, Hk * S * d, H * d, G.stream()), "attn_decode")
+        torch.cuda.synchronize()
+        if whole == 2:
+            assert lib.teo_last_kernel() == b"attn_decode_whole"
+        outs[whole] = out.clone()
+        caches[whole] = (dK, dV, dVT)
+    assert torch.equal(outs[2], outs[0])
+    for a, b_ in zip(caches[2], caches[0]):
+        assert torch.equal(a, b_)
+    for b, n in enumerate(ctx):
+        if rope:
+            c, s_ = cs[n - 1], sn[n - 1]
+            c, s_ = torch.cat([c, c]), torch.cat([s_, s_])
+            rnd_ = G.bf16_round if dtype == torch.bfloat16 else (lambda t: t)
+            q_rot = rnd_(qkv[b, :H] * c + O.rotate_half(qkv[b, :H]) * s_)
+            Kb, Vb = K[b].clone(), V[b].clone()
+            Kb[:, n - 1] = rnd_(qkv[b, H:H + Hk] * c + O.rotate_half(qkv[b, H:H + Hk]) * s_)
+            Vb[:, n - 1] = qkv[b, H + Hk:]
+        else:
+            q_rot, Kb, Vb = qkv[b, :H], K[b], V[b]
+        ref = _decode_attn_ref(q_rot, Kb, Vb, n)
+        if dtype == torch.float32:
+            torch.testing.assert_close(outs[2][b].cpu(), ref, atol=3e-5, rtol=2e-5)
+        else:
+            close_bf16(outs[2][b], G.bf16_round(ref), ulps=2.0, floor=4e-3)
+
+
 def _hf_top_p_keep(logits, temperature, top_k, top_p):
     """HF order: temperature -> TopKLogitsWarper -> TopPLogitsWarper (ascending sort, cumulative <= 1 - top_p removed,
     at least one token kept).  Returns (kept index set, renormalised probabilities)."""

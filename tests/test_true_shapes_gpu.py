@@ -49,16 +49,23 @@ def _threads():
     torch.set_num_threads(max(1, min(n, 32)))
 
 
-def ulp_check(got, ref, tag, report, kernel=True):
-    """got: device tensor (bf16 or f32); ref: oracle output rounded to bf16 (fp32 tensor).  EVERY element within one bf16 ulp."""
+FP32_SUM_ABS = 1e-5      # absolute allowance for the fp32 summation-order difference of a sum whose terms cancel (|ref| << its operands):
+                         # eps_fp32 * sqrt(K) * |terms| ~ 6e-8 * 100 * 1 -- 100x below the round-3 floor of 1e-3, i.e. 0.1 ulp at |ref| = 0.03
+
+
+def ulp_check(got, ref, tag, report, kernel=True, abs_tol=FP32_SUM_ABS):
+    """got: device tensor (bf16 or f32); ref: oracle output rounded to bf16 (fp32 tensor).  EVERY element within ONE EXACT bf16 ulp
+    of the oracle (G.ulp16: from torch.frexp, not 2^-7 |ref| which is up to 2 ulps) plus `abs_tol`; the worst element is printed in
+    ulps."""
     got = got.float().cpu().reshape(ref.shape)
     d = (got - ref).abs()
-    tol = (2.0 ** -7) * ref.abs() + 1e-3
-    bad = int((d > tol).sum())
+    ulp = G.ulp16(ref)
+    bad = int((d > ulp + abs_tol).sum())
     exact = float((d == 0).float().mean())
+    worst = float((d / ulp).max())
     kn = L.load().teo_last_kernel().decode() if kernel else "-"
-    report.append(f"  {tag:<58s} {tuple(ref.shape)!s:<16s} kernel={kn:<18s} bit-equal {exact * 100:6.2f} %  beyond 1 ulp: {bad}")
-    assert bad == 0, f"{tag}: {bad} / {d.numel()} elements beyond 1 bf16 ulp (max diff {float(d.max()):.3e})"
+    report.append(f"  {tag:<58s} {tuple(ref.shape)!s:<16s} kernel={kn:<18s} bit-equal {exact * 100:6.2f} %  worst {worst:5.2f} ulp  beyond 1 ulp: {bad}")
+    assert bad == 0, f"{tag}: {bad} / {d.numel()} elements beyond 1 bf16 ulp + {abs_tol:g} (worst {worst:.2f} ulp, max diff {float(d.max()):.3e})"
 
 
 def _rand(shape, gen, std=1.0):
@@ -368,6 +375,18 @@ def test_c2_c3_prefill_and_decode_against_the_oracle_at_full_width(T, n_out, tag
     # (the walks above), ~0.05-0.3 % of a kernel's outputs land on the other side of a bf16 rounding boundary, and 26 layers x ~8
     # kernels of such flips random-walk to a per-logit sigma of ~3e-3 of max|logit| -- the max over 7e7 logits is a 5.7-sigma event.
     assert mx < 3e-2 and p99 < 1.2e-2 and med < 3e-3 and dmx < 1.5e-2
+    # ---- the control (tests/test_noise_floor.py): the oracle against ITSELF with only the fp32 summation order of its Linear layers
+    # changed (K in 8 chunks, descending, vs the single matmul above) -- the HIP path may differ from the oracle by at most 1.5x what
+    # the oracle differs from itself by, statistic by statistic.  That is a parity statement, not a regression guard.
+    try:
+        O.K_ORDER = (8, True)
+        s_pre, _, _ = O.mm_forward(ids, frames, sd, vcfg, lcfg, mm, None, "bf16", torch.float32)
+    finally:
+        O.K_ORDER = None
+    smx, sp99, smed, _ = _stats(s_pre[0], o_pre)
+    print(f"[{tag} bf16] oracle vs itself (K order changed, nothing else): max {smx:.2e}  p99 {sp99:.2e}  median {smed:.2e};  "
+          f"HIP / self: max {mx / smx:.2f}x  p99 {p99 / sp99:.2f}x  median {med / smed:.2f}x")
+    assert mx <= 1.5 * smx and p99 <= 1.5 * sp99 and med <= 1.5 * smed, (mx, smx, p99, sp99, med, smed)
     del m16
     torch.cuda.empty_cache()
     # ---- fp32 engine (same bf16-valued weights) vs the oracle in fp64: north_star's 1e-5
@@ -469,23 +488,29 @@ def test_w8a8_prefill_layer_walk_at_7b_shapes():
         kern = lib.teo_last_kernel().decode()
         return x_dq, Wdq, out, same, kern
 
-    def check(out, ref, tag, same, kern):
+    def check(out, ref, tag, same, kern, sum_abs):
+        """one exact bf16 ulp + the scaled fp8 MFMA's internal 128-term sums: <= 3e-5 of sum|a||w| (the kernel's stated parity bound,
+        DESIGN.md section 5; an fp32 FMA chain would need 1e-7) -- `sum_abs` is that bound per element, computed from the operands"""
         got = out.float().cpu()
         d = (got - ref).abs()
-        tol = 1.25 * (2.0 ** -7) * ref.abs() + 2e-3
-        bad = int((d > tol).sum())
-        report.append(f"  {tag:<44s} kernel={kern:<18s} quantiser bytes equal {same * 100:7.3f} %  GEMM beyond 1 ulp: {bad} of {d.numel()}")
-        assert bad == 0, f"{tag}: {bad} elements beyond tolerance (max {float(d.max()):.3e})"
+        ulp = G.ulp16(ref)
+        bad = int((d > ulp + sum_abs + FP32_SUM_ABS).sum())
+        worst = float((d / ulp).max())
+        report.append(f"  {tag:<44s} kernel={kern:<18s} quantiser bytes equal {same * 100:7.3f} %  worst {worst:5.2f} ulp  beyond 1 ulp + 3e-5 sum|a||w|: {bad} of {d.numel()}")
+        assert bad == 0, f"{tag}: {bad} elements beyond tolerance (worst {worst:.2f} ulp, max {float(d.max()):.3e})"
+
+    def sabs(x_dq, Wdq):
+        return 3e-5 * (x_dq.abs() @ Wdq.abs().t())
 
     h = _rand((S, D), gen)
     g_in = R(1.0 + 0.1 * torch.randn(D, generator=gen))
     Wqkv = _rand((3 * D, D), gen, 0.02)
     x_dq, Wdq, out, same, kern = qgemm(h, Wqkv, "qkv", norm_w=g_in)
-    check(out, R(x_dq @ Wdq.t()), "rmsnorm + quantise + qkv GEMM N=12288", same, kern)
+    check(out, R(x_dq @ Wdq.t()), "rmsnorm + quantise + qkv GEMM N=12288", same, kern, sabs(x_dq, Wdq))
     a = _rand((S, D), gen)
     Wo = _rand((D, D), gen, 0.02)
     x_dq, Wdq, out, same, kern = qgemm(a, Wo, "o", res=h)
-    check(out, R(h + x_dq @ Wdq.t()), "quantise + o GEMM + residual", same, kern)
+    check(out, R(h + x_dq @ Wdq.t()), "quantise + o GEMM + residual", same, kern, sabs(x_dq, Wdq))
     gate, up = _rand((Fi, D), gen, 0.02), _rand((Fi, D), gen, 0.02)
     Wgu = interleave_gate_up(gate, up)
     q8, sw, Wgu_dq = quantize_fp8_rows(Wgu.to(bf))
@@ -493,11 +518,14 @@ def test_w8a8_prefill_layer_walk_at_7b_shapes():
     x_dq, _, out, same, kern = qgemm(h, Wgu, "gate/up", flags=L.GEMM_SWIGLU16, norm_w=g_post)
     Wf = Wgu_dq.float().view(Fi // 16, 2, 16, D)
     gate_dq, up_dq = Wf[:, 0].reshape(Fi, D), Wf[:, 1].reshape(Fi, D)
-    check(out, R(F.silu(x_dq @ gate_dq.t()) * (x_dq @ up_dq.t())), "rmsnorm + quantise + gate/up + SwiGLU N=22016", same, kern)
+    gg, uu = x_dq @ gate_dq.t(), x_dq @ up_dq.t()
+    # first-order bound through silu(g) * u (|silu'| <= 1.1)
+    check(out, R(F.silu(gg) * uu), "rmsnorm + quantise + gate/up + SwiGLU N=22016", same, kern,
+          1.1 * sabs(x_dq, gate_dq) * uu.abs() + sabs(x_dq, up_dq) * F.silu(gg).abs())
     act = _rand((S, Fi), gen, 0.5)
     Wd = _rand((D, Fi), gen, 0.02)
     x_dq, Wdq, out, same, kern = qgemm(act, Wd, "down", res=h)
-    check(out, R(h + x_dq @ Wdq.t()), "quantise + down GEMM + residual K=11008", same, kern)
+    check(out, R(h + x_dq @ Wdq.t()), "quantise + down GEMM + residual K=11008", same, kern, sabs(x_dq, Wdq))
     print("\n[w8a8 prefill walk at 7B shapes: device quantiser + fp8 MFMA GEMM vs the oracle's quantised-activation mode]\n" + "\n".join(report)
           + f"\n  wall {time.perf_counter() - t0:.1f} s")
 
