@@ -374,10 +374,12 @@ typedef struct {
 /* Prefill of nseq NEW conversations at once (batched generate): d_embeds holds the spliced embedding rows of all
  * sequences back to back ([sum(seq_lens), hidden]); seq_lens is a HOST array.  Norms and GEMMs run over all rows, RoPE /
  * KV append / causal attention per sequence into cache slot b (= the descriptor's cache pointers + b*cache_stride
- * elements).  d_logits [nseq, vocab] fp32: last position of each sequence.  Workspace:
- * teo_llama_prefill_workspace_bytes(d, sum(seq_lens)).  Row for row the results equal teo_llama_prefill's. */
+ * elements).  last_only = 1: d_logits [nseq, vocab] fp32, last position of each sequence (batched generate); last_only = 0:
+ * d_logits [sum(seq_lens), vocab], every row (the training-shape forward with B > 1, llava_llama.py:88-99 called from
+ * train.py:840-901).  Workspace: teo_llama_prefill_workspace_bytes(d, sum(seq_lens)).  Row for row the results equal
+ * teo_llama_prefill's. */
 int teo_llama_prefill_batch(const teo_llama_desc* d, const void* d_embeds, const int* seq_lens, int nseq, long long cache_stride,
-                            float* d_logits, void* d_workspace, size_t workspace_bytes, teo_stream_t stream);
+                            int last_only, float* d_logits, void* d_workspace, size_t workspace_bytes, teo_stream_t stream);
 
 size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d);
 /* Arm a generation: workspace.h <- embed[*d_token] (call once after filling d_token/d_pos; every step's tail then

@@ -151,7 +151,7 @@ class BatchDecoder:
             d0 = self.slot_desc[0]
             ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d0), total))
             arr = (C.c_int * self.B)(*lens)
-            L.check(self.lib.teo_llama_prefill_batch(C.byref(d0), _p(rows), arr, self.B, self.k_cache.stride(1),
+            L.check(self.lib.teo_llama_prefill_batch(C.byref(d0), _p(rows), arr, self.B, self.k_cache.stride(1), 1,
                                                      _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill_batch")
             sid = C.c_void_p(eng.stream.cuda_stream)
             eng._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d0), total, _p(ws), ws.numel(), C.byref(f), sid),

@@ -41,7 +41,7 @@ size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
 int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
                   float* logits, void* ws, size_t ws_bytes, hipStream_t st);
 int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* seq_lens, int nseq, long long cache_stride,
-                        float* logits, void* ws, size_t ws_bytes, hipStream_t st);
+                        int last_only, float* logits, void* ws, size_t ws_bytes, hipStream_t st);
 size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
 int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out, int* count_out,
@@ -303,13 +303,13 @@ int teo_llama_prefill(const teo_llama_desc* d, const void* emb, const int* pos, 
 }
 
 int teo_llama_prefill_batch(const teo_llama_desc* d, const void* emb, const int* seq_lens, int nseq, long long cache_stride,
-                            float* logits, void* ws, size_t wsb, teo_stream_t s) {
+                            int last_only, float* logits, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype); NEED(seq_lens, "seq_lens");
     TEO_CHECK_ARG(nseq >= 0 && (nseq <= 1 || cache_stride > 0), "teo_llama_prefill_batch: nseq %d cache_stride %lld", nseq, cache_stride);
     if (nseq == 0) return TEO_OK;
     NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace");
-    return llama_prefill_batch(d, emb, seq_lens, nseq, cache_stride, logits, ws, wsb, ST(s));
+    return llama_prefill_batch(d, emb, seq_lens, nseq, cache_stride, last_only, logits, ws, wsb, ST(s));
 }
 
 size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d) { return d ? llama_decode_workspace_bytes(d) : 0; }

@@ -117,12 +117,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
                                                              const bf16_t* __restrict__ bias,
                                                              const bf16_t* res, void* Cv,
                                                              int M, int N, int K, int lda, int ldc, int act,
-                                                             int tiles_m, int tiles_n) {
+                                                             int tiles_m, int tiles_n, int nfast) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    // an XCD owns a contiguous run of the tile sequence.  m fastest: the run shares a few W panels (its L2 keeps them) and streams
+    // all of A; n fastest (nfast): it shares a few A row blocks and streams all of W -- the host picks the order that streams the
+    // SMALLER operand through every XCD (ViT out_proj / fc2, projector: W is smaller than A)
+    const int tm = nfast ? tile / tiles_n : tile % tiles_m, tn = nfast ? tile % tiles_n : tile / tiles_m;
     constexpr int BMT = 32 * MF;
     const int m0 = tm * BMT, n0 = tn * BN;
 
@@ -571,10 +574,12 @@ static bool sk_grid_fits_device() {
 }
 static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
 static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
-void gemm_tune_reset() { g_gemm_big = 1; g_gemm_wide = 1; g_gemm_sk_dbg = 0; g_gemm_sk = 1; g_gemm_depth = 0; g_gemm_bm = 0; }
+static int g_gemm_order = 0;   // tile order of the plain kernel: 0 auto (stream the smaller operand through the XCDs), 1 m fastest, 2 n fastest
+void gemm_tune_reset() { g_gemm_order = 0; g_gemm_big = 1; g_gemm_wide = 1; g_gemm_sk_dbg = 0; g_gemm_sk = 1; g_gemm_depth = 0; g_gemm_bm = 0; }
 int gemm_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
     if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
+    if (!strcmp(key, "gemm_order") && value >= 0 && value <= 2) { g_gemm_order = value; return 0; }
     if (!strcmp(key, "gemm_wide")) { g_gemm_wide = value; return 0; }
     if (!strcmp(key, "gemm_big")) { g_gemm_big = value; return 0; }
     if (!strcmp(key, "gemm_sk_dbg")) { g_gemm_sk_dbg = value; return 0; }
@@ -629,10 +634,12 @@ static int gemm_plain_launch(const void* A, const void* W, const void* bias, con
     const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, bm);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 4 * TILE_BYTES;
+    // n fastest when W (N x K) is the smaller operand AND an XCD's share of A rows (M / 8 x K) fits its 4 MB L2
+    const int nfast = g_gemm_order == 2 || (g_gemm_order == 0 && N < M && (size_t)cdiv(M, 8) * K * 2 <= ((size_t)3 << 20));
 #define TEO_GEMM_K(SW, OF, DP, MFV)                                                                                   \
     gemm_mfma_bf16_kernel<SW, OF, DP, MFV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                   (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
-                                                                  tiles_n)
+                                                                  tiles_n, nfast)
 #define TEO_GEMM_LAUNCH(SW, OF)                                                                                      \
     if (bm == 64) { TEO_GEMM_K(SW, OF, 2, 2); }                                                                       \
     else if ((g_gemm_depth == 0 && !(SW)) || g_gemm_depth == 2) { TEO_GEMM_K(SW, OF, 2, 4); }                         \

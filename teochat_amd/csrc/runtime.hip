@@ -262,7 +262,7 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
 // the causal attention run per sequence on its row block and its own cache slot (slot b = cache pointer + b*cache_stride
 // elements, fresh caches: past = 0).  logits [nseq, vocab]: last position of every sequence.
 int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* seq_lens, int nseq, long long cache_stride,
-                        float* logits, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int last_only, float* logits, void* ws, size_t ws_bytes, hipStream_t st) {
     int total = 0;
     for (int b = 0; b < nseq; ++b) {
         TEO_CHECK_ARG(seq_lens[b] >= 1 && seq_lens[b] <= d->max_seq, "teo_llama_prefill_batch: seq_lens[%d] = %d", b, seq_lens[b]);
@@ -320,6 +320,10 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
         TEO_TRY(rmsnorm(w.h, d->post_norm_w[l], w.n, S, D, d->eps, dt, st));
         TEO_TRY(gemm(w.n, d->gateup_w[l], nullptr, nullptr, w.act, S, 2 * F, D, D, F, TEO_ACT_NONE, TEO_GEMM_SWIGLU16, dt, dt, st, w.sk));
         TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
+    }
+    if (!last_only) {                                    // training-shape forward: logits of every row, [sum(seq_lens), vocab]
+        TEO_TRY(rmsnorm(w.h, d->final_norm_w, w.n, S, D, d->eps, dt, st));
+        return gemm(w.n, d->lm_head, nullptr, nullptr, logits, S, d->vocab, D, D, d->vocab, TEO_ACT_NONE, 0, dt, TEO_F32, st, w.sk);
     }
     int row_end = 0;
     for (int b = 0; b < nseq; ++b) {

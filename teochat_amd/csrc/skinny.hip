@@ -34,11 +34,15 @@ constexpr int SK_TP = 16 * 17;      // padded 16x16 partial tile in LDS: [b][i] 
 static int g_sk_tiles = 0;          // 0 = auto
 static int g_sk_nt = 1;
 static int g_sk_stream = 1;         // 0 = never, 1 = auto, 2 = whenever the streaming form is eligible
-void skinny_tune_reset() { g_sk_tiles = 0; g_sk_nt = 1; g_sk_stream = 1; }
+static int g_sk_ring = 0;           // streaming form, register sets in flight: 0 = auto (3 tiles fp8 / 2 tiles bf16), 1 = one tile less
+static int g_sk_unr = 0;            // tile kernel, steps per register set: 0 = auto (8 for long K slices without SwiGLU / in-kernel norm), 4, 8
+void skinny_tune_reset() { g_sk_tiles = 0; g_sk_nt = 1; g_sk_stream = 1; g_sk_unr = 0; g_sk_ring = 0; }
 int skinny_tune_set(const char* key, int value) {
     if (!strcmp(key, "skinny_tiles") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_sk_tiles = value; return 0; }
     if (!strcmp(key, "skinny_nt")) { g_sk_nt = value != 0; return 0; }
     if (!strcmp(key, "skinny_stream") && value >= 0 && value <= 2) { g_sk_stream = value; return 0; }
+    if (!strcmp(key, "skinny_ring") && (value == 0 || value == 1)) { g_sk_ring = value; return 0; }
+    if (!strcmp(key, "skinny_unr") && (value == 0 || value == 4 || value == 8)) { g_sk_unr = value; return 0; }
     return -1;
 }
 
@@ -139,24 +143,31 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
     // Epilogue operands of this thread's first output (fp8 row scales, residual, the next norm's weight), requested AHEAD of
     // the weight stream: after the reduction barrier they would be a serial global round trip at the end of every workgroup
     // (1.5-2 us of a 6-14 us o / down launch).
-    float pf_s0 = 1.f, pf_s1 = 1.f, pf_res = 0.f, pf_g = 0.f;
+    // Unconditional: absent operands read the activation buffer instead (a pointer select) and out-of-range threads a clamped
+    // index -- behind a branch the compiler waits vmcnt(0) at the merge, i.e. one full memory round trip (1.7 us measured,
+    // tools/skinny_probe.py) before the first weight load of the workgroup is even issued.
+    float pf_s0, pf_s1, pf_res, pf_g;
     {
         const int OUTC = SWIGLU ? 8 * RT : 16 * RT;
-        const int b = tid / OUTC, c = tid % OUTC;
-        if (tid < 16 * OUTC && b < MB) {
-            if (SWIGLU) {
-                const int tp = sw8 ? (c >> 3) : (c >> 4), i = sw8 ? (c & 7) : (c & 15);
-                const int ng = n0 + (sw8 ? tp * 16 : tp * 32) + i, nu = ng + (sw8 ? 8 : 16);
-                if (ng < N && wscale) { pf_s0 = wscale[ng]; pf_s1 = wscale[nu]; }
-            } else {
-                const int col = n0 + c;
-                if (col < N) {
-                    if (wscale) pf_s0 = wscale[col];
-                    if (res) pf_res = bf2f(res[(long long)b * ldr + col]);
-                    if (fuse.xg_out) pf_g = bf2f(fuse.next_g[col]);
-                }
-            }
+        const int b = min(tid / OUTC, MB - 1), c = tid % OUTC;
+        const float* ws_p = wscale ? wscale : reinterpret_cast<const float*>(x);
+        const bf16_t* res_p = res ? res : x;
+        const bf16_t* g_p = fuse.xg_out ? reinterpret_cast<const bf16_t*>(fuse.next_g) : x;
+        const int ws_on = wscale ? 1 : 0, res_on = res ? 1 : 0, g_on = fuse.xg_out ? 1 : 0;
+        int n_a, n_b;                                    // SWIGLU: gate row / up row; else the output column (twice)
+        if (SWIGLU) {
+            const int tp = sw8 ? (c >> 3) : (c >> 4), i = sw8 ? (c & 7) : (c & 15);
+            n_a = n0 + (sw8 ? tp * 16 : tp * 32) + i;
+            n_b = n_a + (sw8 ? 8 : 16);
+        } else {
+            n_a = n_b = n0 + c;
         }
+        n_a = min(n_a, N - 1);
+        n_b = min(n_b, N - 1);
+        pf_s0 = ws_p[n_a * ws_on];
+        pf_s1 = ws_p[n_b * ws_on];
+        pf_res = bf2f(res_p[((long long)b * ldr + n_a) * res_on]);
+        pf_g = bf2f(g_p[n_a * g_on]);
     }
 
     // Software pipeline over the wave's K slice: two register sets of UNR steps each; every load is unconditional
@@ -190,44 +201,51 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         }                                                                                                      \
     }
 
+    // producer-side RMSNorm (SkinnyFuse): wave w owns rows w and w + 8; the first 256 partial sums of both rows are REQUESTED
+    // here (unconditional, clamped; a dummy source when the launch takes no partials) and summed by TEO_SK_SSQ_REDUCE after the
+    // wave's first weights are in flight -- they are the oldest entries of the in-order vmcnt queue, so waiting for them waits for
+    // nothing else
 #define TEO_SK_SSQ_LOAD \
         float sq0 = 0.f, sq1 = 0.f; \
-        if (fuse.ssq_in) { \
-            const float* r0 = fuse.ssq_in + (long long)min(wid, MB - 1) * fuse.nparts; \
-            const float* r1 = fuse.ssq_in + (long long)min(wid + 8, MB - 1) * fuse.nparts; \
-            for (int p0 = lane; p0 < fuse.nparts; p0 += 256) { \
-                float a0[4], a1[4]; \
+        const float* ssq_p_ = fuse.ssq_in ? fuse.ssq_in : reinterpret_cast<const float*>(x); \
+        const int ssq_on_ = fuse.ssq_in ? 1 : 0, ssq_n_ = fuse.ssq_in ? fuse.nparts : 1; \
+        float ssq_a0_[4], ssq_a1_[4]; \
+        { \
+            const long long r0_ = (long long)min(wid, MB - 1) * ssq_n_ * ssq_on_, r1_ = (long long)min(wid + 8, MB - 1) * ssq_n_ * ssq_on_; \
 _Pragma("unroll") \
-                for (int i = 0; i < 4; ++i) { \
-                    const int p_ = min(p0 + 64 * i, fuse.nparts - 1); \
-                    a0[i] = r0[p_]; \
-                    a1[i] = r1[p_]; \
-                } \
-_Pragma("unroll") \
-                for (int i = 0; i < 4; ++i) { \
-                    const bool in = p0 + 64 * i < fuse.nparts; \
-                    sq0 += in ? a0[i] : 0.f; \
-                    sq1 += in ? a1[i] : 0.f; \
-                } \
+            for (int i = 0; i < 4; ++i) { \
+                const int p_ = min(lane + 64 * i, ssq_n_ - 1) * ssq_on_; \
+                ssq_a0_[i] = ssq_p_[r0_ + p_]; \
+                ssq_a1_[i] = ssq_p_[r1_ + p_]; \
             } \
         }
 #define TEO_SK_SSQ_REDUCE \
-        if (fuse.ssq_in) { \
+        { \
+            /* unconditional (a launch without partials sums its dummy loads into an inv_s nobody reads): inside `if (ssq_in)` the \
+               compiler sinks the loads above into the branch, behind the weight loads, and drains the queue for them */ \
+_Pragma("unroll") \
+            for (int i = 0; i < 4; ++i) { \
+                const bool in = lane + 64 * i < ssq_n_; \
+                sq0 += in ? ssq_a0_[i] : 0.f; \
+                sq1 += in ? ssq_a1_[i] : 0.f; \
+            } \
+            if (ssq_n_ > 256) {                                         /* more than 256 partials (hidden > 4096): the rare tail */ \
+                for (int p0 = 256 + lane; p0 < fuse.nparts; p0 += 64) { \
+                    sq0 += fuse.ssq_in[(long long)min(wid, MB - 1) * fuse.nparts + p0]; \
+                    sq1 += fuse.ssq_in[(long long)min(wid + 8, MB - 1) * fuse.nparts + p0]; \
+                } \
+            } \
             sq0 = wave_sum(sq0); \
             sq1 = wave_sum(sq1); \
             if (lane == 0) { \
-                if (wid < MB) inv_s[wid] = rsqrtf(sq0 / (float)K + fuse.eps); \
-                if (wid + 8 < MB) inv_s[wid + 8] = rsqrtf(sq1 / (float)K + fuse.eps); \
+                if (wid < MB) inv_s[wid] = rsqrtf(fabsf(sq0) / (float)K + fuse.eps); \
+                if (wid + 8 < MB) inv_s[wid + 8] = rsqrtf(fabsf(sq1) / (float)K + fuse.eps); \
             } \
         }
 
     if (s0 < s1) {
         u32x4 wa[UNR], xa[UNR][XL], wb[UNR], xb[UNR][XL];
         int s = s0;
-        // producer-side RMSNorm (SkinnyFuse): 1/rms of the rows from the producer's partial sums.  Wave w owns rows w
-        // and w + 8.  The partials are requested FIRST and the wave's first weight batch right behind them, so the
-        // reduction's L2 round trip runs under the HBM latency of the weight stream (vmcnt counts in order: waiting for
-        // the older ssq loads does not wait for the weights).
         TEO_SK_SSQ_LOAD
         TEO_SK_LOAD(wa, xa, s)
         TEO_SK_SSQ_REDUCE
@@ -327,228 +345,192 @@ _Pragma("unroll") \
 // ---- streaming form --------------------------------------------------------------------------------------------------
 // The kernel above pays its fixed costs once per 16 weight rows: the workgroup start, the activation fragments (as many
 // bytes as the fp8 weights of the tile, twice that for 16 conversations), the drain into the LDS reduction and the
-// epilogue, during which the workgroup has no weight request in flight.  Measured on the 7B shapes the weight stream of a
-// batched step runs at 3.7-4.2 TB/s (fp8) / 5.5 TB/s (bf16, 8 rows) / 4.2 TB/s (bf16, 16 rows) against 6.4 for a plain
-// read; with the activation loads removed (probe) the 16-row case alone gains 40 %.
+// epilogue, during which the workgroup has no weight request in flight.
 //
-// Here a workgroup is PERSISTENT: 8 streaming waves own one K slice each for the whole launch and walk the row tiles
+// Here a workgroup is PERSISTENT: its 8 waves own one K slice each for the whole launch and walk the row tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ...:
 //   * the slice's activation fragments are loaded ONCE into registers (PER steps x 16 B [x 2 for fp8] per lane = 64
 //     VGPRs at K = 4096) -- no activation traffic after the first tile, and only weight loads in the vmcnt queue;
-//   * the weight stream is one flat double-buffered pipeline ACROSS tiles: the first loads of tile i + 1 are in flight
-//     while tile i's partial sums go to LDS;
-//   * a ninth wave does every epilogue (fixed-order reduction of the 8 partial tiles, 1/rms, fp8 scale, SwiGLU,
-//     residual, rounding, the next norm's hand-off): the streaming waves never issue another global load, so nothing
-//     they wait for sits behind the prefetched weights, and their only synchronisation is one s_barrier per tile
-//     (partial tiles double-buffered; the epilogue of tile i overlaps the stream of tile i + 1).
+//   * the weight stream is one flat ring of NS register sets (8 loads each) ACROSS tiles: 3 tiles of fp8 weights (2 of bf16)
+//     are requested before the first is multiplied -- 24 / 32 KB per wave in flight from the first cycle to the last tile
+//     (round 4, tools/skinny_probe.py: with two sets the first tile of a launch completed 5.4 us after the workgroup
+//     started and every launch ended ~4.5 us later than its bytes / 6.4 TB/s);
+//   * the epilogue is done by ALL waves, one output per thread (fixed-order sum of the 8 partial tiles from double-buffered
+//     LDS, 1/rms, fp8 scale, SwiGLU, residual, rounding, the next norm's hand-off), its operands requested one tile ahead
+//     with unconditional (clamped) loads.  Round 3 had a ninth wave for it: its loads sat behind a branch, so the compiler
+//     drained vmcnt(0) before every barrier and the whole workgroup waited ~1.6 us per tile for that one wave (ISA + timeline);
+//   * one s_barrier per tile.
 // Same arithmetic as the kernel above (same K partition when K / KS is a multiple of 8, same reduction order).
-constexpr int SS_NW = 8;                       // streaming waves; wave SS_NW is the epilogue wave
-constexpr int SS_THREADS = (SS_NW + 1) * 64;
 constexpr int SS_TP = 16 * 20;                 // partial tile in LDS: [b][i] at b*20 + i (16-byte aligned rows)
 
-template <typename WT, int UNR, int SPT, bool SW8, bool TRACE = false>
-__global__ __launch_bounds__(SS_THREADS) void skinny_stream_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
+template <typename WT, int UNR, int SPT, int NS, bool SW8, bool TRACE = false>
+__global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
                                                                    const float* __restrict__ wscale, const bf16_t* res, void* outv,
                                                                    int MB, int N, int K, int ldx, int ldo, int tiled, int out_f32,
                                                                    SkinnyFuse fuse) {
     constexpr bool F8 = sizeof(WT) == 1;
     constexpr int KS = F8 ? 64 : 32, CH = F8 ? 16 : 8, XL = F8 ? 2 : 1;
     constexpr int PER = UNR * SPT;                       // steps of one wave per tile
-    constexpr int TU = (SPT & 1) ? 2 : 1;                // tiles per trip of the unrolled loop (an even number of sets)
-    __shared__ __attribute__((aligned(16))) float red[2][SS_NW][SS_TP];
+    static_assert(NS % SPT == 0 && NS >= 2, "the ring holds whole tiles");
+    __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][SS_TP];
     __shared__ float inv_s[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ntiles = (N + 15) / 16, nsteps = K / KS, G = gridDim.x;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ntiles = N >> 4, nsteps = K / KS, G = gridDim.x;          // N % 16 == 0 (host-checked)
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;        // >= 1: the grid never exceeds the tile count
+    const int total = my_tiles * SPT;                                   // weight sets of this workgroup
+    const int s0 = wid * PER;
+    if (wid == 0) sk_mark<TRACE>(fuse, 0);
+    TEO_SK_SSQ_LOAD
 
-    if (wid == 0 || wid == SS_NW) sk_mark<TRACE>(fuse, wid == 0 ? 0 : 8);
-    if (wid < SS_NW) {
-        const int fr = lane & 15, fg = lane >> 4;
-        const int s0 = wid * PER;
-        int ntrace = 1;
-        TEO_SK_SSQ_LOAD
-        // the slice's activations, once
-        u32x4 xr[PER][XL];
-        {
-            const bf16_t* xp = x + (long long)min(fr, MB - 1) * ldx + fg * CH;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const long long sc = min(s0 + i, nsteps - 1);
-#pragma unroll
-                for (int j = 0; j < XL; ++j) xr[i][j] = *reinterpret_cast<const u32x4*>(xp + sc * KS + j * 8);
-            }
-        }
-        const long long pstep = tiled ? 64 * CH : KS;
-        const long long tstride = (long long)nsteps * (64 * CH);
-        u32x4 w[2][UNR];
-        // weight loads of set ls of tile t (t clamped: a trailing prefetch re-reads the last tile and is dropped)
-#define TEO_SS_LOADW(BUF, T, LS)                                                                               \
-        {                                                                                                      \
-            const int tc = min((T), ntiles - 1);                                                               \
-            const WT* wt = tiled ? W + (long long)tc * tstride + lane * CH                                     \
-                                 : W + (long long)min(tc * 16 + fr, N - 1) * K + fg * CH;                      \
-            _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                                    \
-                w[BUF][u] = sk_ldw<true>(wt + (long long)min(s0 + (LS) * UNR + u, nsteps - 1) * pstep);        \
-        }
-        int t = blockIdx.x;
-        TEO_SS_LOADW(0, t, 0)
-        TEO_SK_SSQ_REDUCE
-#pragma unroll
-        for (int i = 0; i < PER; ++i)                    // steps past the end of K contribute nothing
-            if (s0 + i >= nsteps) {
-#pragma unroll
-                for (int j = 0; j < XL; ++j) xr[i][j] = (u32x4){0u, 0u, 0u, 0u};
-            }
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int par = 0;
-        for (; t < ntiles; t += TU * G) {
-#pragma unroll
-            for (int q = 0; q < TU * SPT; ++q) {
-                const int tq = t + (q / SPT) * G, ls = q % SPT;
-                if (q + 1 < TU * SPT) TEO_SS_LOADW((q + 1) & 1, t + ((q + 1) / SPT) * G, (q + 1) % SPT)
-                else                  TEO_SS_LOADW(0, t + TU * G, 0)
-                {
-                    // (a trailing tile past the end is computed on the clamped re-read and dropped: the loads above must
-                    // stay unconditional users, or the compiler sinks them below the previous tile's barrier)
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const int i = ls * UNR + u;
-                        if (F8) {
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[q & 1][u].x, w[q & 1][u].y),
-                                                                          __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[q & 1][u].z, w[q & 1][u].w),
-                                                                          __builtin_bit_cast(bf16x8, xr[i][XL - 1]), acc, 0, 0, 0);
-                        } else {
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[q & 1][u]),
-                                                                          __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
-                        }
-                    }
-                    if (ls == SPT - 1 && (TU == 1 || q < SPT || tq < ntiles)) {   // tile done: lane holds out[b = fr][rows fg*4 .. +3]
-                        *reinterpret_cast<f32x4*>(&red[par][wid][fr * 20 + fg * 4]) = acc;
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        if (wid == 0 && ntrace < 8) sk_mark<TRACE>(fuse, ntrace++);
-                        acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        par ^= 1;
-                    }
-                }
-            }
-        }
-#undef TEO_SS_LOADW
-    } else {
-        // epilogue wave: lane = (conversation b, 4 consecutive rows of the tile).  The tile's scales / residual / next-norm
-        // weights are requested one tile AHEAD (a global round trip under a saturated HBM pipe is about one tile period:
-        // taken after the barrier it would make this wave the bottleneck of the workgroup)
-        const int b = lane >> 2, i4 = lane & 3;
-        const bool bok = b < MB;
-        const long long rrow = (long long)min(b, MB - 1) * ldo;
-        f32x4 sc_n = (f32x4){1.f, 1.f, 1.f, 1.f};
-        uint2 rv_n = make_uint2(0u, 0u), gv_n = make_uint2(0u, 0u);
+    // ---- epilogue operands: thread (eb = conversation, ec = row of the tile) owns one output per tile; requested one tile ahead,
+    // unconditionally (indices clamped: a thread without an output loads somebody else's operands and drops them)
+    const int eb = tid >> 4, ec = tid & 15;
+    const int ebc = min(eb, MB - 1);
+    const bool e_on = SW8 ? (tid < 256 && ec < 8 && eb < MB) : (tid < 256 && eb < MB);
+    // (absent operands read the activation buffer instead -- a pointer select, never a branch around a load: behind a branch the
+    // compiler drains vmcnt(0), i.e. the whole weight ring, once per tile)
+    const float* ws_p = wscale ? wscale : reinterpret_cast<const float*>(x);
+    const bf16_t* res_p = (!SW8 && res) ? res : x;
+    const bf16_t* g_p = (!SW8 && fuse.xg_out) ? reinterpret_cast<const bf16_t*>(fuse.next_g) : x;
+    const int ws_on = wscale ? 1 : 0, res_on = (!SW8 && res) ? 1 : 0, g_on = (!SW8 && fuse.xg_out) ? 1 : 0;
+    float sc_n, sc_n2, rv_n, gv_n;
 #define TEO_SS_PREFETCH(T)                                                                                     \
-        {                                                                                                      \
-            const int tp = min((T), ntiles - 1), np = tp * 16 + i4 * 4;                                        \
-            if (tp * 16 + 16 <= N) {                                                                           \
-                if (wscale) sc_n = *reinterpret_cast<const f32x4*>(wscale + np);                               \
-                if (!SW8 && res) rv_n = *reinterpret_cast<const uint2*>(res + rrow + np);                      \
-                if (!SW8 && fuse.xg_out) gv_n = *reinterpret_cast<const uint2*>(fuse.next_g + np);             \
-            }                                                                                                  \
+    {                                                                                                          \
+        const int np = min((T), ntiles - 1) * 16 + (SW8 ? (ec & 7) : ec);                                      \
+        sc_n = ws_p[np * ws_on];                                                                               \
+        sc_n2 = ws_p[(np + (SW8 ? 8 : 0)) * ws_on];                                                            \
+        rv_n = bf2f(res_p[((long long)ebc * ldo + np) * res_on]);                                              \
+        gv_n = bf2f(g_p[np * g_on]);                                                                           \
+    }
+    TEO_SS_PREFETCH((int)blockIdx.x)
+
+    // ---- the slice's activations, once
+    u32x4 xr[PER][XL];
+    {
+        const bf16_t* xp = x + (long long)min(fr, MB - 1) * ldx + fg * CH;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const long long sc = min(s0 + i, nsteps - 1);
+#pragma unroll
+            for (int j = 0; j < XL; ++j) xr[i][j] = *reinterpret_cast<const u32x4*>(xp + sc * KS + j * 8);
         }
-        TEO_SS_PREFETCH(blockIdx.x)
-        int par = 0, ntrace = 9;
-        for (int t = blockIdx.x; t < ntiles; t += G) {
-            asm volatile("" ::: "memory");               // the previous tile's LDS reads and stores stay BEFORE this barrier ...
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");               // ... and this tile's partial sums are read AFTER it (s_barrier alone does not order them for the compiler)
-            const f32x4 sc = sc_n;
-            const uint2 rv = rv_n, gv = gv_n;
-            TEO_SS_PREFETCH(t + G)
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- weight ring: set g = (tile g / SPT of this workgroup, steps (g % SPT) * UNR ..).  Sets past the end re-read the
+    // activation buffer (L2-resident, always mapped) so that every load stays unconditional and costs no HBM traffic.
+    const long long pstep = tiled ? 64 * CH : KS;
+    const long long tstride = (long long)nsteps * (64 * CH);
+    u32x4 w[NS][UNR];
+#define TEO_SS_LOADW(SLOT, GI)                                                                                 \
+    {                                                                                                          \
+        const int g_ = (GI);                                                                                   \
+        const int tq = (int)blockIdx.x + (g_ / SPT) * G, ls_ = g_ % SPT;                                       \
+        const WT* wt = tiled ? W + (long long)tq * tstride + lane * CH                                         \
+                             : W + (long long)(tq * 16 + fr) * K + fg * CH;                                    \
+        const bool live_ = g_ < total;                                                                         \
+        _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                      \
+            const WT* pw = wt + (long long)min(s0 + ls_ * UNR + u, nsteps - 1) * pstep;                        \
+            w[SLOT][u] = sk_ldw<true>(live_ ? pw : reinterpret_cast<const WT*>(x) + lane * CH);                \
+        }                                                                                                      \
+    }
 #pragma unroll
-            for (int wv = 0; wv < SS_NW; ++wv) v += *reinterpret_cast<const f32x4*>(&red[par][wv][b * 20 + i4 * 4]);
-            par ^= 1;
-            const int n0 = t * 16, nb = n0 + i4 * 4;    // first weight row of the lane
-            const float inv = fuse.ssq_in ? inv_s[b] : 1.f;
-            const bool full = n0 + 16 <= N;
+    for (int r = 0; r < NS - 1; ++r) TEO_SS_LOADW(r, r)
+    TEO_SK_SSQ_REDUCE
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= inv;
-            if (wscale) {
-                if (full) {
+    for (int i = 0; i < PER; ++i)                        // steps past the end of K contribute nothing
+        if (s0 + i >= nsteps) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= sc[r];
+            for (int j = 0; j < XL; ++j) xr[i][j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int par = 0, ntrace = 1;
+    float sc = 1.f, sc2 = 1.f, rv = 0.f, gv = 0.f;       // epilogue operands of the tile being multiplied
+    for (int g0 = 0; g0 < total; g0 += NS) {
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            const int g = g0 + r;
+            const int ls = r % SPT;                      // NS % SPT == 0: the set's position inside its tile is static
+            if (ls == 0) {
+                // first set of a tile: take the operands requested one tile ago and request the next tile's -- BEFORE this step's
+                // weight set goes out, so that they are older in the (in-order) vmcnt queue than every set still in flight when
+                // the epilogue needs them
+                sc = sc_n; sc2 = sc_n2; rv = rv_n; gv = gv_n;
+                TEO_SS_PREFETCH((int)blockIdx.x + (g / SPT + 1) * G)
+            }
+            TEO_SS_LOADW((r + NS - 1) % NS, g + NS - 1)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = ls * UNR + u;
+                if (F8) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[r][u].x, w[r][u].y),
+                                                                  __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[r][u].z, w[r][u].w),
+                                                                  __builtin_bit_cast(bf16x8, xr[i][XL - 1]), acc, 0, 0, 0);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= wscale[min(nb + r, N - 1)];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[r][u]),
+                                                                  __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
                 }
             }
-            if (SW8) {
-                // rows 0..7 of the tile are gate rows, 8..15 their up rows: lanes i4 < 2 pair with lane + 2
-                f32x4 o;
+            if (ls == SPT - 1 && g < total) {            // tile done (uniform): lane holds out[b = fr][rows fg*4 .. +3]
+                const int t = (int)blockIdx.x + (g / SPT) * G;
+                *reinterpret_cast<f32x4*>(&red[par][wid][fr * 20 + fg * 4]) = acc;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");           // the partial tiles are read AFTER the barrier
+                if (wid == 0 && ntrace < 8) sk_mark<TRACE>(fuse, ntrace++);
+                acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                // ---- epilogue: one output per thread, partial tiles summed in wave order
+                const float inv = fuse.ssq_in ? inv_s[ebc] : 1.f;
+                if (SW8) {
+                    float gsum = 0.f, usum = 0.f;        // rows 0..7 of the tile are gate rows, 8..15 their up rows
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu(v[r]) * __shfl_down(v[r], 2, 64);
-                if (bok && i4 < 2) {
-                    const long long at = (long long)b * ldo + t * 8 + i4 * 4;
-                    if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outv) + at) = o;
-                    else {
-                        uint2 pk;
-                        pk.x = pack_bf2(o[0], o[1]);
-                        pk.y = pack_bf2(o[2], o[3]);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(outv) + at) = pk;
+                    for (int wv = 0; wv < SK_WAVES; ++wv) {
+                        gsum += red[par][wv][ebc * 20 + (ec & 7)];
+                        usum += red[par][wv][ebc * 20 + (ec & 7) + 8];
                     }
-                }
-            } else {
-                const long long at = (long long)b * ldo + nb;
-                float sq = 0.f;
-                if (full) {
-                    if (res) {
-                        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
-                        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    gsum *= inv; usum *= inv;
+                    if (wscale) { gsum *= sc; usum *= sc2; }
+                    const float v = silu(gsum) * usum;
+                    if (e_on) {
+                        const long long at = (long long)eb * ldo + t * 8 + ec;
+                        if (out_f32) reinterpret_cast<float*>(outv)[at] = v;
+                        else reinterpret_cast<bf16_t*>(outv)[at] = f2bf(v);
                     }
-                    if (out_f32) { if (bok) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outv) + at) = v; }
+                } else {
+                    float v = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < SK_WAVES; ++wv) v += red[par][wv][ebc * 20 + ec];
+                    v *= inv;
+                    if (wscale) v *= sc;
+                    if (res) v += rv;
+                    const long long at = (long long)ebc * ldo + t * 16 + ec;
+                    float sq = 0.f;
+                    if (out_f32) { if (e_on) reinterpret_cast<float*>(outv)[at] = v; }
                     else {
-                        uint2 pk;
-                        pk.x = pack_bf2(v[0], v[1]);
-                        pk.y = pack_bf2(v[2], v[3]);
-                        if (bok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(outv) + at) = pk;
+                        const bf16_t hb = f2bf(v);
+                        if (e_on) reinterpret_cast<bf16_t*>(outv)[at] = hb;
                         if (fuse.xg_out) {
                             // what the NEXT layer's RMSNorm needs: bf16(h * g_next) and this tile's share of sum(h^2) per row
-                            const float h0 = __uint_as_float(pk.x << 16), h1 = __uint_as_float(pk.x & 0xffff0000u);
-                            const float h2 = __uint_as_float(pk.y << 16), h3 = __uint_as_float(pk.y & 0xffff0000u);
-                            uint2 xg;
-                            xg.x = pack_bf2(h0 * __uint_as_float(gv.x << 16), h1 * __uint_as_float(gv.x & 0xffff0000u));
-                            xg.y = pack_bf2(h2 * __uint_as_float(gv.y << 16), h3 * __uint_as_float(gv.y & 0xffff0000u));
-                            if (bok) *reinterpret_cast<uint2*>(fuse.xg_out + at) = xg;
-                            sq = h0 * h0 + h1 * h1 + h2 * h2 + h3 * h3;
+                            const float h = bf2f(hb);
+                            if (e_on) fuse.xg_out[at] = f2bf(h * gv);
+                            sq = h * h;
                         }
                     }
-                } else {                                 // ragged last tile: element-wise
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = nb + r;
-                        if (col < N && bok) {
-                            float y = v[r];
-                            if (res) y += bf2f(res[at + r]);
-                            if (out_f32) reinterpret_cast<float*>(outv)[at + r] = y;
-                            else {
-                                const bf16_t hb = f2bf(y);
-                                reinterpret_cast<bf16_t*>(outv)[at + r] = hb;
-                                if (fuse.xg_out) {
-                                    const float h = bf2f(hb);
-                                    fuse.xg_out[at + r] = f2bf(h * bf2f(fuse.next_g[col]));
-                                    sq += h * h;
-                                }
-                            }
-                        }
+                    if (fuse.xg_out) {
+                        sq += __shfl_xor(sq, 8, 64);
+                        sq += __shfl_xor(sq, 4, 64);
+                        sq += __shfl_xor(sq, 2, 64);
+                        sq += __shfl_xor(sq, 1, 64);
+                        if (ec == 0 && e_on) fuse.ssq_out[(long long)eb * ntiles + t] = sq;
                     }
                 }
-                if (fuse.xg_out) {
-                    sq += __shfl_xor(sq, 1, 64);
-                    sq += __shfl_xor(sq, 2, 64);
-                    if (i4 == 0 && bok) fuse.ssq_out[(long long)b * ntiles + t] = sq;
-                }
+                par ^= 1;
+                if (wid == 0 && ntrace < 16) sk_mark<TRACE>(fuse, 8 + (ntrace - 1));
             }
-            if (ntrace < 16) sk_mark<TRACE>(fuse, ntrace++);
         }
-#undef TEO_SS_PREFETCH
     }
+#undef TEO_SS_LOADW
+#undef TEO_SS_PREFETCH
 }
 #undef TEO_SK_SSQ_LOAD
 #undef TEO_SK_SSQ_REDUCE
@@ -586,25 +568,28 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     const int sw8 = (flags & TEO_GEMM_SWIGLU8) ? 1 : 0;   // gate/up interleaved in blocks of 8 rows: a pair fits one tile
     if (swiglu && !sw8 && rt < 2) rt = 2; // 16-row interleave: the gate tile and its up tile meet in the epilogue
     const int ldr = ldo, of = out_dtype == TEO_F32;
-    // streaming form (persistent workgroups, activations in registers): K <= 4096, one row tile per workgroup, vector
-    // epilogue accesses aligned
+    // streaming form (persistent workgroups, activations in registers): K <= 4096, whole 16-row tiles, one row tile at a time
     {
-        const int nsteps = K / (w_fp8 ? 64 : 32), ntiles = cdiv(N, 16);
+        const int nsteps = K / (w_fp8 ? 64 : 32), ntiles = N / 16;
         const auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-        bool ok = g_sk_stream != 0 && !norm_w && !(flags & TEO_GEMM_SWIGLU16) && (g_sk_tiles == 0 || g_sk_tiles == 1) &&
-                  nsteps <= (w_fp8 ? 64 : 128) && ldo % 4 == 0 && al(out, 16) && (!res || al(res, 8)) && (!wscale || al(wscale, 16)) &&
-                  (!fuse.xg_out || (al(fuse.xg_out, 8) && al(fuse.next_g, 8)));
-        // auto: at least two tiles per workgroup, and where it measures faster (fp8 weights: -15 % at 8 rows, -25 % at 16;
-        // bf16: -10..20 % above 8 rows, a tie at 8 or fewer where the duplicate activation rows coalesce)
+        bool ok = g_sk_stream != 0 && !norm_w && !(flags & TEO_GEMM_SWIGLU16) && (g_sk_tiles == 0 || g_sk_tiles == 1) && N % 16 == 0 &&
+                  nsteps <= (w_fp8 ? 64 : 128) && al(x, 16);
+        // auto: where it measures faster than one tile per workgroup -- at least two tiles per workgroup, and fp8 weights or more
+        // than 8 rows (bf16 at <= 8 rows: a tie, the duplicate activation rows of the tile kernel coalesce)
         if (ok && g_sk_stream == 1) ok = ntiles >= 512 && (w_fp8 || MB > 8);
         if (ok) {
             const int cus = device_cu_count();
             const int grid = std::max(1, std::min(ntiles, cus > 0 ? cus : 256));
-#define TEO_SS(WW, UN, SP, SW)                                                                              \
-            skinny_stream_kernel<WW, UN, SP, SW><<<grid, SS_THREADS, 0, st>>>((const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
-                                                                              out, MB, N, K, ldx, ldo, tiled, of, fuse)
-            if (w_fp8) { if (sw8) TEO_SS(fp8_t, 8, 1, true); else TEO_SS(fp8_t, 8, 1, false); }
-            else       { if (sw8) TEO_SS(bf16_t, 8, 2, true); else TEO_SS(bf16_t, 8, 2, false); }
+#define TEO_SS(WW, UN, SP, NSV, SW)                                                                         \
+            skinny_stream_kernel<WW, UN, SP, NSV, SW><<<grid, SK_THREADS, 0, st>>>((const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
+                                                                                   out, MB, N, K, ldx, ldo, tiled, of, fuse)
+            if (g_sk_ring == 1) {
+                if (w_fp8) { if (sw8) TEO_SS(fp8_t, 8, 1, 2, true); else TEO_SS(fp8_t, 8, 1, 2, false); }
+                else       { if (sw8) TEO_SS(bf16_t, 8, 2, 2, true); else TEO_SS(bf16_t, 8, 2, 2, false); }
+            } else {
+                if (w_fp8) { if (sw8) TEO_SS(fp8_t, 8, 1, 3, true); else TEO_SS(fp8_t, 8, 1, 3, false); }
+                else       { if (sw8) TEO_SS(bf16_t, 8, 2, 4, true); else TEO_SS(bf16_t, 8, 2, 4, false); }
+            }
 #undef TEO_SS
             note_kernel("skinny_stream");
             TEO_LAUNCH_CHECK("skinny_gemm (stream)");
@@ -613,6 +598,21 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     }
     const int blocks = cdiv(N, 16 * rt);
     const size_t dyn = norm_w ? (size_t)K * 2 : 0;
+    // long K slices (down projection, K = 11008: 21.5 fp8 / 43 bf16 steps per wave): 8 steps per register set = 16 weight + their
+    // activation loads in flight per wave instead of 8 -- the launch is latency-bound with 64 KB of weights per CU in flight
+    // (3.2 TB/s, tools/skinny_probe.py); fp8 takes 6 steps (its activation fragments are twice the weights: 8 steps spill); 150-200
+    // VGPRs: one workgroup per CU, which is all N = 4096 has anyway
+    const int steps_per_wave = K / (w_fp8 ? 64 : 32) / (SK_WAVES / rt);
+    const bool unr8 = !swiglu && !norm_w && g_sk_nt && (g_sk_unr == 8 || (g_sk_unr == 0 && steps_per_wave >= 16 && blocks <= 2 * std::max(device_cu_count(), 1)));
+    if (unr8) {
+        if (w_fp8) skinny_gemm_kernel<fp8_t, 6, true, false, false><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, nullptr, eps,
+                       (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
+        else       skinny_gemm_kernel<bf16_t, 8, true, false, false><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, nullptr, eps,
+                       (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
+        note_kernel("skinny_gemm_u8");
+        TEO_LAUNCH_CHECK("skinny_gemm");
+        return TEO_OK;
+    }
 #define TEO_SK(WW, NTV, SW, NM)                                                                            \
     skinny_gemm_kernel<WW, 4, NTV, SW, NM><<<blocks, SK_THREADS, dyn, st>>>(                               \
         (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)norm_w, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, \

@@ -440,6 +440,43 @@ class TeoEngine:
         self.cache_len = past + S
         return logits
 
+    def prefill_batch(self, embeds_list):
+        """Training-shape forward of B independent sequences in ONE pass (teo_llama_prefill_batch, last_only = 0): embeds_list[b]
+        is [S_b, D]; the rows are concatenated for the norms / GEMMs, RoPE + causal attention run per sequence on scratch KV slots
+        owned by the engine (allocated on first use, sized [layers, B, Hkv, max_seq, hd] x 3).  Returns fp32 logits
+        [sum(S_b), V], rows in the order of the list.  The single-conversation cache (self.cache_len) is untouched."""
+        B = len(embeds_list)
+        lens = [int(e.shape[0]) for e in embeds_list]
+        if max(lens) > self.max_seq:
+            raise ValueError(f"sequence length {max(lens)} exceeds the engine's max_seq {self.max_seq}")
+        c = self.cfg
+        Lr, Hk, hd, S = c.num_hidden_layers, c.num_key_value_heads, c.head_dim, self.max_seq
+        slot = getattr(self, "_fwd_slots", None)
+        if slot is None or slot["B"] < B:
+            self._fwd_slots = None
+            kv = [torch.zeros(Lr, B, Hk, S, hd, dtype=self.dtype, device=self.device) for _ in range(2)]
+            vt = torch.zeros(Lr, B, Hk, hd, S, dtype=self.dtype, device=self.device)
+            d = L.LlamaDesc.from_buffer_copy(self.llama_desc)
+            d.k_cache = self._arr([kv[0][i, 0] for i in range(Lr)])
+            d.v_cache = self._arr([kv[1][i, 0] for i in range(Lr)])
+            d.vt_cache = self._arr([vt[i, 0] for i in range(Lr)])
+            slot = self._fwd_slots = {"B": B, "k": kv[0], "v": kv[1], "vt": vt, "desc": d}
+            self._option_hooks.append(lambda src, dd=d: (setattr(dd, "prefill_fp8", src.prefill_fp8), setattr(dd, "rope_in_attn", src.rope_in_attn)))
+        d = slot["desc"]
+        total = sum(lens)
+        with self.phase() as st:
+            rows = torch.cat([e.to(device=self.device, dtype=self.dtype) for e in embeds_list], dim=0).contiguous()
+            logits = torch.empty(total, c.vocab_size, dtype=torch.float32, device=self.device)
+            self._flush_handoff_checks("prefill")
+            ws = self._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d), total))
+            arr = (C.c_int * B)(*lens)
+            L.check(self.lib.teo_llama_prefill_batch(C.byref(d), _p(rows), arr, B, slot["k"].stride(1), 0, _p(logits), _p(ws), ws.numel(), st),
+                    "teo_llama_prefill_batch")
+            sid = C.c_void_p(self.stream.cuda_stream)
+            self._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d), total, _p(ws), ws.numel(), C.byref(f), sid),
+                                 "teo_llama_prefill_batch")
+        return logits
+
     def sample(self, logits, temperature, top_k, seed, draw, top_p=1.0):
         """One draw of the device sampler (temperature -> top-k -> softmax -> multinomial) from fp32 logits [V]."""
         tok = torch.empty(1, dtype=torch.int64, device=self.device)

@@ -311,9 +311,10 @@ class LlavaLlamaForCausalLM:
             raise ValueError("the device KV cache holds one sequence; batched continuation is not supported")
         past = eng.cache_len
         logits = torch.zeros(B, S, self.config.vocab_size, dtype=torch.float32, device=eng.device)
+        # the rows that exist: right / left padding leaves one contiguous run of real tokens per sample (llava_arch.py:310-329); padded
+        # positions keep zero logits -- the reference's values there are never consumed (their labels are IGNORE_INDEX, :320-329)
+        spans = []
         for b in range(B):
-            if B > 1:
-                eng.reset_cache()
             if attention_mask is not None:
                 m = attention_mask[b].to(torch.bool)
                 m_new = m[-S:] if m.shape[0] >= S else m
@@ -324,15 +325,33 @@ class LlavaLlamaForCausalLM:
                     raise ValueError("masked positions inside the cached prefix are not supported")
             else:
                 idx = torch.arange(S, device=inputs_embeds.device)
-            if idx.numel() == 0:
-                continue
-            lo, hi = int(idx[0]), int(idx[-1]) + 1
+            spans.append((int(idx[0]), int(idx[-1]) + 1) if idx.numel() else None)
+        if B > 1:
+            # every sample in ONE pass: rows of all samples concatenated for the norms / GEMMs, attention per sample on scratch KV
+            # slots (teo_llama_prefill_batch).  Positions: 0 .. S_b - 1 per sample (what the default position_ids give; explicit
+            # position_ids other than that are a single-sample feature)
+            live = [b for b in range(B) if spans[b] is not None]
+            if position_ids is not None:
+                for b in live:
+                    lo, hi = spans[b]
+                    pr = position_ids[b] if position_ids.dim() == 2 else position_ids
+                    pr = pr[lo:hi] if pr.shape[-1] == S else pr
+                    if not torch.equal(pr.to(torch.long).cpu(), torch.arange(hi - lo)):
+                        raise ValueError("batched forward supports the default position_ids (0 .. len - 1 per sample) only")
+            if live:
+                out = eng.prefill_batch([inputs_embeds[b, spans[b][0]:spans[b][1]] for b in live])
+                r0 = 0
+                for b in live:
+                    lo, hi = spans[b]
+                    logits[b, lo:hi] = out[r0:r0 + hi - lo]
+                    r0 += hi - lo
+        elif spans[0] is not None:
+            lo, hi = spans[0]
             pos = None
             if position_ids is not None:
-                pr = position_ids[b] if position_ids.dim() == 2 else position_ids
+                pr = position_ids[0] if position_ids.dim() == 2 else position_ids
                 pos = pr[lo:hi] if pr.shape[-1] == S else pr
-            out = eng.prefill(inputs_embeds[b, lo:hi], positions=pos, last_only=False)
-            logits[b, lo:hi] = out
+            logits[0, lo:hi] = eng.prefill(inputs_embeds[0, lo:hi], positions=pos, last_only=False)
         loss = None
         if labels is not None:
             # N4: training-shape loss (CrossEntropyLoss over the shifted positions) on the device: row (b, s) pairs

@@ -60,12 +60,22 @@ def ulp_check(got, ref, tag, report, kernel=True, abs_tol=FP32_SUM_ABS):
     got = got.float().cpu().reshape(ref.shape)
     d = (got - ref).abs()
     ulp = G.ulp16(ref)
+    if torch.is_tensor(abs_tol):
+        abs_tol = abs_tol.float().reshape(ref.shape)
     bad = int((d > ulp + abs_tol).sum())
     exact = float((d == 0).float().mean())
     worst = float((d / ulp).max())
     kn = L.load().teo_last_kernel().decode() if kernel else "-"
     report.append(f"  {tag:<58s} {tuple(ref.shape)!s:<16s} kernel={kn:<18s} bit-equal {exact * 100:6.2f} %  worst {worst:5.2f} ulp  beyond 1 ulp: {bad}")
-    assert bad == 0, f"{tag}: {bad} / {d.numel()} elements beyond 1 bf16 ulp + {abs_tol:g} (worst {worst:.2f} ulp, max diff {float(d.max()):.3e})"
+    assert bad == 0, f"{tag}: {bad} / {d.numel()} elements beyond 1 bf16 ulp + allowance (worst {worst:.2f} ulp, max diff {float(d.max()):.3e})"
+
+
+def attn_p_noise(q, k, v, visible, scale):
+    """Per-output allowance for the bf16 rounding of P in softmax(QK^T) V: the kernels and the oracle both round the exponentiated
+    scores to bf16 before the PV product, each at its own 1-ulp-different value, so an output moves by up to
+    2^-8 * sum_j p_j |v_j| whatever its own magnitude (outputs of late causal rows are sums of ~2000 terms that largely cancel).
+    Returned in the layout attention_core returns ([B, H, S, d])."""
+    return (2.0 ** -8) * O.attention_core(q, k, v.abs(), visible, scale, lambda t: t, "exact")
 
 
 def _rand(shape, gen, std=1.0):
@@ -169,7 +179,8 @@ def test_llama_layer_walk_at_7b_shapes():
     a.batch, a.heads, a.kv_heads, a.head_dim, a.q_len, a.kv_len, a.causal, a.scale = 1, H, H, hd, S, S, 1, 1 / math.sqrt(hd)
     L.check(G.lib().teo_attention(C.byref(a), L.TEO_BF16, G.stream()), "attn")
     assert G.lib().teo_last_kernel() == b"attn_flash32"
-    ulp_check(o_k, o_ref, "causal flash attention L=2168 H=32 d=128", report)
+    ulp_check(o_k, o_ref, "causal flash attention L=2168 H=32 d=128", report,
+              abs_tol=attn_p_noise(qq, kk, vv, vis, 1 / math.sqrt(hd)).transpose(1, 2).reshape(S, D) + FP32_SUM_ABS)
     # o projection + residual (stream-K shapes: 272 wide tiles / 544 narrow tiles)
     h1 = R(h + o_ref @ w["o"].t())
     d_o, d_Wo, d_h = G.dev(o_ref, bf), G.dev(w["o"], bf), G.dev(h, bf)
@@ -205,7 +216,8 @@ def test_llama_layer_walk_at_7b_shapes():
     L.check(lib.teo_attn_decode(G.p(d_qd), G.p(kc), G.p(vc), None, None, None, G.p(out), G.p(part), G.p(posd), S_max, H,
                                 H, hd, 1.0 / math.sqrt(hd), L.TEO_BF16, 1, D, H * S_max * hd, D, G.stream()), "attn_decode")
     o_dec = R(O.attention_core(qd[None, :, None, :], kk, vv, None, 1 / math.sqrt(hd), R, "split64")[0, :, 0].reshape(D))
-    ulp_check(out, o_dec, "decode attention ctx=2168 (split-KV + combine)", report, kernel=False)
+    ulp_check(out, o_dec, "decode attention ctx=2168 (split-KV + combine)", report, kernel=False,
+              abs_tol=attn_p_noise(qd[None, :, None, :], kk, vv, None, 1 / math.sqrt(hd))[0, :, 0].reshape(D) + FP32_SUM_ABS)
     # lm_head GEMV with the final norm, fp32 logits
     Wlm = _rand((32000, D), gen, 0.02)
     g_f = R(1.0 + 0.1 * torch.randn(D, generator=gen))
@@ -268,7 +280,8 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes():
     qd, kd, vd = (G.dev(t.contiguous(), bf) for t in (q, k, v))
     o_k = G.attention(qd, kd, vd, False, hd ** -0.5, vt=G.make_vt(vd))
     assert lib.teo_last_kernel() == b"attn_flash32"
-    ulp_check(o_k.reshape(T * N, D), o_ref, "flash attention N=257 d=64 16 heads x 8 frames", report)
+    ulp_check(o_k.reshape(T * N, D), o_ref, "flash attention N=257 d=64 16 heads x 8 frames", report,
+              abs_tol=attn_p_noise(q, k, v, None, hd ** -0.5).transpose(1, 2).reshape(T * N, D) + FP32_SUM_ABS)
     h1 = R(h + o_ref @ w["o"].t() + b["o"])
     gemm_all_families(gw, G.dev(o_ref, bf), G.dev(w["o"], bf), h1, "out_proj + bias + residual N=1024 K=1024", report,
                       families=fam[:2], bias=G.dev(b["o"], bf), res=G.dev(h, bf))

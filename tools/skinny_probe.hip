@@ -28,11 +28,11 @@ extern "C" int skinny_probe_launch(int mode, const void* x, const void* W, const
     if (mode == 1) {
         const int grid = ntiles < grid_cap ? ntiles : grid_cap;
         if (w_fp8) {
-            if (sw8) skinny_stream_kernel<fp8_t, 8, 1, true, true><<<grid, SS_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
-            else     skinny_stream_kernel<fp8_t, 8, 1, false, true><<<grid, SS_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
+            if (sw8) skinny_stream_kernel<fp8_t, 8, 1, 3, true, true><<<grid, SK_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
+            else     skinny_stream_kernel<fp8_t, 8, 1, 3, false, true><<<grid, SK_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
         } else {
-            if (sw8) skinny_stream_kernel<bf16_t, 8, 2, true, true><<<grid, SS_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
-            else     skinny_stream_kernel<bf16_t, 8, 2, false, true><<<grid, SS_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
+            if (sw8) skinny_stream_kernel<bf16_t, 8, 2, 4, true, true><<<grid, SK_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
+            else     skinny_stream_kernel<bf16_t, 8, 2, 4, false, true><<<grid, SK_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, (const bf16_t*)res, out, MB, N, K, K, ldo, 1, 0, fuse);
         }
     } else {
         const int blocks = ntiles;
