@@ -448,6 +448,13 @@ def main():
         model.generate(input_ids=ids, images=frames, do_sample=False, max_new_tokens=n_out, eos_token_id=None)
         torch.cuda.synchronize()
         phases["default_chunk16_tokens_per_s"] = n_out / (time.perf_counter() - t)
+        # the reference's DEFAULT call samples (eval/inference.py:64-72: do_sample=True, temperature=0.2; HF's default top_k=50): the
+        # device sampler (radix select over the 32 000 logits + multinomial inside decode_tail) replaces the argmax, nothing else
+        model.generate(input_ids=ids, images=frames, do_sample=True, temperature=0.2, top_k=50, max_new_tokens=n_out, eos_token_id=None, chunk=n_out)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        model.generate(input_ids=ids, images=frames, do_sample=True, temperature=0.2, top_k=50, max_new_tokens=n_out, eos_token_id=None, chunk=n_out)
+        torch.cuda.synchronize()
+        phases["sampled_tokens_per_s"] = n_out / (time.perf_counter() - t)
     phases = {k: round(v, 3) for k, v in phases.items()}
 
     # ---- roofline of the dominant kernel (decode gate/up GEMV: 43 % of the weight bytes of a token).
@@ -465,11 +472,22 @@ def main():
     kv_bytes = 2 * cfg.num_key_value_heads * cfg.head_dim * 2 * ctx_prof
     alg_bytes = {"qkv_rope_gemv": QKVn * Dh * w_bytes, "o_gemv": Dh * Dh * w_bytes, "gateup_gemv": 2 * Fi * Dh * w_bytes,
                  "down_gemv": Dh * Fi * w_bytes, "lm_head_gemv": Vv * Dh * w_bytes, "attn_decode_partial": kv_bytes}
-    eng.reset_cache()
-    lg = eng.prefill(emb[0], last_only=True)
-    eng.decode_begin(int(lg[0].argmax()))
-    eng.decode_steps_profiled(2)                                       # warm
-    prof = eng.decode_steps_profiled(8)
+    if B > 1:
+        # the batched step (what this line's `value` is made of): B conversations prefilled again, then profiled batched steps
+        dec = model._batch_decoder
+        dec.reset()
+        lgb = dec.prefill_all(seqs)
+        dec.begin([int(lgb[b].argmax()) for b in range(B)])
+        dec.steps_profiled(2)                                          # warm
+        prof = dec.steps_profiled(4)
+        for k_ in ("attn_decode_partial",):
+            alg_bytes[k_] = kv_bytes * B                               # every conversation streams its own K / V
+    else:
+        eng.reset_cache()
+        lg = eng.prefill(emb[0], last_only=True)
+        eng.decode_begin(int(lg[0].argmax()))
+        eng.decode_steps_profiled(2)                                   # warm
+        prof = eng.decode_steps_profiled(8)
     in_run = {}
     for name, (per_step, us) in prof.items():
         e = {"launches_per_token": per_step, "avg_us": round(us, 2)}
@@ -479,8 +497,8 @@ def main():
             e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
         in_run[name] = e
     pair_us = prof["attn_decode_partial"][1] + prof.get("attn_decode_combine", (0, 0.0))[1]
-    in_run["attention_pair"] = {"avg_us": round(pair_us, 2), "algorithmic_bytes": int(kv_bytes),
-                                "frac_of_hbm_peak": round(kv_bytes / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    in_run["attention_pair"] = {"avg_us": round(pair_us, 2), "algorithmic_bytes": int(alg_bytes["attn_decode_partial"]),
+                                "frac_of_hbm_peak": round(alg_bytes["attn_decode_partial"] / (pair_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
     step_kernel_us = sum(per_step * us for per_step, us in prof.values())
     gemv_bytes = 2 * Fi * Dh * w_bytes
     gu_us = prof["gateup_gemv"][1]
@@ -525,16 +543,46 @@ def main():
     # back-to-back launches.  (2) is what `rocprofv3 --kernel-trace --stats` of this command agrees with (its per-kernel averages carry
     # the inter-kernel gap of the replayed graph: they add up to slightly MORE than the step); `achieved` / `frac` use the LONGER of
     # the two, so the headline fraction never exceeds what the committed rocprofv3 summary supports; both are reported.
-    avg_ms = gu_us * 1e-3 if chain_ms is None else max(gu_us * 1e-3, chain_ms)
-    achieved = gemv_bytes / (avg_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "gemv_kernel<bf16,bf16,R=2,U=4,NT,SWIGLU> (decode rmsnorm + gate/up + SwiGLU, N=22016 K=4096)"
-                                          if args.weights == "bf16" else "gemv_kernel<fp8 weights, SWIGLU> (decode rmsnorm + gate/up + SwiGLU)",
+    # The DOMINANT kernel of the step this line measures = the class with the largest share of the profiled step (launches x time):
+    # the gate/up GEMV for one conversation (bf16 and fp8), the batched attention kernel for --batch B -- the line describes the run
+    # it made.  (The attention class counts its combine launch when the split form ran.)
+    share = {k_: v_[0] * v_[1] for k_, v_ in prof.items()}
+    share["attn_decode_partial"] = share.get("attn_decode_partial", 0.0) + share.pop("attn_decode_combine", 0.0)
+    dom = max(share, key=share.get)
+    w_tag = "fp8-e4m3 weights" if args.weights == "fp8" else "bf16 weights"
+    if B > 1:
+        kern_names = {"attn_decode_partial": f"attn_decode_whole_kernel<bf16, 16 lanes per row, 64-key chunks, RoPE + KV append> (batched decode attention: {B} conversations x 32 heads x {ctx_prof} keys)",
+                      "gateup_gemv": f"skinny_stream_kernel<{w_tag}, SWIGLU8> (batched decode gate/up + SwiGLU, {B} rows, N=22016 K=4096)",
+                      "qkv_rope_gemv": f"skinny_stream_kernel<{w_tag}> (batched decode qkv, {B} rows, N=12288 K=4096)",
+                      "down_gemv": f"skinny_gemm_kernel<{w_tag}> (batched decode down + residual, {B} rows, N=4096 K=11008)",
+                      "o_gemv": f"skinny_gemm_kernel<{w_tag}> (batched decode o + residual, {B} rows)",
+                      "lm_head_gemv": f"skinny_stream_kernel<{w_tag}> (batched lm_head, {B} rows, N=32000)"}
+    else:
+        kern_names = {"gateup_gemv": ("gemv_kernel<bf16,bf16,R=2,U=4,NT,SWIGLU> (decode rmsnorm + gate/up + SwiGLU, N=22016 K=4096)" if args.weights == "bf16"
+                                      else "gemv_kernel<fp8 weights, SWIGLU> (decode rmsnorm + gate/up + SwiGLU)"),
+                      "attn_decode_partial": "attn_decode_partial_kernel + attn_decode_combine_kernel (decode attention pair)",
+                      "qkv_rope_gemv": f"gemv_qkv_rope_kernel<{w_tag}> (decode rmsnorm + qkv + RoPE + KV append)",
+                      "down_gemv": f"gemv_splitk_kernel<{w_tag}> (decode down + residual)", "o_gemv": f"gemv_splitk_kernel<{w_tag}> (decode o + residual)",
+                      "lm_head_gemv": f"gemv_kernel<{w_tag}, f32 out> (rmsnorm + lm_head)"}
+    if dom == "gateup_gemv" and B == 1:
+        avg_ms = gu_us * 1e-3 if chain_ms is None else max(gu_us * 1e-3, chain_ms)
+        dom_bytes, dom_in_run_ms = gemv_bytes, gu_us * 1e-3
+    else:
+        dom_us = prof[dom][1] + (prof.get("attn_decode_combine", (0, 0.0))[1] if dom == "attn_decode_partial" else 0.0)
+        avg_ms = dom_in_run_ms = dom_us * 1e-3
+        dom_bytes = int(alg_bytes[dom])
+        traffic = (traffic_all or {}).get(dom, {}).get("hbm_bytes_per_launch") if (B == 1 and isinstance(traffic_all, dict)) else None
+    achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": kern_names.get(dom, dom),
+                "share_of_profiled_step": round(share[dom] / sum(share.values()), 4),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": gemv_bytes, "avg_launch_ms": round(avg_ms, 5),
-                "measured": "the longer of: in-run per-launch dispatch timestamps over 8 decode steps x 32 layers after a real prefill (ctx %d); "
-                            "HIP events around 32 matrices x 5 back-to-back launches" % ctx_prof,
-                "in_run_avg_launch_ms": round(gu_us * 1e-3, 5), "in_run_frac": round(gemv_bytes / (gu_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(avg_ms, 5),
+                "measured": ("the longer of: in-run per-launch dispatch timestamps over 8 decode steps x 32 layers after a real prefill (ctx %d); "
+                             "HIP events around 32 matrices x 5 back-to-back launches" % ctx_prof) if (dom == "gateup_gemv" and B == 1) else
+                            ("in-run per-launch dispatch timestamps over %d profiled %s x 32 layers after a real prefill (ctx %d)"
+                             % (4 if B > 1 else 8, "batched steps" if B > 1 else "decode steps", ctx_prof)),
+                "in_run_avg_launch_ms": round(dom_in_run_ms, 5), "in_run_frac": round(dom_bytes / (dom_in_run_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "chain_microbench_avg_launch_ms": None if chain_ms is None else round(chain_ms, 5),
                 "chain_microbench_frac": None if chain_ms is None else round(gemv_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "decode_kernels_in_run": in_run,
@@ -552,11 +600,17 @@ def main():
     roofline["prefill_frac_of_mfma_peak"] = round(roofline["prefill_tflops"] / MFMA_PEAK_TFLOPS, 4)
     roofline["vit_projector_tflops"] = round(vit_tf / (phases["encode_plus_splice_ms"] * 1e-3), 1)
     roofline["decode_step_frac_of_hbm_peak"] = round(tok_bytes / (phases["decode_ms_per_token"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-    # t_min = FLOPs_dense / peak_mfma + Bytes_decode / peak_hbm over the whole job; end_to_end_frac = t_min / t_measured
-    t_min_s = (vit_tf + prefill_tf) / MFMA_PEAK_TFLOPS + (n_out - 1) * tok_bytes / (HBM_PEAK_GBS * 1e9)
-    t_meas_s = dt / (args.steps * max(B, 1)) if B == 1 else None
+    # t_min = FLOPs_dense / peak_mfma + Bytes_decode / peak_hbm over the whole job; end_to_end_frac = t_min / t_measured.
+    # A batched step reads the weights ONCE and every conversation's K / V: bytes per step = weights + B x KV
+    w_tok = 6.738e9 * (1 if args.weights == "fp8" else 2)
+    kv_tok = tok_bytes - w_tok
+    step_bytes = w_tok + B * kv_tok
+    if B > 1:
+        roofline["batched_step_frac_of_hbm_peak"] = round(step_bytes / (phases["batched_decode_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    t_min_s = B * (vit_tf + prefill_tf) / MFMA_PEAK_TFLOPS + (n_out - 1) * step_bytes / (HBM_PEAK_GBS * 1e9)
+    t_meas_s = dt / args.steps                       # one step = B conversations prepared and decoded together
     roofline["t_min_ms"] = round(t_min_s * 1e3, 3)
-    roofline["end_to_end_frac"] = None if t_meas_s is None else round(t_min_s / t_meas_s, 4)
+    roofline["end_to_end_frac"] = round(t_min_s / t_meas_s, 4)
 
     result = {
         "metric": "end-to-end tokens/sec (prefill+decode), T=8 frames, LLaMA-2-7B",

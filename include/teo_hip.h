@@ -58,13 +58,16 @@ const char* teo_last_kernel(void);
  * for benchmarks and for tests that force one kernel family; the library's defaults are what ships.  Keys (value 0 / 1 unless said):
  *   decode GEMV   : "gemv_variant" (-1 default; 0..2, 10..13: row-group geometry; fp32 order), "gemv_nt" (non-temporal weight loads),
  *                   "gemv_max_blocks" (workgroup cap), "gemv_small_k" (x prologue sized to K <= 4096), "gemv_splitk_u" (0 auto, 2/4/6)
- *   prefill GEMM  : "gemm_depth", "gemm_sk" (stream-K: 0 off, 1 auto, 2 force), "gemm_sk_dbg", "gemm_wide" (0 off, 1 auto, 2 force),
- *                   "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force), "gemm_big_group", "gemm_big_hybrid"
- *                   (0 off, 1 auto, 2 force), "gemm_fp8_wide" (0..3), "gemm_fp8_big" (0..2), "gemm_splitk" (split-K form of the
- *                   short-N tower GEMMs: 0 off, 1 auto) -- all bit-identical families
- *   decode attn   : "attn_chunk" (keys per decode workgroup: 0 auto, 32/64/128/256; fp32 order of the split merge), "attn_whole"
- *                   (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto; bit-identical)
- *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible) */
+ *   prefill GEMM  : "gemm_bm" (tile rows of the plain kernel: 0 auto, 64, 128), "gemm_depth", "gemm_sk" (stream-K: 0 off, 1 auto, 2 force),
+ *                   "gemm_sk_dbg" (timing diagnostics of the hand-off: WRONG results, never set outside tools/), "gemm_wide" (0 off, 1 auto,
+ *                   2 force), "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force), "gemm_big_group", "gemm_big_hybrid"
+ *                   (0 off, 1 auto, 2 force), "gemm_fp8_wide" (0..3), "gemm_fp8_big" (0..2) -- all bit-identical families
+ *   decode attn   : "attn_chunk" (keys per decode chunk: 0 auto, 32/64/128/256; fp32 order of the split merge + where P is rounded),
+ *                   "attn_whole" (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto, 2 whenever the shape
+ *                   allows; bit-identical to the split + combine pair at the same chunk)
+ *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible), "skinny_ring"
+ *                   (weight tiles in flight of the streaming form: 0 default, 1 one more), "skinny_unr" (tile kernel steps per register
+ *                   set: 0 auto, 4, 8) -- bit-identical at K = 4096, fp32 order elsewhere */
 int teo_tune_set(const char* key, int value);
 /* Every knob back to the library default (what ships). */
 int teo_tune_reset(void);
@@ -446,6 +449,11 @@ int teo_llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch
                                  size_t workspace_bytes, teo_stream_t stream);
 int teo_llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace,
                                 size_t workspace_bytes, teo_stream_t stream);
+/* Measurement aid, the batched counterpart of teo_llama_decode_step_profile: ONE batched step with every launch timed by its own
+ * dispatch timestamps; the same TEO_PROF_* classes (the attention class covers the whole-context kernel, or the split kernel with
+ * its combine in TEO_PROF_ATTN_COMBINE). */
+int teo_llama_decode_batch_step_profile(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace, size_t workspace_bytes,
+                                        float* ms_out /* [TEO_PROF_CLASSES] */, int* count_out /* [TEO_PROF_CLASSES] */, teo_stream_t stream);
 int teo_llama_decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* st, void* d_workspace,
                                         size_t workspace_bytes, teo_stream_t stream, teo_graph** out);
 

@@ -140,6 +140,8 @@ _SIGS = {
     "teo_llama_decode_batch_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc), C.c_int]),
     "teo_llama_decode_batch_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_batch_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "teo_llama_decode_batch_step_profile": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t,
+                                                      C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
     "teo_llama_decode_batch_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t,
                                                       C.c_void_p, C.POINTER(C.c_void_p)]),
     "teo_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

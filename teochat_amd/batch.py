@@ -221,6 +221,29 @@ class BatchDecoder:
         self.cache_len = [x + n for x in self.cache_len]
         self._steps_done += n
 
+    def steps_profiled(self, n):
+        """n batched steps as plain launches, every kernel timed by its own dispatch timestamps (teo_llama_decode_batch_step_profile).
+        Returns {class: (launches per step, mean microseconds per launch)}; advances the caches like steps()."""
+        from .engine import TeoEngine
+        eng = self.eng
+        if max(self.cache_len) + n > eng.max_seq or self._steps_done + n > self.max_new:
+            raise ValueError("steps_profiled: would exceed max_seq / the output buffer")
+        ws = self._workspace()
+        names = TeoEngine.PROF_CLASSES
+        K = len(names)
+        tot, cnt = [0.0] * K, [0] * K
+        ms, ct = (C.c_float * K)(), (C.c_int * K)()
+        with eng.phase() as st:
+            for _ in range(n):
+                L.check(self.lib.teo_llama_decode_batch_step_profile(C.byref(self.desc), C.byref(self.state), _p(ws), ws.numel(), ms, ct, st),
+                        "teo_llama_decode_batch_step_profile")
+                for k in range(K):
+                    tot[k] += ms[k]
+                    cnt[k] += ct[k]
+        self.cache_len = [x + n for x in self.cache_len]
+        self._steps_done += n
+        return {name: (cnt[k] // n, tot[k] / cnt[k] * 1e3) for k, name in enumerate(names) if cnt[k]}
+
     def generated(self):
         """[B, steps] int64: the tokens produced by the steps so far (the first token of each conversation excluded)."""
         n = self._steps_done

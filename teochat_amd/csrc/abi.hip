@@ -46,6 +46,8 @@ size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
 int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out, int* count_out,
                               hipStream_t st);
+int llama_decode_batch_step_profile(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes, float* ms_out,
+                                    int* count_out, hipStream_t st);
 int llama_prefill_workspace_status(const teo_llama_desc* d, int S, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
 int vit_workspace_status(const teo_vit_desc* d, int T, void* ws, size_t ws_bytes, int* host_flag, hipStream_t st);
 int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
@@ -396,6 +398,14 @@ int teo_llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_
     { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
     NEED(ws, "workspace");
     return llama_decode_batch_step(d, st, ws, wsb, ST(s));
+}
+
+int teo_llama_decode_batch_step_profile(const teo_llama_desc* d, const teo_decode_batch_state* st, void* ws, size_t wsb, float* ms_out,
+                                        int* count_out, teo_stream_t s) {
+    ENTER();
+    { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    NEED(ws, "workspace"); NEED(ms_out, "ms_out"); NEED(count_out, "count_out");
+    return llama_decode_batch_step_profile(d, st, ws, wsb, ms_out, count_out, ST(s));
 }
 
 int teo_llama_decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* st, void* ws, size_t wsb,

@@ -117,15 +117,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
                                                              const bf16_t* __restrict__ bias,
                                                              const bf16_t* res, void* Cv,
                                                              int M, int N, int K, int lda, int ldc, int act,
-                                                             int tiles_m, int tiles_n, int nfast) {
+                                                             int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    // an XCD owns a contiguous run of the tile sequence.  m fastest: the run shares a few W panels (its L2 keeps them) and streams
-    // all of A; n fastest (nfast): it shares a few A row blocks and streams all of W -- the host picks the order that streams the
-    // SMALLER operand through every XCD (ViT out_proj / fc2, projector: W is smaller than A)
-    const int tm = nfast ? tile / tiles_n : tile % tiles_m, tn = nfast ? tile % tiles_n : tile / tiles_m;
+    // an XCD owns a contiguous run of the tile sequence, m fastest: the run shares a few W panels (its L2 keeps them).  (n fastest --
+    // sharing A row blocks and streaming W -- was measured for the shapes where W is the smaller operand, ViT out_proj / fc2: 1-5 %
+    // slower, tools/vit_gemm_probe.py round 4; not kept.)
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
     constexpr int BMT = 32 * MF;
     const int m0 = tm * BMT, n0 = tn * BN;
 
@@ -574,12 +574,10 @@ static bool sk_grid_fits_device() {
 }
 static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
 static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
-static int g_gemm_order = 0;   // tile order of the plain kernel: 0 auto (stream the smaller operand through the XCDs), 1 m fastest, 2 n fastest
-void gemm_tune_reset() { g_gemm_order = 0; g_gemm_big = 1; g_gemm_wide = 1; g_gemm_sk_dbg = 0; g_gemm_sk = 1; g_gemm_depth = 0; g_gemm_bm = 0; }
+void gemm_tune_reset() { g_gemm_big = 1; g_gemm_wide = 1; g_gemm_sk_dbg = 0; g_gemm_sk = 1; g_gemm_depth = 0; g_gemm_bm = 0; }
 int gemm_tune_set(const char* key, int value) {
     if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
     if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
-    if (!strcmp(key, "gemm_order") && value >= 0 && value <= 2) { g_gemm_order = value; return 0; }
     if (!strcmp(key, "gemm_wide")) { g_gemm_wide = value; return 0; }
     if (!strcmp(key, "gemm_big")) { g_gemm_big = value; return 0; }
     if (!strcmp(key, "gemm_sk_dbg")) { g_gemm_sk_dbg = value; return 0; }
@@ -608,7 +606,9 @@ static bool gemm_wide_wins(int M, int N, int K, bool forced) {
     if (K < 2 * BK) return false;
     const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256), t_plain = (long long)cdiv(M, 128) * cdiv(N, 128);
     if (forced) return true;
-    if (t_wide < 208) return false;                                  // not enough tiles to fill the chip once (240 at M = 638, N = 12288: 57 vs 79 us)
+    // not enough tiles to fill the chip once (240 at M = 638, N = 12288: 57 vs 79 us); with a short K loop (K <= 1024: the tower's
+    // qkv at M = 2056, 204 wide tiles) the single round of wide tiles wins from 192 on (23.9 vs 29.6 us, tools/vit_gemm_probe.py)
+    if (t_wide < 208 && !(K <= 1024 && t_wide >= 192)) return false;
     // cost in rounds of the plain kernel; its ragged last round runs faster when it leaves one workgroup per CU (x 0.66, measured)
     const long long rem = t_plain % 512;
     const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
@@ -634,12 +634,10 @@ static int gemm_plain_launch(const void* A, const void* W, const void* bias, con
     const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, bm);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 4 * TILE_BYTES;
-    // n fastest when W (N x K) is the smaller operand AND an XCD's share of A rows (M / 8 x K) fits its 4 MB L2
-    const int nfast = g_gemm_order == 2 || (g_gemm_order == 0 && N < M && (size_t)cdiv(M, 8) * K * 2 <= ((size_t)3 << 20));
 #define TEO_GEMM_K(SW, OF, DP, MFV)                                                                                   \
     gemm_mfma_bf16_kernel<SW, OF, DP, MFV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                   (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
-                                                                  tiles_n, nfast)
+                                                                  tiles_n)
 #define TEO_GEMM_LAUNCH(SW, OF)                                                                                      \
     if (bm == 64) { TEO_GEMM_K(SW, OF, 2, 2); }                                                                       \
     else if ((g_gemm_depth == 0 && !(SW)) || g_gemm_depth == 2) { TEO_GEMM_K(SW, OF, 2, 4); }                         \

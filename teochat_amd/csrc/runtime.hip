@@ -514,31 +514,40 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
         const void* dn_w = w8 ? d->down_w8[l] : d->down_w[l];
         const float *qkv_s = w8 ? d->qkv_s[l] : nullptr, *o_s = w8 ? d->o_s[l] : nullptr;
         const float *gu_s = w8 ? d->gateup_s[l] : nullptr, *dn_s = w8 ? d->down_s[l] : nullptr;
+        prof_class(TEO_PROF_QKV);
         if (skinny) {
             TEO_TRY(skinny_gemm(w.hg, qkv_w, qkv_s, w8, nullptr, 0.f, nullptr, w.qkv, B, QKV, D, D, QKV, tl, dt, st, take));
         } else {
             TEO_TRY(batch_linear_rows(B, w.h, D, qkv_w, qkv_s, w8, d->in_norm_w[l], nullptr, w.qkv, QKV, QKV, D, d->eps, 0, dt, dt, st));
         }
         // RoPE + KV append of the B new tokens inside the attention kernel, each conversation at its own position
+        prof_class(TEO_PROF_ATTN);
         TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
                             s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt));
         if (skinny) {
             SkinnyFuse give;                               // h += attn Wo^T; hand post_norm its inputs
             give.next_g = (const unsigned short*)d->post_norm_w[l]; give.xg_out = (unsigned short*)w.hg; give.ssq_out = w.ssq;
+            prof_class(TEO_PROF_O);
             TEO_TRY(skinny_gemm(w.attn, o_w, o_s, w8, nullptr, 0.f, w.h, w.h, B, D, H * hd, H * hd, D, tl, dt, st, give));
+            prof_class(TEO_PROF_GATEUP);
             TEO_TRY(skinny_gemm(w.hg, gu_w, gu_s, w8, nullptr, 0.f, nullptr, w.act, B, 2 * F, D, D, F,
                                 tl | (s->gateup_block8 ? TEO_GEMM_SWIGLU8 : TEO_GEMM_SWIGLU16), dt, st, take));
             give.next_g = (const unsigned short*)(l + 1 < d->layers ? d->in_norm_w[l + 1] : d->final_norm_w);
+            prof_class(TEO_PROF_DOWN);
             TEO_TRY(skinny_gemm(w.act, dn_w, dn_s, w8, nullptr, 0.f, w.h, w.h, B, D, F, F, D, tl, dt, st, give));
         } else {
+            prof_class(TEO_PROF_O);
             TEO_TRY(batch_linear_rows(B, w.attn, H * hd, o_w, o_s, w8, nullptr, w.h, w.h, D, D, H * hd, d->eps, 0, dt, dt, st));
+            prof_class(TEO_PROF_GATEUP);
             TEO_TRY(batch_linear_rows(B, w.h, D, gu_w, gu_s, w8, d->post_norm_w[l], nullptr, w.act, F, 2 * F, D, d->eps,
                                       TEO_GEMM_SWIGLU16, dt, dt, st));
+            prof_class(TEO_PROF_DOWN);
             TEO_TRY(batch_linear_rows(B, w.act, F, dn_w, dn_s, w8, nullptr, w.h, w.h, D, D, F, d->eps, 0, dt, dt, st));
         }
     }
     const void* head_w = h8 ? d->lm_head8 : d->lm_head;
     const float* head_s = h8 ? d->lm_head_s : nullptr;
+    prof_class(TEO_PROF_LM_HEAD);
     if (skinny) {
         TEO_TRY(skinny_gemm(w.hg, head_w, head_s, h8, nullptr, 0.f, nullptr, s->d_logits, B, d->vocab, D, D, d->vocab, tl, TEO_F32, st, take));
     } else {
@@ -546,6 +555,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
                                   dt, TEO_F32, st));
     }
     const teo_decode_state t = batch_as_state(s);
+    prof_class(TEO_PROF_TAIL);
     if (skinny)
         return decode_tail(s->d_logits, &t, d->embed, w.h, d->vocab, D, dt, st, B, s->out_stride, d->in_norm_w[0], w.hg, w.ssq, w.nparts);
     return decode_tail(s->d_logits, &t, d->embed, w.h, d->vocab, D, dt, st, B, s->out_stride);
@@ -589,13 +599,13 @@ __global__ void prof_hold_kernel(unsigned long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
-int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out,
-                              int* count_out, hipStream_t st) {
+template <typename F>
+static int profiled_step(F step, float* ms_out, int* count_out, hipStream_t st, size_t reserve) {
     std::vector<ProfRec> recs;
-    recs.reserve(8 * (size_t)d->layers + 8);
+    recs.reserve(reserve);
     prof_hold_kernel<<<1, 64, 0, st>>>(400000ull);            // 4 ms
     g_prof = &recs;
-    const int rc = llama_decode_step(d, s, ws, ws_bytes, st);
+    const int rc = step();
     g_prof = nullptr;
     g_prof_cls = 0;
     hipError_t e = hipStreamSynchronize(st);
@@ -609,6 +619,17 @@ int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s
     }
     if (rc != TEO_OK) return rc;
     return e == hipSuccess ? TEO_OK : hip_fail(e, "teo_llama_decode_step_profile");
+}
+
+int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out,
+                              int* count_out, hipStream_t st) {
+    return profiled_step([&]() { return llama_decode_step(d, s, ws, ws_bytes, st); }, ms_out, count_out, st, 8 * (size_t)d->layers + 8);
+}
+
+int llama_decode_batch_step_profile(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes, float* ms_out,
+                                    int* count_out, hipStream_t st) {
+    return profiled_step([&]() { return llama_decode_batch_step(d, s, ws, ws_bytes, st); }, ms_out, count_out, st,
+                         8 * (size_t)d->layers * (size_t)std::max(1, s->batch) + 16);
 }
 
 // ------------------------------------------------------------------------------------------------

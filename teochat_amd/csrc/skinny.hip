@@ -34,7 +34,8 @@ constexpr int SK_TP = 16 * 17;      // padded 16x16 partial tile in LDS: [b][i] 
 static int g_sk_tiles = 0;          // 0 = auto
 static int g_sk_nt = 1;
 static int g_sk_stream = 1;         // 0 = never, 1 = auto, 2 = whenever the streaming form is eligible
-static int g_sk_ring = 0;           // streaming form, register sets in flight: 0 = auto (3 tiles fp8 / 2 tiles bf16), 1 = one tile less
+static int g_sk_ring = 0;           // streaming form, weight tiles in flight per wave: 0 = default (2 fp8 / 1 bf16: measured best end to end,
+                                    // B = 8 fp8 step 3.455 vs 3.54 ms), 1 = one more (3 / 2)
 static int g_sk_unr = 0;            // tile kernel, steps per register set: 0 = auto (8 for long K slices without SwiGLU / in-kernel norm), 4, 8
 void skinny_tune_reset() { g_sk_tiles = 0; g_sk_nt = 1; g_sk_stream = 1; g_sk_unr = 0; g_sk_ring = 0; }
 int skinny_tune_set(const char* key, int value) {
@@ -351,10 +352,10 @@ _Pragma("unroll") \
 // blockIdx.x, blockIdx.x + gridDim.x, ...:
 //   * the slice's activation fragments are loaded ONCE into registers (PER steps x 16 B [x 2 for fp8] per lane = 64
 //     VGPRs at K = 4096) -- no activation traffic after the first tile, and only weight loads in the vmcnt queue;
-//   * the weight stream is one flat ring of NS register sets (8 loads each) ACROSS tiles: 3 tiles of fp8 weights (2 of bf16)
-//     are requested before the first is multiplied -- 24 / 32 KB per wave in flight from the first cycle to the last tile
-//     (round 4, tools/skinny_probe.py: with two sets the first tile of a launch completed 5.4 us after the workgroup
-//     started and every launch ended ~4.5 us later than its bytes / 6.4 TB/s);
+//   * the weight stream is one flat ring of NS register sets (8 loads each) ACROSS tiles.  Measured (round 4, tools/skinny_probe.py,
+//     bench.py --batch 8 --weights fp8): deeper is NOT better -- the memory system returns the sets of all waves interleaved, so
+//     with 3 fp8 tiles requested up front the FIRST tile of a workgroup completes after 7.2 us instead of 5.4 and the tiles then
+//     finish 1.9 us apart (the conversion + MFMA rate of a CU), 3.54 ms per B = 8 step against 3.455 with 2 tiles: NS = 2 ships;
 //   * the epilogue is done by ALL waves, one output per thread (fixed-order sum of the 8 partial tiles from double-buffered
 //     LDS, 1/rms, fp8 scale, SwiGLU, residual, rounding, the next norm's hand-off), its operands requested one tile ahead
 //     with unconditional (clamped) loads.  Round 3 had a ninth wave for it: its loads sat behind a branch, so the compiler
@@ -581,9 +582,9 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
             const int cus = device_cu_count();
             const int grid = std::max(1, std::min(ntiles, cus > 0 ? cus : 256));
 #define TEO_SS(WW, UN, SP, NSV, SW)                                                                         \
-            skinny_stream_kernel<WW, UN, SP, NSV, SW><<<grid, SK_THREADS, 0, st>>>((const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
-                                                                                   out, MB, N, K, ldx, ldo, tiled, of, fuse)
-            if (g_sk_ring == 1) {
+            TEO_KLAUNCH((skinny_stream_kernel<WW, UN, SP, NSV, SW>), grid, SK_THREADS, 0, st, (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
+                        out, MB, N, K, ldx, ldo, tiled, of, fuse)
+            if (g_sk_ring == 0) {
                 if (w_fp8) { if (sw8) TEO_SS(fp8_t, 8, 1, 2, true); else TEO_SS(fp8_t, 8, 1, 2, false); }
                 else       { if (sw8) TEO_SS(bf16_t, 8, 2, 2, true); else TEO_SS(bf16_t, 8, 2, 2, false); }
             } else {
@@ -605,16 +606,16 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     const int steps_per_wave = K / (w_fp8 ? 64 : 32) / (SK_WAVES / rt);
     const bool unr8 = !swiglu && !norm_w && g_sk_nt && (g_sk_unr == 8 || (g_sk_unr == 0 && steps_per_wave >= 16 && blocks <= 2 * std::max(device_cu_count(), 1)));
     if (unr8) {
-        if (w_fp8) skinny_gemm_kernel<fp8_t, 6, true, false, false><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, nullptr, eps,
-                       (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
-        else       skinny_gemm_kernel<bf16_t, 8, true, false, false><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, nullptr, eps,
-                       (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
+        if (w_fp8) TEO_KLAUNCH((skinny_gemm_kernel<fp8_t, 6, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const fp8_t*)W, wscale,
+                               (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
+        else       TEO_KLAUNCH((skinny_gemm_kernel<bf16_t, 8, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const bf16_t*)W, wscale,
+                               (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
         note_kernel("skinny_gemm_u8");
         TEO_LAUNCH_CHECK("skinny_gemm");
         return TEO_OK;
     }
 #define TEO_SK(WW, NTV, SW, NM)                                                                            \
-    skinny_gemm_kernel<WW, 4, NTV, SW, NM><<<blocks, SK_THREADS, dyn, st>>>(                               \
+    TEO_KLAUNCH((skinny_gemm_kernel<WW, 4, NTV, SW, NM>), blocks, SK_THREADS, dyn, st,                     \
         (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)norm_w, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, \
         tiled, of, rt, fuse, sw8)
 #define TEO_SK_N(WW, NTV, SW) if (norm_w) { TEO_SK(WW, NTV, SW, true); } else { TEO_SK(WW, NTV, SW, false); }

@@ -26,11 +26,17 @@ def R(t):
     return t.to(bf).float()
 
 
-def within_one_ulp(got, ref, tag):
+def p_noise(q, k, v, visible, scale):
+    """allowance for the bf16 rounding of P before the PV product (both sides round P, each at its own 1-ulp-different value):
+    2^-8 * sum_j p_j |v_j| per output, whatever the output's own magnitude -- see tests/test_true_shapes_gpu.py attn_p_noise"""
+    return (2.0 ** -8) * O.attention_core(q, k, v.abs(), visible, scale, lambda t: t, "exact")
+
+
+def within_one_ulp(got, ref, tag, abs_tol=0.0):
     got = got.float().cpu()
     d = (got - ref).abs()
     ulp = G.ulp16(ref)                                       # exact ulp of the oracle's value (frexp), + 1e-5 for fp32 summation order
-    bad = int((d > ulp + 1e-5).sum())
+    bad = int((d > ulp + 1e-5 + abs_tol).sum())
     assert bad == 0, f"{tag}: {bad} / {d.numel()} elements beyond 1 bf16 ulp (worst {float((d / ulp).max()):.2f} ulp, max diff {float(d.max()):.3e})"
 
 
@@ -72,7 +78,7 @@ def test_llama_layer_walk_bf16_mfma():
     a.vt_hs, a.vt_rs, a.o_rs = hd * S_max, S_max, H * hd
     a.batch, a.heads, a.kv_heads, a.head_dim, a.q_len, a.kv_len, a.causal, a.scale = 1, H, H, hd, S, S, 1, 1 / math.sqrt(hd)
     L.check(G.lib().teo_attention(C.byref(a), L.TEO_BF16, G.stream()), "attn")
-    within_one_ulp(o_k, o_ref, "flash attention")
+    within_one_ulp(o_k, o_ref, "flash attention", p_noise(qq, kk, vv, vis, 1 / math.sqrt(hd)).transpose(1, 2).reshape(S, H * hd))
     Wo = sd[p + "self_attn.o_proj.weight"]
     h1 = R(h + o_ref @ Wo.t())
     within_one_ulp(G.gemm(G.dev(o_ref, bf), G.dev(Wo, bf), res=G.dev(h, bf)), h1, "o_proj + residual")
@@ -111,7 +117,7 @@ def test_vit_layer_walk_bf16_mfma():
     o_ref = R(O.attention_core(q, k, v, None, hd ** -0.5, R, "flash64").transpose(1, 2).reshape(T * N, D))
     qd, kd, vd = (G.dev(t.contiguous(), bf) for t in (q, k, v))
     o_k = G.attention(qd, kd, vd, False, hd ** -0.5, vt=G.make_vt(vd))
-    within_one_ulp(o_k.reshape(T * N, D), o_ref, "flash attention (N=257, d=64)")
+    within_one_ulp(o_k.reshape(T * N, D), o_ref, "flash attention (N=257, d=64)", p_noise(q, k, v, None, hd ** -0.5).transpose(1, 2).reshape(T * N, D))
     Wo, bo = sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"]
     h1 = R(h + o_ref @ Wo.t() + bo)
     within_one_ulp(G.gemm(G.dev(o_ref, bf), G.dev(Wo, bf), bias=G.dev(bo, bf), res=G.dev(h, bf)), h1, "out_proj + bias + residual")

@@ -289,8 +289,8 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes():
     m = R(F.gelu(ln2 @ w["fc1"].t() + b["fc1"]))
     gemm_all_families(gw, G.dev(ln2, bf), G.dev(w["fc1"], bf), m, "fc1 + bias + GELU(erf) N=4096", report, families=fam,
                       bias=G.dev(b["fc1"], bf), act=L.ACT_GELU_ERF)
-    mq = R(ln2 @ w["fc1"].t() + b["fc1"])
-    mq = R(mq * torch.sigmoid(1.702 * mq))
+    zq = ln2 @ w["fc1"].t() + b["fc1"]                     # one rounding, after the activation: what oracle.vit_layer and the kernel do
+    mq = R(zq * torch.sigmoid(1.702 * zq))
     gemm_all_families(gw, G.dev(ln2, bf), G.dev(w["fc1"], bf), mq, "fc1 + bias + quick_gelu N=4096", report, families=fam[:1],
                       bias=G.dev(b["fc1"], bf), act=L.ACT_QUICK_GELU)
     h2 = R(h1 + m @ w["fc2"].t() + b["fc2"])

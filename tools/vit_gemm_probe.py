@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The four GEMMs of a ViT-L/14 encoder layer at T = 8 (M = 2056) and the projector (M = 2048): every tile family and both tile
-orders of the plain kernel (gemm_order 1 = m fastest, 2 = n fastest), weights of 8 layers in rotation.  usage: python tools/vit_gemm_probe.py"""
+"""The four GEMMs of a ViT-L/14 encoder layer at T = 8 (M = 2056) and the projector (M = 2048): every tile family, weights of 8 layers in
+rotation.  (Round 4 also ran it with an n-fastest tile order and an in-workgroup split-K kernel; both lost -- profiles/r04_vit_gemm_probe.txt.)  usage: python tools/vit_gemm_probe.py"""
 import os
 import sys
 
@@ -13,10 +13,8 @@ from tests import _gpu as G  # noqa: E402
 
 lib = L.load()
 bf = torch.bfloat16
-FAM = (("auto", {}), ("plain m-fast", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_order": 1}),
-       ("plain n-fast", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_order": 2}),
-       ("plain 128 rows m", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_bm": 128, "gemm_order": 1}),
-       ("plain 128 rows n", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_bm": 128, "gemm_order": 2}),
+FAM = (("auto", {}), ("plain", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0}),
+       ("plain 128 rows", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_bm": 128}),
        ("128 sk", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2}), ("128x256", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0}),
        ("128x256 sk", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}), ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0}),
        ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2}))
