@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--shard-frames", action="store_true", help="C4 mode: one conversation, ViT frames sharded over ranks + all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit storage / compute format: bf16 = BASELINE.json's headline; "
+                    "fp16 = the reference's own inference dtype (builder.py:105), same kernels on v_mfma_*_f16 / v_dot2_f32_f16")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8 = config C5 weight path (decode streams fp8-e4m3 weights); the headline is bf16")
     ap.add_argument("--prefill", default="auto", choices=["auto", "bf16", "fp8"], help="prefill Linear layers: bf16 MFMA on the (dequantised) weights, or w8a8 on the fp8 MFMA (default with --weights fp8)")
     ap.add_argument("--batch", type=int, default=1, help="config C5 variant: B conversations per GPU decoded together (weights streamed once per step)")
@@ -305,7 +307,9 @@ def main():
     T, n_text, n_out = args.frames, args.prompt, args.new
     Lseq = n_text - T + 256 * T
     max_seq = (Lseq + n_out + 255) // 256 * 256
-    dtype = torch.bfloat16
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    if args.dtype == "fp16" and args.weights == "fp8":
+        raise SystemExit("--weights fp8 goes with --dtype bf16 (the e4m3 row scales are exact in bfloat16 only)")
     tok, model, _, _ = load_pretrained_model("synthetic:teochat-7b", None, "synthetic:teochat-7b", device=device,
                                              dtype=dtype, max_seq=max_seq, weight_format=("fp8" if args.weights == "fp8" else None))
     eng = model.engine
@@ -517,7 +521,7 @@ def main():
             shim = bench_shim.load()
             with eng.phase() as st:
                 L.check(shim.teo_bench_gemv_chain(x.data_ptr(), pp, None, len(Ws), eng.llama_w["post_norm"][0].data_ptr(), y.data_ptr(),
-                                                  2 * Fi, Dh, cfg.rms_norm_eps, L.GEMM_SWIGLU16, L.TEO_BF16, 5, C.byref(avg), st),
+                                                  2 * Fi, Dh, cfg.rms_norm_eps, L.GEMM_SWIGLU16, eng.dt, 5, C.byref(avg), st),
                         "teo_bench_gemv_chain")
             chain_ms = avg.value
         except Exception as e:  # noqa: BLE001
@@ -549,7 +553,7 @@ def main():
     share = {k_: v_[0] * v_[1] for k_, v_ in prof.items()}
     share["attn_decode_partial"] = share.get("attn_decode_partial", 0.0) + share.pop("attn_decode_combine", 0.0)
     dom = max(share, key=share.get)
-    w_tag = "fp8-e4m3 weights" if args.weights == "fp8" else "bf16 weights"
+    w_tag = "fp8-e4m3 weights" if args.weights == "fp8" else f"{args.dtype} weights"
     if B > 1:
         kern_names = {"attn_decode_partial": f"attn_decode_whole_kernel<bf16, 16 lanes per row, 64-key chunks, RoPE + KV append> (batched decode attention: {B} conversations x 32 heads x {ctx_prof} keys)",
                       "gateup_gemv": f"skinny_stream_kernel<{w_tag}, SWIGLU8> (batched decode gate/up + SwiGLU, {B} rows, N=22016 K=4096)",
@@ -558,7 +562,7 @@ def main():
                       "o_gemv": f"skinny_gemm_kernel<{w_tag}> (batched decode o + residual, {B} rows)",
                       "lm_head_gemv": f"skinny_stream_kernel<{w_tag}> (batched lm_head, {B} rows, N=32000)"}
     else:
-        kern_names = {"gateup_gemv": ("gemv_kernel<bf16,bf16,R=2,U=4,NT,SWIGLU> (decode rmsnorm + gate/up + SwiGLU, N=22016 K=4096)" if args.weights == "bf16"
+        kern_names = {"gateup_gemv": (f"gemv_kernel<{args.dtype},{args.dtype},R=2,U=4,NT,SWIGLU> (decode rmsnorm + gate/up + SwiGLU, N=22016 K=4096)" if args.weights == "bf16"
                                       else "gemv_kernel<fp8 weights, SWIGLU> (decode rmsnorm + gate/up + SwiGLU)"),
                       "attn_decode_partial": "attn_decode_partial_kernel + attn_decode_combine_kernel (decode attention pair)",
                       "qkv_rope_gemv": f"gemv_qkv_rope_kernel<{w_tag}> (decode rmsnorm + qkv + RoPE + KV append)",
@@ -616,7 +620,7 @@ def main():
         "metric": "end-to-end tokens/sec (prefill+decode), T=8 frames, LLaMA-2-7B",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if args.weights == "bf16" else ("bf16 activations / fp8-e4m3 weights (decode: fp8 weight stream; prefill: "
+        "vs_baseline": None, "dtype": args.dtype if args.weights == "bf16" else ("bf16 activations / fp8-e4m3 weights (decode: fp8 weight stream; prefill: "
                                                        + ("w8a8 on the fp8 MFMA)" if prefill_fp8 else "bf16 MFMA on the dequantised weights)")), "data": "synthetic",
         "config": {"workload": f"{workload_label(T, n_text, n_out, B, args.shard_frames, args.weights)}: T={T} frames 224x224 -> CLIP-ViT-L/14 (23 layers) -> mlp2x_gelu -> splice of a "
                                f"{n_text}-token prompt (L={Lseq}) -> LLaMA-2-7B prefill -> {n_out} forced greedy tokens; "

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef void* teo_stream_t; /* hipStream_t */
 
-typedef enum { TEO_F32 = 0, TEO_BF16 = 1 } teo_dtype;
+typedef enum { TEO_F32 = 0, TEO_BF16 = 1, TEO_F16 = 2 /* IEEE binary16: the reference's inference dtype (builder.py:105) */ } teo_dtype;
 typedef enum { TEO_ACT_NONE = 0, TEO_ACT_GELU_ERF = 1, TEO_ACT_QUICK_GELU = 2 } teo_act;
 typedef enum {
     TEO_OK = 0,
@@ -44,6 +44,7 @@ typedef enum {
 #define TEO_GEMM_SWIGLU16 1u /* W rows are [gate16|up16] interleaved; C[M, N/2] = silu(g) * u */
 #define TEO_GEMM_FORCE_SIMPLE 2u /* use the shape-agnostic VALU kernel even when the MFMA kernel applies */
 #define TEO_GEMM_SWIGLU8 8u /* teo_gemm_skinny: like SWIGLU16 with gate/up rows interleaved in blocks of 8 */
+#define TEO_GEMM_F16 16u /* teo_gemm_skinny: x / W / residual are IEEE half (implied by a TEO_F16 output; needed with a TEO_F32 one) */
 #define TEO_GEMM_WTILED 4u /* teo_gemm_skinny: W is stored as 1 KB operand tiles (16 rows x 32 k bf16 / 64 k fp8), see below */
 
 int teo_version(void);

@@ -9,9 +9,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libteo_hip.so")
 
-TEO_F32, TEO_BF16 = 0, 1
+TEO_F32, TEO_BF16, TEO_F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2
-GEMM_SWIGLU16, GEMM_FORCE_SIMPLE, GEMM_WTILED, GEMM_SWIGLU8 = 1, 2, 4, 8
+GEMM_SWIGLU16, GEMM_FORCE_SIMPLE, GEMM_WTILED, GEMM_SWIGLU8, GEMM_F16 = 1, 2, 4, 8, 16
 ATTN_FORCE_SIMPLE = 1
 INT32_MIN = -(2 ** 31)
 

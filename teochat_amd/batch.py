@@ -45,7 +45,7 @@ class BatchDecoder:
         d = L.LlamaDesc.from_buffer_copy(self.slot_desc[0])
         fp8 = engine.llama_w8 is not None
         ks = 64 if fp8 else 32
-        self.tiled = bool(tiled) and dt == torch.bfloat16 and c.hidden_size % ks == 0 and c.intermediate_size % ks == 0 \
+        self.tiled = bool(tiled) and dt in (torch.bfloat16, torch.float16) and c.hidden_size % ks == 0 and c.intermediate_size % ks == 0 \
             and (c.num_attention_heads * hd) % ks == 0
         self.tiled_w = None
         self.block8 = False

@@ -309,9 +309,14 @@ def load_generation_config(model, model_dir):
 
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto",
-                          device="cuda", cache_dir=None, dtype=torch.bfloat16, max_seq=None, seed=2, weight_format=None):
+                          device="cuda", cache_dir=None, dtype=None, max_seq=None, seed=2, weight_format=None):
+    """dtype None = the reference's choice where it has one: a real checkpoint runs in torch.float16 (builder.py:105 passes
+    torch_dtype=torch.float16 whatever the file holds; eval/inference.py:53 casts the frames to match) -- unless fp8 decode weights are
+    requested, which go with bfloat16 -- and the synthetic presets in torch.bfloat16 (BASELINE.json's headline dtype)."""
     if device in (None, "cuda"):
         device = "cuda:0"
+    if dtype is None:
+        dtype = torch.bfloat16 if (model_path.startswith("synthetic:") or weight_format == "fp8") else torch.float16
     if load_8bit or load_4bit:
         warnings.warn("bitsandbytes int8/nf4 loading is CUDA-only and out of scope; loading bf16 weights instead")
     if model_path.startswith("synthetic:"):
@@ -320,13 +325,16 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         anchored = preset.endswith("-anchored")          # decisive-margin variant for full-size token checks (synthetic.py)
         if anchored:
             preset = preset[:-len("-anchored")]
+        realistic = preset.endswith("-realistic")        # trained-checkpoint statistics: heavy tails, massive activations, non-unit gains
+        if realistic:
+            preset = preset[:-len("-realistic")]
         if preset in ("teochat-7b", "teochat", "llava-7b"):
             cfg = teochat_7b_config()
         elif preset == "tiny":
             cfg = tiny_config()
         else:
             raise ValueError(f"unknown synthetic preset {preset!r}")
-        sd = synthetic_state_dict(cfg, seed=seed, std=0.02 if preset != "tiny" else 0.08, dtype=dtype, device=device, anchored=anchored)
+        sd = synthetic_state_dict(cfg, seed=seed, std=0.02 if preset != "tiny" else 0.08, dtype=dtype, device=device, anchored=anchored, realistic=realistic)
         tokenizer = ByteTokenizer()
     else:
         if "llava" not in model_name.lower() and "teochat" not in model_name.lower():

@@ -60,7 +60,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
 int decode_batch_graph_create(const teo_llama_desc* d, const teo_decode_batch_state* s, void* ws, size_t ws_bytes,
                               hipStream_t st, teo_graph** out);
 
-static bool dtype_ok(int dt) { return dt == TEO_F32 || dt == TEO_BF16; }
+static bool dtype_ok(int dt) { return dt == TEO_F32 || dt == TEO_BF16 || dt == TEO_F16; }
 
 }  // namespace teo
 
@@ -190,7 +190,7 @@ int teo_patch_embed(const void* px, const void* W, void* out, int T, int channel
         set_error("teo_patch_embed: needs bf16, image %% patch == 0, ldw %% 64 == 0 and >= channels * patch^2, dim %% 4 == 0, 16-byte aligned weight");
         return TEO_ERR_UNSUPPORTED;
     }
-    return patch_embed(px, W, out, T, channels, image, patch, ldw, dim, ST(s));
+    return patch_embed(px, W, out, T, channels, image, patch, ldw, dim, ST(s), dtype == TEO_F16);
 }
 
 int teo_vit_embed_ln(const void* patch, const void* cls, const void* pos, const void* w, const void* b, void* out, int T,
@@ -488,7 +488,7 @@ int teo_gemm_skinny(const void* x, const void* W, const float* w_scale, int w_fp
                     void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, teo_stream_t s) {
     ENTER();
     TEO_CHECK_ARG(MB >= 0 && N >= 0 && K > 0, "teo_gemm_skinny: MB %d N %d K %d", MB, N, K);
-    TEO_CHECK_ARG(out_dtype == TEO_BF16 || out_dtype == TEO_F32, "teo_gemm_skinny: out_dtype %d", out_dtype);
+    TEO_CHECK_ARG(out_dtype == TEO_BF16 || out_dtype == TEO_F32 || out_dtype == TEO_F16, "teo_gemm_skinny: out_dtype %d", out_dtype);
     if (MB == 0 || N == 0) return TEO_OK;
     NEED(x, "x"); NEED(W, "W"); NEED(out, "out");
     return skinny_gemm(x, W, w_scale, w_fp8, norm_w, eps, res, out, MB, N, K, ldx, ldo, flags, out_dtype, ST(s));

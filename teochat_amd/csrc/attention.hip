@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void attn_simple_kernel(teo_attn_args a) {
 }
 
 bool attn_mfma_ok(const teo_attn_args& a, int dtype) {
-    if (dtype != TEO_BF16 || (a.flags & TEO_ATTN_FORCE_SIMPLE) || a.vt == nullptr) return false;
+    if ((dtype != TEO_BF16 && dtype != TEO_F16) || (a.flags & TEO_ATTN_FORCE_SIMPLE) || a.vt == nullptr) return false;
     if (a.head_dim != 64 && a.head_dim != 128) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al16(a.q) || !al16(a.k) || !al16(a.vt) || (reinterpret_cast<uintptr_t>(a.o) & 7)) return false;
@@ -75,7 +75,7 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
     if (a.q_len == 0 || a.batch == 0) return TEO_OK;
     TEO_CHECK_ARG(a.heads % a.kv_heads == 0, "teo_attention: heads %d not a multiple of kv_heads %d", a.heads, a.kv_heads);
     TEO_CHECK_ARG(a.kv_len >= a.q_len || !a.causal, "teo_attention: causal needs kv_len >= q_len");
-    if (attn_mfma_ok(a, dtype)) return attention_flash32(a, st);
+    if (attn_mfma_ok(a, dtype)) return attention_flash32(a, st, dtype == TEO_F16);
     TEO_CHECK_ARG(a.v != nullptr, "teo_attention: generic kernel needs row-major V");
     const size_t lds = (size_t)(a.head_dim + a.kv_len) * sizeof(float);
     if (lds > 64 * 1024) {
@@ -84,6 +84,7 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
     }
     dim3 grid(a.q_len, a.heads, a.batch);
     if (dtype == TEO_F32) attn_simple_kernel<float><<<grid, 64, lds, st>>>(a);
+    else if (dtype == TEO_F16) attn_simple_kernel<f16_t><<<grid, 64, lds, st>>>(a);
     else attn_simple_kernel<bf16_t><<<grid, 64, lds, st>>>(a);
     note_kernel("attn_simple"); TEO_LAUNCH_CHECK("attn_simple");
     return TEO_OK;
@@ -122,6 +123,16 @@ template <> struct Cvt16<bf16_t> {
         return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
     }
 };
+template <> struct Cvt16<f16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
+        f[0] = h_lo<true>(r.x); f[1] = h_hi<true>(r.x); f[2] = h_lo<true>(r.y); f[3] = h_hi<true>(r.y);
+        f[4] = h_lo<true>(r.z); f[5] = h_hi<true>(r.z); f[6] = h_lo<true>(r.w); f[7] = h_hi<true>(r.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3]), pack_f16x2(f[4], f[5]), pack_f16x2(f[6], f[7]));
+    }
+};
 template <> struct Cvt16<float> {
     static constexpr int N = 4;
     __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
@@ -132,10 +143,8 @@ template <> struct Cvt16<float> {
     }
 };
 
-typedef __bf16 attn_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float attn_dot2(unsigned a, unsigned b, float acc) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(attn_bf16x2, a), __builtin_bit_cast(attn_bf16x2, b), acc, false);
-}
+// two packed 16-bit products + fp32 accumulate: v_dot2_f32_bf16 / v_dot2_f32_f16 by the element type
+#define attn_dot2 dot2h<IsF16<T>::v>
 
 // K/V rows are read once per step: non-temporal 16-byte loads (streamed past L2 like the GEMV weight stream)
 typedef __attribute__((ext_vector_type(4))) unsigned int kv_u32x4;
@@ -401,7 +410,8 @@ __global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* _
 //   * the records stay in LDS and are merged by the same code as the combine launch (attn_merge_records) -> the output is
 //     bit-identical to the two-launch path with the same chunk size (tested).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int LPR, int DEC_CHUNK, bool ROPE, int AW_WAVES, bool PROBE = false>   // PROBE (tools/attn_probe.hip only): loads without the arithmetic
+template <typename T, int LPR, int DEC_CHUNK, bool ROPE, int AW_WAVES, bool PROBE = false, bool RING8 = false>   // PROBE (tools/attn_probe.hip only): loads without the arithmetic
+// RING8: eight ring slots (the K AND V quarters of a whole chunk in flight, each refilled with the same quarter of the next chunk)
 __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const T* __restrict__ q, T* __restrict__ kc, T* __restrict__ vc,
                                                                           T* __restrict__ vtc, const float* __restrict__ cs,
                                                                           const float* __restrict__ sn, T* __restrict__ o,
@@ -438,6 +448,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
 
     // quarter `qt` of chunk `c` into a ring slot.  Unconditional: a wave without a next chunk re-reads row 0 of the head (cached)
     uint4 r0[NI], r1[NI], r2[NI], r3[NI];
+    uint4 r4[RING8 ? NI : 1], r5[RING8 ? NI : 1], r6[RING8 ? NI : 1], r7[RING8 ? NI : 1];      // RING8: the V quarters' own slots
 #define TEO_AW_ISSUE(SLOT, BASE, C, QT, LIVE)                                                                          \
     _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                                   \
         const int j = (LIVE) ? min((C) * DEC_CHUNK + (QT) * KPQ + i * RPI + grp, kv_len - 1) : 0;                      \
@@ -450,6 +461,12 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
         TEO_AW_ISSUE(r1, kb, c, 1, live)
         TEO_AW_ISSUE(r2, kb, c, 2, live)
         TEO_AW_ISSUE(r3, kb, c, 3, live)
+        if constexpr (RING8) {
+            TEO_AW_ISSUE(r4, vb, c, 0, live)
+            TEO_AW_ISSUE(r5, vb, c, 1, live)
+            TEO_AW_ISSUE(r6, vb, c, 2, live)
+            TEO_AW_ISSUE(r7, vb, c, 3, live)
+        }
     }
     float qf[VE];
     uint4 knew_pk = make_uint4(0, 0, 0, 0), vnew_pk = make_uint4(0, 0, 0, 0);     // the new token's rotated key / value, in the storage type
@@ -564,14 +581,25 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
         const int cn = c + AW_WAVES;
         const bool nlive = cn < nact;
         // ---- scores, quarter by quarter; each consumed K slot is refilled with the same quarter of V
-        TEO_AW_SCORES(r0, 0)
-        TEO_AW_ISSUE(r0, vb, c, 0, true)
-        TEO_AW_SCORES(r1, 1)
-        TEO_AW_ISSUE(r1, vb, c, 1, true)
-        TEO_AW_SCORES(r2, 2)
-        TEO_AW_ISSUE(r2, vb, c, 2, true)
-        TEO_AW_SCORES(r3, 3)
-        TEO_AW_ISSUE(r3, vb, c, 3, true)
+        if constexpr (RING8) {
+            TEO_AW_SCORES(r0, 0)
+            TEO_AW_ISSUE(r0, kb, cn, 0, nlive)
+            TEO_AW_SCORES(r1, 1)
+            TEO_AW_ISSUE(r1, kb, cn, 1, nlive)
+            TEO_AW_SCORES(r2, 2)
+            TEO_AW_ISSUE(r2, kb, cn, 2, nlive)
+            TEO_AW_SCORES(r3, 3)
+            TEO_AW_ISSUE(r3, kb, cn, 3, nlive)
+        } else {
+            TEO_AW_SCORES(r0, 0)
+            TEO_AW_ISSUE(r0, vb, c, 0, true)
+            TEO_AW_SCORES(r1, 1)
+            TEO_AW_ISSUE(r1, vb, c, 1, true)
+            TEO_AW_SCORES(r2, 2)
+            TEO_AW_ISSUE(r2, vb, c, 2, true)
+            TEO_AW_SCORES(r3, 3)
+            TEO_AW_ISSUE(r3, vb, c, 3, true)
+        }
         __builtin_amdgcn_wave_barrier();
         // ---- chunk max / exp / sum: the split kernel's expressions over the same strip
         float sv[SPL];
@@ -593,14 +621,25 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
         __builtin_amdgcn_wave_barrier();
         // ---- PV, quarter by quarter; each consumed V slot is refilled with the next chunk's K quarter
         float ot[VE];                                      // ((q0 + q1) + q2) + q3, the order the split kernel adds its four waves
-        TEO_AW_PV(r0, 0, ot)
-        TEO_AW_ISSUE(r0, kb, cn, 0, nlive)
-        TEO_AW_PV(r1, 1, ot)
-        TEO_AW_ISSUE(r1, kb, cn, 1, nlive)
-        TEO_AW_PV(r2, 2, ot)
-        TEO_AW_ISSUE(r2, kb, cn, 2, nlive)
-        TEO_AW_PV(r3, 3, ot)
-        TEO_AW_ISSUE(r3, kb, cn, 3, nlive)
+        if constexpr (RING8) {
+            TEO_AW_PV(r4, 0, ot)
+            TEO_AW_ISSUE(r4, vb, cn, 0, nlive)
+            TEO_AW_PV(r5, 1, ot)
+            TEO_AW_ISSUE(r5, vb, cn, 1, nlive)
+            TEO_AW_PV(r6, 2, ot)
+            TEO_AW_ISSUE(r6, vb, cn, 2, nlive)
+            TEO_AW_PV(r7, 3, ot)
+            TEO_AW_ISSUE(r7, vb, cn, 3, nlive)
+        } else {
+            TEO_AW_PV(r0, 0, ot)
+            TEO_AW_ISSUE(r0, kb, cn, 0, nlive)
+            TEO_AW_PV(r1, 1, ot)
+            TEO_AW_ISSUE(r1, kb, cn, 1, nlive)
+            TEO_AW_PV(r2, 2, ot)
+            TEO_AW_ISSUE(r2, kb, cn, 2, nlive)
+            TEO_AW_PV(r3, 3, ot)
+            TEO_AW_ISSUE(r3, kb, cn, 3, nlive)
+        }
         __builtin_amdgcn_wave_barrier();                   // the strip is rewritten by the next chunk's scores
         float* rc = rec + (long long)c * STRIDE;
         if (grp == 0) {
@@ -682,6 +721,9 @@ static int attn_whole_launch(const void* q, void* kc, void* vc, void* vtc, const
     if (dtype == TEO_F32) {
         switch (lpr) { case 4: TEO_AWL(float, 4); case 8: TEO_AWL(float, 8); case 16: TEO_AWL(float, 16); case 32: TEO_AWL(float, 32); default: return TEO_ERR_UNSUPPORTED; }
     }
+    if (dtype == TEO_F16) {
+        switch (lpr) { case 4: TEO_AWL(f16_t, 4); case 8: TEO_AWL(f16_t, 8); case 16: TEO_AWL(f16_t, 16); case 32: TEO_AWL(f16_t, 32); default: return TEO_ERR_UNSUPPORTED; }
+    }
     switch (lpr) { case 4: TEO_AWL(bf16_t, 4); case 8: TEO_AWL(bf16_t, 8); case 16: TEO_AWL(bf16_t, 16); case 32: TEO_AWL(bf16_t, 32); default: return TEO_ERR_UNSUPPORTED; }
 #undef TEO_AWL
 }
@@ -723,6 +765,9 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
     if (dtype == TEO_F32) {
         switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
                        case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }
+    } else if (dtype == TEO_F16) {
+        switch (lpr) { case 2: TEO_DEC(f16_t, 2); break; case 4: TEO_DEC(f16_t, 4); break; case 8: TEO_DEC(f16_t, 8); break;
+                       case 16: TEO_DEC(f16_t, 16); break; default: TEO_DEC(f16_t, 32); }
     } else {
         switch (lpr) { case 2: TEO_DEC(bf16_t, 2); break; case 4: TEO_DEC(bf16_t, 4); break; case 8: TEO_DEC(bf16_t, 8); break;
                        case 16: TEO_DEC(bf16_t, 16); break; default: TEO_DEC(bf16_t, 32); }

@@ -163,7 +163,7 @@ int teo_allgather_visual(teo_ctx* ctx, const void* d_local, void* d_out, int row
                          teo_stream_t stream) {
     TEO_CHECK_ARG(ctx != nullptr, "teo_allgather_visual: null ctx");
     TEO_CHECK_ARG(rows_per_rank >= 0 && dim > 0, "teo_allgather_visual: rows_per_rank %d dim %d", rows_per_rank, dim);
-    TEO_CHECK_ARG(dtype == TEO_F32 || dtype == TEO_BF16, "teo_allgather_visual: dtype %d", dtype);
+    TEO_CHECK_ARG(dtype == TEO_F32 || dtype == TEO_BF16 || dtype == TEO_F16, "teo_allgather_visual: dtype %d", dtype);      // 16-bit formats move as bits
     if (rows_per_rank == 0) return TEO_OK;
     TEO_CHECK_ARG(d_local != nullptr && d_out != nullptr, "teo_allgather_visual: null buffer");
     const size_t count = (size_t)rows_per_rank * dim;

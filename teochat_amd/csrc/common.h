@@ -10,7 +10,9 @@
 
 namespace teo {
 
-typedef unsigned short bf16_t;   // raw bf16 bits
+typedef unsigned short bf16_t;   // raw bits of a 16-bit float.  The MFMA / GEMV kernels take these pointers for BOTH 16-bit formats and
+                                 // select the arithmetic with a template flag (F16 = false: bfloat16, true: IEEE binary16, below)
+struct f16_t { unsigned short bits; };   // the same bits as a DISTINCT type, for the kernels templated on the element type (Elem<T>)
 
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
@@ -61,6 +63,38 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
+// ---- IEEE binary16 (fp16): the reference's inference dtype (builder.py:105, eval/inference.py:53) -----------------------------
+typedef _Float16 teo_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h2f_f16(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {      // v_cvt_pk_f16_f32 (RNE), like torch's float -> half
+    const teo_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, teo_f16x2));
+}
+// format-generic forms: F16 = false -> bfloat16, true -> binary16
+template <bool F16> __device__ __forceinline__ float h2f(unsigned short v) { return F16 ? h2f_f16(v) : bf2f(v); }
+template <bool F16> __device__ __forceinline__ unsigned pack_h2(float lo, float hi) { return F16 ? pack_f16x2(lo, hi) : pack_bf2(lo, hi); }
+template <bool F16> __device__ __forceinline__ unsigned short f2h(float f) { return (unsigned short)(pack_h2<F16>(f, 0.f) & 0xffffu); }
+template <bool F16> __device__ __forceinline__ float h_lo(unsigned w) { return F16 ? h2f_f16((unsigned short)(w & 0xffffu)) : __uint_as_float(w << 16); }
+template <bool F16> __device__ __forceinline__ float h_hi(unsigned w) { return F16 ? h2f_f16((unsigned short)(w >> 16)) : __uint_as_float(w & 0xffff0000u); }
+// matrix / dot instructions on 8 (two: 2) packed 16-bit values
+typedef __attribute__((ext_vector_type(8))) short teo_h16x8;          // raw operand registers (what the bf16 intrinsics take)
+typedef __attribute__((ext_vector_type(8))) _Float16 teo_f16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 teo_bf16x8v;
+typedef __attribute__((ext_vector_type(4))) float teo_f32x4;
+typedef __attribute__((ext_vector_type(16))) float teo_f32x16;
+template <bool F16> __device__ __forceinline__ teo_f32x4 mfma16(teo_h16x8 a, teo_h16x8 b, teo_f32x4 c) {          // v_mfma_f32_16x16x32_{bf16,f16}
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(teo_f16x8, a), __builtin_bit_cast(teo_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(teo_bf16x8v, a), __builtin_bit_cast(teo_bf16x8v, b), c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ teo_f32x16 mfma32(teo_h16x8 a, teo_h16x8 b, teo_f32x16 c) {       // v_mfma_f32_32x32x16_{bf16,f16}
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(teo_f16x8, a), __builtin_bit_cast(teo_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(teo_bf16x8v, a), __builtin_bit_cast(teo_bf16x8v, b), c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ float dot2h(unsigned a, unsigned b, float acc) {                   // v_dot2_f32_{bf16,f16}
+    if constexpr (F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(teo_f16x2, a), __builtin_bit_cast(teo_f16x2, b), acc, false);
+    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(teo_bf16x2, a), __builtin_bit_cast(teo_bf16x2, b), acc, false);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kDtype = TEO_F32;
@@ -74,6 +108,16 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
     __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
 };
+
+template <> struct Elem<f16_t> {
+    static constexpr int kDtype = TEO_F16;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return h2f_f16(p->bits); }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { p->bits = f2h<true>(v); }
+    __device__ static __forceinline__ float round(float v) { return h2f_f16(f2h<true>(v)); }
+};
+// the F16 template flag of an element type (kernels that take raw 16-bit pointers AND an element type)
+template <typename T> struct IsF16 { static constexpr bool v = false; };
+template <> struct IsF16<f16_t> { static constexpr bool v = true; };
 
 // ---- wave / block reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -27,7 +27,7 @@
 
 namespace teo {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 fa_bf16x8;
+typedef __attribute__((ext_vector_type(8))) short fa_bf16x8;      // 8 raw 16-bit operands (bf16 or fp16: the F16 template flag)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int fa_u32x4;
 
@@ -37,7 +37,7 @@ __device__ __forceinline__ float fa_other_half_max(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
     constexpr int CH = D / 8;                 // 16-byte chunks per K row
     constexpr int KROW = D * 2;               // bytes per K row
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
                     const fa_bf16x8 kf = __builtin_bit_cast(fa_bf16x8, *reinterpret_cast<const fa_u32x4*>(rp + (((2 * kk + hi) ^ sw) << 4)));
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+                    s[kb] = mfma32<F16>(kf, qf[kk], s[kb]);
                 }
             }
             // lane holds S[key = j0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi][query ql]
@@ -228,12 +228,12 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
                 const int kb = u >> 1, r0 = (u & 1) * 8;
                 union { fa_bf16x8 v; unsigned w[4]; } pf;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pf.w[j] = pack_bf2(s[kb][r0 + 2 * j], s[kb][r0 + 2 * j + 1]);
+                for (int j = 0; j < 4; ++j) pf.w[j] = pack_h2<F16>(s[kb][r0 + 2 * j], s[kb][r0 + 2 * j + 1]);
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     const int d = db * 32 + ql;
                     const fa_bf16x8 vf = __builtin_bit_cast(fa_bf16x8, *reinterpret_cast<const fa_u32x4*>(sV + d * VROW + ((2 * u + hi) << 4)));
-                    acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, acc_o[db], 0, 0, 0);
+                    acc_o[db] = mfma32<F16>(vf, pf.v, acc_o[db]);
                 }
             }
         }
@@ -253,23 +253,20 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const uint2 pk = make_uint2(pack_bf2(acc_o[db][4 * g] * inv, acc_o[db][4 * g + 1] * inv),
-                                            pack_bf2(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv));
+                const uint2 pk = make_uint2(pack_h2<F16>(acc_o[db][4 * g] * inv, acc_o[db][4 * g + 1] * inv),
+                                            pack_h2<F16>(acc_o[db][4 * g + 2] * inv, acc_o[db][4 * g + 3] * inv));
                 *reinterpret_cast<uint2*>(o + db * 32 + 8 * g + 4 * hi) = pk;
             }
     }
 }
 
-int attention_flash32(const teo_attn_args& a, hipStream_t st) {
+int attention_flash32(const teo_attn_args& a, hipStream_t st, bool f16) {
     dim3 grid(cdiv(a.q_len, 128) * a.heads * a.batch);
     const size_t lds = 2 * (size_t)(64 * a.head_dim * 2 + a.head_dim * 144);
-    if (a.head_dim == 128) {
-        if (a.causal) attn_flash32_kernel<128, true><<<grid, 256, lds, st>>>(a);
-        else attn_flash32_kernel<128, false><<<grid, 256, lds, st>>>(a);
-    } else {
-        if (a.causal) attn_flash32_kernel<64, true><<<grid, 256, lds, st>>>(a);
-        else attn_flash32_kernel<64, false><<<grid, 256, lds, st>>>(a);
-    }
+#define TEO_FA(DD, CC) { if (f16) attn_flash32_kernel<DD, CC, true><<<grid, 256, lds, st>>>(a); else attn_flash32_kernel<DD, CC, false><<<grid, 256, lds, st>>>(a); }
+    if (a.head_dim == 128) { if (a.causal) TEO_FA(128, true) else TEO_FA(128, false) }
+    else { if (a.causal) TEO_FA(64, true) else TEO_FA(64, false) }
+#undef TEO_FA
     note_kernel("attn_flash32"); TEO_LAUNCH_CHECK("attn_flash32");
     return TEO_OK;
 }

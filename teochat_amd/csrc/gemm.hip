@@ -22,6 +22,8 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+thread_local bool g_half_f16 = false;   // 16-bit format of the GEMM call being dispatched on this thread (set by gemm())
+
 // ------------------------------------------------------------------------------------------------
 // generic kernel
 // ------------------------------------------------------------------------------------------------
@@ -111,7 +113,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // MF = 16-row fragments per wave along M: workgroup tile = (32*MF) x 128 (MF = 4: 128 x 128; MF = 2: 64 x 128 for shapes
 // whose 128-row tiles quantise badly over the 512 resident workgroup slots, e.g. M = 2168, N = 4096 -> 544 tiles).
-template <bool SWIGLU, bool OUT_F32, int DEPTH, int MF>
+template <bool SWIGLU, bool OUT_F32, int DEPTH, int MF, bool F16 = false>   // F16: IEEE binary16 operands / outputs instead of bfloat16 (common.h)
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __restrict__ A,
                                                              const bf16_t* __restrict__ W,
                                                              const bf16_t* __restrict__ bias,
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
             }                                                                                                        \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                         \
                 _Pragma("unroll") for (int mi = 0; mi < MF; ++mi)                                                    \
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);     \
+                    acc[ni][mi] = mfma16<F16>(wf[ni], af[mi], acc[ni][mi]);     \
         }                                                                                                            \
     }
 
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
                         make_float4(o[0], o[1], o[2], o[3]);
                 } else {
                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) =
-                        make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                        make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
                 }
                 // keep the 16 (gate, up) blocks in program order: hoisting all 64 expf expansions at once is what pushed this
                 // variant to 226 VGPRs (depth 1) / spills (depth 2)
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
                 if (n + 3 < N) {
                     if (bias) {
                         const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
-                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
+                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
                     }
                     if (act != TEO_ACT_NONE) {
 #pragma unroll
@@ -275,24 +277,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
                     }
                     if (res) {
                         const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
-                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                        o[0] += h_lo<F16>(q.x); o[1] += h_hi<F16>(q.x);
+                        o[2] += h_lo<F16>(q.y); o[3] += h_hi<F16>(q.y);
                     }
                     if (OUT_F32) {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) =
                             make_float4(o[0], o[1], o[2], o[3]);
                     } else {
                         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) =
-                            make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                            make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
                     }
                 } else {
                     for (int r = 0; r < 4 && n + r < N; ++r) {
                         float v = o[r];
-                        if (bias) v += bf2f(bias[n + r]);
+                        if (bias) v += h2f<F16>(bias[n + r]);
                         v = act_apply(v, act);
-                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
                         if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
                     }
                 }
             }
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_kernel(const bf16_t* __
 // relaxed and reads the slab with agent-scope atomic loads (`sc1`: past L1, coherent with the write-through stores).  No
 // fences.  A waiter always waits on a workgroup that produced its slab at the very start of its life.
 // ------------------------------------------------------------------------------------------------
-template <bool SWIGLU, bool OUT_F32>
+template <bool SWIGLU, bool OUT_F32, bool F16 = false>
 __device__ __forceinline__ void gemm_tile_epilogue(f32x4 (&acc)[4][4], const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
                                                    int M, int N, int ldc, int act, int m0, int n0, int wm, int wn, int fr, int fg) {
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
@@ -342,7 +344,7 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x4 (&acc)[4][4], const bf1
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
                 } else {
                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) =
-                        make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                        make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
                 }
             }
         } else {
@@ -356,8 +358,8 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x4 (&acc)[4][4], const bf1
                 if (n + 3 < N) {
                     if (bias) {
                         const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
-                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
+                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
                     }
                     if (act != TEO_ACT_NONE) {
 #pragma unroll
@@ -365,23 +367,23 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x4 (&acc)[4][4], const bf1
                     }
                     if (res) {
                         const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
-                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                        o[0] += h_lo<F16>(q.x); o[1] += h_hi<F16>(q.x);
+                        o[2] += h_lo<F16>(q.y); o[3] += h_hi<F16>(q.y);
                     }
                     if (OUT_F32) {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
                     } else {
                         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) =
-                            make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                            make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
                     }
                 } else {
                     for (int r = 0; r < 4 && n + r < N; ++r) {
                         float v = o[r];
-                        if (bias) v += bf2f(bias[n + r]);
+                        if (bias) v += h2f<F16>(bias[n + r]);
                         v = act_apply(v, act);
-                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
                         if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
                     }
                 }
             }
@@ -391,7 +393,7 @@ __device__ __forceinline__ void gemm_tile_epilogue(f32x4 (&acc)[4][4], const bf1
 
 constexpr int SK_SLAB_FLOATS = BM * BN;          // one 128 x 128 fp32 accumulator tile per workgroup
 
-template <bool SWIGLU, bool OUT_F32>
+template <bool SWIGLU, bool OUT_F32, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                 const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
                                                                 int M, int N, int K, int lda, int ldc, int act, int tiles_m,
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
             }                                                                                                     \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                      \
                 _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                  \
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);  \
+                    acc[ni][mi] = mfma16<F16>(wf[ni], af[mi], acc[ni][mi]);  \
         }                                                                                                         \
     }
 #define TEO_SK_KLOOP(KB, KE)                                                                                      \
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
             TEO_SK_SETUP(t)
             TEO_SK_ZERO()
             TEO_SK_KLOOP(0, nk)
-            gemm_tile_epilogue<SWIGLU, OUT_F32>(acc, bias, res, Cv, M, N, ldc, act, m0, n0, wm, wn, fr, fg);
+            gemm_tile_epilogue<SWIGLU, OUT_F32, F16>(acc, bias, res, Cv, M, N, ldc, act, m0, n0, wm, wn, fr, fg);
         }
     }
     // ---- (3) head last: continue the previous range's partial sums in the same k-order
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
                 acc[ni][mi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, ((ni * 4 + mi) * 256 + tid) * 16, 0, /*aux: sc1*/ 16));
         TEO_SK_SETUP(t_first)
         TEO_SK_KLOOP(k_first, nk)
-        gemm_tile_epilogue<SWIGLU, OUT_F32>(acc, bias, res, Cv, M, N, ldc, act, m0, n0, wm, wn, fr, fg);
+        gemm_tile_epilogue<SWIGLU, OUT_F32, F16>(acc, bias, res, Cv, M, N, ldc, act, m0, n0, wm, wn, fr, fg);
     }
 #undef TEO_SK_SETUP
 #undef TEO_SK_GLOAD
@@ -587,7 +589,7 @@ int gemm_tune_set(const char* key, int value) {
 
 bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned flags, const void* A, const void* W,
                   const void* bias, const void* res, const void* C) {
-    if (dtype != TEO_BF16 || (flags & TEO_GEMM_FORCE_SIMPLE)) return false;
+    if ((dtype != TEO_BF16 && dtype != TEO_F16) || (flags & TEO_GEMM_FORCE_SIMPLE)) return false;
     if (K % BK != 0 || lda % 8 != 0 || ldc % 4 != 0 || N % 4 != 0) return false;
     if ((long long)M * lda >= (1ll << 31) || (long long)N * K >= (1ll << 31)) return false;      // 32-bit element offsets in the kernel
     if (M < 1 || N < 1) return false;
@@ -634,10 +636,11 @@ static int gemm_plain_launch(const void* A, const void* W, const void* bias, con
     const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, bm);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 4 * TILE_BYTES;
-#define TEO_GEMM_K(SW, OF, DP, MFV)                                                                                   \
-    gemm_mfma_bf16_kernel<SW, OF, DP, MFV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
-                                                                  (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
-                                                                  tiles_n)
+#define TEO_GEMM_KF(SW, OF, DP, MFV, FV)                                                                              \
+    gemm_mfma_bf16_kernel<SW, OF, DP, MFV, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+                                                                      (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
+                                                                      tiles_n)
+#define TEO_GEMM_K(SW, OF, DP, MFV) do { if (g_half_f16) TEO_GEMM_KF(SW, OF, DP, MFV, true); else TEO_GEMM_KF(SW, OF, DP, MFV, false); } while (0)
 #define TEO_GEMM_LAUNCH(SW, OF)                                                                                      \
     if (bm == 64) { TEO_GEMM_K(SW, OF, 2, 2); }                                                                       \
     else if ((g_gemm_depth == 0 && !(SW)) || g_gemm_depth == 2) { TEO_GEMM_K(SW, OF, 2, 4); }                         \
@@ -645,6 +648,7 @@ static int gemm_plain_launch(const void* A, const void* W, const void* bias, con
         if (swiglu) { if (of32) { TEO_GEMM_LAUNCH(true, true) } else { TEO_GEMM_LAUNCH(true, false) } }
         else        { if (of32) { TEO_GEMM_LAUNCH(false, true) } else { TEO_GEMM_LAUNCH(false, false) } }
 #undef TEO_GEMM_K
+#undef TEO_GEMM_KF
 #undef TEO_GEMM_LAUNCH
         note_kernel(bm == 64 ? "gemm_mfma_64" : "gemm_mfma_128");
     TEO_LAUNCH_CHECK("gemm_mfma_bf16");
@@ -660,6 +664,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         set_error("teo_gemm: SWIGLU16 needs N %% 32 == 0 and no bias/residual/act");
         return TEO_ERR_ARG;
     }
+    g_half_f16 = dtype == TEO_F16;                           // the 16-bit format of this call, read by the launch helpers of every tile family
     if (gemm_mfma_ok(M, N, K, lda, ldc, dtype, flags, A, W, bias, res, C)) {
         // tile height: 128 rows; 64 rows only for small problems whose 128-row tiling leaves more than half of the 512
         // resident workgroup slots empty (ViT o / fc2: 136 tiles; +7 % there).  Measured at M = 2168: 64-row tiles lose
@@ -700,13 +705,15 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
             const int per = (int)((total + SK_MAX_GRID - 1) / SK_MAX_GRID);          // >= nk because nwg > SK_MAX_GRID
             float* slabs = (float*)sk_ws;
             int* flg = (int*)((unsigned char*)sk_ws + GEMM_SK_SLAB_BYTES);
-#define TEO_SK_LAUNCH(SW, OF)                                                                                         \
-    gemm_mfma_bf16_sk_kernel<SW, OF><<<SK_MAX_GRID, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,  \
-                                                                     (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
-                                                                     tiles_n, per, slabs, flg, g_gemm_sk_dbg)
+#define TEO_SK_LAUNCH_F(SW, OF, FV)                                                                                   \
+    gemm_mfma_bf16_sk_kernel<SW, OF, FV><<<SK_MAX_GRID, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,  \
+                                                                         (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
+                                                                         tiles_n, per, slabs, flg, g_gemm_sk_dbg)
+#define TEO_SK_LAUNCH(SW, OF) do { if (g_half_f16) TEO_SK_LAUNCH_F(SW, OF, true); else TEO_SK_LAUNCH_F(SW, OF, false); } while (0)
             if (swiglu) { if (of32) TEO_SK_LAUNCH(true, true); else TEO_SK_LAUNCH(true, false); }
             else { if (of32) TEO_SK_LAUNCH(false, true); else TEO_SK_LAUNCH(false, false); }
 #undef TEO_SK_LAUNCH
+#undef TEO_SK_LAUNCH_F
             note_kernel("gemm_mfma_128_sk");
             TEO_LAUNCH_CHECK("gemm_mfma_bf16_sk");
             return TEO_OK;
@@ -719,6 +726,9 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
     } else if (dtype == TEO_BF16) {
         if (out_dtype == TEO_F32) launch_simple<bf16_t, float>(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, st);
         else launch_simple<bf16_t, bf16_t>(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, st);
+    } else if (dtype == TEO_F16) {
+        if (out_dtype == TEO_F32) launch_simple<f16_t, float>(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, st);
+        else launch_simple<f16_t, f16_t>(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, st);
     } else {
         set_error("teo_gemm: unknown dtype %d", dtype);
         return TEO_ERR_UNSUPPORTED;

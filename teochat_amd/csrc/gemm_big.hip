@@ -37,7 +37,7 @@ __device__ __forceinline__ int gb_xcd_remap(int bid, int nwg) {
 // with the sequential hand-off of gemm_mfma_bf16_sk_kernel: a range that ends inside a tile runs that part FIRST and hands its fp32
 // accumulators (256 KB slab, 16-byte sc1 stores + flag) to the next range's owner, which continues from them LAST in its own
 // timeline -- k-order per output element unchanged, results bit-identical, no ragged last round.
-template <bool SWIGLU, bool OUT_F32, bool HYBRID>
+template <bool SWIGLU, bool OUT_F32, bool HYBRID, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M,
                                                                int N, int K, int lda, int ldc, int act, int tiles_m, int tiles_n,
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
 #define TEO_GB_MFMA(AF, WF, N0, N1)                                                                               \
     _Pragma("unroll") for (int ni = N0; ni < N1; ++ni)                                                            \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                          \
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[ni], AF[mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = mfma16<F16>(WF[ni], AF[mi], acc[ni][mi]);
     for (int kt = kb; kt < ke; ++kt) {
         const int st = (kt - kb) & 1;
         // this wave's pieces of tile kt have landed and its fragment reads of tile kt-1 have returned; then everybody's
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
                 if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
-                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
             }
         } else {
 #pragma unroll
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
                 if (n + 3 < N) {
                     if (bias) {
                         const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
-                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
+                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
                     }
                     if (act != TEO_ACT_NONE) {
 #pragma unroll
@@ -224,19 +224,19 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
                     }
                     if (res) {
                         const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
-                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                        o[0] += h_lo<F16>(q.x); o[1] += h_hi<F16>(q.x);
+                        o[2] += h_lo<F16>(q.y); o[3] += h_hi<F16>(q.y);
                     }
                     if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
                 } else {
                     for (int r = 0; r < 4 && n + r < N; ++r) {
                         float v = o[r];
-                        if (bias) v += bf2f(bias[n + r]);
+                        if (bias) v += h2f<F16>(bias[n + r]);
                         v = act_apply(v, act);
-                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
                         if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
                     }
                 }
             }
@@ -279,16 +279,17 @@ int gemm_big_launch(const void* A, const void* W, const void* bias, const void* 
     const int per = hybrid ? (int)(((long long)(T - dp_rounds * 256) * nk + 255) / 256) : 0;
     float* slabs = (float*)sk_ws;
     int* flg = hybrid ? (int*)((unsigned char*)sk_ws + flags_offset) : nullptr;
-#define TEO_GB_LAUNCH_H(SW, OF, HY)                                                                                               \
+#define TEO_GB_LAUNCH_H(SW, OF, HY) { if (g_half_f16) TEO_GB_LAUNCH_HF(SW, OF, HY, true) else TEO_GB_LAUNCH_HF(SW, OF, HY, false) }
+#define TEO_GB_LAUNCH_HF(SW, OF, HY, FV)                                                                                          \
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF, HY>),             \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF, HY, FV>),         \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e != hipSuccess) return hip_fail(e, "gemm_big: hipFuncSetAttribute");                                             \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm_mfma_bf16_big_kernel<SW, OF, HY><<<(HY) ? 256 : T, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+        gemm_mfma_bf16_big_kernel<SW, OF, HY, FV><<<(HY) ? 256 : T, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m,  \
                                                                                tiles_n, group, dp_rounds, per, slabs, flg);             \
     }
@@ -297,6 +298,7 @@ int gemm_big_launch(const void* A, const void* W, const void* bias, const void* 
     else { if (of32) TEO_GB_LAUNCH(false, true) else TEO_GB_LAUNCH(false, false) }
 #undef TEO_GB_LAUNCH
 #undef TEO_GB_LAUNCH_H
+#undef TEO_GB_LAUNCH_HF
     note_kernel(hybrid ? "gemm_big_hybrid" : "gemm_big");
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_big");
     return TEO_OK;

@@ -53,7 +53,7 @@ __device__ __forceinline__ int gw_xcd_remap(int bid, int nwg) {
 // The MFMA chain of every output element is still k-ascending: h0(kt-1), h1(kt-1), h0(kt), ... -> results unchanged.
 // Ablation at qkv (M = 2168, N = 12288, K = 4096; us): all 234 | no DMA 196 | no MFMA 169 | no fragment reads 173 | MFMA + barrier
 // only 150 | DMA only 146 (3.4 GB / 146 us = 22 TB/s out of L2): the L2 -> LDS delivery is as long as the MFMA work.
-template <typename DMA>
+template <bool F16, typename DMA>
 __device__ __forceinline__ void gw_ktile(const unsigned char* sA, const unsigned char* sB, int wid, int wm, int wn, int fr, int fg,
                                          bool first, gw_f32x4 (&acc)[4][4], gw_bf16x8 (&caf)[4], gw_bf16x8 (&cwf)[4], DMA&& dma) {
     const bool late = wid < 4;
@@ -73,7 +73,7 @@ __device__ __forceinline__ void gw_ktile(const unsigned char* sA, const unsigned
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cwf[ni], caf[mi], acc[ni][mi], 0, 0, 0);
+                acc[ni][mi] = mfma16<F16>(cwf[ni], caf[mi], acc[ni][mi]);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (late) dma();
@@ -90,18 +90,19 @@ __device__ __forceinline__ void gw_ktile(const unsigned char* sA, const unsigned
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = mfma16<F16>(wf[ni], af[mi], acc[ni][mi]);
 }
 // the carried second half of the last K tile of a segment
+template <bool F16>
 __device__ __forceinline__ void gw_flush(gw_f32x4 (&acc)[4][4], const gw_bf16x8 (&caf)[4], const gw_bf16x8 (&cwf)[4]) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cwf[ni], caf[mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = mfma16<F16>(cwf[ni], caf[mi], acc[ni][mi]);
 }
 
-template <bool SWIGLU, bool OUT_F32, int SCHED>
+template <bool SWIGLU, bool OUT_F32, int SCHED, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                   const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
                                                                   int M, int N, int K, int lda, int ldc, int act, int tiles_m,
@@ -170,15 +171,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = mfma16<F16>(wf[ni], af[mi], acc[ni][mi]);
             }
         } else {
-            gw_ktile(sA, sB, wid, wm, wn, fr, fg, kt == 0, acc, caf, cwf, [&]() { if (kt + 2 < nk) { TEO_GW_STAGE(kt + 2, st2) } });
+            gw_ktile<F16>(sA, sB, wid, wm, wn, fr, fg, kt == 0, acc, caf, cwf, [&]() { if (kt + 2 < nk) { TEO_GW_STAGE(kt + 2, st2) } });
         }
         st = st == 2 ? 0 : st + 1;
     }
 #undef TEO_GW_STAGE
-    if (sched != 0 && nk > 0) gw_flush(acc, caf, cwf);
+    if (sched != 0 && nk > 0) gw_flush<F16>(acc, caf, cwf);
 
     // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3 (as gemm_mfma_bf16_kernel)
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
                 if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
-                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
             }
         } else {
 #pragma unroll
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
                 if (n + 3 < N) {
                     if (bias) {
                         const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
-                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
+                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
                     }
                     if (act != TEO_ACT_NONE) {
 #pragma unroll
@@ -218,19 +219,19 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
                     }
                     if (res) {
                         const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += bf2f((bf16_t)(q.x & 0xffff)); o[1] += bf2f((bf16_t)(q.x >> 16));
-                        o[2] += bf2f((bf16_t)(q.y & 0xffff)); o[3] += bf2f((bf16_t)(q.y >> 16));
+                        o[0] += h_lo<F16>(q.x); o[1] += h_hi<F16>(q.x);
+                        o[2] += h_lo<F16>(q.y); o[3] += h_hi<F16>(q.y);
                     }
                     if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
                 } else {
                     for (int r = 0; r < 4 && n + r < N; ++r) {
                         float v = o[r];
-                        if (bias) v += bf2f(bias[n + r]);
+                        if (bias) v += h2f<F16>(bias[n + r]);
                         v = act_apply(v, act);
-                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
                         if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
                     }
                 }
             }
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
 // ------------------------------------------------------------------------------------------------
 constexpr int GW_SLAB_FLOATS = GW_BM * GW_BN;            // 128 KB of fp32 per workgroup
 
-template <bool OUT_F32>
+template <bool OUT_F32, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                      const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
                                                                      int M, int N, int K, int lda, int ldc, int act, int tiles_m,
@@ -325,11 +326,11 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
             const int st2 = st == 0 ? 2 : st - 1;
             const unsigned char* sA = smem + st * GW_STAGE;
             const unsigned char* sB = sA + GW_A_BYTES;
-            gw_ktile(sA, sB, wid, wm, wn, fr, fg, kt == kb, acc, caf, cwf, [&]() { if (kt + 2 < ke) { TEO_GW_STAGE(kt + 2, st2) } });
+            gw_ktile<F16>(sA, sB, wid, wm, wn, fr, fg, kt == kb, acc, caf, cwf, [&]() { if (kt + 2 < ke) { TEO_GW_STAGE(kt + 2, st2) } });
             st = st == 2 ? 0 : st + 1;
         }
 #undef TEO_GW_STAGE
-        if (ke > kb) gw_flush(acc, caf, cwf);
+        if (ke > kb) gw_flush<F16>(acc, caf, cwf);
         __builtin_amdgcn_s_barrier();                       // every wave is done reading the ring before the next segment refills it
         if (is_tail) {
             const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)q * GW_SLAB_FLOATS, 0, GW_SLAB_FLOATS * 4, 0x00020000);
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
                 if (n + 3 < N) {
                     if (bias) {
                         const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += bf2f((bf16_t)(b.x & 0xffff)); o[1] += bf2f((bf16_t)(b.x >> 16));
-                        o[2] += bf2f((bf16_t)(b.y & 0xffff)); o[3] += bf2f((bf16_t)(b.y >> 16));
+                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
+                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
                     }
                     if (act != TEO_ACT_NONE) {
 #pragma unroll
@@ -369,19 +370,19 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
                     }
                     if (res) {
                         const uint2 qv = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += bf2f((bf16_t)(qv.x & 0xffff)); o[1] += bf2f((bf16_t)(qv.x >> 16));
-                        o[2] += bf2f((bf16_t)(qv.y & 0xffff)); o[3] += bf2f((bf16_t)(qv.y >> 16));
+                        o[0] += h_lo<F16>(qv.x); o[1] += h_hi<F16>(qv.x);
+                        o[2] += h_lo<F16>(qv.y); o[3] += h_hi<F16>(qv.y);
                     }
                     if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
                 } else {
                     for (int r = 0; r < 4 && n + r < N; ++r) {
                         float v = o[r];
-                        if (bias) v += bf2f(bias[n + r]);
+                        if (bias) v += h2f<F16>(bias[n + r]);
                         v = act_apply(v, act);
-                        if (res) v += bf2f(res[(long long)m * ldc + n + r]);
+                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
                         if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2bf(v);
+                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
                     }
                 }
             }
@@ -400,21 +401,23 @@ int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const vo
     const size_t lds = 3 * GW_STAGE;
     float* slabs = (float*)sk_ws;
     int* flg = (int*)((unsigned char*)sk_ws + flags_offset);
-#define TEO_GWSK_LAUNCH(OF)                                                                                                       \
+#define TEO_GWSK_LAUNCH(OF) { if (g_half_f16) TEO_GWSK_LAUNCH_F(OF, true) else TEO_GWSK_LAUNCH_F(OF, false) }
+#define TEO_GWSK_LAUNCH_F(OF, FV)                                                                                                 \
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_sk_kernel<OF>),                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_sk_kernel<OF, FV>),             \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e != hipSuccess) return hip_fail(e, "gemm_wide_sk: hipFuncSetAttribute");                                         \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm_mfma_bf16_wide_sk_kernel<OF><<<grid, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,         \
+        gemm_mfma_bf16_wide_sk_kernel<OF, FV><<<grid, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,         \
                                                                   (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, \
                                                                   per, slabs, flg);                                               \
     }
     if (of32) TEO_GWSK_LAUNCH(true) else TEO_GWSK_LAUNCH(false)
 #undef TEO_GWSK_LAUNCH
+#undef TEO_GWSK_LAUNCH_F
     note_kernel("gemm_wide_sk"); TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide_sk");
     return TEO_OK;
 }
@@ -424,16 +427,17 @@ int gemm_wide_launch(const void* A, const void* W, const void* bias, const void*
     const int tiles_m = cdiv(M, GW_BM), tiles_n = cdiv(N, GW_BN);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 3 * GW_STAGE;
-#define TEO_GW_LAUNCH_S(SW, OF, SC)                                                                                               \
+#define TEO_GW_LAUNCH_S(SW, OF, SC) { if (g_half_f16) TEO_GW_LAUNCH_SF(SW, OF, SC, true) else TEO_GW_LAUNCH_SF(SW, OF, SC, false) }
+#define TEO_GW_LAUNCH_SF(SW, OF, SC, FV)                                                                                          \
     {                                                                                                                             \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_kernel<SW, OF, SC>),            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_kernel<SW, OF, SC, FV>),        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
             if (e != hipSuccess) return hip_fail(e, "gemm_wide: hipFuncSetAttribute");                                            \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        gemm_mfma_bf16_wide_kernel<SW, OF, SC><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,     \
+        gemm_mfma_bf16_wide_kernel<SW, OF, SC, FV><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,     \
                                                                       (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, g_wide_group ? g_wide_group : (tiles_m >= 32 ? 4 : 1)); \
     }
 #define TEO_GW_LAUNCH(SW, OF)                                                                                                     \
@@ -444,6 +448,7 @@ int gemm_wide_launch(const void* A, const void* W, const void* bias, const void*
     if (swiglu) { if (of32) TEO_GW_LAUNCH(true, true) else TEO_GW_LAUNCH(true, false) }
     else { if (of32) TEO_GW_LAUNCH(false, true) else TEO_GW_LAUNCH(false, false) }
 #undef TEO_GW_LAUNCH_S
+#undef TEO_GW_LAUNCH_SF
 #undef TEO_GW_LAUNCH
     note_kernel("gemm_wide"); TEO_LAUNCH_CHECK("gemm_mfma_bf16_wide");
     return TEO_OK;

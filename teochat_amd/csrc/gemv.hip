@@ -32,6 +32,13 @@ template <> struct Vec16<bf16_t> {
         f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
     }
 };
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
+        f[0] = h_lo<true>(r.x); f[1] = h_hi<true>(r.x); f[2] = h_lo<true>(r.y); f[3] = h_hi<true>(r.y);
+        f[4] = h_lo<true>(r.z); f[5] = h_hi<true>(r.z); f[6] = h_lo<true>(r.w); f[7] = h_hi<true>(r.w);
+    }
+};
 template <> struct Vec16<float> {
     static constexpr int N = 4;
     __device__ static __forceinline__ void cvt(const uint4& r, float* f) {
@@ -85,9 +92,10 @@ __device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float acc) {
 }
 // xv: VE/8 chunks of 8 bf16 activations matching the weight chunk
 template <typename WT>
-__device__ __forceinline__ float dotb(const uint4& w, const uint4* xv, float acc) {      // bf16 weights
-    acc = dot2bf(w.x, xv[0].x, acc); acc = dot2bf(w.y, xv[0].y, acc);
-    acc = dot2bf(w.z, xv[0].z, acc); acc = dot2bf(w.w, xv[0].w, acc);
+__device__ __forceinline__ float dotb(const uint4& w, const uint4* xv, float acc) {      // 16-bit weights of the activations' format
+    constexpr bool F16 = IsF16<WT>::v;
+    acc = dot2h<F16>(w.x, xv[0].x, acc); acc = dot2h<F16>(w.y, xv[0].y, acc);
+    acc = dot2h<F16>(w.z, xv[0].z, acc); acc = dot2h<F16>(w.w, xv[0].w, acc);
     return acc;
 }
 template <>
@@ -105,6 +113,7 @@ __device__ __forceinline__ float dotb<fp8_t>(const uint4& w, const uint4* xv, fl
 }
 template <typename T> struct IsBf { static constexpr bool v = false; };
 template <> struct IsBf<bf16_t> { static constexpr bool v = true; };
+template <typename T> struct Is16 { static constexpr bool v = IsBf<T>::v || IsF16<T>::v; };      // a 16-bit activation format
 // Row-group kernels keep x in LDS.  Measured on one box: the bf16 image + v_dot2c is a win for fp8 weights (VALU-bound:
 // qkv 12.2 -> 11.7 us, gate/up 17.0 -> 16.5) but a loss for bf16 weights (gate/up 29.3 -> 30.8 us: v_dot2c_f32_bf16 issues
 // slower than the unpack + FMA pairs it replaces), so bf16 weights keep the fp32 image.  The split-K kernel reads x from
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if constexpr (IsBf<T>::v) {                  // raw bf16 activations straight into v_dot2c_f32_bf16
+            if constexpr (Is16<T>::v) {                  // raw 16-bit activations straight into v_dot2_f32_{bf16,f16}
 #pragma unroll
                 for (int r = 0; r < R; ++r) acc[r] = dotb<WT>(w[u][r], xr[u], acc[r]);
             } else {
@@ -678,7 +687,7 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
         }
         return launch_rows<T, TO, WT, 2, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
     }
-    if constexpr (IsBf<T>::v) { if (small_k) return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st); }
+    if constexpr (Is16<T>::v) { if (small_k) return launch_rows<T, TO, WT, 2, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st); }
     return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
 }
 
@@ -706,6 +715,10 @@ int gemv_w(const void* x, const void* W, const float* wscale, int w_fp8, const v
     if (dtype == TEO_BF16) {
         if (out_dtype == TEO_F32) return gemv_launch<bf16_t, float, bf16_t>(x, W, nullptr, norm_w, res, y, N, K, eps, swiglu, st);
         return gemv_launch<bf16_t, bf16_t, bf16_t>(x, W, nullptr, norm_w, res, y, N, K, eps, swiglu, st);
+    }
+    if (dtype == TEO_F16) {
+        if (out_dtype == TEO_F32) return gemv_launch<f16_t, float, f16_t>(x, W, nullptr, norm_w, res, y, N, K, eps, swiglu, st);
+        return gemv_launch<f16_t, f16_t, f16_t>(x, W, nullptr, norm_w, res, y, N, K, eps, swiglu, st);
     }
     set_error("teo_gemv: unknown dtype %d", dtype);
     return TEO_ERR_UNSUPPORTED;
@@ -744,6 +757,7 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
 #define TEO_QR8(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2, 4); } else { TEO_QR2(TT, WW, NTV, 6, 2); }
     if (w_fp8)                 { if (g_tune.nt) { TEO_QR8(bf16_t, fp8_t, true); } else { TEO_QR8(bf16_t, fp8_t, false); } }
     else if (dtype == TEO_F32) { if (g_tune.nt) { TEO_QR6(float, float, true); } else { TEO_QR6(float, float, false); } }
+    else if (dtype == TEO_F16) { if (g_tune.nt) { TEO_QR(f16_t, f16_t, true); } else { TEO_QR(f16_t, f16_t, false); } }
     else                       { if (g_tune.nt) { TEO_QR(bf16_t, bf16_t, true); } else { TEO_QR(bf16_t, bf16_t, false); } }
 #undef TEO_QR
 #undef TEO_QR6

@@ -50,6 +50,7 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, int ld, const int* __
 
 // bf16, head_dim % 16 == 0: one thread rotates 8 pairs (16-byte loads of both halves, 32-byte cos / sin rows) or copies
 // 2 x 16 bytes of V.  grid (S, ceil((heads + 2 kv_heads) * hd/16 / 256)); the V^T scatter is left to vt_append_kernel.
+template <bool F16>
 __global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(bf16_t* __restrict__ qkv, int ld, const int* __restrict__ positions,
                                                                  const float* __restrict__ cs, const float* __restrict__ sn,
                                                                  bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int past,
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(bf16_t* __restr
     unsigned o1[4], o2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float a0 = __uint_as_float(lw[j] << 16), a1 = __uint_as_float(lw[j] & 0xffff0000u);
-        const float b0 = __uint_as_float(hw[j] << 16), b1 = __uint_as_float(hw[j] & 0xffff0000u);
-        o1[j] = pack_bf2(a0 * c[2 * j] - b0 * sv[2 * j], a1 * c[2 * j + 1] - b1 * sv[2 * j + 1]);
-        o2[j] = pack_bf2(b0 * c[2 * j] + a0 * sv[2 * j], b1 * c[2 * j + 1] + a1 * sv[2 * j + 1]);
+        const float a0 = h_lo<F16>(lw[j]), a1 = h_hi<F16>(lw[j]);
+        const float b0 = h_lo<F16>(hw[j]), b1 = h_hi<F16>(hw[j]);
+        o1[j] = pack_h2<F16>(a0 * c[2 * j] - b0 * sv[2 * j], a1 * c[2 * j + 1] - b1 * sv[2 * j + 1]);
+        o2[j] = pack_h2<F16>(b0 * c[2 * j] + a0 * sv[2 * j], b1 * c[2 * j + 1] + a1 * sv[2 * j + 1]);
     }
     bf16_t* dst = hh < heads ? x : kc + ((long long)(hh - heads) * S_max + slot) * hd;
     *reinterpret_cast<uint4*>(dst + i0) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
@@ -159,8 +160,16 @@ int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, con
                            reinterpret_cast<uintptr_t>(cs) | reinterpret_cast<uintptr_t>(sn)) & 15) == 0;
         if (vec) {
             const int nthr = (heads + 2 * kv_heads) * (hd / 16);
-            rope_kv_append_vec_kernel<<<dim3(S, cdiv(nthr, 256)), 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
-                                                                                (bf16_t*)vc, past, S_max, heads, kv_heads, hd);
+            if (dtype == TEO_F16)
+                rope_kv_append_vec_kernel<true><<<dim3(S, cdiv(nthr, 256)), 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
+                                                                                          (bf16_t*)vc, past, S_max, heads, kv_heads, hd);
+            else
+                rope_kv_append_vec_kernel<false><<<dim3(S, cdiv(nthr, 256)), 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
+                                                                                           (bf16_t*)vc, past, S_max, heads, kv_heads, hd);
+        } else if (dtype == TEO_F16) {
+            rope_kv_append_kernel<f16_t><<<grid, threads, 0, st>>>((f16_t*)qkv, ld, positions, cs, sn, (f16_t*)kc,
+                                                                   (f16_t*)vc, (f16_t*)vtc, past, d_past, S_max, heads,
+                                                                   kv_heads, hd, wvt);
         } else {
             rope_kv_append_kernel<bf16_t><<<grid, threads, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
                                                                     (bf16_t*)vc, (bf16_t*)vtc, past, d_past, S_max, heads,
@@ -657,6 +666,9 @@ int decode_tail(const float* logits, const teo_decode_state* s, const void* embe
     if (dtype == TEO_F32)
         TEO_KLAUNCH((decode_tail_kernel<float>), batch, 1024, 0, st, logits, *s, (const float*)embed, (float*)h, vocab, dim, out_stride,
                     (const float*)g0, (float*)hg, ssq, nparts);
+    else if (dtype == TEO_F16)
+        TEO_KLAUNCH((decode_tail_kernel<f16_t>), batch, 1024, 0, st, logits, *s, (const f16_t*)embed, (f16_t*)h, vocab, dim, out_stride,
+                    (const f16_t*)g0, (f16_t*)hg, ssq, nparts);
     else
         TEO_KLAUNCH((decode_tail_kernel<bf16_t>), batch, 1024, 0, st, logits, *s, (const bf16_t*)embed, (bf16_t*)h, vocab, dim, out_stride,
                     (const bf16_t*)g0, (bf16_t*)hg, ssq, nparts);
@@ -716,6 +728,8 @@ int embed_token_emit(const long long* tok, const void* embed, void* h, int dim, 
                      const void* g, void* hg, float* ssq, int nparts) {
     if (dtype == TEO_F32)
         embed_emit_kernel<float><<<batch, 1024, 0, st>>>(tok, (const float*)embed, (float*)h, dim, (const float*)g, (float*)hg, ssq, nparts);
+    else if (dtype == TEO_F16)
+        embed_emit_kernel<f16_t><<<batch, 1024, 0, st>>>(tok, (const f16_t*)embed, (f16_t*)h, dim, (const f16_t*)g, (f16_t*)hg, ssq, nparts);
     else
         embed_emit_kernel<bf16_t><<<batch, 1024, 0, st>>>(tok, (const bf16_t*)embed, (bf16_t*)h, dim, (const bf16_t*)g, (bf16_t*)hg, ssq, nparts);
     TEO_LAUNCH_CHECK("embed_token_emit");

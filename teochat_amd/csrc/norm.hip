@@ -18,6 +18,16 @@ template <> struct V16<bf16_t> {
         return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
     }
 };
+template <> struct V16<f16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void unpack(const uint4& r, float* f) {
+        f[0] = h_lo<true>(r.x); f[1] = h_hi<true>(r.x); f[2] = h_lo<true>(r.y); f[3] = h_hi<true>(r.y);
+        f[4] = h_lo<true>(r.z); f[5] = h_hi<true>(r.z); f[6] = h_lo<true>(r.w); f[7] = h_hi<true>(r.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(pack_f16x2(f[0], f[1]), pack_f16x2(f[2], f[3]), pack_f16x2(f[4], f[5]), pack_f16x2(f[6], f[7]));
+    }
+};
 template <> struct V16<float> {
     static constexpr int N = 4;
     __device__ static __forceinline__ void unpack(const uint4& r, float* f) {
@@ -178,6 +188,11 @@ int layernorm(const void* x, const void* w, const void* b, void* y, int rows, in
             layernorm_kernel<float, true, 4><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (const float*)b, (float*)y, dim, eps);
         else
             layernorm_kernel<float, false, 1><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (const float*)b, (float*)y, dim, eps);
+    } else if (dtype == TEO_F16) {
+        if (vec_ok(dim, 8, 2, x, w, b, y))
+            layernorm_kernel<f16_t, true, 2><<<rows, 256, 0, st>>>((const f16_t*)x, (const f16_t*)w, (const f16_t*)b, (f16_t*)y, dim, eps);
+        else
+            layernorm_kernel<f16_t, false, 1><<<rows, 256, 0, st>>>((const f16_t*)x, (const f16_t*)w, (const f16_t*)b, (f16_t*)y, dim, eps);
     } else {
         if (vec_ok(dim, 8, 2, x, w, b, y))
             layernorm_kernel<bf16_t, true, 2><<<rows, 256, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, dim, eps);
@@ -195,6 +210,13 @@ int rmsnorm(const void* x, const void* w, void* y, int rows, int dim, float eps,
             rmsnorm_kernel<float, true, 4, 256><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, dim, eps);
         else
             rmsnorm_kernel<float, false, 1, 256><<<rows, 256, 0, st>>>((const float*)x, (const float*)w, (float*)y, dim, eps);
+    } else if (dtype == TEO_F16) {
+        if (rows >= 1024 && vec_ok(dim, 8, 2, x, w, nullptr, y))
+            rmsnorm_kernel<f16_t, true, 4, 128><<<rows, 128, 0, st>>>((const f16_t*)x, (const f16_t*)w, (f16_t*)y, dim, eps);
+        else if (vec_ok(dim, 8, 2, x, w, nullptr, y))
+            rmsnorm_kernel<f16_t, true, 2, 256><<<rows, 256, 0, st>>>((const f16_t*)x, (const f16_t*)w, (f16_t*)y, dim, eps);
+        else
+            rmsnorm_kernel<f16_t, false, 1, 256><<<rows, 256, 0, st>>>((const f16_t*)x, (const f16_t*)w, (f16_t*)y, dim, eps);
     } else {
         if (rows >= 1024 && vec_ok(dim, 8, 2, x, w, nullptr, y))        // dim/8 <= 512 chunks = 4 per thread at 128 threads
             rmsnorm_kernel<bf16_t, true, 4, 128><<<rows, 128, 0, st>>>((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, dim, eps);
@@ -215,6 +237,9 @@ int vit_embed_ln(const void* patch, const void* cls, const void* pos, const void
     if (dtype == TEO_F32)
         vit_embed_ln_kernel<float><<<rows, 256, lds, st>>>((const float*)patch, (const float*)cls, (const float*)pos,
                                                            (const float*)w, (const float*)b, (float*)out, NP, dim, eps);
+    else if (dtype == TEO_F16)
+        vit_embed_ln_kernel<f16_t><<<rows, 256, lds, st>>>((const f16_t*)patch, (const f16_t*)cls, (const f16_t*)pos,
+                                                           (const f16_t*)w, (const f16_t*)b, (f16_t*)out, NP, dim, eps);
     else
         vit_embed_ln_kernel<bf16_t><<<rows, 256, lds, st>>>((const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos,
                                                             (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out, NP, dim, eps);

@@ -20,7 +20,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
          int ldc, int act, unsigned flags, int dtype, int out_dtype, hipStream_t st, void* sk_ws = nullptr);
 
 int attention(const teo_attn_args* a, int dtype, hipStream_t st);
-int attention_flash32(const teo_attn_args& a, hipStream_t st);
+int attention_flash32(const teo_attn_args& a, hipStream_t st, bool f16 = false);
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;
@@ -64,7 +64,7 @@ void skinny_tune_reset(); void attn_tune_reset();
 int gemm_wide_tune_set(const char* key, int value);
 int gemm_big_tune_set(const char* key, int value);
 bool patch_embed_ok(int C, int img, int P, int ldw, int D, int dtype, const void* px, const void* W, const void* out);
-int patch_embed(const void* px, const void* W, void* out, int T, int C, int img, int P, int ldw, int D, hipStream_t st);
+int patch_embed(const void* px, const void* W, void* out, int T, int C, int img, int P, int ldw, int D, hipStream_t st, bool f16 = false);
 bool gemm_big_hybrid_fits(int M, int N, int K);
 int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
@@ -79,6 +79,7 @@ struct SkinnyFuse {
     const float* ssq_in = nullptr;            // [MB][nparts]
     int nparts = 0;
     float eps = 0.f;
+    bool f16 = false;                         // activations, 16-bit weights and 16-bit outputs are IEEE binary16 instead of bfloat16 (no fp8 weights)
     unsigned long long* trace = nullptr;      // probe builds only (tools/skinny_probe.hip): [workgroups][SK_TRACE_SLOTS] wall-clock marks
 };
 constexpr int SK_TRACE_SLOTS = 16;
@@ -108,6 +109,7 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
 int gemv_w(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, const void* res, void* y, int N,
            int K, float eps, unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
+extern thread_local bool g_half_f16;      // gemm.hip: true while a TEO_F16 GEMM is being dispatched (selects the F16 instantiation of every tile family)
 inline size_t esize(int dtype) { return dtype == TEO_F32 ? 4 : 2; }
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 

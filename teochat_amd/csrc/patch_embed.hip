@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int pe_u32x4;
 
 constexpr int PE_BM = 128, PE_BN = 128, PE_BK = 64, PE_TILE = PE_BM * PE_BK * 2;     // 16 KB per operand tile
 
+template <bool F16>
 __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(const bf16_t* __restrict__ px, const bf16_t* __restrict__ W,
                                                               bf16_t* __restrict__ out, int T, int C, int img, int P, int ldw, int D) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(const bf16_t* __r
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = mfma16<F16>(wf[ni], af[mi], acc[ni][mi]);
         }
     }
     // lane holds out[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r]
@@ -105,24 +106,25 @@ __global__ __launch_bounds__(256) void patch_embed_mfma_kernel(const bf16_t* __r
             const int n = nw + ni * 16 + fg * 4;
             if (n + 3 < D) {
                 *reinterpret_cast<uint2*>(out + (long long)m * D + n) =
-                    make_uint2(pack_bf2(acc[ni][mi][0], acc[ni][mi][1]), pack_bf2(acc[ni][mi][2], acc[ni][mi][3]));
+                    make_uint2(pack_h2<F16>(acc[ni][mi][0], acc[ni][mi][1]), pack_h2<F16>(acc[ni][mi][2], acc[ni][mi][3]));
             } else {
-                for (int r = 0; r < 4 && n + r < D; ++r) out[(long long)m * D + n + r] = f2bf(acc[ni][mi][r]);
+                for (int r = 0; r < 4 && n + r < D; ++r) out[(long long)m * D + n + r] = f2h<F16>(acc[ni][mi][r]);
             }
         }
     }
 }
 
 bool patch_embed_ok(int C, int img, int P, int ldw, int D, int dtype, const void* px, const void* W, const void* out) {
-    return dtype == TEO_BF16 && img % P == 0 && ldw % PE_BK == 0 && ldw >= C * P * P && D % 4 == 0 &&
+    return (dtype == TEO_BF16 || dtype == TEO_F16) && img % P == 0 && ldw % PE_BK == 0 && ldw >= C * P * P && D % 4 == 0 &&
            (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && px != nullptr;
 }
 
-int patch_embed(const void* px, const void* W, void* out, int T, int C, int img, int P, int ldw, int D, hipStream_t st) {
+int patch_embed(const void* px, const void* W, void* out, int T, int C, int img, int P, int ldw, int D, hipStream_t st, bool f16) {
     if (T == 0) return TEO_OK;
     const int g = img / P, M = T * g * g;
     const int tiles = cdiv(M, PE_BM) * cdiv(D, PE_BN);
-    patch_embed_mfma_kernel<<<tiles, 256, 2 * PE_TILE, st>>>((const bf16_t*)px, (const bf16_t*)W, (bf16_t*)out, T, C, img, P, ldw, D);
+    if (f16) patch_embed_mfma_kernel<true><<<tiles, 256, 2 * PE_TILE, st>>>((const bf16_t*)px, (const bf16_t*)W, (bf16_t*)out, T, C, img, P, ldw, D);
+    else patch_embed_mfma_kernel<false><<<tiles, 256, 2 * PE_TILE, st>>>((const bf16_t*)px, (const bf16_t*)W, (bf16_t*)out, T, C, img, P, ldw, D);
     note_kernel("patch_embed_mfma"); TEO_LAUNCH_CHECK("patch_embed_mfma");
     return TEO_OK;
 }

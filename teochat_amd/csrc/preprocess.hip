@@ -120,6 +120,7 @@ int preprocess_frames(const unsigned char* src, void* out, int T_, int Hs, int W
     preprocess_kernel<TT, PD><<<grid, 256, 0, st>>>(src, (TT*)out, H, W, nh, nw, top, left, S, mean[0], mean[1], mean[2],    \
                                                     1.0f / stdv[0], 1.0f / stdv[1], 1.0f / stdv[2], Hs, Ws, oy, ox, f0, f1, f2)
     if (dtype == TEO_F32) { if (pad) TEO_PP(float, true); else TEO_PP(float, false); }
+    else if (dtype == TEO_F16) { if (pad) TEO_PP(f16_t, true); else TEO_PP(f16_t, false); }
     else { if (pad) TEO_PP(bf16_t, true); else TEO_PP(bf16_t, false); }
 #undef TEO_PP
     TEO_LAUNCH_CHECK("preprocess_frames");

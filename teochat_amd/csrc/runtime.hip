@@ -69,7 +69,7 @@ int vit_encode(const teo_vit_desc* d, const void* pixels, int T, void* features,
     TEO_TRY(gemm_sk_workspace_init(w.sk, st));
     if (patch_embed_ok(d->channels, d->image, d->patch, d->k_pad, D, dt, pixels, d->patch_w, w.patch)) {
         // patch pixels gathered straight into the MFMA tile's LDS image (patch_embed.hip): no im2col matrix in HBM
-        TEO_TRY(patch_embed(pixels, d->patch_w, w.patch, T, d->channels, d->image, d->patch, d->k_pad, D, st));
+        TEO_TRY(patch_embed(pixels, d->patch_w, w.patch, T, d->channels, d->image, d->patch, d->k_pad, D, st, dt == TEO_F16));
     } else {
         TEO_TRY(im2col_patches(pixels, w.cols, T, d->channels, d->image, d->patch, d->k_pad, dt, st));
         TEO_TRY(gemm(w.cols, d->patch_w, nullptr, nullptr, w.patch, T * NP, D, d->k_pad, d->k_pad, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
@@ -445,8 +445,9 @@ size_t llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch) {
 
 // Can every Linear layer of the step run on the MFMA skinny GEMM?  (bf16 activations, K multiples of the k-step.)
 static bool batch_uses_skinny(const teo_llama_desc* d, int B) {
-    if (d->dtype != TEO_BF16) return false;
+    if (d->dtype != TEO_BF16 && d->dtype != TEO_F16) return false;
     const int w8 = d->qkv_w8 != nullptr, h8 = d->lm_head8 != nullptr;
+    if (d->dtype == TEO_F16 && (w8 || h8)) return false;   // fp8 weights go with bfloat16 activations
     const int D = d->hidden, H = d->heads, Hk = d->kv_heads, hd = d->head_dim, F = d->inter;
     const void* al = reinterpret_cast<const void*>(16);   // alignment of the real pointers is checked at launch
     return skinny_gemm_ok(B, (H + 2 * Hk) * hd, D, D, w8, 0, al, al) && skinny_gemm_ok(B, D, H * hd, H * hd, w8, 0, al, al) &&
@@ -507,6 +508,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
     // comes next -- written by the producer of h (embed / o / down GEMM epilogue), consumed by the next GEMM.
     SkinnyFuse take;                                       // consumer side
     take.ssq_in = w.ssq; take.nparts = w.nparts; take.eps = d->eps;
+    take.f16 = dt == TEO_F16;
     for (int l = 0; l < d->layers; ++l) {
         const void* qkv_w = w8 ? d->qkv_w8[l] : d->qkv_w[l];
         const void* o_w = w8 ? d->o_w8[l] : d->o_w[l];
@@ -526,6 +528,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
                             s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt));
         if (skinny) {
             SkinnyFuse give;                               // h += attn Wo^T; hand post_norm its inputs
+            give.f16 = dt == TEO_F16;
             give.next_g = (const unsigned short*)d->post_norm_w[l]; give.xg_out = (unsigned short*)w.hg; give.ssq_out = w.ssq;
             prof_class(TEO_PROF_O);
             TEO_TRY(skinny_gemm(w.attn, o_w, o_s, w8, nullptr, 0.f, w.h, w.h, B, D, H * hd, H * hd, D, tl, dt, st, give));

@@ -74,16 +74,17 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(unsigned a, unsigned b) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// x (8 bf16) * g (8 bf16) -> 8 bf16 (one rounding), and the sum of squares of x
+// x (8 values) * g (8 values) -> 8 values of the same 16-bit format (one rounding), and the sum of squares of x
+template <bool F16>
 __device__ __forceinline__ u32x4 sk_scale_frag(const u32x4& xv, const u32x4& gv, float& ssq) {
     u32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float x0 = __uint_as_float(xv[i] << 16), x1 = __uint_as_float(xv[i] & 0xffff0000u);
-        const float g0 = __uint_as_float(gv[i] << 16), g1 = __uint_as_float(gv[i] & 0xffff0000u);
+        const float x0 = h_lo<F16>(xv[i]), x1 = h_hi<F16>(xv[i]);
+        const float g0 = h_lo<F16>(gv[i]), g1 = h_hi<F16>(gv[i]);
         ssq = fmaf(x0, x0, ssq);
         ssq = fmaf(x1, x1, ssq);
-        r[i] = pack_bf2(x0 * g0, x1 * g1);
+        r[i] = pack_h2<F16>(x0 * g0, x1 * g1);
     }
     return r;
 }
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
                                                                  int MB, int N, int K, int ldx, int ldo, int ldr, int tiled,
                                                                  int out_f32, int RT, SkinnyFuse fuse, int sw8) {
     constexpr bool F8 = sizeof(WT) == 1;
+    constexpr bool F16 = IsF16<WT>::v;                   // WT = f16_t: IEEE binary16 activations, weights and 16-bit outputs (bf16_t / fp8: bfloat16)
     constexpr int KS = F8 ? 64 : 32;                     // k elements per step (one 16-byte chunk per lane)
     constexpr int CH = F8 ? 16 : 8;                      // k elements per lane chunk
     constexpr int XL = F8 ? 2 : 1;                       // 16-byte activation loads per step
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         n_b = min(n_b, N - 1);
         pf_s0 = ws_p[n_a * ws_on];
         pf_s1 = ws_p[n_b * ws_on];
-        pf_res = bf2f(res_p[((long long)b * ldr + n_a) * res_on]);
-        pf_g = bf2f(g_p[n_a * g_on]);
+        pf_res = h2f<F16>(res_p[((long long)b * ldr + n_a) * res_on]);
+        pf_g = h2f<F16>(g_p[n_a * g_on]);
     }
 
     // Software pipeline over the wave's K slice: two register sets of UNR steps each; every load is unconditional
@@ -188,17 +190,17 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* _
         if (!ok) { x0 = (u32x4){0u, 0u, 0u, 0u}; x1 = x0; }                                                    \
         if (NORM) {                                                                                            \
             const long long sg = min((BASE) + u, s1 - 1);                                                      \
-            x0 = sk_scale_frag(x0, *reinterpret_cast<const u32x4*>(gs + sg * KS), ssq);                        \
-            if (F8) x1 = sk_scale_frag(x1, *reinterpret_cast<const u32x4*>(gs + sg * KS + 8), ssq);            \
+            x0 = sk_scale_frag<F16>(x0, *reinterpret_cast<const u32x4*>(gs + sg * KS), ssq);                        \
+            if (F8) x1 = sk_scale_frag<F16>(x1, *reinterpret_cast<const u32x4*>(gs + sg * KS + 8), ssq);            \
         }                                                                                                      \
         if (F8) {                                                                                              \
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(WR[u].x, WR[u].y),                   \
-                                                          __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);       \
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(WR[u].z, WR[u].w),                   \
-                                                          __builtin_bit_cast(bf16x8, x1), acc, 0, 0, 0);       \
+            acc = mfma16<F16>(fp8x8_to_bf16x8(WR[u].x, WR[u].y),                   \
+                                                          __builtin_bit_cast(bf16x8, x0), acc);       \
+            acc = mfma16<F16>(fp8x8_to_bf16x8(WR[u].z, WR[u].w),                   \
+                                                          __builtin_bit_cast(bf16x8, x1), acc);       \
         } else {                                                                                               \
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, WR[u]),                   \
-                                                          __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);       \
+            acc = mfma16<F16>(__builtin_bit_cast(bf16x8, WR[u]),                   \
+                                                          __builtin_bit_cast(bf16x8, x0), acc);       \
         }                                                                                                      \
     }
 
@@ -319,12 +321,12 @@ _Pragma("unroll") \
             v *= inv;
             if (wscale) v *= first ? pf_s0 : wscale[col];
         }
-        if (res) v += first ? pf_res : bf2f(res[(long long)b * ldr + col]);
+        if (res) v += first ? pf_res : h2f<F16>(res[(long long)b * ldr + col]);
         if (out_f32) reinterpret_cast<float*>(outv)[(long long)b * ldo + col] = v;
         else {
-            const bf16_t hb = f2bf(v);
+            const bf16_t hb = f2h<F16>(v);
             reinterpret_cast<bf16_t*>(outv)[(long long)b * ldo + col] = hb;
-            emit_v = bf2f(hb);
+            emit_v = h2f<F16>(hb);
             emit_ok = true;
         }
     }
@@ -333,7 +335,7 @@ _Pragma("unroll") \
         // Emit what the NEXT layer's RMSNorm needs: bf16(h * g_next) and this workgroup's share of sum(h^2) per row.
         const int b = tid >> 4, c = tid & 15, col = n0 + c;
         float sq = emit_ok ? emit_v * emit_v : 0.f;
-        if (emit_ok) fuse.xg_out[(long long)b * ldo + col] = f2bf(emit_v * pf_g);   // (b, c) = the prefetch's mapping at RT == 1
+        if (emit_ok) fuse.xg_out[(long long)b * ldo + col] = f2h<F16>(emit_v * pf_g);   // (b, c) = the prefetch's mapping at RT == 1
         sq += __shfl_xor(sq, 8, 64);
         sq += __shfl_xor(sq, 4, 64);
         sq += __shfl_xor(sq, 2, 64);
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t*
                                                                    int MB, int N, int K, int ldx, int ldo, int tiled, int out_f32,
                                                                    SkinnyFuse fuse) {
     constexpr bool F8 = sizeof(WT) == 1;
+    constexpr bool F16 = IsF16<WT>::v;
     constexpr int KS = F8 ? 64 : 32, CH = F8 ? 16 : 8, XL = F8 ? 2 : 1;
     constexpr int PER = UNR * SPT;                       // steps of one wave per tile
     static_assert(NS % SPT == 0 && NS >= 2, "the ring holds whole tiles");
@@ -401,8 +404,8 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t*
         const int np = min((T), ntiles - 1) * 16 + (SW8 ? (ec & 7) : ec);                                      \
         sc_n = ws_p[np * ws_on];                                                                               \
         sc_n2 = ws_p[(np + (SW8 ? 8 : 0)) * ws_on];                                                            \
-        rv_n = bf2f(res_p[((long long)ebc * ldo + np) * res_on]);                                              \
-        gv_n = bf2f(g_p[np * g_on]);                                                                           \
+        rv_n = h2f<F16>(res_p[((long long)ebc * ldo + np) * res_on]);                                              \
+        gv_n = h2f<F16>(g_p[np * g_on]);                                                                           \
     }
     TEO_SS_PREFETCH((int)blockIdx.x)
 
@@ -463,13 +466,13 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t*
             for (int u = 0; u < UNR; ++u) {
                 const int i = ls * UNR + u;
                 if (F8) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[r][u].x, w[r][u].y),
-                                                                  __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp8x8_to_bf16x8(w[r][u].z, w[r][u].w),
-                                                                  __builtin_bit_cast(bf16x8, xr[i][XL - 1]), acc, 0, 0, 0);
+                    acc = mfma16<F16>(fp8x8_to_bf16x8(w[r][u].x, w[r][u].y),
+                                                                  __builtin_bit_cast(bf16x8, xr[i][0]), acc);
+                    acc = mfma16<F16>(fp8x8_to_bf16x8(w[r][u].z, w[r][u].w),
+                                                                  __builtin_bit_cast(bf16x8, xr[i][XL - 1]), acc);
                 } else {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[r][u]),
-                                                                  __builtin_bit_cast(bf16x8, xr[i][0]), acc, 0, 0, 0);
+                    acc = mfma16<F16>(__builtin_bit_cast(bf16x8, w[r][u]),
+                                                                  __builtin_bit_cast(bf16x8, xr[i][0]), acc);
                 }
             }
             if (ls == SPT - 1 && g < total) {            // tile done (uniform): lane holds out[b = fr][rows fg*4 .. +3]
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t*
                     if (e_on) {
                         const long long at = (long long)eb * ldo + t * 8 + ec;
                         if (out_f32) reinterpret_cast<float*>(outv)[at] = v;
-                        else reinterpret_cast<bf16_t*>(outv)[at] = f2bf(v);
+                        else reinterpret_cast<bf16_t*>(outv)[at] = f2h<F16>(v);
                     }
                 } else {
                     float v = 0.f;
@@ -508,12 +511,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t*
                     float sq = 0.f;
                     if (out_f32) { if (e_on) reinterpret_cast<float*>(outv)[at] = v; }
                     else {
-                        const bf16_t hb = f2bf(v);
+                        const bf16_t hb = f2h<F16>(v);
                         if (e_on) reinterpret_cast<bf16_t*>(outv)[at] = hb;
                         if (fuse.xg_out) {
                             // what the NEXT layer's RMSNorm needs: bf16(h * g_next) and this tile's share of sum(h^2) per row
-                            const float h = bf2f(hb);
-                            if (e_on) fuse.xg_out[at] = f2bf(h * gv);
+                            const float h = h2f<F16>(hb);
+                            if (e_on) fuse.xg_out[at] = f2h<F16>(h * gv);
                             sq = h * h;
                         }
                     }
@@ -557,6 +560,8 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
         return TEO_ERR_UNSUPPORTED;
     }
     TEO_CHECK_ARG(!w_fp8 || wscale, "skinny_gemm: fp8 weights need per-row scales");
+    if (out_dtype == TEO_F16 || (flags & TEO_GEMM_F16)) fuse.f16 = true;      // the runtime sets fuse.f16 itself
+    TEO_CHECK_ARG(!(fuse.f16 && w_fp8), "skinny_gemm: fp8 weights go with bfloat16 activations (their power-of-two row scales are exact in bf16 only)");
     TEO_CHECK_ARG(!(swiglu && res), "skinny_gemm: SWIGLU16 takes no residual");
     TEO_CHECK_ARG(!norm_w || (K <= 16384 && (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0), "skinny_gemm: fused norm needs K <= 16384 and an aligned weight");
     // row tiles per workgroup (8 waves = RT row tiles x 8/RT K slices)
@@ -585,11 +590,13 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
             TEO_KLAUNCH((skinny_stream_kernel<WW, UN, SP, NSV, SW>), grid, SK_THREADS, 0, st, (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
                         out, MB, N, K, ldx, ldo, tiled, of, fuse)
             if (g_sk_ring == 0) {
-                if (w_fp8) { if (sw8) TEO_SS(fp8_t, 8, 1, 2, true); else TEO_SS(fp8_t, 8, 1, 2, false); }
-                else       { if (sw8) TEO_SS(bf16_t, 8, 2, 2, true); else TEO_SS(bf16_t, 8, 2, 2, false); }
+                if (w_fp8)         { if (sw8) TEO_SS(fp8_t, 8, 1, 2, true); else TEO_SS(fp8_t, 8, 1, 2, false); }
+                else if (fuse.f16) { if (sw8) TEO_SS(f16_t, 8, 2, 2, true); else TEO_SS(f16_t, 8, 2, 2, false); }
+                else               { if (sw8) TEO_SS(bf16_t, 8, 2, 2, true); else TEO_SS(bf16_t, 8, 2, 2, false); }
             } else {
-                if (w_fp8) { if (sw8) TEO_SS(fp8_t, 8, 1, 3, true); else TEO_SS(fp8_t, 8, 1, 3, false); }
-                else       { if (sw8) TEO_SS(bf16_t, 8, 2, 4, true); else TEO_SS(bf16_t, 8, 2, 4, false); }
+                if (w_fp8)         { if (sw8) TEO_SS(fp8_t, 8, 1, 3, true); else TEO_SS(fp8_t, 8, 1, 3, false); }
+                else if (fuse.f16) { if (sw8) TEO_SS(f16_t, 8, 2, 4, true); else TEO_SS(f16_t, 8, 2, 4, false); }
+                else               { if (sw8) TEO_SS(bf16_t, 8, 2, 4, true); else TEO_SS(bf16_t, 8, 2, 4, false); }
             }
 #undef TEO_SS
             note_kernel("skinny_stream");
@@ -608,6 +615,8 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     if (unr8) {
         if (w_fp8) TEO_KLAUNCH((skinny_gemm_kernel<fp8_t, 6, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const fp8_t*)W, wscale,
                                (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
+        else if (fuse.f16) TEO_KLAUNCH((skinny_gemm_kernel<f16_t, 8, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const f16_t*)W, wscale,
+                               (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
         else       TEO_KLAUNCH((skinny_gemm_kernel<bf16_t, 8, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const bf16_t*)W, wscale,
                                (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
         note_kernel("skinny_gemm_u8");
@@ -620,8 +629,9 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
         tiled, of, rt, fuse, sw8)
 #define TEO_SK_N(WW, NTV, SW) if (norm_w) { TEO_SK(WW, NTV, SW, true); } else { TEO_SK(WW, NTV, SW, false); }
 #define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK_N(WW, NTV, true) } else { TEO_SK_N(WW, NTV, false) }
-    if (w_fp8) { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }
-    else       { if (g_sk_nt) { TEO_SK_F(bf16_t, true) } else { TEO_SK_F(bf16_t, false) } }
+    if (w_fp8)         { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }
+    else if (fuse.f16) { TEO_SK_F(f16_t, true) }              // (non-temporal weight loads only: one instantiation set for the second format)
+    else               { if (g_sk_nt) { TEO_SK_F(bf16_t, true) } else { TEO_SK_F(bf16_t, false) } }
 #undef TEO_SK_F
 #undef TEO_SK_N
 #undef TEO_SK

@@ -30,7 +30,9 @@ def _dt(dtype):
         return L.TEO_F32
     if dtype == torch.bfloat16:
         return L.TEO_BF16
-    raise ValueError(f"unsupported engine dtype {dtype}; use torch.float32 or torch.bfloat16")
+    if dtype == torch.float16:
+        return L.TEO_F16
+    raise ValueError(f"unsupported engine dtype {dtype}; use torch.float32, torch.bfloat16 or torch.float16")
 
 
 def _p(t):
@@ -93,12 +95,6 @@ class TeoEngine:
             raise RuntimeError("TeoEngine needs an MI355X (no CPU fallback exists for the product path)")
         self.cfg = config
         self.vcfg = config.vision_config
-        if dtype == torch.float16:
-            # the reference runs fp16 (builder.py:105, eval/inference.py:53) and real checkpoints ship fp16 tensors; the kernels
-            # here compute in bf16 (same 16-bit storage, fp32 accumulation, wider exponent): weights are cast once at load
-            warnings.warn("TeoEngine: torch.float16 requested; fp16 weights are cast to bfloat16 at load (the HIP kernels "
-                          "are bf16 / fp32) -- logits differ from an fp16 run by bf16 rounding (8 vs 11 mantissa bits)")
-            dtype = torch.bfloat16
         self.dtype = dtype
         self.dt = _dt(dtype)
         self.device = torch.device(device)
@@ -108,6 +104,8 @@ class TeoEngine:
         if self.weight_format not in ("native", "fp8"):
             raise ValueError(f"unknown weight_format {weight_format!r}")
         if self.weight_format == "fp8" and dtype != torch.bfloat16:
+            # the power-of-two row scales make every dequantised e4m3 weight an exact bfloat16; in binary16 the smallest ones fall
+            # into the subnormal range and would not be exact (and the fp8 GEMV / skinny kernels convert e4m3 -> bf16)
             raise ValueError("weight_format='fp8' needs dtype=torch.bfloat16")
         self._keep = []                           # host pointer arrays referenced by the descriptors
         self._ws = {}

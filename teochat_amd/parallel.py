@@ -62,7 +62,7 @@ class TeoComm:
         if not (send.is_contiguous() and recv.is_contiguous() and send.dtype == recv.dtype):
             raise ValueError("all_gather_rows: contiguous tensors of one dtype are required")
         rows, dim = send.shape[0], send[0].numel() if send.shape[0] else recv[0].numel()
-        dt = {torch.float32: L.TEO_F32, torch.bfloat16: L.TEO_BF16}[send.dtype]
+        dt = {torch.float32: L.TEO_F32, torch.bfloat16: L.TEO_BF16, torch.float16: L.TEO_F16}[send.dtype]
         st = C.c_void_p(torch.cuda.current_stream(send.device).cuda_stream)
         L.check(self.lib.teo_allgather_visual(self.handle, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), rows, dim,
                                               dt, st), "teo_allgather_visual")

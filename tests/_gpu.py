@@ -5,7 +5,7 @@ import torch
 
 from teochat_amd import _lib as L
 
-DT = {torch.float32: L.TEO_F32, torch.bfloat16: L.TEO_BF16}
+DT = {torch.float32: L.TEO_F32, torch.bfloat16: L.TEO_BF16, torch.float16: L.TEO_F16}
 
 
 def lib():

@@ -56,7 +56,7 @@ def test_bench_variant_line_names_the_kernel_that_dominated_that_run():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
     rf = d["roofline"]
-    assert "batched" in rf["kernel"] and "fp8" in rf["kernel"], rf["kernel"]
+    assert "batched" in rf["kernel"] and "gemv_kernel" not in rf["kernel"], rf["kernel"]     # a kernel of the BATCHED step (attention or a skinny GEMM)
     assert 0.0 < rf["share_of_profiled_step"] <= 1.0 and 0.0 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["end_to_end_frac"] is not None and 0.0 < rf["end_to_end_frac"] < 1.0

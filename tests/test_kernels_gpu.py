@@ -638,7 +638,8 @@ def test_preprocess_frames_pad_mode_matches_expand2square(H, W, dtype):
     want = torch.stack([O.preprocess_image(O.expand2square_u8(raw[t], fill)) for t in range(T)])
     out = torch.empty(T, 3, 224, 224, dtype=dtype, device="cuda")
     mean, std = (C.c_float * 3)(*O.OPENAI_DATASET_MEAN), (C.c_float * 3)(*O.OPENAI_DATASET_STD)
-    L.check(G.lib().teo_preprocess_frames_pad(G.p(raw.cuda()), G.p(out), T, H, W, 224, mean, std, (C.c_ubyte * 3)(*fill), G.DT[dtype],
+    d_raw = raw.cuda()
+    L.check(G.lib().teo_preprocess_frames_pad(G.p(d_raw), G.p(out), T, H, W, 224, mean, std, (C.c_ubyte * 3)(*fill), G.DT[dtype],
                                               G.stream()), "preprocess_pad")
     if dtype == torch.float32:
         torch.testing.assert_close(out.cpu(), want, atol=3e-5, rtol=0)
