@@ -30,15 +30,42 @@ def anchor_gains(vocab, device="cpu"):
     return g
 
 
-def synthetic_state_dict(cfg, seed=2, std=0.02, dtype=torch.bfloat16, device="cuda:0", anchored=False):
+MASSIVE_CHANNELS = (1415, 2533, 97, 3001)        # the first two are where LLaMA-2-7B's massive activations sit; two more for width
+MASSIVE_LAYER, MASSIVE_GAIN = 1, 250.0
+
+
+def synthetic_state_dict(cfg, seed=2, std=0.02, dtype=torch.bfloat16, device="cuda:0", anchored=False, realistic=False):
+    """realistic = True: the statistics of a TRAINED LLaMA-2-class checkpoint that N(0, std^2) weights lack and that stress range,
+    the power-of-two fp8 row scales and the per-token e4m3 activation quantiser (VERDICT r03 "What's missing" #3; no real weights
+    exist in this environment -- what a real checkpoint goes through is videollava/model/builder.py:94-112):
+      * heavy-tailed Linear weights: Student-t (4 degrees of freedom) scaled to the same std -- kurtosis of trained weights, rows
+        whose absmax is 5-10 sigma (one outlier decides a row's e4m3 scale);
+      * massive activations: MASSIVE_CHANNELS of the residual stream carry values 10^2-10^3 x the median from layer MASSIVE_LAYER on
+        (down_proj rows of that layer scaled by MASSIVE_GAIN), as LLaMA-2-7B does in channels 1415 / 2533;
+      * non-unit norm gains: log-normal around 0.4 (RMSNorm) / 1.0 (LayerNorm), small (0.05) at the massive channels -- what keeps a
+        trained model's normalised activations bounded."""
     g = torch.Generator(device=device).manual_seed(seed)
     v = cfg.vision_config
 
     def rn(*shape, s=std):
-        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * s).to(dtype)
+        z = torch.randn(*shape, generator=g, device=device, dtype=torch.float32)
+        if realistic and len(shape) >= 2:
+            # Student-t, 4 dof: z / sqrt(chi2_4 / 4), variance 2 -> rescaled to unit variance
+            chi = torch.zeros(*shape, device=device, dtype=torch.float32)
+            for _ in range(4):
+                chi += torch.randn(*shape, generator=g, device=device, dtype=torch.float32) ** 2
+            z = z / torch.sqrt(chi / 4.0) * (0.5 ** 0.5)
+            z.clamp_(-12.0, 12.0)
+        return (z * s).to(dtype)
 
-    def near_one(n):
-        return (1.0 + torch.randn(n, generator=g, device=device, dtype=torch.float32) * 0.1).to(dtype)
+    def near_one(n, rms=False):
+        z = torch.randn(n, generator=g, device=device, dtype=torch.float32)
+        if not realistic:
+            return (1.0 + z * 0.1).to(dtype)
+        gain = torch.exp(z * 0.5) * (0.4 if rms else 1.0)
+        if rms and n > max(MASSIVE_CHANNELS):
+            gain[list(MASSIVE_CHANNELS)] = 0.05
+        return gain.to(dtype)
 
     sd = {}
     D, F_, V, hd = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.head_dim
@@ -52,9 +79,12 @@ def synthetic_state_dict(cfg, seed=2, std=0.02, dtype=torch.bfloat16, device="cu
         sd[p + "mlp.gate_proj.weight"] = rn(F_, D)
         sd[p + "mlp.up_proj.weight"] = rn(F_, D)
         sd[p + "mlp.down_proj.weight"] = rn(D, F_)
-        sd[p + "input_layernorm.weight"] = near_one(D)
-        sd[p + "post_attention_layernorm.weight"] = near_one(D)
-    sd["model.norm.weight"] = near_one(D)
+        sd[p + "input_layernorm.weight"] = near_one(D, rms=True)
+        sd[p + "post_attention_layernorm.weight"] = near_one(D, rms=True)
+        if realistic and i == min(MASSIVE_LAYER, cfg.num_hidden_layers - 1) and D > max(MASSIVE_CHANNELS):
+            w = sd[p + "mlp.down_proj.weight"]
+            w[list(MASSIVE_CHANNELS)] = (w[list(MASSIVE_CHANNELS)].float() * MASSIVE_GAIN).to(dtype)
+    sd["model.norm.weight"] = near_one(D, rms=True)
     sd["lm_head.weight"] = rn(V, D)
     if anchored:
         if V < ANCHOR_BASE_ID + ANCHOR_COUNT:
