@@ -42,7 +42,14 @@ extern "C" int attn_probe_launch(int variant, int chunk, int waves, const void* 
         attn_decode_whole_kernel<bf16_t, 16, CH, true, NW, PB><<<grid, NW * 64, lds, st>>>((const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, cs, sn, \
                                                                                       (bf16_t*)o, d_pos, S_max, heads, heads, scale, bt); \
     }
-#define L2_(CH, NW) { if (variant == 2) L_(CH, NW, true) else L_(CH, NW, false) }
+#define L8_(CH, NW)                                                                                                              \
+    {                                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_whole_kernel<bf16_t, 16, CH, true, NW, false, true>),   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                        \
+        attn_decode_whole_kernel<bf16_t, 16, CH, true, NW, false, true><<<grid, NW * 64, lds, st>>>((const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, cs, sn, \
+                                                                                               (bf16_t*)o, d_pos, S_max, heads, heads, scale, bt); \
+    }
+#define L2_(CH, NW) { if (variant == 3) L8_(CH, NW) else if (variant == 2) L_(CH, NW, true) else L_(CH, NW, false) }
     if (chunk == 64 && waves == 8) L2_(64, 8)
     else if (chunk == 64 && waves == 16) L2_(64, 16)
     else if (chunk == 32 && waves == 8) L2_(32, 8)
