@@ -14,12 +14,12 @@ int device_cu_count() { return 256; }
 bool prof_take(hipEvent_t*, hipEvent_t*) { return false; }
 void prof_class(int) {}
 void prof_bump(int) {}
-int attention_flash32(const teo_attn_args&, hipStream_t) { return TEO_ERR_UNSUPPORTED; }
+int attention_flash32(const teo_attn_args&, hipStream_t, bool) { return TEO_ERR_UNSUPPORTED; }
 }  // namespace teo
 
 using namespace teo;
 
-// variant: 0 = split + combine (chunk), 1 = whole (chunk, waves), 2 = whole PROBE (chunk, waves)
+// variant: 0 = split + combine (chunk), 1 = whole (chunk, waves), 2 = whole PROBE (chunk, waves), 4 = split with the in-kernel merge
 extern "C" int attn_probe_launch(int variant, int chunk, int waves, const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn,
                                  void* o, float* part, const int* d_pos, int S_max, int heads, int batch, long long q_stride,
                                  long long cache_stride, void* stream) {
@@ -27,8 +27,9 @@ extern "C" int attn_probe_launch(int variant, int chunk, int waves, const void* 
     AttnBatch bt;
     bt.batch = batch; bt.q_stride = q_stride; bt.cache_stride = cache_stride; bt.o_stride = (long long)heads * 128;
     const float scale = 0.08838834764831845f;
-    if (variant == 0) {
+    if (variant == 0 || variant == 4) {
         attn_tune_set("attn_whole", 0);
+        attn_tune_set("attn_fused", variant == 4 ? 2 : 0);
         attn_tune_set("attn_chunk", chunk);
         return attn_decode(q, kc, vc, vtc, cs, sn, o, part, d_pos, S_max, heads, heads, 128, scale, TEO_BF16, st, bt);
     }
@@ -42,14 +43,7 @@ extern "C" int attn_probe_launch(int variant, int chunk, int waves, const void* 
         attn_decode_whole_kernel<bf16_t, 16, CH, true, NW, PB><<<grid, NW * 64, lds, st>>>((const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, cs, sn, \
                                                                                       (bf16_t*)o, d_pos, S_max, heads, heads, scale, bt); \
     }
-#define L8_(CH, NW)                                                                                                              \
-    {                                                                                                                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_whole_kernel<bf16_t, 16, CH, true, NW, false, true>),   \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                                        \
-        attn_decode_whole_kernel<bf16_t, 16, CH, true, NW, false, true><<<grid, NW * 64, lds, st>>>((const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, cs, sn, \
-                                                                                               (bf16_t*)o, d_pos, S_max, heads, heads, scale, bt); \
-    }
-#define L2_(CH, NW) { if (variant == 3) L8_(CH, NW) else if (variant == 2) L_(CH, NW, true) else L_(CH, NW, false) }
+#define L2_(CH, NW) { if (variant == 2) L_(CH, NW, true) else L_(CH, NW, false) }
     if (chunk == 64 && waves == 8) L2_(64, 8)
     else if (chunk == 64 && waves == 16) L2_(64, 16)
     else if (chunk == 32 && waves == 8) L2_(32, 8)

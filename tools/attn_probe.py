@@ -38,7 +38,7 @@ def main():
     VT = torch.zeros(nl, B, H, d, S, device=dev, dtype=bf)
     qkv = torch.randn(B, 3 * H * d, device=dev).to(bf)
     out = torch.zeros(B, H * d, device=dev, dtype=bf)
-    part = torch.empty(B * H * (S // 32) * 130 * 4 + 4096, dtype=torch.uint8, device=dev)
+    part = torch.zeros(B * H * (S // 32) * 130 * 4 + 8192, dtype=torch.uint8, device=dev)      # zeroed: the arrival counters live behind the records
     pos = torch.full((B,), ctx - 1, dtype=torch.int32, device=dev)
     ang = torch.arange(S, dtype=torch.float32)[:, None] * (1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float32) / d)))[None]
     cs, sn = ang.cos().to(dev).contiguous(), ang.sin().to(dev).contiguous()
@@ -65,7 +65,7 @@ def main():
     for name, v, ch, w in (("split + combine, 128 keys", 0, 128, 0), ("split + combine, 64 keys", 0, 64, 0),
                            ("whole 64 keys, 8 waves", 1, 64, 8), ("whole 64 keys, 16 waves", 1, 64, 16),
                            ("whole 32 keys, 8 waves", 1, 32, 8), ("whole 32 keys, 16 waves", 1, 32, 16), ("whole 128 keys, 8 waves", 1, 128, 8),
-                           ("whole 64 keys, 8 waves, 8-slot ring", 3, 64, 8), ("whole 32 keys, 8 waves, 8-slot ring", 3, 32, 8),
+                           ("split, merged by the last arriver, 64 keys", 4, 64, 0), ("split, merged by the last arriver, 128 keys", 4, 128, 0),
                            ("loads only, 64 keys, 8 waves", 2, 64, 8), ("loads only, 64 keys, 16 waves", 2, 64, 16),
                            ("loads only, 32 keys, 16 waves", 2, 32, 16), ("loads only, 128 keys, 8 waves", 2, 128, 8)):
         us = min(run(v, ch, w) for _ in range(3))
