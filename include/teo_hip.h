@@ -65,10 +65,7 @@ const char* teo_last_kernel(void);
  *                   (0 off, 1 auto, 2 force), "gemm_fp8_wide" (0..3), "gemm_fp8_big" (0..2) -- all bit-identical families
  *   decode attn   : "attn_chunk" (keys per decode chunk: 0 auto, 32/64/128/256; fp32 order of the split merge + where P is rounded),
  *                   "attn_whole" (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto, 2 whenever the shape
- *                   allows; bit-identical to the split + combine pair at the same chunk), "attn_fused" (the split kernel's last-arriving
- *                   workgroup of a head merges the head's records -- no combine launch: 0 off, 1 inside the composed decode steps, 2 also
- *                   for teo_attn_decode, whose d_partials must then be ZEROED once by the caller: its tail holds the arrival counters;
- *                   needs heads % 8 == 0 and the measured workgroup -> XCD map; bit-identical to the split + combine pair)
+ *                   allows; bit-identical to the split + combine pair at the same chunk)
  *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible), "skinny_ring"
  *                   (weight tiles in flight of the streaming form: 0 default, 1 one more), "skinny_unr" (tile kernel steps per register
  *                   set: 0 auto, 4, 8) -- bit-identical at K = 4096, fp32 order elsewhere */
@@ -205,8 +202,7 @@ int teo_embed_splice(const int* d_plan, const void* d_embed, const void* d_visua
  *   rope_cos == NULL : d_q holds the rotated query [heads*head_dim]; the caches already contain the new token's K/V.
  *   rope_cos != NULL : d_q holds the raw [q | k | v] row of the QKV projection; the kernel applies RoPE at d_pos[b] to q
  *                      and k and appends k, v (and V^T when d_vt_cache != NULL) to the caches before attending.
- * KV-split partials + combine; d_partials is teo_attn_decode_workspace_bytes(...) of scratch (split records, then the arrival counters
- * the composed decode steps use to merge inside the attention kernel; teo_attn_decode itself runs the combine launch). */
+ * KV-split partials + combine; d_partials is teo_attn_decode_workspace_bytes(...) of scratch. */
 size_t teo_attn_decode_workspace_bytes(int heads, int head_dim, int max_seq, int batch);
 int teo_attn_decode(const void* d_q, void* d_k_cache, void* d_v_cache, void* d_vt_cache, const float* d_rope_cos,
                     const float* d_rope_sin, void* d_out, float* d_partials, const int* d_pos, int max_seq, int heads,

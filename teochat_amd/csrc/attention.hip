@@ -6,8 +6,6 @@
 //  attn_decode_*           : q_len == 1 (decode).  Split over the KV length (grid heads x splits, fixed for hipGraph
 //                            replay; kv_len comes from device memory), then a combine kernel.  HBM-bound:
 //                            algorithmic bytes = 2 * kv_heads * kv_len * head_dim * sizeof(T) per layer.
-#include <vector>
-
 #include "common.h"
 #include "ops.h"
 
@@ -103,17 +101,10 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 static int g_dec_chunk = 0;       // keys per workgroup (32 / 64 / 128 / 256); 0 = auto: 64 for one conversation (2.83 vs 2.86 ms/token
                                   // at 128, 2.87 at 32, 2.94 at 256), 128 for a batched step (4.74 vs 4.79 ms/step at 64)
-static int g_attn_fused = 1;      // split kernel merges in its last-arriving workgroup (no combine launch): 0 off, 1 when the step provides arrival
-                                  // counters, 2 counters at the tail of the caller's workspace (tests / probes).  Bit-identical to split + combine.
 static int g_attn_whole = 1;      // batched steps: whole-context kernel (one workgroup per (conversation, head), no combine launch): 0 off, 1 auto
                                   // (batch * heads >= half the CUs), 2 whenever the shape allows.  Bit-identical to the split + combine pair.
-void attn_tune_reset() { g_dec_chunk = 0; g_attn_whole = 1; g_attn_fused = 1; }
+void attn_tune_reset() { g_dec_chunk = 0; g_attn_whole = 1; }
 int attn_tune_set(const char* key, int value) {
-    if (!strcmp(key, "attn_fused") && value >= 0 && value <= 2) {
-        g_attn_fused = value;
-        if (value == 2) (void)xcd_map_measure(nullptr);        // tests / probes call teo_attn_decode directly: no decode_begin measured the map
-        return 0;
-    }
     if (!strcmp(key, "attn_whole") && value >= 0 && value <= 2) { g_attn_whole = value; return 0; }
     if (!strcmp(key, "attn_chunk") && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
     return -1;
@@ -162,101 +153,27 @@ __device__ __forceinline__ uint4 ld_kv(const void* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// Merge of one head's split records (m, l, o[hd]) by 512 (virtual) threads: shared by the combine launch (records in global memory),
-// the whole-context kernel (records in LDS) and the split kernel's last-arriver tail (256 threads, VT = 2: every thread plays virtual
-// threads tid and tid + 256) so all three evaluate the same expressions in the same order.
-// Split weights: one thread per split (parallel loads).  Output: virtual thread = (column d, split group g); it owns every G-th
-// split (G = 512 / hd) and keeps its loads in flight, the G partial sums of a column meet in LDS -- one or two round trips
-// instead of a dependent chain over all splits.  pb: records of this head, `stride` floats apart; nact <= 256 splits hold keys.
-template <typename T, int VT = 1>
-__device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb, int stride, int nact, int hd, T* __restrict__ o_row,
-                                                   float* w /* [256] */, float* red /* [16] */, float* accs /* [512] */) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const bool on = tid < 512 / VT;                                         // a larger workgroup: the other waves only join the barriers
-    const int G = 512 / hd;                                                 // hd is a power of two <= 256
-    const int d = tid % hd;
-    int g[VT];
-#pragma unroll
-    for (int u = 0; u < VT; ++u) g[u] = on ? (tid + u * (512 / VT)) / hd : 0;
-    // the first NB splits of a virtual thread are requested together with the split statistics (they do not depend on them): ONE round
-    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split)
-    constexpr int NB = 12;
-    float v0[VT][NB];
-#pragma unroll
-    for (int u = 0; u < VT; ++u) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) v0[u][i] = pb[(long long)min(g[u] + i * G, nact - 1) * stride + 2 + d];
-    }
-    float m0 = -INFINITY, l0 = 0.f;
-    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
-    float M = wave_max(m0);
-    if (lane == 0 && on) red[wid] = M;
-    __syncthreads();
-    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));               // splits live in threads 0..255 = waves 0..3
-    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
-    if (tid < 256) w[tid] = w0;
-    float L = wave_sum(l0 * w0);
-    if (lane == 0 && on) red[8 + wid] = L;
-    __syncthreads();
-    const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
-#pragma unroll
-    for (int u = 0; u < VT; ++u) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) a += (g[u] + i * G < nact) ? v0[u][i] * w[min(g[u] + i * G, 255)] : 0.f;
-        for (int s0 = g[u] + NB * G; s0 < nact; s0 += 8 * G) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = pb[(long long)min(s0 + i * G, nact - 1) * stride + 2 + d];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * w[min(s0 + i * G, 255)] : 0.f;
-        }
-        if (on) accs[tid + u * (512 / VT)] = a;
-    }
-    __syncthreads();
-    if (on && tid < hd) {
-        float t = 0.f;
-        for (int k = 0; k < G; ++k) t += accs[d + k * hd];
-        Elem<T>::st(o_row + d, t * inv);
-    }
-}
-
 // q: [heads*hd] (already rotated), K/V cache [kv_heads][S_max][hd]; partial: [heads][nsplit][hd + 2] fp32 (m, l, o[hd])
 // ROPE: `q` is the raw [q | k | v] row of the new token (GEMV output, not yet rotated).  The kernel rotates q on load,
 // and the one lane group that owns key `pos` rotates the new k, takes the new v, appends both to the caches (K, V, V^T)
 // and uses them directly -- RoPE + KV append cost no launch and no pass of their own.
-// Grid: (heads * nsplit, batch), workgroup x = split * heads + head.
-//
-// FUSED: the merge of a head's records happens in this kernel, by the LAST of the head's workgroups to arrive -- no combine launch.
-// What makes that cheap on this machine: consecutive workgroup ids of a launch go round the 8 XCDs (id % 8, measured for every grid
-// shape: profiles/r04_xcc_probe.txt), so with heads % 8 == 0 every workgroup of head h runs on XCD h % 8 and shares ONE L2: the records
-// are plain stores (complete in that L2 once vmcnt drains), the arrival counter is an L2-local (workgroup-scope) atomic, and the merger
-// reads the records back from the same L2 -- no write-through, no device-scope atomic, no fence beyond an L1 invalidate in the one
-// merging workgroup (the device-scope version of this tail cost every workgroup two trips to memory: profiles/r03_decode_experiments.md
-// section 5).  Every workgroup checks its XCC id against the map and traps if the hardware ever places it elsewhere.  `tickets`
-// [batch][heads] start at zero (attn_decode_ws_init) and are re-armed by the merger.
-template <typename T, int LPR, int DEC_CHUNK, bool ROPE, bool FUSED = false>
+template <typename T, int LPR, int DEC_CHUNK, bool ROPE>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, T* __restrict__ kc,
                                                                   T* __restrict__ vc, T* __restrict__ vtc,
                                                                   const float* __restrict__ cs, const float* __restrict__ sn,
                                                                   float* __restrict__ part, const int* __restrict__ d_pos,
                                                                   int S_max, int heads, int kv_heads, float scale, int nsplit,
-                                                                  AttnBatch bt, T* __restrict__ o, int* __restrict__ tickets) {
+                                                                  AttnBatch bt) {
     constexpr int VE = Cvt16<T>::N;
     constexpr int HD = LPR * VE;
-    if constexpr (FUSED) {
-        // HW_REG_XCC_ID (hwreg 20), bits 3:0 = the XCD this wave runs on
-        if ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u) != (blockIdx.x & 7u)) __builtin_trap();
-    }
-    {   // conversation blockIdx.y of a batched step: its own query row, caches, position and partial slab
-        const long long bz = blockIdx.y;
+    {   // conversation blockIdx.z of a batched step: its own query row, caches, position and partial slab
+        const long long bz = blockIdx.z;
         q += bz * bt.q_stride;
         kc += bz * bt.cache_stride;
         vc += bz * bt.cache_stride;
         if (vtc) vtc += bz * bt.cache_stride;
         d_pos += bz;
         part += bz * (long long)heads * nsplit * (HD + 2);
-        if constexpr (FUSED) { o += bz * bt.o_stride; tickets += bz * heads; }
     }
     constexpr int RPI = 64 / LPR;                       // rows (keys) per wave-wide load instruction
     constexpr int KPW = DEC_CHUNK / 4;                  // keys per wave
@@ -264,13 +181,12 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     __shared__ float sc[DEC_CHUNK];
     __shared__ float red[8];
     __shared__ float obuf[4][HD];
-    const int h = blockIdx.x % heads, sp = blockIdx.x / heads, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hk = h / (heads / kv_heads);
     const int kv_len = *d_pos + 1;
     const int c0 = sp * DEC_CHUNK;
     float* out = part + ((long long)h * nsplit + sp) * (HD + 2);
-    if (c0 >= kv_len) {                                 // nothing here: neutral partial (FUSED: the merger only reads splits that hold keys)
-        if (FUSED) return;
+    if (c0 >= kv_len) {                                 // nothing here: neutral partial
         if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
         for (int d = tid; d < HD; d += 256) out[2 + d] = 0.f;
         return;
@@ -411,22 +327,54 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     __syncthreads();
     for (int d = tid; d < HD; d += 256) out[2 + d] = obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d];
     if (tid == 0) { out[0] = mx; out[1] = sum; }
-    if constexpr (FUSED) {
-        __shared__ int s_last;
-        __shared__ float mw[256], mred[16], maccs[512];
-        const int nact = (kv_len + DEC_CHUNK - 1) / DEC_CHUNK;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this workgroup's record is complete in the XCD's L2
-        __syncthreads();
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(tickets + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int last = old == nact - 1;
-            if (last) __hip_atomic_store(tickets + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // re-armed for the next layer's launch
-            s_last = last;
-        }
-        __syncthreads();
-        if (!s_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // L1 invalidate: the other workgroups' records come from L2
-        attn_merge_records<T, 2>(part + (long long)h * nsplit * (HD + 2), HD + 2, nact, HD, o + h * HD, mw, mred, maccs);
+}
+
+// Merge of one head's split records (m, l, o[hd]) by 512 threads: shared by the combine launch (records in global memory)
+// and the whole-context kernel (records in LDS) so both evaluate the same expressions in the same order.
+// Split weights: one thread per split (parallel loads).  Output: thread = (column d, split group g); a thread owns every G-th
+// split (G = 512 / hd) and keeps its loads in flight, the G partial sums of a column meet in LDS -- one or two round trips
+// instead of a dependent chain over all splits.  pb: records of this head, `stride` floats apart; nact <= 256 splits hold keys.
+template <typename T>
+__device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb, int stride, int nact, int hd, T* __restrict__ o_row,
+                                                   float* w /* [256] */, float* red /* [16] */, float* accs /* [512] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool on = tid < 512;                                              // a larger workgroup: the other waves only join the barriers
+    const int G = 512 / hd;                                                 // hd is a power of two <= 256
+    const int g = on ? tid / hd : 0, d = tid % hd;
+    // the first NB splits of this thread are requested together with the split statistics (they do not depend on them): ONE round
+    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split)
+    constexpr int NB = 12;
+    float v0[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v0[i] = pb[(long long)min(g + i * G, nact - 1) * stride + 2 + d];
+    float m0 = -INFINITY, l0 = 0.f;
+    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
+    float M = wave_max(m0);
+    if (lane == 0 && on) red[wid] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));               // splits live in threads 0..255 = waves 0..3
+    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
+    if (tid < 256) w[tid] = w0;
+    float L = wave_sum(l0 * w0);
+    if (lane == 0 && on) red[8 + wid] = L;
+    __syncthreads();
+    const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) a += (g + i * G < nact) ? v0[i] * w[min(g + i * G, 255)] : 0.f;
+    for (int s0 = g + NB * G; s0 < nact; s0 += 8 * G) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = pb[(long long)min(s0 + i * G, nact - 1) * stride + 2 + d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * w[min(s0 + i * G, 255)] : 0.f;
+    }
+    if (on) accs[tid] = a;
+    __syncthreads();
+    if (on && g == 0) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += accs[d + k * hd];
+        Elem<T>::st(o_row + d, t * inv);
     }
 }
 
@@ -678,66 +626,20 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
     attn_merge_records<T>(rec, STRIDE, nact, HD, o + h * HD, w, w + 256, w + 272);
 }
 
-static size_t attn_decode_record_bytes(int heads, int hd, int S_max, int batch) {
-    const int nsplit = cdiv(S_max, 32);      // sized for the smallest chunk
-    return (((size_t)batch * heads * nsplit * (hd + 2) * sizeof(float)) + 255) / 256 * 256;
-}
-// records, then the arrival counters of the in-kernel merge [batch][heads]
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
-    return attn_decode_record_bytes(heads, hd, S_max, batch) + ((size_t)batch * heads * sizeof(int) + 255) / 256 * 256;
-}
-int* attn_decode_tickets(float* part, int heads, int hd, int S_max, int batch) {
-    return reinterpret_cast<int*>(reinterpret_cast<char*>(part) + attn_decode_record_bytes(heads, hd, S_max, batch));
-}
-int attn_decode_ws_init(float* part, int heads, int hd, int S_max, int batch, hipStream_t st) {
-    const hipError_t e = hipMemsetAsync(attn_decode_tickets(part, heads, hd, S_max, batch), 0, (size_t)batch * heads * sizeof(int), st);
-    return e == hipSuccess ? TEO_OK : hip_fail(e, "attn_decode_ws_init");
-}
-
-// ---- workgroup id -> XCD map of this device, measured once: the in-kernel merge needs id % 8 (8 XCDs, round robin)
-__global__ void xcd_map_kernel(int* out) {
-    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u);
-}
-static int g_xcd_map_ok = -1;          // -1 not measured yet, 0 some other placement (the two-launch path stays), 1 id % 8
-bool xcd_map_known_good() { return g_xcd_map_ok == 1; }
-int xcd_map_measure(hipStream_t st) {
-    if (g_xcd_map_ok >= 0) return TEO_OK;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return TEO_OK;      // not inside a capture: later
-    constexpr int NB = 1280;
-    int* d_out = nullptr;
-    const hipError_t em = hipMalloc(&d_out, NB * sizeof(int));
-    if (em != hipSuccess) return hip_fail(em, "xcd_map_measure: hipMalloc");
-    std::vector<int> host(NB);
-    bool ok = device_cu_count() == 256;
-    for (int threads : {256, 512}) {
-        for (int blocks : {256, 1152, NB}) {
-            if (!ok) break;
-            xcd_map_kernel<<<blocks, threads, 0, st>>>(d_out);
-            if (hipMemcpyAsync(host.data(), d_out, blocks * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { ok = false; break; }
-            for (int i = 0; i < blocks; ++i) ok = ok && host[i] == (i & 7);
-        }
-    }
-    (void)hipFree(d_out);
-    g_xcd_map_ok = ok ? 1 : 0;
-    return TEO_OK;
+    const int nsplit = cdiv(S_max, 32);      // sized for the smallest chunk
+    return (size_t)batch * heads * nsplit * (hd + 2) * sizeof(float);
 }
 
 template <typename T, int LPR>
 static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o,
                                float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale,
-                               int nsplit, int chunk, bool rope, AttnBatch bt, int* tickets, hipStream_t st) {
-    dim3 grid(heads * nsplit, bt.batch);
-    const bool fused = tickets != nullptr && (chunk == 64 || chunk == 128);        // the chunk sizes the steps use
-#define TEO_PART(CH, RP, FU)                                                                                              \
-    TEO_KLAUNCH((attn_decode_partial_kernel<T, LPR, CH, RP, FU>), grid, 256, 0, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
-                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt, (T*)o, tickets)
-#define TEO_PART_R(CH)                                                                                       \
-    if constexpr (CH == 64 || CH == 128) {                                                                   \
-        if (fused) { if (rope) { TEO_PART(CH, true, true); } else { TEO_PART(CH, false, true); } }          \
-        else       { if (rope) { TEO_PART(CH, true, false); } else { TEO_PART(CH, false, false); } }        \
-    } else { if (rope) { TEO_PART(CH, true, false); } else { TEO_PART(CH, false, false); } }
+                               int nsplit, int chunk, bool rope, AttnBatch bt, hipStream_t st) {
+    dim3 grid(heads, nsplit, bt.batch);
+#define TEO_PART(CH, RP)                                                                                              \
+    TEO_KLAUNCH((attn_decode_partial_kernel<T, LPR, CH, RP>), grid, 256, 0, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
+                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt)
+#define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
     if constexpr (32 / 4 >= 64 / LPR) {
         if (chunk == 32) { TEO_PART_R(32) } else if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
     } else if constexpr (64 / 4 >= 64 / LPR) {
@@ -747,8 +649,6 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
     }
 #undef TEO_PART_R
 #undef TEO_PART
-    if (fused) { note_kernel("attn_decode_fused"); return; }
-    note_kernel("attn_decode_split");
     prof_bump(1);
     TEO_KLAUNCH((attn_decode_combine_kernel<T>), dim3(heads, bt.batch), 512, 0, st, part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
     prof_bump(-1);
@@ -831,12 +731,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
             if (rcw != TEO_ERR_UNSUPPORTED) return rcw;
         }
     }
-    // in-kernel merge (see the kernel): needs the arrival counters (bt.tickets: the runtime's steps; "attn_fused" = 2: the tail of `part`,
-    // zeroed by the caller), every head's workgroups on one XCD (heads % 8 == 0, the measured map) and splits that the merger's 256
-    // threads cover
-    int* tickets = g_attn_fused == 2 ? attn_decode_tickets(part, heads, hd, S_max, bt.batch) : (g_attn_fused == 1 ? bt.tickets : nullptr);
-    if (tickets && !(heads % 8 == 0 && (hd & (hd - 1)) == 0 && hd <= 256 && xcd_map_known_good())) tickets = nullptr;
-#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, tickets, st)
+#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, st)
     if (dtype == TEO_F32) {
         switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
                        case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }

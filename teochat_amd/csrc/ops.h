@@ -25,12 +25,7 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;
     long long q_stride = 0, cache_stride = 0, o_stride = 0;
-    int* tickets = nullptr;     // [batch][heads] arrival counters of the in-kernel merge (attn_decode_tickets), NULL: combine launch
 };
-int* attn_decode_tickets(float* part, int heads, int hd, int S_max, int batch);
-int attn_decode_ws_init(float* part, int heads, int hd, int S_max, int batch, hipStream_t st);
-int xcd_map_measure(hipStream_t st);        // once per process, outside stream capture; the in-kernel merge stays off until it ran
-bool xcd_map_known_good();
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
                 hipStream_t st, AttnBatch bt = AttnBatch());
