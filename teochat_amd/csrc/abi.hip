@@ -80,14 +80,14 @@ const char* teo_last_error(void) { return g_err; }
 const char* teo_last_kernel(void) { return teo::g_last_kernel; }
 
 int teo_tune_set(const char* key, int value) {
-    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || gemm_big_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0)) return TEO_OK;
+    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || gemm_big_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0 || flash_tune_set(key, value) == 0)) return TEO_OK;
     set_error("teo_tune_set: unknown key");
     return TEO_ERR_ARG;
 }
 
 int teo_tune_reset(void) {
     gemv_tune_reset(); gemm_tune_reset(); gemm_wide_tune_reset(); gemm_big_tune_reset(); gemm_fp8_tune_reset(); skinny_tune_reset();
-    attn_tune_reset();
+    attn_tune_reset(); flash_tune_reset();
     return TEO_OK;
 }
 

@@ -22,6 +22,8 @@
 // P rounded to bf16 per tile for the PV product, normaliser from the unrounded P, fp32 rescale (skipped, bit-identically,
 // when no row maximum of the wave moved).
 // Roofline: MFMA bf16 dense (2.5 PFLOP/s); algorithmic FLOPs = 4 * q_len * kv_len * D * heads (half of it when causal).
+#include <string.h>
+
 #include "common.h"
 #include "ops.h"
 
@@ -30,6 +32,7 @@ namespace teo {
 typedef __attribute__((ext_vector_type(8))) short fa_bf16x8;      // 8 raw 16-bit operands (bf16 or fp16: the F16 template flag)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int fa_u32x4;
+constexpr int FA_TRACE_ITERS = 40;            // TRACE: iterations recorded per wave (tools/flash_probe.hip)
 
 __device__ __forceinline__ float fa_other_half_max(float x) {
     // max of this lane's value and lane ^ 32's: v_permlane32_swap exchanges the upper half of vdst with the lower half of src
@@ -37,8 +40,10 @@ __device__ __forceinline__ float fa_other_half_max(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int D, bool CAUSAL, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
+// pair_c (causal only): workgroup slots per XCD that the dispatcher fills in its first pass (CUs per XCD); 0 = plain heavy-first order
+// TRACE (tools/flash_probe.hip only): 100 MHz wall-clock marks of every loop phase of the heaviest workgroup's waves
+template <int D, bool CAUSAL, bool F16 = false, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a, int pair_c, unsigned long long* trace) {
     constexpr int CH = D / 8;                 // 16-byte chunks per K row
     constexpr int KROW = D * 2;               // bytes per K row
     constexpr int RPB = 256 / KROW > 0 ? 256 / KROW : 1;
@@ -55,12 +60,21 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
     // 1-D grid -> (batch*head, query block).  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2):
     // XCD x takes the heads = x (mod 8), so every query block of a head streams that head's K / V^T through ONE L2, and
     // inside an XCD consecutive slots walk the heads at equal query block, late (heavy, causal) query blocks first.
+    // Two workgroups share a CU (LDS): the dispatcher's first pass puts one workgroup on every CU of the XCD (slots 0 .. C-1, the
+    // heaviest), its second pass the next C in the same CU order -- those are taken in MIRRORED weight order, so the heaviest of
+    // the first pass is joined by the lightest of the second (causal work 34 + 4, 32 + 6, ... key tiles at L = 2168 instead of
+    // 34 + 18 ... 20 + 4); what is left (the lightest of all) fills the slots that free up first.  Same tiles, same arithmetic.
     const int nqb = (a.q_len + 127) >> 7, nbh = a.heads * a.batch;
     int bh, qidx;
     if ((nbh & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, hpx = nbh >> 3;
-        bh = xcd + 8 * (slot % hpx);
-        qidx = slot / hpx;
+        int j = slot;
+        if (CAUSAL && pair_c > 0) {
+            const int n = hpx * nqb, e2 = min(2 * pair_c, n);
+            if (slot >= pair_c && slot < e2) j = pair_c + e2 - 1 - slot;
+        }
+        bh = xcd + 8 * (j % hpx);
+        qidx = j / hpx;
     } else {
         bh = blockIdx.x % nbh;
         qidx = blockIdx.x / nbh;
@@ -150,13 +164,20 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
     if (ntiles > 1) TEO_FA_LOAD(1)
     __syncthreads();
 
+    // TRACE: marks 0 loop top, 1 staged (LDS writes + global loads issued), 2 scores done, 3 softmax done, 4 PV done, 5 past the barrier
+#define TEO_FA_MARK(PH)                                                                                            \
+    if constexpr (TRACE) {                                                                                         \
+        if (blockIdx.x == 0 && lane == 0 && t < FA_TRACE_ITERS) trace[((wid * FA_TRACE_ITERS + t) * 6) + (PH)] = wall_clock64(); \
+    }
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 64;
         const int cur = t & 1;
+        TEO_FA_MARK(0)
         if (t + 1 < ntiles) {
             TEO_FA_WRITE(t + 1, cur ^ 1)                 // that buffer was last read in iteration t-1 (barrier since)
             if (t + 2 < ntiles) TEO_FA_LOAD(t + 2)
         }
+        TEO_FA_MARK(1)
         // a wave whose queries all lie before this tile has nothing to add (causal); it still staged and meets the barrier
         if (!CAUSAL || j0 <= wave_qpos_max) {
             const unsigned char* sK = smem + cur * BUF;
@@ -176,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
                     s[kb] = mfma32<F16>(kf, qf[kk], s[kb]);
                 }
             }
+            if constexpr (TRACE) { asm volatile("s_nop 0" :: "v"(s[0][0]), "v"(s[1][0])); }      // the marks below wait for the results
+            TEO_FA_MARK(2)
             // lane holds S[key = j0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi][query ql]
             const bool need_mask = (j0 + 64 > a.kv_len) || (CAUSAL && j0 + 63 > wave_qpos_min);
             float tmax = -INFINITY;
@@ -222,6 +245,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
             }
             l_run += psum;
             m_run = m_new;
+            if constexpr (TRACE) { asm volatile("s_nop 0" :: "v"(l_run), "v"(s[0][15]), "v"(s[1][15])); }
+            TEO_FA_MARK(3)
             // ---- O^T += V^T . P^T : 4 blocks of 16 keys x NDB d-blocks
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -236,9 +261,13 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
                     acc_o[db] = mfma32<F16>(vf, pf.v, acc_o[db]);
                 }
             }
+            if constexpr (TRACE) { asm volatile("s_nop 0" :: "v"(acc_o[0][0]), "v"(acc_o[NDB - 1][15])); }
         }
+        TEO_FA_MARK(4)
         __syncthreads();
+        TEO_FA_MARK(5)
     }
+#undef TEO_FA_MARK
 #undef TEO_FA_LOAD
 #undef TEO_FA_WRITE
     // ---- finish: l over the two lanes that share a query, normalise, store O[q][h*D + db*32 + (r&3) + 8*(r>>2) + 4*hi]
@@ -260,10 +289,19 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a) {
     }
 }
 
+static int g_flash_order = 1;      // causal workgroup order: 0 heavy-first, 1 heavy-first with the second dispatch pass mirrored (see the kernel)
+void flash_tune_reset() { g_flash_order = 1; }
+int flash_tune_set(const char* key, int value) {
+    if (!strcmp(key, "flash_order") && value >= 0 && value <= 1) { g_flash_order = value; return 0; }
+    return -1;
+}
+
 int attention_flash32(const teo_attn_args& a, hipStream_t st, bool f16) {
     dim3 grid(cdiv(a.q_len, 128) * a.heads * a.batch);
+    const int cus = device_cu_count();
+    const int pair_c = (g_flash_order == 1 && a.causal && cus >= 8) ? cus / 8 : 0;
     const size_t lds = 2 * (size_t)(64 * a.head_dim * 2 + a.head_dim * 144);
-#define TEO_FA(DD, CC) { if (f16) attn_flash32_kernel<DD, CC, true><<<grid, 256, lds, st>>>(a); else attn_flash32_kernel<DD, CC, false><<<grid, 256, lds, st>>>(a); }
+#define TEO_FA(DD, CC) { if (f16) attn_flash32_kernel<DD, CC, true><<<grid, 256, lds, st>>>(a, pair_c, nullptr); else attn_flash32_kernel<DD, CC, false><<<grid, 256, lds, st>>>(a, pair_c, nullptr); }
     if (a.head_dim == 128) { if (a.causal) TEO_FA(128, true) else TEO_FA(128, false) }
     else { if (a.causal) TEO_FA(64, true) else TEO_FA(64, false) }
 #undef TEO_FA

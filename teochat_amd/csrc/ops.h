@@ -103,6 +103,8 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
 int quant_rows_fp8(const void* x, const void* norm_w, void* q, float* s, int M, int K, int ldx, float eps, hipStream_t st);
 int gemm_sk_workspace_init(void* ws, hipStream_t st);
 int attn_tune_set(const char* key, int value);
+int flash_tune_set(const char* key, int value);
+void flash_tune_reset();
 int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,
                   const float* cs, const float* sn, const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk,
                   int hd, int K, float eps, int dtype, hipStream_t st);

@@ -1,0 +1,29 @@
+// Timeline probe of the prefill flash-attention kernel (NOT product code): compiles teochat_amd/csrc/flash.hip into this object
+// with the kernel's TRACE template flag on, so the waves of workgroup 0 (the heaviest causal query block) write 100 MHz wall-clock
+// marks at every phase of every KV-tile iteration.  Built as tools/libflash_probe.so by tools/flash_probe.py; the product library only
+// instantiates TRACE = false.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../teochat_amd/csrc/flash.hip"
+
+namespace teo {
+void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
+int hip_fail(hipError_t e, const char* what) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return TEO_ERR_HIP; }
+void note_kernel(const char*) {}
+int device_cu_count() { return 256; }
+}  // namespace teo
+
+using namespace teo;
+
+extern "C" int flash_probe_trace_iters() { return FA_TRACE_ITERS; }
+
+extern "C" int flash_probe_launch(const teo_attn_args* a, int pair_c, unsigned long long* trace, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(((a->q_len + 127) / 128) * a->heads * a->batch);
+    const size_t lds = 2 * (size_t)(64 * a->head_dim * 2 + a->head_dim * 144);
+    if (a->head_dim != 128 || !a->causal) return -2;
+    if (trace) attn_flash32_kernel<128, true, false, true><<<grid, 256, lds, st>>>(*a, pair_c, trace);
+    else       attn_flash32_kernel<128, true, false, false><<<grid, 256, lds, st>>>(*a, pair_c, nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
