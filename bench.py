@@ -332,13 +332,19 @@ def main():
         from teochat_amd.parallel import TeoComm
         import threading
         box = {}
+        # the check's host-side exchange (the communicator's unique id) runs on its OWN gloo group: if the helper thread is still inside
+        # it at the deadline, the timed region's barrier / all_reduce on the default group stay ordered across ranks
+        try:
+            chk_group = dist.new_group(backend="gloo")
+        except Exception:  # noqa: BLE001 -- no gloo on this build: the default group carries the id (the round-3 behaviour)
+            chk_group = None
 
         def rccl_check():
             # runs on a helper thread with a deadline: a communicator that never forms (a rank missing, a fabric fault) must not
             # hang the throughput line of the data-parallel replicas, which does not depend on it
             try:
                 torch.cuda.set_device(local_rank)
-                c = TeoComm(rank, world, local_rank)
+                c = TeoComm(rank, world, local_rank, group=chk_group)
                 r_, w_, cu_, hbm_ = c.info()
                 send = torch.full((512, 1024), float(rank + 1), dtype=dtype, device=device)
                 recv = torch.zeros(world * 512, 1024, dtype=dtype, device=device)
@@ -465,7 +471,7 @@ def main():
     # (1) IN-RUN: 8 real decode steps right after a real prefill (plain launches on the engine stream), every kernel launch timed
     #     by its own dispatch timestamps (teo_llama_decode_step_profile -> hipExtLaunchKernel start / stop events): kernel time
     #     only, per launch, in the real sequence of the step -- the quantity `rocprofv3 --kernel-trace --stats` reports for the same
-    #     kernels (profiles/r03_bench_kernel_stats.md).  `achieved` / `frac` are computed from THIS number.
+    #     kernels (profiles/r04_bench_kernel_stats.md).  `achieved` / `frac` are computed from THIS number.
     # (2) chain microbenchmark: the same kernel over the 32 layers' matrices back to back between two HIP events (5.8 GB > L3);
     #     it has no neighbours of other kinds and is a few % faster; reported beside (1), never instead of it.
     cfg = model.config
@@ -531,7 +537,7 @@ def main():
     # FETCH_SIZE x2 on gfx950 + WRITE_SIZE); it is NOT measured inside this run: the numbers below are read from the committed
     # summary of those passes (tools/pmc_traffic.sh) and labelled with the file and the commit they were taken at.
     traffic, traffic_src, traffic_all = None, None, None
-    for name in ("r03_pmc_decode_traffic.json", "r02_pmc_gemv_gateup.json", "pmc_gemv_gateup.json"):
+    for name in ("r04_pmc_decode_traffic.json", "r03_pmc_decode_traffic.json", "r02_pmc_gemv_gateup.json", "pmc_gemv_gateup.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:

@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/profile_variants.sh  -> gpurun_out/r03/bench_<variant>_kernel_stats.md
+# usage (on the GPU box): bash tools/profile_variants.sh  -> gpurun_out/r04p/bench_<variant>_kernel_stats.md
 # rocprofv3 kernel summaries of the other north-star shapes (the default C3 one is made by tools/refresh_profiles.sh).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r03
+OUT=$ROOT/gpurun_out/r04p
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 prof() { name=$1; shift; rm -rf /tmp/prof_$name
@@ -13,3 +13,4 @@ prof() { name=$1; shift; rm -rf /tmp/prof_$name
 prof frames16 --frames 16
 prof weightsfp8 --weights fp8
 prof batch8weightsfp8 --batch 8 --weights fp8
+prof batch8 --batch 8

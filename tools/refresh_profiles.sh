@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/refresh_profiles.sh   -> gpurun_out/r03/{bench*.json, kernel_stats.md}
-# The bench lines and the rocprofv3 kernel summary that profiles/r03_* are copied from.
+# usage (on the GPU box): bash tools/refresh_profiles.sh   -> gpurun_out/r04p/{bench*.json, kernel_stats.md}
+# The bench lines and the rocprofv3 kernel summary that profiles/r04_* are copied from.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r03
+OUT=$ROOT/gpurun_out/r04p
 mkdir -p $OUT
 cd $ROOT
 timeout 900 python3 bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
@@ -15,6 +15,8 @@ run batch8 --batch 8
 run batch8weightsfp8 --batch 8 --weights fp8
 run batch16 --batch 16
 run batch16weightsfp8 --batch 16 --weights fp8
+run fp16 --dtype fp16
+run frames16weightsfp8 --frames 16 --weights fp8
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_bench
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_bench.log 2>&1
