@@ -84,6 +84,8 @@ def bench_skinny():
     tiled = L.GEMM_WTILED if int(os.environ.get("SK_TILED", "1")) else 0      # tiled and row-major cost the same to set up here
     lib.teo_tune_set(b"skinny_nt", int(os.environ.get("SK_NT", "1")))
     lib.teo_tune_set(b"skinny_stream", int(os.environ.get("SK_STREAM", "1")))
+    lib.teo_tune_set(b"skinny_ring", int(os.environ.get("SK_RING", "0")))
+    lib.teo_tune_set(b"skinny_unr", int(os.environ.get("SK_UNR", "0")))
     for fp8 in (False, True):
         for name, N, K, flags in shapes:
             wb = 1 if fp8 else 2
