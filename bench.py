@@ -582,6 +582,21 @@ def main():
         avg_ms = dom_in_run_ms = dom_us * 1e-3
         dom_bytes = int(alg_bytes[dom])
         traffic = (traffic_all or {}).get(dom, {}).get("hbm_bytes_per_launch") if (B == 1 and isinstance(traffic_all, dict)) else None
+        if B > 1:
+            # the batched step's own PMC passes exist for config C5's per-GPU shape (8 conversations, fp8 weights: tools/pmc_batch_traffic.sh)
+            traffic_all, traffic_src = None, None
+            pmc_b = os.path.join(ROOT, "profiles", "r04_pmc_batch_traffic.json")
+            if B == 8 and args.weights == "fp8" and abs(ctx_prof - 2178) <= 64 and os.path.exists(pmc_b):       # same shape as the PMC passes
+                try:
+                    blob = json.load(open(pmc_b))
+                    key = {"attn_decode_partial": "attn_decode_whole", "gateup_gemv": "gateup_stream_fp8", "qkv_rope_gemv": "qkv_lmhead_stream_fp8",
+                           "o_gemv": "o_tile_fp8", "down_gemv": "down_tile_fp8"}.get(dom)
+                    traffic_all = blob.get("kernels")
+                    traffic = (traffic_all or {}).get(key, {}).get("hbm_bytes_per_launch")
+                    traffic_src = {"from_profiles": "profiles/r04_pmc_batch_traffic.json", "commit": blob.get("commit"),
+                                   "note": "separate rocprofv3 --pmc passes over `bench.py --batch 8 --weights fp8` (ctx 2178); not measured in this run"}
+                except Exception:  # noqa: BLE001
+                    traffic, traffic_all, traffic_src = None, None, None
     achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": kern_names.get(dom, dom),
                 "share_of_profiled_step": round(share[dom] / sum(share.values()), 4),
