@@ -393,13 +393,15 @@ def bench_attn_prefill():
         res = {}
         for rnd_ in range(3):
             for flash in (1, 0, 2):
-                lib.teo_tune_set(b"flash_order", flash)
+                lib.teo_tune_set(b"flash_order", 1)
+                lib.teo_tune_set(b"flash_pipe", 0 if flash == 2 else -1)
+                lib.teo_tune_set(b"flash_order", 0 if flash == 0 else 1)
                 us = timeit(lambda: G.attention(q, k, v, causal, d ** -0.5, vt=vt))
                 res.setdefault(flash, []).append(us)
-        lib.teo_tune_set(b"flash_order", 1)
+        lib.teo_tune_reset()
         a, b_ = min(res[1]), min(res[0])
         print(f"attn prefill B={B} H={H} S={S} d={d} causal={causal}: mirrored {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s | "
-              f"heavy-first {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | alternating {min(res[2]):8.1f} us", flush=True)
+              f"heavy-first {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | one tile at a time {min(res[2]):8.1f} us", flush=True)
 
 
 def bench_norm():

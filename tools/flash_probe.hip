@@ -18,12 +18,18 @@ using namespace teo;
 
 extern "C" int flash_probe_trace_iters() { return FA_TRACE_ITERS; }
 
-extern "C" int flash_probe_launch(const teo_attn_args* a, int pair_c, unsigned long long* trace, void* stream) {
+// pipe: 1 = the in-wave software pipeline, 0 = one tile at a time (both stage by LDS-DMA)
+extern "C" int flash_probe_launch(const teo_attn_args* a, int pair_c, unsigned long long* trace, void* stream, int pipe) {
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(((a->q_len + 127) / 128) * a->heads * a->batch);
-    const size_t lds = 2 * (size_t)(64 * a->head_dim * 2 + a->head_dim * 144);
+    const size_t lds = 2 * (size_t)(64 * a->head_dim * 2 + a->head_dim * 128);
     if (a->head_dim != 128 || !a->causal) return -2;
-    if (trace) attn_flash32_kernel<128, true, false, true><<<grid, 256, lds, st>>>(*a, pair_c, trace);
-    else       attn_flash32_kernel<128, true, false, false><<<grid, 256, lds, st>>>(*a, pair_c, nullptr);
+    if (pipe) {
+        if (trace) attn_flash32_kernel<128, true, false, true, true><<<grid, 256, lds, st>>>(*a, pair_c, trace);
+        else       attn_flash32_kernel<128, true, false, false, true><<<grid, 256, lds, st>>>(*a, pair_c, nullptr);
+    } else {
+        if (trace) attn_flash32_kernel<128, true, false, true, false><<<grid, 256, lds, st>>>(*a, pair_c, trace);
+        else       attn_flash32_kernel<128, true, false, false, false><<<grid, 256, lds, st>>>(*a, pair_c, nullptr);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

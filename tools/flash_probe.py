@@ -30,7 +30,7 @@ def main():
     if not os.path.exists(SO):
         build()
     lib = C.CDLL(SO)
-    lib.flash_probe_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.flash_probe_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     NIT = lib.flash_probe_trace_iters()
     B, H, d = 1, 32, 128
     bf = torch.bfloat16
@@ -51,27 +51,33 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     trace = torch.zeros(4 * NIT * 6, dtype=torch.int64, device="cuda")
 
-    def timed(pair_c, n=20):
+    def timed(pair_c, pipe=1, n=20):
         for _ in range(3):
-            assert lib.flash_probe_launch(C.byref(a), pair_c, None, st) == 0
+            assert lib.flash_probe_launch(C.byref(a), pair_c, None, st, pipe) == 0
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):
-            lib.flash_probe_launch(C.byref(a), pair_c, None, st)
+            lib.flash_probe_launch(C.byref(a), pair_c, None, st, pipe)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e3
 
-    print(f"S={S}: kernel {timed(32):.1f} us (mirrored order), {timed(0):.1f} us (heavy-first)")
+    print(f"S={S}: kernel {timed(32):.1f} us (in-wave pipeline, mirrored order), {timed(0):.1f} us (pipeline, heavy-first), "
+          f"{timed(32, 0):.1f} us (one tile at a time, mirrored order)")
+    o_pipe = o.clone()
+    assert lib.flash_probe_launch(C.byref(a), 32, None, st, 0) == 0
+    torch.cuda.synchronize()
+    print("pipeline == one tile at a time, bitwise:", bool(torch.equal(o, o_pipe)))
+    pipe = int(os.environ.get("FA_PIPE", "1"))
     for rep in range(2):
         trace.zero_()
-        assert lib.flash_probe_launch(C.byref(a), 32, trace.data_ptr(), st) == 0
+        assert lib.flash_probe_launch(C.byref(a), 32, trace.data_ptr(), st, pipe) == 0
         torch.cuda.synchronize()
     tr = trace.cpu().view(4, NIT, 6).double() * 0.01                            # us
     nt = min(NIT, (S + 63) // 64)
     t0 = tr[:, 0, 0].min()
-    names = ["stage", "scores", "softmax", "PV", "barrier"]
+    names = ["DMA issue", "scores(+1) | softmax", "PV", "wait DMA", "barrier"]
     print(f"workgroup 0 (heaviest query block, {nt} KV tiles); per wave: mean us per iteration in each phase, and the iteration period")
     for w in range(4):
         ph = tr[w, :nt, 1:] - tr[w, :nt, :-1]
