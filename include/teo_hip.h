@@ -63,8 +63,9 @@ const char* teo_last_kernel(void);
  *                   "gemm_sk_dbg" (timing diagnostics of the hand-off: WRONG results, never set outside tools/), "gemm_wide" (0 off, 1 auto,
  *                   2 force), "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force), "gemm_big_group", "gemm_big_hybrid"
  *                   (0 off, 1 auto, 2 force), "gemm_fp8_wide" (0..3), "gemm_fp8_big" (0..2) -- all bit-identical families
- *   prefill attn  : "flash_order" (causal workgroup order of the flash kernel: 0 heavy-first, 1 second dispatch pass mirrored, 2 alternating;
- *                   same tiles and arithmetic)
+ *   prefill attn  : "flash_order" (causal workgroup order of the flash kernel: 0 heavy-first, 1 second dispatch pass mirrored), "flash_pipe"
+ *                   (software pipeline inside the wave: -1 auto = causal kernels, 0 one tile at a time, 1 wherever the form exists) --
+ *                   same tiles, same arithmetic: bit-identical
  *   decode attn   : "attn_chunk" (keys per decode chunk: 0 auto, 32/64/128/256; fp32 order of the split merge + where P is rounded),
  *                   "attn_whole" (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto, 2 whenever the shape
  *                   allows; bit-identical to the split + combine pair at the same chunk)

@@ -207,6 +207,32 @@ def test_attention_mfma_bf16(B, H, Hk, Sq, Sk, d, causal):
     torch.testing.assert_close(o.float(), os_.float(), atol=1.5e-2, rtol=1.5e-2)
 
 
+@pytest.mark.parametrize("B,H,Hk,Sq,Sk,d,causal", [(1, 8, 8, 700, 700, 128, True),      # several query blocks, tail tile (700 % 64 = 60)
+                                                   (1, 8, 2, 333, 901, 128, True),      # chunked prefill (past 568), GQA, ragged both ways
+                                                   (2, 16, 16, 257, 257, 64, False),    # the tower's shape: four tile pairs, one-key tail
+                                                   (1, 8, 8, 130, 130, 64, True)])
+def test_attention_flash_pipeline_and_workgroup_order_do_not_change_a_bit(B, H, Hk, Sq, Sk, d, causal):
+    """The in-wave software pipeline (score MFMAs of tile t+1 issued with the softmax of tile t; "flash_pipe") and the mirrored order of
+    the causal workgroups ("flash_order") change WHEN things happen, never what is computed: outputs are bit-identical to the
+    one-tile-at-a-time loop in plain heavy-first order, also with NaN in the V^T padding beyond kv_len."""
+    bf = torch.bfloat16
+    lib = G.lib()
+    q, k, v = (G.bf16_round(rnd(B, H, Sq, d, seed=4)), G.bf16_round(rnd(B, Hk, Sk, d, seed=5)), G.bf16_round(rnd(B, Hk, Sk, d, seed=6)))
+    qd, kd, vd = G.dev(q, bf), G.dev(k, bf), G.dev(v, bf)
+    vt = G.make_vt(vd)
+    vt[..., Sk:] = float("nan")
+    outs = {}
+    for pipe, order in ((0, 0), (1, 1), (1, 0), (0, 1), (-1, 1)):
+        assert lib.teo_tune_set(b"flash_pipe", pipe) == 0 and lib.teo_tune_set(b"flash_order", order) == 0
+        outs[(pipe, order)] = G.attention(qd, kd, vd, causal, d ** -0.5, vt=vt)
+        assert lib.teo_last_kernel() == b"attn_flash32"
+    lib.teo_tune_reset()
+    base = outs[(0, 0)]
+    assert torch.isfinite(base.float()).all()
+    for key, o in outs.items():
+        assert torch.equal(o, base), key
+
+
 def test_attention_mfma_online_softmax_rescale_branch():
     """Force the running max to jump late in the key sequence (spike one key against one query)."""
     bf = torch.bfloat16
