@@ -341,8 +341,9 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // Sampler: temperature -> top-k -> softmax -> multinomial, one 1024-thread workgroup, logits stay in L2.
-//   k-th largest value by a 4-pass radix select on the order-preserving uint image of the floats (LDS histogram),
-//   survivors (>= threshold, at most TOPK_CAP) gathered in index order, softmax over them in fp32, inverse-CDF draw.
+//   k-th largest value on the order-preserving uint image of the floats: vocab <= 32768 -> the row in registers (32 consecutive logits
+//   per thread) and a bisection on the key; larger -> 4-pass radix select (LDS histogram).  Survivors (>= threshold, at most TOPK_CAP)
+//   gathered in index order, softmax over them in fp32, inverse-CDF draw.  Both forms select the same set and draw the same token.
 //   RNG: splitmix64(seed, draw) -> 24-bit uniform in [0,1): counter based, so a hipGraph replay only needs the draw
 //   counter in device memory.
 // ------------------------------------------------------------------------------------------------
@@ -413,52 +414,122 @@ __device__ int sample_topk_block(const float* __restrict__ logits, int vocab, fl
     if (k == vocab && vocab > TOPK_CAP && !(top_p > 0.f && top_p < 1.f))      // filter off: full-vocabulary multinomial
         return sample_full_block(logits, vocab, temperature, u, sel_val, s_misc);
     if (k > TOPK_CAP) k = TOPK_CAP;                 // host entry points reject this case (teo_sampler_supported)
-    // ---- radix select of the k-th largest key
-    unsigned prefix = 0, mask = 0;
-    int want = k;                                   // rank (1 = largest) still to find inside the current prefix class
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int i = tid; i < 256; i += 1024) hist[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < vocab; i += 1024) {
-            const unsigned key = f2ord(logits[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0, b = 255;
-            for (; b > 0; --b) {
-                if (acc + (int)hist[b] >= want) break;
-                acc += (int)hist[b];
+    // ---- the k-th largest key and the survivors (>= that key, ties kept) in index order
+    constexpr int VPT = 32;                         // logits per thread of the register-resident form
+    if (vocab <= 1024 * VPT && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        // round 4: every thread keeps its 32 CONSECUTIVE logits in registers (one pass over the 128 KB row instead of 4 radix passes + a
+        // 32-strip compaction, and no LDS histogram: the first radix pass put ~all keys into a few exponent bins = serialised atomics).
+        // The threshold is found by bisection on the 32-bit ordered key: 32 rounds of (32 compares per thread, one block-wide count).
+        unsigned key[VPT];
+        const int lo = tid * VPT;
+#pragma unroll
+        for (int j = 0; j < VPT; j += 4) {
+            if (lo + j + 3 < vocab) {
+                const float4 v = *reinterpret_cast<const float4*>(logits + lo + j);
+                key[j] = f2ord(v.x); key[j + 1] = f2ord(v.y); key[j + 2] = f2ord(v.z); key[j + 3] = f2ord(v.w);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) key[j + e] = lo + j + e < vocab ? f2ord(logits[lo + j + e]) : 0u;    // 0: below every float's key
             }
-            s_misc[0] = b;
-            s_misc[1] = want - acc;
         }
-        __syncthreads();
-        prefix |= ((unsigned)s_misc[0]) << shift;
-        mask |= 255u << shift;
-        want = s_misc[1];
-        __syncthreads();
-    }
-    const unsigned thr = prefix;                    // key of the k-th largest logit; ties at thr are all kept (as torch.topk
-                                                    // keeps an arbitrary subset, the distribution only differs on exact ties)
-    // ---- gather survivors in index order (deterministic): ordered compaction by 1024-element strips
-    if (tid == 0) s_misc[2] = 0;
-    __syncthreads();
-    for (int base = 0; base < vocab; base += 1024) {
-        const int i = base + tid;
-        const bool keep = i < vocab && f2ord(logits[i]) >= thr;
-        const unsigned long long bal = __ballot(keep);
+        unsigned lo_k = 1u, hi_k = 0xFFFFFFFFu;       // invariant: count(key >= lo_k) >= k  (k <= vocab real keys, all >= 1)
+        for (int it = 0; it < 32 && lo_k < hi_k; ++it) {
+            const unsigned mid = lo_k + ((hi_k - lo_k) >> 1) + ((hi_k - lo_k) & 1u);       // upper middle: the range always shrinks
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) c += key[j] >= mid ? 1 : 0;
+            const float cw = wave_sum((float)c);      // <= 2048 per wave: exact in fp32
+            unsigned* cnt = hist + (it & 1) * 16;
+            if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)cw;
+            __syncthreads();
+            unsigned total = 0;
+#pragma unroll
+            for (int ww = 0; ww < 16; ++ww) total += cnt[ww];
+            if ((int)total >= k) lo_k = mid; else hi_k = mid - 1u;
+        }
+        const unsigned thr = lo_k;
+        // ordered compaction: exclusive scan of the per-thread survivor counts (wave scan + wave totals)
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) mine += key[j] >= thr ? 1 : 0;
         const int lane = tid & 63, w = tid >> 6;
-        if (lane == 0) hist[w] = (unsigned)__popcll(bal);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        __syncthreads();                              // the counts of the last bisection round are read
+        if (lane == 63) hist[32 + w] = (unsigned)incl;
         __syncthreads();
-        int off = s_misc[2];
-        for (int ww = 0; ww < w; ++ww) off += (int)hist[ww];
-        const int my = off + __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep && my < TOPK_CAP) { sel_idx[my] = i; sel_val[my] = logits[i]; }
+        int pos = incl - mine;
+        int total = 0;
+#pragma unroll
+        for (int ww = 0; ww < 16; ++ww) {
+            const int t = (int)hist[32 + ww];
+            if (ww < w) pos += t;
+            total += t;
+        }
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            if (key[j] >= thr) {
+                if (pos < TOPK_CAP) {
+                    sel_idx[pos] = lo + j;
+                    sel_val[pos] = __uint_as_float((key[j] & 0x80000000u) ? (key[j] ^ 0x80000000u) : ~key[j]);
+                }
+                ++pos;
+            }
+        }
+        if (tid == 0) s_misc[2] = total;
         __syncthreads();
-        if (tid == 0) { int t = 0; for (int ww = 0; ww < 16; ++ww) t += (int)hist[ww]; s_misc[2] += t; }
+    } else {
+        // ---- radix select of the k-th largest key
+        unsigned prefix = 0, mask = 0;
+        int want = k;                                   // rank (1 = largest) still to find inside the current prefix class
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < vocab; i += 1024) {
+                const unsigned key = f2ord(logits[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, b = 255;
+                for (; b > 0; --b) {
+                    if (acc + (int)hist[b] >= want) break;
+                    acc += (int)hist[b];
+                }
+                s_misc[0] = b;
+                s_misc[1] = want - acc;
+            }
+            __syncthreads();
+            prefix |= ((unsigned)s_misc[0]) << shift;
+            mask |= 255u << shift;
+            want = s_misc[1];
+            __syncthreads();
+        }
+        const unsigned thr = prefix;                    // key of the k-th largest logit; ties at thr are all kept (as torch.topk
+                                                        // keeps an arbitrary subset, the distribution only differs on exact ties)
+        // ---- gather survivors in index order (deterministic): ordered compaction by 1024-element strips
+        if (tid == 0) s_misc[2] = 0;
         __syncthreads();
+        for (int base = 0; base < vocab; base += 1024) {
+            const int i = base + tid;
+            const bool keep = i < vocab && f2ord(logits[i]) >= thr;
+            const unsigned long long bal = __ballot(keep);
+            const int lane = tid & 63, w = tid >> 6;
+            if (lane == 0) hist[w] = (unsigned)__popcll(bal);
+            __syncthreads();
+            int off = s_misc[2];
+            for (int ww = 0; ww < w; ++ww) off += (int)hist[ww];
+            const int my = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && my < TOPK_CAP) { sel_idx[my] = i; sel_val[my] = logits[i]; }
+            __syncthreads();
+            if (tid == 0) { int t = 0; for (int ww = 0; ww < 16; ++ww) t += (int)hist[ww]; s_misc[2] += t; }
+            __syncthreads();
+        }
     }
     const int n = min(s_misc[2], TOPK_CAP);
     // ---- softmax over the survivors at the given temperature, inverse CDF in index order
@@ -616,7 +687,7 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
     }
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    const int nv4 = vocab >> 2;
+    const int nv4 = st.do_sample ? 0 : vocab >> 2;          // the argmax pass only when the token is not sampled
     const float4* l4 = reinterpret_cast<const float4*>(logits);
     for (int i = threadIdx.x; i < nv4; i += 1024) {
         const float4 v = l4[i];
@@ -626,7 +697,7 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
         if (v.z > best) { best = v.z; bi = b + 2; }
         if (v.w > best) { best = v.w; bi = b + 3; }
     }
-    for (int i = (nv4 << 2) + threadIdx.x; i < vocab; i += 1024) {
+    for (int i = (nv4 << 2) + threadIdx.x; i < (st.do_sample ? 0 : vocab); i += 1024) {
         const float v = logits[i];
         if (v > best || bi == 0x7fffffff) { best = v; bi = i; }
     }

@@ -460,6 +460,25 @@ def test_sampler_distribution_matches_softmax_of_topk():
     assert bool(((counts - n * p).abs() < 5 * sigma).all()), (counts, n * p)
 
 
+@pytest.mark.parametrize("vocab,top_k,top_p", [(32000, 50, 1.0), (32000, 1000, 0.9), (32000, 7, 1.0), (5000, 50, 0.8), (32768, 50, 1.0)])
+def test_sampler_register_form_draws_what_the_radix_form_draws(vocab, top_k, top_p):
+    """vocab <= 32768: the row is held in registers and the k-th largest key found by bisection (round 4); larger rows -- and rows that
+    are not 16-byte aligned -- take the 4-pass radix select.  Same threshold, same survivors in the same order, same draw: the two forms
+    return the same token for every (seed, draw), duplicates of the k-th value included."""
+    g = torch.Generator().manual_seed(vocab + top_k)
+    lg = torch.randn(vocab, generator=g) * 3.0
+    lg[torch.randint(0, vocab, (40,), generator=g)] = float(lg.topk(top_k).values[-1])       # ties AT the threshold
+    aligned = lg.cuda()
+    pad = torch.empty(vocab + 1, device="cuda")
+    pad[1:] = aligned
+    shifted = pad[1:]                                                                          # 4 bytes off: the radix form
+    assert aligned.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 != 0
+    for seed in (1, 77):
+        a = [_sample(aligned, 3.0, top_k, seed, d, top_p) for d in range(48)]
+        b = [_sample(shifted, 3.0, top_k, seed, d, top_p) for d in range(48)]
+        assert a == b, (seed, a, b)
+
+
 def test_sampler_ties_and_small_vocab():
     lg = torch.zeros(300).cuda()                               # all tied: every index may be drawn, never out of range
     s = {_sample(lg, 1.0, 50, 3, d) for d in range(200)}
