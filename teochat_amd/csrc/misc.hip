@@ -446,6 +446,7 @@ __device__ int sample_topk_block(const float* __restrict__ logits, int vocab, fl
 #pragma unroll
             for (int ww = 0; ww < 16; ++ww) total += cnt[ww];
             if ((int)total >= k) lo_k = mid; else hi_k = mid - 1u;
+            if ((int)total == k) break;               // exactly the top k lie at or above mid: the survivor set is already final
         }
         const unsigned thr = lo_k;
         // ordered compaction: exclusive scan of the per-thread survivor counts (wave scan + wave totals)
