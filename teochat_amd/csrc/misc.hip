@@ -215,9 +215,41 @@ __global__ __launch_bounds__(256) void vit_vt_kernel(const T* __restrict__ qkv, 
     }
 }
 
+// 16-bit variant with 16-byte global accesses on both sides (the shape of vt_append_vec_kernel): block = (64 tokens, one head, one frame),
+// hd <= 128; tokens j >= N are written as zeros.  9.5 -> ~4 us per tower layer at T = 8.
+__global__ __launch_bounds__(256) void vit_vt_vec_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt, int N, int heads, int hd,
+                                                         int ldv) {
+    __shared__ bf16_t tile[64][136];                       // row stride 272 B: 16-byte aligned rows, column reads spread over banks
+    const int j0 = blockIdx.x * 64, h = blockIdx.y, t = blockIdx.z;
+    const int D = heads * hd, nc = hd >> 3;                // 16-byte chunks per row
+    const bf16_t* src = qkv + ((long long)t * N + j0) * (3 * D) + 2 * D + h * hd;
+    for (int id = threadIdx.x; id < 64 * nc; id += 256) {
+        const int r = id / nc, c = id % nc;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (j0 + r < N) v = *reinterpret_cast<const uint4*>(src + (long long)r * (3 * D) + c * 8);
+        *reinterpret_cast<uint4*>(&tile[r][c * 8]) = v;
+    }
+    __syncthreads();
+    bf16_t* dst = vt + (((long long)t * heads + h) * hd) * ldv + j0;
+    for (int id = threadIdx.x; id < hd * 8; id += 256) {
+        const int d = id >> 3, pc = id & 7;                // 8 tokens pc*8 .. +8 of dim d
+        if (j0 + pc * 8 >= ldv) continue;
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = (unsigned)tile[pc * 8 + 2 * e][d] | ((unsigned)tile[pc * 8 + 2 * e + 1][d] << 16);
+        *reinterpret_cast<uint4*>(dst + (long long)d * ldv + pc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 int vit_value_transpose(const void* qkv, void* vt, int T_, int N, int heads, int hd, int ldv, int dtype, hipStream_t st) {
     if (T_ == 0) return TEO_OK;
     dim3 grid(cdiv(ldv, 64), heads, T_);
+    if (dtype != TEO_F32 && hd % 8 == 0 && hd <= 128 && ldv % 8 == 0 && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(vt)) & 15) == 0) {
+        vit_vt_vec_kernel<<<grid, 256, 0, st>>>((const bf16_t*)qkv, (bf16_t*)vt, N, heads, hd, ldv);       // bf16 and fp16: a 16-bit move
+        TEO_LAUNCH_CHECK("vit_value_transpose");
+        return TEO_OK;
+    }
     if (dtype == TEO_F32) vit_vt_kernel<float><<<grid, 256, 0, st>>>((const float*)qkv, (float*)vt, N, heads, hd, ldv);
     else vit_vt_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)qkv, (bf16_t*)vt, N, heads, hd, ldv);
     TEO_LAUNCH_CHECK("vit_value_transpose");

@@ -342,6 +342,16 @@ def test_im2col_vt_dropcls_bit_exact():
     L.check(G.lib().teo_vit_value_transpose(G.p(d_qkv), G.p(vt), T, N, H, hd, ldv, L.TEO_F32, G.stream()), "vt")
     v = qkv.view(T, N, 3, H, hd)[:, :, 2]                       # [T,N,H,hd]
     assert torch.equal(vt[..., :N].cpu(), v.permute(0, 2, 3, 1)) and float(vt[..., N:].abs().sum()) == 0
+    # the 16-bit form (16-byte accesses through an LDS transpose) at the tower's shape: N = 257, ldv = 320, and a ragged one
+    for (Tv, Nv, Hv, hdv, ldvv, dt, code) in ((3, 257, 16, 64, 320, torch.bfloat16, L.TEO_BF16), (2, 70, 2, 128, 128, torch.float16, L.TEO_F16),
+                                              (1, 9, 1, 32, 16, torch.bfloat16, L.TEO_BF16)):
+        Dv = Hv * hdv
+        q16 = rnd(Tv * Nv, 3 * Dv, seed=5).to(dt)
+        vt16 = torch.full((Tv, Hv, hdv, ldvv), 7.0, dtype=dt, device="cuda")
+        d_q16 = q16.cuda()
+        L.check(G.lib().teo_vit_value_transpose(G.p(d_q16), G.p(vt16), Tv, Nv, Hv, hdv, ldvv, code, G.stream()), "vt16")
+        v16 = q16.view(Tv, Nv, 3, Hv, hdv)[:, :, 2]
+        assert torch.equal(vt16[..., :Nv].cpu(), v16.permute(0, 2, 3, 1)) and float(vt16[..., Nv:].float().abs().sum()) == 0
     # drop CLS
     h = rnd(T, N, D, seed=3)
     out = torch.empty(T, N - 1, D, device="cuda")
