@@ -574,6 +574,13 @@ def main():
                       "qkv_rope_gemv": f"gemv_qkv_rope_kernel<{w_tag}> (decode rmsnorm + qkv + RoPE + KV append)",
                       "down_gemv": f"gemv_splitk_kernel<{w_tag}> (decode down + residual)", "o_gemv": f"gemv_splitk_kernel<{w_tag}> (decode o + residual)",
                       "lm_head_gemv": f"gemv_kernel<{w_tag}, f32 out> (rmsnorm + lm_head)"}
+    # the committed PMC passes were taken on the bf16 C3 run: GEMV traffic applies to any bf16 run (it does not depend on the context),
+    # attention traffic only at that context; fp8 / fp16 runs stream other bytes through other instantiations -> no traffic figure
+    pmc_applies = B == 1 and args.weights == "bf16" and args.dtype == "bf16"
+    if not pmc_applies:
+        traffic, traffic_all_b1 = None, None
+    else:
+        traffic_all_b1 = traffic_all
     if dom == "gateup_gemv" and B == 1:
         avg_ms = gu_us * 1e-3 if chain_ms is None else max(gu_us * 1e-3, chain_ms)
         dom_bytes, dom_in_run_ms = gemv_bytes, gu_us * 1e-3
@@ -581,7 +588,9 @@ def main():
         dom_us = prof[dom][1] + (prof.get("attn_decode_combine", (0, 0.0))[1] if dom == "attn_decode_partial" else 0.0)
         avg_ms = dom_in_run_ms = dom_us * 1e-3
         dom_bytes = int(alg_bytes[dom])
-        traffic = (traffic_all or {}).get(dom, {}).get("hbm_bytes_per_launch") if (B == 1 and isinstance(traffic_all, dict)) else None
+        traffic = (traffic_all_b1 or {}).get(dom, {}).get("hbm_bytes_per_launch") if isinstance(traffic_all_b1, dict) else None
+        if dom.startswith("attn") and abs(ctx_prof - 2176) > 64:
+            traffic = None
         if B > 1:
             # the batched step's own PMC passes exist for config C5's per-GPU shape (8 conversations, fp8 weights: tools/pmc_batch_traffic.sh)
             traffic_all, traffic_src = None, None
@@ -612,7 +621,7 @@ def main():
                 "chain_microbench_frac": None if chain_ms is None else round(gemv_bytes / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "decode_kernels_in_run": in_run,
                 "decode_step_sum_of_kernels_ms": round(step_kernel_us * 1e-3, 4)}
-    if traffic_all:
+    if traffic_all and (B > 1 or pmc_applies):
         roofline["traffic_per_kernel"] = traffic_all
     # whole decode step against the HBM roofline (weights + KV per token)
     kv_ctx = Lseq + n_out / 2.0
