@@ -1,5 +1,12 @@
-import torch, sys, time
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""Device sampler (teo_sample_topk) per draw: the register-resident bisection form (16-byte aligned rows of <= 32768 logits) against the
+4-pass radix select (taken for a row that is 4 bytes off).  usage: python tools/sampler_time.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from teochat_amd import _lib as L
 from tests import _gpu as G
 lib = L.load()
