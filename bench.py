@@ -277,6 +277,7 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--rccl-timeout", type=float, default=180.0, help="deadline (s) of the once-per-run RCCL communicator check")
     ap.add_argument("--tune", action="append", default=[], help="key=value passed to teo_tune_set (perf knobs only)")
+    ap.add_argument("--rope-in-attn", type=int, default=None, choices=[0, 1], help="A/B of the engine option: RoPE + KV append inside the decode attention kernel (1) or in the QKV GEMV epilogue (0, the single-conversation default); same values")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -318,6 +319,8 @@ def main():
         if args.weights != "fp8":
             raise SystemExit("--prefill fp8 needs --weights fp8 (the e4m3 weight copies)")
         eng.set_options(prefill_fp8=True)
+    if args.rope_in_attn is not None:
+        eng.set_options(rope_in_attn=bool(args.rope_in_attn))
     for kv in args.tune:
         k_, v_ = kv.split("=")
         L.check(eng.lib.teo_tune_set(k_.encode(), int(v_)), "teo_tune_set")
