@@ -101,13 +101,10 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 static int g_dec_chunk = 0;       // keys per workgroup (32 / 64 / 128 / 256); 0 = auto: 64 for one conversation (2.83 vs 2.86 ms/token
                                   // at 128, 2.87 at 32, 2.94 at 256), 128 for a batched step (4.74 vs 4.79 ms/step at 64)
-static int g_attn_fused = 1;      // split kernel + merger workgroups polling tagged records (no combine launch): 0 off, 1 when the step provides the
-                                  // epoch and layer, 2 also for direct attn_decode calls (tests / probes).  Bit-identical to split + combine.
 static int g_attn_whole = 1;      // batched steps: whole-context kernel (one workgroup per (conversation, head), no combine launch): 0 off, 1 auto
                                   // (batch * heads >= half the CUs), 2 whenever the shape allows.  Bit-identical to the split + combine pair.
-void attn_tune_reset() { g_dec_chunk = 0; g_attn_whole = 1; g_attn_fused = 1; }
+void attn_tune_reset() { g_dec_chunk = 0; g_attn_whole = 1; }
 int attn_tune_set(const char* key, int value) {
-    if (!strcmp(key, "attn_fused") && value >= 0 && value <= 2) { g_attn_fused = value; return 0; }
     if (!strcmp(key, "attn_whole") && value >= 0 && value <= 2) { g_attn_whole = value; return 0; }
     if (!strcmp(key, "attn_chunk") && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
     return -1;
@@ -156,151 +153,27 @@ __device__ __forceinline__ uint4 ld_kv(const void* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// Merge of one head's split records (m, l, o[hd]) by 512 (virtual) threads: shared by the combine launch (records in global memory),
-// the whole-context kernel (records in LDS) and the split kernel's merger workgroups (256 threads, VT = 2: every thread plays virtual
-// threads tid and tid + 256) so all three evaluate the same expressions in the same order.
-// Split weights: one thread per split (parallel loads).  Output: virtual thread = (column d, split group g); it owns every G-th
-// split (G = 512 / hd) and keeps its loads in flight, the G partial sums of a column meet in LDS -- one or two round trips
-// instead of a dependent chain over all splits.  pb: records of this head, `stride` floats apart; nact <= 256 splits hold keys.
-template <typename T, int VT = 1>
-__device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb, int stride, int nact, int hd, T* __restrict__ o_row,
-                                                   float* w /* [256] */, float* red /* [16] */, float* accs /* [512] */) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const bool on = tid < 512 / VT;                                         // a larger workgroup: the other waves only join the barriers
-    const int G = 512 / hd;                                                 // hd is a power of two <= 256
-    const int d = tid % hd;
-    int g[VT];
-#pragma unroll
-    for (int u = 0; u < VT; ++u) g[u] = on ? (tid + u * (512 / VT)) / hd : 0;
-    // the first NB splits of a virtual thread are requested together with the split statistics (they do not depend on them): ONE round
-    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split)
-    constexpr int NB = 12;
-    float v0[VT][NB];
-#pragma unroll
-    for (int u = 0; u < VT; ++u) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) v0[u][i] = pb[(long long)min(g[u] + i * G, nact - 1) * stride + 2 + d];
-    }
-    float m0 = -INFINITY, l0 = 0.f;
-    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
-    float M = wave_max(m0);
-    if (lane == 0 && on) red[wid] = M;
-    __syncthreads();
-    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));               // splits live in threads 0..255 = waves 0..3
-    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
-    if (tid < 256) w[tid] = w0;
-    float L = wave_sum(l0 * w0);
-    if (lane == 0 && on) red[8 + wid] = L;
-    __syncthreads();
-    const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
-#pragma unroll
-    for (int u = 0; u < VT; ++u) {
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) a += (g[u] + i * G < nact) ? v0[u][i] * w[min(g[u] + i * G, 255)] : 0.f;
-        for (int s0 = g[u] + NB * G; s0 < nact; s0 += 8 * G) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = pb[(long long)min(s0 + i * G, nact - 1) * stride + 2 + d];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * w[min(s0 + i * G, 255)] : 0.f;
-        }
-        if (on) accs[tid + u * (512 / VT)] = a;
-    }
-    __syncthreads();
-    if (on && tid < hd) {
-        float t = 0.f;
-        for (int k = 0; k < G; ++k) t += accs[d + k * hd];
-        Elem<T>::st(o_row + d, t * inv);
-    }
-}
-
 // q: [heads*hd] (already rotated), K/V cache [kv_heads][S_max][hd]; partial: [heads][nsplit][hd + 2] fp32 (m, l, o[hd])
 // ROPE: `q` is the raw [q | k | v] row of the new token (GEMV output, not yet rotated).  The kernel rotates q on load,
 // and the one lane group that owns key `pos` rotates the new k, takes the new v, appends both to the caches (K, V, V^T)
 // and uses them directly -- RoPE + KV append cost no launch and no pass of their own.
-// Grid: (heads * nsplit [+ heads], batch), workgroup x = split * heads + head.
-//
-// POLL (round 4): no combine launch.  `heads` extra workgroups at the END of the grid -- dispatched after every split workgroup, so
-// they can wait for them without a deadlock at any grid size -- each merge one head.  A split workgroup does not wait for anything:
-// it writes its record as 16-byte pieces {3 floats, tag} with write-through (sc1) stores and is done; the merger of the head keeps
-// re-reading (sc1 loads) the pieces that do not carry this launch's tag yet, moves the ones that do into an LDS image of the
-// records, and runs the combine's own merge code on it once all are there (bit-identical output).  The tag is
-// f(generation epoch in device memory, position, layer): a piece left over from an earlier launch never matches.  With
-// x = split * heads + head and heads % 8 == 0 the merger sits on the XCD of its head's split workgroups (workgroup id % 8,
-// profiles/r04_xcc_probe.txt) -- a latency matter only: correctness rests on the tags and the write-through stores.
-template <typename T, int LPR, int DEC_CHUNK, bool ROPE, bool POLL = false>
+template <typename T, int LPR, int DEC_CHUNK, bool ROPE>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, T* __restrict__ kc,
                                                                   T* __restrict__ vc, T* __restrict__ vtc,
                                                                   const float* __restrict__ cs, const float* __restrict__ sn,
                                                                   float* __restrict__ part, const int* __restrict__ d_pos,
                                                                   int S_max, int heads, int kv_heads, float scale, int nsplit,
-                                                                  AttnBatch bt, T* __restrict__ o, unsigned salt) {
+                                                                  AttnBatch bt) {
     constexpr int VE = Cvt16<T>::N;
     constexpr int HD = LPR * VE;
-    constexpr int NPC = (HD + 2 + 2) / 3;               // POLL: 16-byte pieces per record (3 floats + tag each)
-    constexpr int RECF = POLL ? NPC * 4 : HD + 2;       // floats per record in `part`
-    {   // conversation blockIdx.y of a batched step: its own query row, caches, position and partial slab
-        const long long bz = blockIdx.y;
+    {   // conversation blockIdx.z of a batched step: its own query row, caches, position and partial slab
+        const long long bz = blockIdx.z;
         q += bz * bt.q_stride;
         kc += bz * bt.cache_stride;
         vc += bz * bt.cache_stride;
         if (vtc) vtc += bz * bt.cache_stride;
         d_pos += bz;
-        part += bz * (long long)heads * nsplit * RECF;
-        if (POLL) o += bz * bt.o_stride;
-    }
-    unsigned tag = 0;
-    if constexpr (POLL) {
-        const unsigned epoch = bt.d_epoch ? *bt.d_epoch : 0u;
-        tag = (epoch * 2654435761u) ^ ((unsigned)*d_pos << 7) ^ (salt * 40503u) ^ 0x80000001u;
-        if ((int)blockIdx.x >= heads * nsplit) {            // ---- a merger workgroup
-            extern __shared__ __attribute__((aligned(16))) float pm_lds[];
-            const int h = blockIdx.x - heads * nsplit, tid = threadIdx.x;
-            const int nact = min(nsplit, (*d_pos + 1 + DEC_CHUNK - 1) / DEC_CHUNK);
-            float* rec = pm_lds;                             // [nact][HD + 2], then the merge scratch
-            const auto src = __builtin_amdgcn_make_buffer_rsrc(part + (long long)h * nsplit * RECF, 0, nsplit * RECF * 4, 0x00020000);
-            const int total = nact * NPC;                    // pieces of this head
-            constexpr int OWN = 8;                           // pieces in flight per thread and round
-            for (int base = 0; base < total; base += 256 * OWN) {
-                unsigned missing = 0;
-#pragma unroll
-                for (int j = 0; j < OWN; ++j) missing |= (base + j * 256 + tid < total) ? (1u << j) : 0u;
-                int spins = 0;
-                while (true) {
-                    kv_u32x4 v[OWN];
-                    // the first rounds read through the XCD's L2 (L1 invalidated, plain loads): the head's split workgroups run on this
-                    // XCD and their write-through stores update that L2 -- a hit costs a third of a trip to memory.  Should the placement
-                    // ever differ, the L2 copy stays stale and the later rounds, device-coherent (sc1) loads, still see the records.
-                    if (spins < 12) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-                        for (int j = 0; j < OWN; ++j)
-                            if (missing & (1u << j)) v[j] = __builtin_amdgcn_raw_buffer_load_b128(src, (base + j * 256 + tid) * 16, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < OWN; ++j)
-                            if (missing & (1u << j)) v[j] = __builtin_amdgcn_raw_buffer_load_b128(src, (base + j * 256 + tid) * 16, 0, /*aux: sc1*/ 16);
-                    }
-#pragma unroll
-                    for (int j = 0; j < OWN; ++j) {
-                        if ((missing & (1u << j)) && v[j].w == tag) {
-                            const int id = base + j * 256 + tid, c = id / NPC, i3 = (id % NPC) * 3;
-                            float* r = rec + c * (HD + 2) + i3;
-                            r[0] = __uint_as_float(v[j].x);
-                            if (i3 + 1 < HD + 2) r[1] = __uint_as_float(v[j].y);
-                            if (i3 + 2 < HD + 2) r[2] = __uint_as_float(v[j].z);
-                            missing &= ~(1u << j);
-                        }
-                    }
-                    if (__syncthreads_and(missing == 0)) break;
-                    if (++spins > (1 << 22)) __builtin_trap();       // a split workgroup never wrote: loud, not silent
-                }
-            }
-            float* w = rec + (long long)nact * (HD + 2);
-            attn_merge_records<T, 2>(rec, HD + 2, nact, HD, o + h * HD, w, w + 256, w + 272);
-            return;
-        }
+        part += bz * (long long)heads * nsplit * (HD + 2);
     }
     constexpr int RPI = 64 / LPR;                       // rows (keys) per wave-wide load instruction
     constexpr int KPW = DEC_CHUNK / 4;                  // keys per wave
@@ -308,13 +181,12 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     __shared__ float sc[DEC_CHUNK];
     __shared__ float red[8];
     __shared__ float obuf[4][HD];
-    const int h = blockIdx.x % heads, sp = blockIdx.x / heads, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hk = h / (heads / kv_heads);
     const int kv_len = *d_pos + 1;
     const int c0 = sp * DEC_CHUNK;
-    float* out = part + ((long long)h * nsplit + sp) * RECF;
-    if (c0 >= kv_len) {                                 // nothing here: neutral partial (POLL: the merger only reads splits that hold keys)
-        if (POLL) return;
+    float* out = part + ((long long)h * nsplit + sp) * (HD + 2);
+    if (c0 >= kv_len) {                                 // nothing here: neutral partial
         if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
         for (int d = tid; d < HD; d += 256) out[2 + d] = 0.f;
         return;
@@ -453,21 +325,56 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
         for (int e = 0; e < VE; ++e) obuf[wid][sub * VE + e] = acc[e];
     }
     __syncthreads();
-    if constexpr (POLL) {
-        if (tid < NPC) {                                // piece tid = floats 3 tid .. 3 tid + 2 of (m, l, o[0 .. HD-1], 0, 0) + the tag
-            float f[3];
+    for (int d = tid; d < HD; d += 256) out[2 + d] = obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d];
+    if (tid == 0) { out[0] = mx; out[1] = sum; }
+}
+
+// Merge of one head's split records (m, l, o[hd]) by 512 threads: shared by the combine launch (records in global memory)
+// and the whole-context kernel (records in LDS) so both evaluate the same expressions in the same order.
+// Split weights: one thread per split (parallel loads).  Output: thread = (column d, split group g); a thread owns every G-th
+// split (G = 512 / hd) and keeps its loads in flight, the G partial sums of a column meet in LDS -- one or two round trips
+// instead of a dependent chain over all splits.  pb: records of this head, `stride` floats apart; nact <= 256 splits hold keys.
+template <typename T>
+__device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb, int stride, int nact, int hd, T* __restrict__ o_row,
+                                                   float* w /* [256] */, float* red /* [16] */, float* accs /* [512] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool on = tid < 512;                                              // a larger workgroup: the other waves only join the barriers
+    const int G = 512 / hd;                                                 // hd is a power of two <= 256
+    const int g = on ? tid / hd : 0, d = tid % hd;
+    // the first NB splits of this thread are requested together with the split statistics (they do not depend on them): ONE round
+    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split)
+    constexpr int NB = 12;
+    float v0[NB];
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const int i = 3 * tid + e;
-                f[e] = i == 0 ? mx : (i == 1 ? sum : (i - 2 < HD ? obuf[0][i - 2] + obuf[1][i - 2] + obuf[2][i - 2] + obuf[3][i - 2] : 0.f));
-            }
-            const auto dst = __builtin_amdgcn_make_buffer_rsrc(out, 0, RECF * 4, 0x00020000);
-            const kv_u32x4 pk = {__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), tag};
-            __builtin_amdgcn_raw_buffer_store_b128(pk, dst, tid * 16, 0, /*aux: sc1*/ 16);
-        }
-    } else {
-        for (int d = tid; d < HD; d += 256) out[2 + d] = obuf[0][d] + obuf[1][d] + obuf[2][d] + obuf[3][d];
-        if (tid == 0) { out[0] = mx; out[1] = sum; }
+    for (int i = 0; i < NB; ++i) v0[i] = pb[(long long)min(g + i * G, nact - 1) * stride + 2 + d];
+    float m0 = -INFINITY, l0 = 0.f;
+    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
+    float M = wave_max(m0);
+    if (lane == 0 && on) red[wid] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));               // splits live in threads 0..255 = waves 0..3
+    const float w0 = (m0 == -INFINITY) ? 0.f : expf(m0 - M);
+    if (tid < 256) w[tid] = w0;
+    float L = wave_sum(l0 * w0);
+    if (lane == 0 && on) red[8 + wid] = L;
+    __syncthreads();
+    const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) a += (g + i * G < nact) ? v0[i] * w[min(g + i * G, 255)] : 0.f;
+    for (int s0 = g + NB * G; s0 < nact; s0 += 8 * G) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = pb[(long long)min(s0 + i * G, nact - 1) * stride + 2 + d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * w[min(s0 + i * G, 255)] : 0.f;
+    }
+    if (on) accs[tid] = a;
+    __syncthreads();
+    if (on && g == 0) {
+        float t = 0.f;
+        for (int k = 0; k < G; ++k) t += accs[d + k * hd];
+        Elem<T>::st(o_row + d, t * inv);
     }
 }
 
@@ -727,17 +634,12 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
 template <typename T, int LPR>
 static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn, void* o,
                                float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale,
-                               int nsplit, int chunk, bool rope, AttnBatch bt, bool poll, unsigned salt, hipStream_t st) {
-    const size_t lds = poll ? ((size_t)nsplit * (hd + 2) + 784) * sizeof(float) : 0;       // the mergers' record image + merge scratch
-    dim3 grid(heads * nsplit + (poll ? heads : 0), bt.batch);
-#define TEO_PART(CH, RP, PL)                                                                                          \
-    TEO_KLAUNCH((attn_decode_partial_kernel<T, LPR, CH, RP, PL>), grid, 256, lds, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
-                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt, (T*)o, salt)
-#define TEO_PART_R(CH)                                                                                       \
-    if constexpr (CH == 64 || CH == 128) {              /* the chunk sizes the steps use: only those carry the POLL form */ \
-        if (poll) { if (rope) { TEO_PART(CH, true, true); } else { TEO_PART(CH, false, true); } }           \
-        else      { if (rope) { TEO_PART(CH, true, false); } else { TEO_PART(CH, false, false); } }         \
-    } else { if (rope) { TEO_PART(CH, true, false); } else { TEO_PART(CH, false, false); } }
+                               int nsplit, int chunk, bool rope, AttnBatch bt, hipStream_t st) {
+    dim3 grid(heads, nsplit, bt.batch);
+#define TEO_PART(CH, RP)                                                                                              \
+    TEO_KLAUNCH((attn_decode_partial_kernel<T, LPR, CH, RP>), grid, 256, 0, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
+                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt)
+#define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
     if constexpr (32 / 4 >= 64 / LPR) {
         if (chunk == 32) { TEO_PART_R(32) } else if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
     } else if constexpr (64 / 4 >= 64 / LPR) {
@@ -747,18 +649,9 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
     }
 #undef TEO_PART_R
 #undef TEO_PART
-    if (poll) { note_kernel("attn_decode_poll"); return; }
-    note_kernel("attn_decode_split");
     prof_bump(1);
     TEO_KLAUNCH((attn_decode_combine_kernel<T>), dim3(heads, bt.batch), 512, 0, st, part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
     prof_bump(-1);
-}
-
-__global__ void attn_epoch_bump_kernel(unsigned* e) { *e = *e + 1u; }
-int attn_epoch_bump(unsigned* d_epoch, hipStream_t st) {
-    attn_epoch_bump_kernel<<<1, 1, 0, st>>>(d_epoch);
-    TEO_LAUNCH_CHECK("attn_epoch_bump");
-    return TEO_OK;
 }
 
 template <typename T, int LPR, int NW>
@@ -838,14 +731,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
             if (rcw != TEO_ERR_UNSUPPORTED) return rcw;
         }
     }
-    // in-kernel merge by polling merger workgroups (see the kernel): the composed steps ask for it through bt.layer / bt.d_epoch;
-    // "attn_fused" = 2 turns it on for direct teo_attn_decode calls too (tests / probes: the tag then carries a per-call counter)
-    static unsigned call_counter = 0;
-    const bool asked = g_attn_fused == 2 || (g_attn_fused == 1 && bt.layer >= 0 && bt.d_epoch != nullptr);
-    const bool poll = asked && (chunk == 64 || chunk == 128) && (hd & (hd - 1)) == 0 && hd <= 256 && hd >= 8 &&
-                      ((size_t)nsplit * (hd + 2) + 784) * sizeof(float) <= 48 * 1024;
-    const unsigned salt = bt.layer >= 0 ? (unsigned)bt.layer : (0x10000u + (++call_counter));
-#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, poll, salt, st)
+#define TEO_DEC(TT, LL) attn_decode_launch<TT, LL>(q, kc, vc, vtc, rope_cos, rope_sin, o, part, d_pos, S_max, heads, kv_heads, hd, scale, nsplit, chunk, rope, bt, st)
     if (dtype == TEO_F32) {
         switch (lpr) { case 2: TEO_DEC(float, 2); break; case 4: TEO_DEC(float, 4); break; case 8: TEO_DEC(float, 8); break;
                        case 16: TEO_DEC(float, 16); break; default: TEO_DEC(float, 32); }

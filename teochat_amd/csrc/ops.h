@@ -25,12 +25,7 @@ size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;
     long long q_stride = 0, cache_stride = 0, o_stride = 0;
-    // in-kernel merge of the split records (attention.hip, POLL): the composed decode steps pass a per-generation epoch in device memory
-    // (set by the *_decode_begin calls) and the layer index; layer < 0: the combine launch
-    const unsigned* d_epoch = nullptr;
-    int layer = -1;
 };
-int attn_epoch_bump(unsigned* d_epoch, hipStream_t st);        // a new generation: no record of an earlier one can match its tags
 int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_cos, const float* rope_sin, void* o,
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
                 hipStream_t st, AttnBatch bt = AttnBatch());

@@ -340,7 +340,6 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
 struct DecodeWs {
     void *h, *qkv, *attn, *act;
     float* part;
-    unsigned* epoch;       // generation counter of the attention kernel's record tags (bumped by llama_decode_begin)
     size_t total;
 };
 
@@ -354,7 +353,6 @@ static DecodeWs decode_carve(const teo_llama_desc* d, void* ws, size_t cap) {
     w.attn = c.take((size_t)d->heads * d->head_dim * e);
     w.act = c.take((size_t)d->inter * e);
     w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq));
-    w.epoch = (unsigned*)c.take(256);
     w.total = c.off;
     return w;
 }
@@ -372,10 +370,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
     const int QKV = (H + 2 * Hk) * hd;
     // w.h holds the embedding of *s->d_token: written by the previous step's tail (or by teo_llama_decode_begin)
     const bool w8 = d->qkv_w8 != nullptr;              // decode streams the fp8 copies when they are present
-    AttnBatch one;
-    one.d_epoch = w.epoch;
     for (int l = 0; l < d->layers; ++l) {
-        one.layer = l;
         if (d->rope_in_attn) {
             // rmsnorm + QKV projection (plain weight stream); RoPE + KV append ride inside the attention kernel
             // (position read from s->d_pos on the device)
@@ -384,7 +379,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
                            w.qkv, QKV, D, d->eps, 0, dt, dt, st));
             prof_class(TEO_PROF_ATTN);
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
-                                s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, one));
+                                s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
         } else {
             // rmsnorm -> QKV projection -> RoPE -> KV append in the GEMV epilogue
             prof_class(TEO_PROF_QKV);
@@ -393,7 +388,7 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
                                   H, Hk, hd, D, d->eps, dt, st));
             prof_class(TEO_PROF_ATTN);
             TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], nullptr, nullptr, nullptr, w.attn, w.part, s->d_pos,
-                                d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, one));
+                                d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st));
         }
         prof_class(TEO_PROF_O);
         TEO_TRY(gemv_w(w.attn, w8 ? d->o_w8[l] : d->o_w[l], w8 ? d->o_s[l] : nullptr, w8, nullptr, w.h, w.h, D, H * hd, d->eps,
@@ -423,7 +418,6 @@ int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* 
 struct DecodeBatchWs {
     void *h, *hg, *qkv, *attn, *act;
     float *ssq, *part;
-    unsigned* epoch;
     int nparts;
     size_t total;
 };
@@ -441,7 +435,6 @@ static DecodeBatchWs decode_batch_carve(const teo_llama_desc* d, int B, void* ws
     w.attn = c.take((size_t)B * d->heads * d->head_dim * e);
     w.act = c.take((size_t)B * d->inter * e);
     w.part = (float*)c.take(attn_decode_ws_bytes(d->heads, d->head_dim, d->max_seq, B));
-    w.epoch = (unsigned*)c.take(256);
     w.total = c.off;
     return w;
 }
@@ -487,7 +480,6 @@ int llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_sta
         set_error("teo_llama_decode_batch_begin: workspace %zu < %zu", ws_bytes, w.total);
         return TEO_ERR_WORKSPACE;
     }
-    TEO_TRY(attn_epoch_bump(w.epoch, st));
     if (batch_uses_skinny(d, s->batch))                   // also hand layer 0's RMSNorm its inputs (SkinnyFuse)
         return embed_token_emit(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch, d->in_norm_w[0], w.hg, w.ssq, w.nparts);
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st, s->batch);
@@ -511,7 +503,7 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
     }
     const unsigned tl = s->w_tiled ? TEO_GEMM_WTILED : 0u;
     AttnBatch bt;
-    bt.batch = B; bt.q_stride = QKV; bt.cache_stride = s->cache_stride; bt.o_stride = (long long)H * hd; bt.d_epoch = w.epoch;
+    bt.batch = B; bt.q_stride = QKV; bt.cache_stride = s->cache_stride; bt.o_stride = (long long)H * hd;
     // w.h holds the residual stream; on the skinny path w.hg = bf16(h * g) and w.ssq = partial sum(h^2) of the norm that
     // comes next -- written by the producer of h (embed / o / down GEMM epilogue), consumed by the next GEMM.
     SkinnyFuse take;                                       // consumer side
@@ -532,7 +524,6 @@ int llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_stat
         }
         // RoPE + KV append of the B new tokens inside the attention kernel, each conversation at its own position
         prof_class(TEO_PROF_ATTN);
-        bt.layer = l;
         TEO_TRY(attn_decode(w.qkv, d->k_cache[l], d->v_cache[l], d->vt_cache[l], d->rope_cos, d->rope_sin, w.attn, w.part,
                             s->d_pos, d->max_seq, H, Hk, hd, 1.0f / sqrtf((float)hd), dt, st, bt));
         if (skinny) {
@@ -580,7 +571,6 @@ int llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* s, void*
         set_error("teo_llama_decode_begin: workspace %zu < %zu", ws_bytes, w.total);
         return TEO_ERR_WORKSPACE;
     }
-    TEO_TRY(attn_epoch_bump(w.epoch, st));
     return embed_token(s->d_token, d->embed, w.h, d->hidden, d->dtype, st);
 }
 

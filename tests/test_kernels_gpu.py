@@ -938,48 +938,6 @@ def test_attn_decode_whole_context_is_bitwise_the_split_pair(dtype, H, Hk, d, S,
             close_bf16(outs[2][b], G.bf16_round(ref), ulps=2.0, floor=4e-3)
 
 
-@pytest.mark.parametrize("dtype,H,Hk,d,S,ctx", [(torch.bfloat16, 32, 32, 128, 2560, [2299]), (torch.bfloat16, 32, 32, 128, 2560, [1, 2560, 64]),
-                                                (torch.bfloat16, 32, 32, 128, 4608, [4255, 4608]), (torch.float16, 32, 8, 128, 1024, [700]),
-                                                (torch.bfloat16, 6, 2, 64, 512, [300, 512, 5]), (torch.float32, 16, 16, 32, 512, [17, 200, 512])])
-@pytest.mark.parametrize("chunk", [64, 128])
-@pytest.mark.parametrize("rope", [False, True])
-def test_attn_decode_polling_mergers_are_bitwise_the_combine_launch(dtype, H, Hk, d, S, ctx, chunk, rope):
-    """"attn_fused": `heads` merger workgroups at the end of the split kernel's grid poll the head's records (16-byte pieces carrying a
-    per-launch tag, written through by the split workgroups, which wait for nothing) into LDS and run the combine launch's merge code
-    (256 threads as 512 virtual ones).  Same records, same merge order -> BIT-identical outputs and caches, launch after launch on
-    the same (never cleared) workspace with new data, one-key / ragged / full contexts, every storage type, any head count."""
-    from teochat_amd.engine import rope_tables
-    B = len(ctx)
-    lib = G.lib()
-    g = torch.Generator().manual_seed(77 + chunk + int(rope))
-    rnd_ = {torch.bfloat16: G.bf16_round, torch.float16: lambda t: t.half().float(), torch.float32: lambda t: t}[dtype]
-    cs, sn = rope_tables(d, 10000.0, S)
-    d_cs, d_sn = cs.cuda(), sn.cuda()
-    pos = torch.tensor([n - 1 for n in ctx], dtype=torch.int32, device="cuda")
-    part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, B), dtype=torch.uint8, device="cuda")
-    part.fill_(0xA5)                                                               # stale bytes: no piece may be mistaken for a record
-    qs = (H + 2 * Hk) * d if rope else H * d
-    for rep in range(4):                                                           # the same workspace, the same positions, new data
-        K, V = rnd_(torch.randn(B, Hk, S, d, generator=g)), rnd_(torch.randn(B, Hk, S, d, generator=g))
-        qkv = rnd_(torch.randn(B, H + 2 * Hk, d, generator=g))
-        res = {}
-        for fused in (2, 0):
-            dK, dV = K.to("cuda", dtype).contiguous(), V.to("cuda", dtype).contiguous()
-            dVT = torch.zeros(B, Hk, d, S, dtype=dtype, device="cuda")
-            out = torch.zeros(B, H * d, dtype=dtype, device="cuda")
-            dq = (qkv if rope else qkv[:, :H]).reshape(B, -1).to("cuda", dtype).contiguous()
-            assert lib.teo_tune_set(b"attn_whole", 0) == 0 and lib.teo_tune_set(b"attn_chunk", chunk) == 0 and lib.teo_tune_set(b"attn_fused", fused) == 0
-            L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), G.p(dVT) if rope else None, G.p(d_cs) if rope else None,
-                                        G.p(d_sn) if rope else None, G.p(out), G.p(part), G.p(pos), S, H, Hk, d, 1.0 / d ** 0.5,
-                                        G.DT[dtype], B, qs, Hk * S * d, H * d, G.stream()), "attn_decode")
-            torch.cuda.synchronize()
-            assert lib.teo_last_kernel() == (b"attn_decode_poll" if fused else b"attn_decode_split")
-            res[fused] = (out, dK, dV, dVT)
-        for a, b_ in zip(res[2], res[0]):
-            assert torch.equal(a, b_), rep
-    lib.teo_tune_reset()
-
-
 def _hf_top_p_keep(logits, temperature, top_k, top_p):
     """HF order: temperature -> TopKLogitsWarper -> TopPLogitsWarper (ascending sort, cumulative <= 1 - top_p removed,
     at least one token kept).  Returns (kept index set, renormalised probabilities)."""

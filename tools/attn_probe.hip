@@ -19,7 +19,7 @@ int attention_flash32(const teo_attn_args&, hipStream_t, bool) { return TEO_ERR_
 
 using namespace teo;
 
-// variant: 0 = split + combine (chunk), 1 = whole (chunk, waves), 2 = whole PROBE (chunk, waves), 4 = split with polling merger workgroups
+// variant: 0 = split + combine (chunk), 1 = whole (chunk, waves), 2 = whole PROBE (chunk, waves)
 extern "C" int attn_probe_launch(int variant, int chunk, int waves, const void* q, void* kc, void* vc, void* vtc, const float* cs, const float* sn,
                                  void* o, float* part, const int* d_pos, int S_max, int heads, int batch, long long q_stride,
                                  long long cache_stride, void* stream) {
@@ -27,9 +27,8 @@ extern "C" int attn_probe_launch(int variant, int chunk, int waves, const void* 
     AttnBatch bt;
     bt.batch = batch; bt.q_stride = q_stride; bt.cache_stride = cache_stride; bt.o_stride = (long long)heads * 128;
     const float scale = 0.08838834764831845f;
-    if (variant == 0 || variant == 4) {
+    if (variant == 0) {
         attn_tune_set("attn_whole", 0);
-        attn_tune_set("attn_fused", variant == 4 ? 2 : 0);
         attn_tune_set("attn_chunk", chunk);
         return attn_decode(q, kc, vc, vtc, cs, sn, o, part, d_pos, S_max, heads, heads, 128, scale, TEO_BF16, st, bt);
     }

@@ -65,7 +65,6 @@ def main():
     for name, v, ch, w in (("split + combine, 128 keys", 0, 128, 0), ("split + combine, 64 keys", 0, 64, 0),
                            ("whole 64 keys, 8 waves", 1, 64, 8), ("whole 64 keys, 16 waves", 1, 64, 16),
                            ("whole 32 keys, 8 waves", 1, 32, 8), ("whole 32 keys, 16 waves", 1, 32, 16), ("whole 128 keys, 8 waves", 1, 128, 8),
-                           ("split + polling mergers, 64 keys", 4, 64, 0), ("split + polling mergers, 128 keys", 4, 128, 0),
                            ("loads only, 64 keys, 8 waves", 2, 64, 8), ("loads only, 64 keys, 16 waves", 2, 64, 16),
                            ("loads only, 32 keys, 16 waves", 2, 32, 16), ("loads only, 128 keys, 8 waves", 2, 128, 8)):
         us = min(run(v, ch, w) for _ in range(3))
