@@ -23,6 +23,12 @@ extern "C" int flash_probe_launch(const teo_attn_args* a, int pair_c, unsigned l
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(((a->q_len + 127) / 128) * a->heads * a->batch);
     const size_t lds = 2 * (size_t)(64 * a->head_dim * 2 + a->head_dim * 128);
+    if (a->head_dim == 64 && !a->causal) {              // the tower's shape: one tile at a time, four tile pairs in LDS
+        const size_t lds4 = 4 * (size_t)(64 * 64 * 2 + 64 * 128);
+        if (trace) attn_flash32_kernel<64, false, false, true, false, 4><<<grid, 256, lds4, st>>>(*a, pair_c, trace);
+        else       attn_flash32_kernel<64, false, false, false, false, 4><<<grid, 256, lds4, st>>>(*a, pair_c, nullptr);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
     if (a->head_dim != 128 || !a->causal) return -2;
     if (pipe) {
         if (trace) attn_flash32_kernel<128, true, false, true, true><<<grid, 256, lds, st>>>(*a, pair_c, trace);

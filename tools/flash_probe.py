@@ -25,7 +25,52 @@ def build():
         raise RuntimeError(r.stderr[-4000:])
 
 
+def vit():
+    """the tower's attention: 8 frames x 16 heads x 257 tokens x 64, non-causal"""
+    if not os.path.exists(SO):
+        build()
+    lib = C.CDLL(SO)
+    lib.flash_probe_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    NIT = lib.flash_probe_trace_iters()
+    B, H, S, d = 8, 16, 257, 64
+    bf = torch.bfloat16
+    q, k, v = (torch.randn(B, H, S, d, device="cuda").to(bf) for _ in range(3))
+    vt = G.make_vt(v)
+    o = torch.empty(B, S, H * d, dtype=bf, device="cuda")
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.o, a.vt = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), vt.data_ptr()
+    a.q_bs, a.q_hs, a.q_rs = q.stride(0), q.stride(1), q.stride(2)
+    a.k_bs, a.k_hs, a.k_rs = k.stride(0), k.stride(1), k.stride(2)
+    a.v_bs, a.v_hs, a.v_rs = v.stride(0), v.stride(1), v.stride(2)
+    a.vt_bs, a.vt_hs, a.vt_rs = vt.stride(0), vt.stride(1), vt.stride(2)
+    a.o_bs, a.o_rs = o.stride(0), o.stride(1)
+    a.batch, a.heads, a.kv_heads, a.head_dim, a.q_len, a.kv_len = B, H, H, d, S, S
+    a.causal, a.scale = 0, d ** -0.5
+    st = torch.cuda.current_stream().cuda_stream
+    trace = torch.zeros(4 * NIT * 6, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        assert lib.flash_probe_launch(C.byref(a), 0, None, st, 0) == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        lib.flash_probe_launch(C.byref(a), 0, None, st, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"tower attention (8 x 16 x 257 x 64): {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per launch back to back")
+    for rep in range(2):
+        trace.zero_()
+        assert lib.flash_probe_launch(C.byref(a), 0, trace.data_ptr(), st, 0) == 0
+        torch.cuda.synchronize()
+    tr = trace.cpu().view(4, NIT, 6).double() * 0.01
+    t0 = tr[:, 0, 0].min()
+    print("workgroup 0, wave 0: marks of the 5 iterations, us since its first mark (loop top | DMA issued | scores + softmax | PV | DMA landed | past the barrier):")
+    print("   " + " | ".join(" ".join(f"{float(tr[0, t, p] - t0):.2f}" for p in range(6)) for t in range(5)))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "vit":
+        return vit()
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 2168
     if not os.path.exists(SO):
         build()
