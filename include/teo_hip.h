@@ -58,7 +58,7 @@ const char* teo_last_kernel(void);
  * are NOT here: they are fields of the descriptors (teo_llama_desc.prefill_fp8, .rope_in_attn).  The state is process-wide and meant
  * for benchmarks and for tests that force one kernel family; the library's defaults are what ships.  Keys (value 0 / 1 unless said):
  *   decode GEMV   : "gemv_variant" (-1 default; 0..2, 10..13: row-group geometry; fp32 order), "gemv_nt" (non-temporal weight loads),
- *                   "gemv_max_blocks" (workgroup cap), "gemv_small_k" (x prologue sized to K <= 4096), "gemv_splitk_u" (0 auto, 2/4/6)
+ *                   "gemv_max_blocks" (workgroup cap), "gemv_small_k" (x prologue sized to K <= 4096), "gemv_splitk_u" (chunks per thread and step of the split-K GEMV: 0 auto, 1/2/3/4/6), "gemv_splitk_r" (its rows per workgroup: 0 auto, 2/4)
  *   prefill GEMM  : "gemm_bm" (tile rows of the plain kernel: 0 auto, 64, 128), "gemm_depth", "gemm_sk" (stream-K: 0 off, 1 auto, 2 force),
  *                   "gemm_sk_dbg" (timing diagnostics of the hand-off: WRONG results, never set outside tools/), "gemm_wide" (0 off, 1 auto,
  *                   2 force), "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force), "gemm_big_group", "gemm_big_hybrid"

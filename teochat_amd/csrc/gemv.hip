@@ -128,7 +128,7 @@ __device__ __forceinline__ uint4 ld16(const void* p) {
 }
 
 // Tunables (teo_tune_set): non-temporal loads on/off, workgroup cap, variant of the row-group kernel.
-struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; int small_k = 1; };
+struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; int splitk_r = 0; int small_k = 1; };
 static GemvTune g_tune;
 void gemv_tune_reset() { g_tune = GemvTune(); }
 int gemv_tune_set(const char* key, int value) {
@@ -136,7 +136,8 @@ int gemv_tune_set(const char* key, int value) {
     else if (!strcmp(key, "gemv_nt")) g_tune.nt = value;
     else if (!strcmp(key, "gemv_max_blocks")) g_tune.max_blocks = value;
     else if (!strcmp(key, "gemv_small_k")) g_tune.small_k = value != 0;
-    else if (!strcmp(key, "gemv_splitk_u") && (value == 0 || value == 2 || value == 4 || value == 6)) g_tune.splitk_u = value;
+    else if (!strcmp(key, "gemv_splitk_u") && (value >= 0 && value <= 6 && value != 5)) g_tune.splitk_u = value;
+    else if (!strcmp(key, "gemv_splitk_r") && (value == 0 || value == 2 || value == 4)) g_tune.splitk_r = value;
     else return -1;
     return 0;
 }
@@ -651,9 +652,16 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
     // instead of 2-3 dependent steps (down projection, K = 11008: 3 steps of U = 2 -> 1 step of U = 6).
     if (!swiglu && norm_w == nullptr && N <= 8192 && g_tune.variant < 0) {
         const int nchunk = K / Vec16<WT>::N;
-        const int u = g_tune.splitk_u > 0 ? g_tune.splitk_u : (nchunk <= 512 ? 2 : (nchunk <= 1024 ? 4 : (nchunk <= 1536 ? 6 : 2)));
-        if (u == 4) return launch_splitk<T, TO, WT, 2, 4>(x, W, ws, res, y, N, K, st);
-        if (u == 6) return launch_splitk<T, TO, WT, 2, 6>(x, W, ws, res, y, N, K, st);
+        // round 4 sweep (tools/bench_kernels.py gemv_splitk_sweep -> profiles/r04_gemv_splitk_sweep.txt): a row of <= 256 chunks (fp8 o
+        // projection) takes U = 1 -- with U = 2 half of the step's instructions are masked (5.39 -> 4.95 us alone, 5.24 -> 4.72 in
+        // the step); 4 rows per workgroup are within noise alone and lose in the step (fp8 down 9.94 -> 10.53 us).  The chunk ->
+        // (wave, lane) map and every lane's order of accumulation do not depend on R or U: all forms give the same bits (tested)
+        const int u = g_tune.splitk_u > 0 ? g_tune.splitk_u : (nchunk <= 256 ? 1 : (nchunk <= 512 ? 2 : (nchunk <= 1024 ? 4 : (nchunk <= 1536 ? 6 : 2))));
+        const int r = g_tune.splitk_r > 0 ? g_tune.splitk_r : 2;
+#define TEO_SPK(RR, UU) if (r == RR && u == UU) return launch_splitk<T, TO, WT, RR, UU>(x, W, ws, res, y, N, K, st)
+        TEO_SPK(2, 1); TEO_SPK(2, 3); TEO_SPK(2, 4); TEO_SPK(2, 6);
+        TEO_SPK(4, 1); TEO_SPK(4, 2); TEO_SPK(4, 3); TEO_SPK(4, 4); TEO_SPK(4, 6);
+#undef TEO_SPK
         return launch_splitk<T, TO, WT, 2, 2>(x, W, ws, res, y, N, K, st);
     }
     switch (g_tune.variant) {          // tuning sweep (tools/bench_kernels.py): R rows x U chunks, prefetch on/off

@@ -532,6 +532,41 @@ def test_gemv_fp8_weights(N, K, norm, swiglu):
     torch.testing.assert_close(y8.cpu(), ref, atol=3e-4, rtol=2e-4)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 11008), (130, 1168), (6, 64)])
+def test_gemv_splitk_rows_and_chunks_per_step_do_not_change_a_bit(N, K, fp8):
+    """The o / down projections of the decode step run a split-K GEMV (no fused norm, N <= 8192); `gemv_splitk_r` / `gemv_splitk_u`
+    pick rows per workgroup and 16-byte chunks per thread and step.  A chunk's (wave, lane) and every lane's order of accumulation
+    do not depend on either, so every form must give the bits of every other -- including rows shorter than a step (masked lanes),
+    ragged row counts and K that is not a multiple of the step."""
+    from teochat_amd.engine import quantize_fp8_rows
+    bf = torch.bfloat16
+    lib = G.lib()
+    W = G.bf16_round(rnd(N, K, seed=2, scale=0.02 if K > 256 else 0.1))
+    x, res = G.dev(G.bf16_round(rnd(K, seed=1)), bf), G.dev(G.bf16_round(rnd(N, seed=3)), bf)
+    q, s, dq = quantize_fp8_rows(W.to(bf))
+    q_d, s_d, dW = q.cuda(), s.cuda(), G.dev(W, bf)
+    outs = {}
+    try:
+        for r in (0, 2, 4):
+            for u in (0, 1, 2, 3, 4, 6):
+                assert lib.teo_tune_set(b"gemv_splitk_r", r) == 0 and lib.teo_tune_set(b"gemv_splitk_u", u) == 0
+                y = torch.empty(N, dtype=torch.float32, device="cuda")
+                if fp8:
+                    L.check(lib.teo_gemv_w8(G.p(x), G.p(q_d), G.p(s_d), None, G.p(res), G.p(y), N, K, 1e-5, 0, L.TEO_F32, G.stream()), "gemv_w8")
+                else:
+                    y = G.gemv(x, dW, res=res, out_dtype=torch.float32)
+                outs[(r, u)] = y.cpu()
+    finally:
+        lib.teo_tune_set(b"gemv_splitk_r", 0)
+        lib.teo_tune_set(b"gemv_splitk_u", 0)
+    base = outs[(2, 2)]
+    for k_, v in outs.items():
+        assert torch.equal(v, base), k_
+    ref = ((dq.float() if fp8 else W).double() @ x.cpu().double() + res.cpu().double()).float()
+    torch.testing.assert_close(base, ref, atol=3e-4, rtol=2e-4)
+
+
 # ---------------------------------------------------------------------------------------------- batched-decode GEMM
 @pytest.mark.parametrize("MB", [1, 3, 8, 16])
 @pytest.mark.parametrize("N,K", [(64, 64), (300, 128), (4096, 4096), (12288, 4096), (4096, 11008), (32000, 4096)])

@@ -35,6 +35,8 @@ def timeit(fn, iters=20, warm=3):
 def bench_gemv():
     shapes = [("qkv", 12288, 4096, True, 0), ("o", 4096, 4096, False, 0), ("gateup", 22016, 4096, True, L.GEMM_SWIGLU16),
               ("down", 4096, 11008, False, 0), ("lm_head", 32000, 4096, True, 0)]
+    if os.environ.get("GV_SHAPES") == "splitk":
+        shapes = [("o", 4096, 4096, False, 0), ("down", 4096, 11008, False, 0)]
     for name, N, K, norm, flags in shapes:
         n = max(2, int(600e6 // (N * K * 2)))          # > 256 MB L3 in rotation
         Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
@@ -131,9 +133,25 @@ def bench_gemv_fp8_sweep():
     lib.teo_tune_set(b"gemv_variant", -1)
 
 
+def bench_gemv_splitk_sweep():
+    """o / down projections of the single-conversation step: rows per workgroup x chunks per thread of the split-K GEMV."""
+    os.environ["GV_SHAPES"] = "splitk"
+    for r in (2, 4):
+        for u in (1, 2, 3, 4, 6):
+            lib.teo_tune_set(b"gemv_splitk_r", r)
+            lib.teo_tune_set(b"gemv_splitk_u", u)
+            print(f"split-K rows {r} chunks {u}", flush=True)
+            bench_gemv_fp8()
+            bench_gemv()
+    lib.teo_tune_set(b"gemv_splitk_r", 0)
+    lib.teo_tune_set(b"gemv_splitk_u", 0)
+
+
 def bench_gemv_fp8():
     shapes = [("qkv", 12288, 4096, True, 0), ("o", 4096, 4096, False, 0), ("gateup", 22016, 4096, True, L.GEMM_SWIGLU16),
               ("down", 4096, 11008, False, 0), ("lm_head", 32000, 4096, True, 0)]
+    if os.environ.get("GV_SHAPES") == "splitk":
+        shapes = [("o", 4096, 4096, False, 0), ("down", 4096, 11008, False, 0)]
     for name, N, K, norm, flags in shapes:
         n = max(2, int(600e6 // (N * K)))
         Ws = [torch.randint(0, 120, (N, K), dtype=torch.uint8, device="cuda") for _ in range(n)]
@@ -437,5 +455,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_prefetch": bench_gemm_prefetch, "gemm_cold": bench_gemm_cold, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_splitk_sweep": bench_gemv_splitk_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_prefetch": bench_gemm_prefetch, "gemm_cold": bench_gemm_cold, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 
