@@ -120,12 +120,45 @@ template <typename T> struct IsF16 { static constexpr bool v = false; };
 template <> struct IsF16<f16_t> { static constexpr bool v = true; };
 
 // ---- wave / block reductions ----------------------------------------------------------------
+// The xor butterfly 32, 16, 8, 4, 2, 1 without the LDS crossbar (`__shfl_xor` compiles to ds_bpermute_b32 + 5 address VALU ops per
+// step, ~100 cycles of latency each): v_permlane32_swap / v_permlane16_swap broadcast the two halves / the odd and even rows, DPP
+// row_ror:8/4/2/1 supplies the rest.  Operand VALUES per lane are those of the xor butterfly at every step (after the step with
+// offset 2o every lane's value has period 2o inside its row, so lane (i + o) % 16 holds what lane i ^ o holds; + and max commute),
+// hence every lane ends with the bits the __shfl_xor form produced (tools/wave_probe.py checks that on the device).
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane(float v) {        // CTRL 0x120 + n: row_ror:n (lane i of a 16-lane row reads lane (i + n) % 16)
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+#define TEO_WAVE_BUTTERFLY(OP)                                                                                        \
+    {                                                                                                                 \
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);        \
+        v = OP(__uint_as_float(r[0]), __uint_as_float(r[1]));                      /* lanes i and i ^ 32 */          \
+    }                                                                                                                 \
+    {                                                                                                                 \
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);        \
+        v = OP(__uint_as_float(r[0]), __uint_as_float(r[1]));                      /* lanes i and i ^ 16 */          \
+    }                                                                                                                 \
+    v = OP(v, dpp_lane<0x128>(v));                                                                                    \
+    v = OP(v, dpp_lane<0x124>(v));                                                                                    \
+    v = OP(v, dpp_lane<0x122>(v));                                                                                    \
+    v = OP(v, dpp_lane<0x121>(v));
+__device__ __forceinline__ float teo_addf(float a, float b) { return a + b; }
 __device__ __forceinline__ float wave_sum(float v) {
+    TEO_WAVE_BUTTERFLY(teo_addf)
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    TEO_WAVE_BUTTERFLY(fmaxf)
+    return v;
+}
+#undef TEO_WAVE_BUTTERFLY
+// the same reductions through __shfl_xor (reference form of tools/wave_probe.hip)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ float wave_max_shfl(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;

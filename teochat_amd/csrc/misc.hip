@@ -464,13 +464,15 @@ __device__ int sample_topk_block(const float* __restrict__ logits, int vocab, fl
                 for (int e = 0; e < 4; ++e) key[j + e] = lo + j + e < vocab ? f2ord(logits[lo + j + e]) : 0u;    // 0: below every float's key
             }
         }
+        // A round's count is taken wave-wide with the scalar unit: v_cmp writes the 64-lane mask, s_bcnt1 counts it -- one VALU
+        // instruction per key instead of compare + add per lane and a cross-lane reduction at the end (the rounds are compare-bound:
+        // an 8-way section search with 7 thresholds per round, 11 rounds, was slower -- 44 vs 34 us -- because it does 2.4x the compares).
         unsigned lo_k = 1u, hi_k = 0xFFFFFFFFu;       // invariant: count(key >= lo_k) >= k  (k <= vocab real keys, all >= 1)
         for (int it = 0; it < 32 && lo_k < hi_k; ++it) {
             const unsigned mid = lo_k + ((hi_k - lo_k) >> 1) + ((hi_k - lo_k) & 1u);       // upper middle: the range always shrinks
-            int c = 0;
+            int cw = 0;                               // wave-uniform
 #pragma unroll
-            for (int j = 0; j < VPT; ++j) c += key[j] >= mid ? 1 : 0;
-            const float cw = wave_sum((float)c);      // <= 2048 per wave: exact in fp32
+            for (int j = 0; j < VPT; ++j) cw += __popcll(__ballot(key[j] >= mid));
             unsigned* cnt = hist + (it & 1) * 16;
             if ((tid & 63) == 0) cnt[tid >> 6] = (unsigned)cw;
             __syncthreads();
@@ -626,7 +628,7 @@ __device__ int sample_topk_block(const float* __restrict__ logits, int vocab, fl
 __global__ __launch_bounds__(1024) void sample_topk_kernel(const float* __restrict__ logits, long long* __restrict__ tok,
                                                            int vocab, float temperature, int top_k, float top_p,
                                                            unsigned long long seed, unsigned long long draw) {
-    __shared__ unsigned hist[256];
+    __shared__ __attribute__((aligned(16))) unsigned hist[256];
     __shared__ int sel_idx[TOPK_CAP];
     __shared__ float sel_val[TOPK_CAP];
     __shared__ int s_misc[4];
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ long long s_tok;
-    __shared__ unsigned hist[256];
+    __shared__ __attribute__((aligned(16))) unsigned hist[256];
     __shared__ int sel_idx[TOPK_CAP];
     __shared__ float sel_val[TOPK_CAP];
     __shared__ int s_misc[4];
