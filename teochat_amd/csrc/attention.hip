@@ -273,8 +273,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
 #pragma unroll
             for (int e = 0; e < VE; ++e) s = fmaf(qf[e], kf[e], s);
         }
-#pragma unroll
-        for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s = group_sum<LPR>(s);
         if (sub == 0) sc[j - c0] = (j < kv_len) ? s * scale : -INFINITY;
     }
     __syncthreads();
@@ -316,10 +315,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
         for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
     }
 #pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) {
-#pragma unroll
-        for (int e = 0; e < VE; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-    }
+    for (int e = 0; e < VE; ++e) acc[e] = cross_group_sum<LPR>(acc[e]);
     if (grp == 0) {
 #pragma unroll
         for (int e = 0; e < VE; ++e) obuf[wid][sub * VE + e] = acc[e];
@@ -524,7 +520,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
             Cvt16<T>::cvt(kraw, kf);                                                                                   \
             _Pragma("unroll") for (int e = 0; e < VE; ++e) s = fmaf(qf[e], kf[e], s);                                  \
         }                                                                                                              \
-        _Pragma("unroll") for (int o_ = LPR >> 1; o_ > 0; o_ >>= 1) s += __shfl_xor(s, o_, 64);                        \
+        s = group_sum<LPR>(s);                                                                                         \
         if (sub == 0) sc[j - c0] = (j < kv_len) ? s * scale : -INFINITY;                                               \
     }
     // PV of quarter QT from ring slot SLOT: the split kernel's per-wave partial sum, reduced over the key groups
@@ -542,9 +538,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
             Cvt16<T>::cvt(vraw, vf);                                                                                   \
             _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);                            \
         }                                                                                                              \
-        _Pragma("unroll") for (int o_ = LPR; o_ < 64; o_ <<= 1) {                                                      \
-            _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] += __shfl_xor(acc[e], o_, 64);                       \
-        }                                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] = cross_group_sum<LPR>(acc[e]);                          \
         if ((QT) == 0) { _Pragma("unroll") for (int e = 0; e < VE; ++e) OUT[e] = acc[e]; }                             \
         else           { _Pragma("unroll") for (int e = 0; e < VE; ++e) OUT[e] = OUT[e] + acc[e]; }                    \
     }

@@ -152,6 +152,49 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 #undef TEO_WAVE_BUTTERFLY
+// v[i] + v[i ^ O] in every lane, bitwise what `v + __shfl_xor(v, O, 64)` gives: O = 32 / 16 through the permlane swaps, 8 through row_ror:8
+// (inside a 16-lane row (i + 8) % 16 == i ^ 8), 2 / 1 through quad_perm; 4 has no exact DPP pattern on this target and stays a shuffle
+template <int O>
+__device__ __forceinline__ float xor_add(float v) {
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (O == 8) {
+        return v + dpp_lane<0x128>(v);
+    } else if constexpr (O == 2) {
+        return v + dpp_lane<0x4E>(v);               // quad_perm:[2,3,0,1]
+    } else if constexpr (O == 1) {
+        return v + dpp_lane<0xB1>(v);               // quad_perm:[1,0,3,2]
+    } else {
+        return v + __shfl_xor(v, O, 64);
+    }
+}
+// butterfly W/2, ..., 2, 1 inside aligned groups of W lanes (W = 8 .. 64): the bits of the __shfl_xor loop.  The offset-4 step follows the
+// offset-8 step whenever W >= 16, so row_ror:4 reads a lane that holds what lane i ^ 4 holds (see wave_sum)
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (W >= 64) v = xor_add<32>(v);
+    if constexpr (W >= 32) v = xor_add<16>(v);
+    if constexpr (W >= 16) { v = xor_add<8>(v); v = v + dpp_lane<0x124>(v); }
+    else if constexpr (W >= 8) v = xor_add<4>(v);
+    if constexpr (W >= 4) v = xor_add<2>(v);
+    if constexpr (W >= 2) v = xor_add<1>(v);
+    return v;
+}
+// butterfly L, 2L, ..., 32 ACROSS the groups of L lanes (ascending offsets): the bits of `for (o = L; o < 64; o <<= 1) v += __shfl_xor(v, o)`
+template <int L>
+__device__ __forceinline__ float cross_group_sum(float v) {
+    if constexpr (L <= 1) v = xor_add<1>(v);
+    if constexpr (L <= 2) v = xor_add<2>(v);
+    if constexpr (L <= 4) v = xor_add<4>(v);
+    if constexpr (L <= 8) v = xor_add<8>(v);
+    if constexpr (L <= 16) v = xor_add<16>(v);
+    if constexpr (L <= 32) v = xor_add<32>(v);
+    return v;
+}
 // the same reductions through __shfl_xor (reference form of tools/wave_probe.hip)
 __device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll

@@ -273,8 +273,7 @@ _Pragma("unroll") \
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wid][fr * 17 + fg * 4 + r] = acc[r];
     if (NORM) {                                          // lanes (fr, fg = 0..3) hold row fr's partial sum of squares
-        ssq += __shfl_xor(ssq, 16, 64);
-        ssq += __shfl_xor(ssq, 32, 64);
+        ssq = cross_group_sum<16>(ssq);
         if (fg == 0) ssq_part[wid][fr] = ssq;
     }
     if (wid == 0) sk_mark<TRACE>(fuse, 2);
@@ -336,10 +335,7 @@ _Pragma("unroll") \
         const int b = tid >> 4, c = tid & 15, col = n0 + c;
         float sq = emit_ok ? emit_v * emit_v : 0.f;
         if (emit_ok) fuse.xg_out[(long long)b * ldo + col] = f2h<F16>(emit_v * pf_g);   // (b, c) = the prefetch's mapping at RT == 1
-        sq += __shfl_xor(sq, 8, 64);
-        sq += __shfl_xor(sq, 4, 64);
-        sq += __shfl_xor(sq, 2, 64);
-        sq += __shfl_xor(sq, 1, 64);
+        sq = group_sum<16>(sq);
         if (c == 0 && b < MB) fuse.ssq_out[(long long)b * gridDim.x + blockIdx.x] = sq;
     }
     if (wid == 0) sk_mark<TRACE>(fuse, 4);
@@ -521,10 +517,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t*
                         }
                     }
                     if (fuse.xg_out) {
-                        sq += __shfl_xor(sq, 8, 64);
-                        sq += __shfl_xor(sq, 4, 64);
-                        sq += __shfl_xor(sq, 2, 64);
-                        sq += __shfl_xor(sq, 1, 64);
+                        sq = group_sum<16>(sq);
                         if (ec == 0 && e_on) fuse.ssq_out[(long long)eb * ntiles + t] = sq;
                     }
                 }

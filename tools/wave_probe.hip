@@ -11,6 +11,27 @@ __global__ void wave_probe_kernel(const float* in, unsigned* diff, int n_waves) 
     unsigned bad = 0;
     if (__float_as_uint(a) != __float_as_uint(b)) bad |= 1u;
     if (__float_as_uint(c) != __float_as_uint(d) && !(c != c && d != d)) bad |= 2u;
+    // the partial butterflies of the decode attention / batched GEMM epilogues
+    {
+        float e = v, f = v;
+        for (int o = 8; o > 0; o >>= 1) f += __shfl_xor(f, o, 64);
+        if (__float_as_uint(group_sum<16>(e)) != __float_as_uint(f)) bad |= 4u;
+        e = v; f = v;
+        for (int o = 16; o > 0; o >>= 1) f += __shfl_xor(f, o, 64);
+        if (__float_as_uint(group_sum<32>(e)) != __float_as_uint(f)) bad |= 8u;
+        e = v; f = v;
+        for (int o = 4; o > 0; o >>= 1) f += __shfl_xor(f, o, 64);
+        if (__float_as_uint(group_sum<8>(e)) != __float_as_uint(f)) bad |= 16u;
+        e = v; f = v;
+        for (int o = 16; o < 64; o <<= 1) f += __shfl_xor(f, o, 64);
+        if (__float_as_uint(cross_group_sum<16>(e)) != __float_as_uint(f)) bad |= 32u;
+        e = v; f = v;
+        for (int o = 8; o < 64; o <<= 1) f += __shfl_xor(f, o, 64);
+        if (__float_as_uint(cross_group_sum<8>(e)) != __float_as_uint(f)) bad |= 64u;
+        e = v; f = v;
+        for (int o = 32; o < 64; o <<= 1) f += __shfl_xor(f, o, 64);
+        if (__float_as_uint(cross_group_sum<32>(e)) != __float_as_uint(f)) bad |= 128u;
+    }
     if (bad) atomicOr(diff, bad), atomicAdd(diff + 1, 1u);
 }
 template <bool NEW>

@@ -27,7 +27,7 @@ for name, x in cases.items():
     assert lib.wave_probe(x.data_ptr(), diff.data_ptr(), n_waves, st) == 0
     torch.cuda.synchronize()
     d = diff.tolist()
-    print(f"{name:32s}: {n_waves} waves x 64 lanes, sum and max in every lane: {'bit-identical' if d[0] == 0 else f'DIFFERENT (mask {d[0]}, {d[1]} lanes)'}")
+    print(f"{name:32s}: {n_waves} waves x 64 lanes, wave sum / max and the 16- / 32- / 8-lane and cross-group butterflies in every lane: {'bit-identical' if d[0] == 0 else f'DIFFERENT (mask {d[0]}, {d[1]} lanes)'}")
     ok = ok and d[0] == 0
 out = torch.zeros(64, device="cuda")
 cyc = torch.zeros(1, dtype=torch.int64, device="cuda")
