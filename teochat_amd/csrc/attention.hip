@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     constexpr int KPW = DEC_CHUNK / 4;                  // keys per wave
     constexpr int NI = KPW / RPI;                       // load instructions per wave per operand
     __shared__ float sc[DEC_CHUNK];
+    __shared__ float pstrip[4][DEC_CHUNK];
     __shared__ float red[8];
     __shared__ float obuf[4][HD];
     const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -291,20 +292,18 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
 #pragma unroll
     for (int i = 0; i < SPL; ++i) { sv[i] = expf(sv[i] - mx); sum += sv[i]; }      // -inf -> 0
     sum = wave_sum(sum);
-    __syncthreads();
-    if (wid == 0) {
+    // every wave holds the chunk's rounded probabilities (same values in all four): each writes its own strip and reads it back --
+    // ordered inside the wave, so no workgroup barrier between the softmax and PV
 #pragma unroll
-        for (int i = 0; i < SPL; ++i)
-            if (DEC_CHUNK >= 64 || lane + 64 * i < DEC_CHUNK) sc[lane + 64 * i] = Elem<T>::round(sv[i]);
-    }
-    __syncthreads();
+    for (int i = 0; i < SPL; ++i)
+        if (DEC_CHUNK >= 64 || lane + 64 * i < DEC_CHUNK) pstrip[wid][lane + 64 * i] = Elem<T>::round(sv[i]);
     // ---- PV on this wave's keys
     float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const float p = sc[wid * KPW + i * RPI + grp];           // 0 for keys >= kv_len
+        const float p = pstrip[wid][wid * KPW + i * RPI + grp];      // 0 for keys >= kv_len
         float vf[VE];
         Cvt16<T>::cvt(vr[i], vf);
         if (ROPE && kw0 + i * RPI + grp == pos) {
@@ -709,7 +708,8 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
         set_error("attn_decode: unsupported head_dim %d / max_seq %d", hd, S_max);
         return TEO_ERR_UNSUPPORTED;
     }
-    // whole-context form (batched steps).  Its default chunk is 64 keys (quarter-chunks of 4 load instructions: a 4-slot ring of 64
+    // whole-context form (batched steps with at least one workgroup per CU: B >= 8 at 32 heads; with the reductions on DPP the split form
+    // wins below that -- B = 4: 30.1 vs 31.8 us, profiles/r04_attn_probe_b4.txt).  Its default chunk is 64 keys (quarter-chunks of 4 load instructions: a 4-slot ring of 64
     // VGPRs; with 128-key chunks the bf16 / head_dim 128 kernel needs more than 256 registers), "attn_chunk" forces another.
     {
         int cw = g_dec_chunk ? g_dec_chunk : 64;
@@ -720,7 +720,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
         const size_t lds = ((size_t)8 * cw + (size_t)nsw * (hd + 2) + 784) * sizeof(float);
         const int cus = device_cu_count();
         const bool fits = ni >= 1 && ni <= 8 && (hd & (hd - 1)) == 0 && hd <= 256 && lds <= 96 * 1024 && nsw <= 256 && (cw == 32 || cw == 64 || cw == 128);
-        if (fits && (g_attn_whole == 2 || (g_attn_whole == 1 && bt.batch > 1 && 2 * bt.batch * heads >= (cus > 0 ? cus : 256)))) {
+        if (fits && (g_attn_whole == 2 || (g_attn_whole == 1 && bt.batch > 1 && bt.batch * heads >= (cus > 0 ? cus : 256)))) {
             const int rcw = attn_whole_launch(q, kc, vc, vtc, rope_cos, rope_sin, o, d_pos, S_max, heads, kv_heads, hd, scale, cw, lpr, dtype, bt, lds, st);
             if (rcw != TEO_ERR_UNSUPPORTED) return rcw;
         }

@@ -195,6 +195,36 @@ __device__ __forceinline__ float cross_group_sum(float v) {
     if constexpr (L <= 32) v = xor_add<32>(v);
     return v;
 }
+// the 32-bit value lane i ^ O holds, O = 32 / 16 (permlane swaps + a select on the lane's half / row parity)
+template <int O>
+__device__ __forceinline__ unsigned xor_get(unsigned v) {
+    static_assert(O == 32 || O == 16, "xor_get: the exact exchanges");
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);       // r[0] = lower half twice, r[1] = upper half twice
+        return (lane & 32u) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);       // r[0] = rows 0 0 2 2, r[1] = rows 1 1 3 3
+        return (lane & 16u) ? r[0] : r[1];
+    }
+}
+// wave-wide argmax, ties to the smaller index: the __shfl_xor butterfly 32 .. 1 of (value, index) pairs.  After every step both partners
+// hold the same pair (the rule is symmetric), so the row_ror steps read what lane i ^ o holds (as in wave_sum); NaN-free inputs.
+__device__ __forceinline__ void wave_argmax(float& best, int& bi) {
+#define TEO_ARGMAX_STEP(OV, OI)                                                                   \
+    {                                                                                             \
+        const float ov_ = (OV);                                                                   \
+        const int oi_ = (OI);                                                                     \
+        if (ov_ > best || (ov_ == best && oi_ < bi)) { best = ov_; bi = oi_; }                    \
+    }
+    TEO_ARGMAX_STEP(__uint_as_float(xor_get<32>(__float_as_uint(best))), (int)xor_get<32>((unsigned)bi))
+    TEO_ARGMAX_STEP(__uint_as_float(xor_get<16>(__float_as_uint(best))), (int)xor_get<16>((unsigned)bi))
+    TEO_ARGMAX_STEP(dpp_lane<0x128>(best), (int)__float_as_uint(dpp_lane<0x128>(__uint_as_float((unsigned)bi))))
+    TEO_ARGMAX_STEP(dpp_lane<0x124>(best), (int)__float_as_uint(dpp_lane<0x124>(__uint_as_float((unsigned)bi))))
+    TEO_ARGMAX_STEP(dpp_lane<0x122>(best), (int)__float_as_uint(dpp_lane<0x122>(__uint_as_float((unsigned)bi))))
+    TEO_ARGMAX_STEP(dpp_lane<0x121>(best), (int)__float_as_uint(dpp_lane<0x121>(__uint_as_float((unsigned)bi))))
+#undef TEO_ARGMAX_STEP
+}
 // the same reductions through __shfl_xor (reference form of tools/wave_probe.hip)
 __device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll

@@ -355,12 +355,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         const float v = row[i];
         if (v > best || bi == 0x7fffffff) { best = v; bi = i; }   // indices ascend per thread: strict > keeps the first
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
+    wave_argmax(best, bi);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
     __syncthreads();
@@ -736,12 +731,7 @@ __global__ __launch_bounds__(1024) void decode_tail_kernel(const float* __restri
         const float v = logits[i];
         if (v > best || bi == 0x7fffffff) { best = v; bi = i; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
+    wave_argmax(best, bi);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
     __syncthreads();

@@ -32,6 +32,18 @@ __global__ void wave_probe_kernel(const float* in, unsigned* diff, int n_waves) 
         for (int o = 32; o < 64; o <<= 1) f += __shfl_xor(f, o, 64);
         if (__float_as_uint(cross_group_sum<32>(e)) != __float_as_uint(f)) bad |= 128u;
     }
+    {   // argmax butterfly of (value, index) pairs: quantised values so that ties occur
+        float b1 = floorf(v * 4.f), b2 = b1;
+        int i1 = (int)((threadIdx.x * 37u) & 63u), i2 = i1;
+        if (b1 != b1) b1 = b2 = 0.f;
+        wave_argmax(b1, i1);
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(b2, o, 64);
+            const int oi = __shfl_xor(i2, o, 64);
+            if (ov > b2 || (ov == b2 && oi < i2)) { b2 = ov; i2 = oi; }
+        }
+        if (__float_as_uint(b1) != __float_as_uint(b2) || i1 != i2) bad |= 256u;
+    }
     if (bad) atomicOr(diff, bad), atomicAdd(diff + 1, 1u);
 }
 template <bool NEW>
