@@ -158,21 +158,22 @@ __device__ __forceinline__ uint4 ld_kv(const void* p) {
 // and the one lane group that owns key `pos` rotates the new k, takes the new v, appends both to the caches (K, V, V^T)
 // and uses them directly -- RoPE + KV append cost no launch and no pass of their own.
 template <typename T, int LPR, int DEC_CHUNK, bool ROPE>
-__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __restrict__ q, T* __restrict__ kc,
-                                                                  T* __restrict__ vc, T* __restrict__ vtc,
-                                                                  const float* __restrict__ cs, const float* __restrict__ sn,
-                                                                  float* __restrict__ part, const int* __restrict__ d_pos,
-                                                                  int S_max, int heads, int kv_heads, float scale, int nsplit,
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const int* __restrict__ d_pos, T* __restrict__ kc, T* __restrict__ vc,
+                                                                  const T* __restrict__ q, int S_max, int heads, int kv_heads, int nsplit,
+                                                                  T* __restrict__ vtc, const float* __restrict__ cs,
+                                                                  const float* __restrict__ sn, float* __restrict__ part, float scale,
                                                                   AttnBatch bt) {
+    // argument order: what the first K / V request needs (the position, the caches, the geometry) sits in the 12 dwords that arrive
+    // preloaded in SGPRs (Makefile: -amdgpu-kernarg-preload-count) -- the position load is the first instruction, not the second round trip
     constexpr int VE = Cvt16<T>::N;
     constexpr int HD = LPR * VE;
+    const int kv_len = d_pos[blockIdx.z] + 1;           // requested first: the K / V requests wait for it, the rest of the arguments load beside it
     {   // conversation blockIdx.z of a batched step: its own query row, caches, position and partial slab
         const long long bz = blockIdx.z;
         q += bz * bt.q_stride;
         kc += bz * bt.cache_stride;
         vc += bz * bt.cache_stride;
         if (vtc) vtc += bz * bt.cache_stride;
-        d_pos += bz;
         part += bz * (long long)heads * nsplit * (HD + 2);
     }
     constexpr int RPI = 64 / LPR;                       // rows (keys) per wave-wide load instruction
@@ -183,8 +184,7 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const T* __res
     __shared__ float red[8];
     __shared__ float obuf[4][HD];
     const int h = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int hk = h / (heads / kv_heads);
-    const int kv_len = *d_pos + 1;
+    const int hk = (heads == kv_heads) ? h : h / (heads / kv_heads);      // MHA: no integer division in front of the first request
     const int c0 = sp * DEC_CHUNK;
     float* out = part + ((long long)h * nsplit + sp) * (HD + 2);
     if (c0 >= kv_len) {                                 // nothing here: neutral partial
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
         o += bz * bt.o_stride;
     }
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int hk = h / (heads / kv_heads);
+    const int hk = (heads == kv_heads) ? h : h / (heads / kv_heads);      // MHA: no integer division in front of the first request
     const int kv_len = *d_pos + 1;
     const int nact = (kv_len + DEC_CHUNK - 1) / DEC_CHUNK;
     const int sub = lane % LPR, grp = lane / LPR;
@@ -630,8 +630,8 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
                                int nsplit, int chunk, bool rope, AttnBatch bt, hipStream_t st) {
     dim3 grid(heads, nsplit, bt.batch);
 #define TEO_PART(CH, RP)                                                                                              \
-    TEO_KLAUNCH((attn_decode_partial_kernel<T, LPR, CH, RP>), grid, 256, 0, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, part, \
-                                                                     d_pos, S_max, heads, kv_heads, scale, nsplit, bt)
+    TEO_KLAUNCH((attn_decode_partial_kernel<T, LPR, CH, RP>), grid, 256, 0, st, d_pos, (T*)kc, (T*)vc, (const T*)q, S_max, heads, kv_heads,      \
+                                                                     nsplit, (T*)vtc, cs, sn, part, scale, bt)
 #define TEO_PART_R(CH) if (rope) { TEO_PART(CH, true); } else { TEO_PART(CH, false); }
     if constexpr (32 / 4 >= 64 / LPR) {
         if (chunk == 32) { TEO_PART_R(32) } else if (chunk == 64) { TEO_PART_R(64) } else if (chunk == 256) { TEO_PART_R(256) } else { TEO_PART_R(128) }
