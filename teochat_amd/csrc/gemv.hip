@@ -514,13 +514,13 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_splitk_kernel(const T* __rest
 //   replayed from a hipGraph.  Rounding points are those of the unfused path: round(linear) -> rotate in fp32 -> round.
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename WT, bool NT, bool PF, int U, int XPT>
-__global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const T* __restrict__ x, const WT* __restrict__ W,
-                                                                   const float* __restrict__ wscale,
-                                                                   const T* __restrict__ norm_w, T* __restrict__ qout,
-                                                                   const float* __restrict__ cs, const float* __restrict__ sn,
-                                                                   const int* __restrict__ d_pos, T* __restrict__ kc,
-                                                                   T* __restrict__ vc, T* __restrict__ vtc, int S_max, int H,
-                                                                   int Hk, int hd, int K, float eps) {
+__global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const WT* __restrict__ W, const T* __restrict__ x,
+                                                                   const T* __restrict__ norm_w, const float* __restrict__ wscale,
+                                                                   const int* __restrict__ d_pos, int K, int H, int Hk, int hd,
+                                                                   T* __restrict__ qout, const float* __restrict__ cs,
+                                                                   const float* __restrict__ sn, T* __restrict__ kc,
+                                                                   T* __restrict__ vc, T* __restrict__ vtc, int S_max, float eps) {
+    // (argument order: the weight stream's operands and the position pointer first -- those 14 dwords arrive preloaded in SGPRs)
     extern __shared__ __attribute__((aligned(16))) float xs[];
     constexpr int VE = Vec16<WT>::N;
     constexpr int R = 2, STEP = 64 * U;                  // U chunks per row per step (4 for 2-byte weights, 2 for fp8)
@@ -754,12 +754,12 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
     const int uu = (w_fp8 && !small_k) ? 2 : 4;
     const bool pf = K / ve >= 64 * uu;
 #define TEO_QR2(TT, WW, NTV, XP, UU)                                                                                      \
-    if (pf) TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, true, UU, XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
-                                                                       (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
-                                                                       S_max, H, Hk, hd, K, eps);                            \
-    else TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, false, UU, XP>), blocks, GV_THREADS, lds, st, (const TT*)x, (const WW*)W, wscale, (const TT*)norm_w, \
-                                                                       (TT*)qout, cs, sn, d_pos, (TT*)kc, (TT*)vc, (TT*)vtc, \
-                                                                       S_max, H, Hk, hd, K, eps)
+    if (pf) TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, true, UU, XP>), blocks, GV_THREADS, lds, st, (const WW*)W, (const TT*)x, (const TT*)norm_w, wscale, \
+                                                                       d_pos, K, H, Hk, hd, (TT*)qout, cs, sn, (TT*)kc, (TT*)vc, (TT*)vtc, \
+                                                                       S_max, eps);                                          \
+    else TEO_KLAUNCH((gemv_qkv_rope_kernel<TT, WW, NTV, false, UU, XP>), blocks, GV_THREADS, lds, st, (const WW*)W, (const TT*)x, (const TT*)norm_w, wscale, \
+                                                                       d_pos, K, H, Hk, hd, (TT*)qout, cs, sn, (TT*)kc, (TT*)vc, (TT*)vtc, \
+                                                                       S_max, eps)
 #define TEO_QR(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2, 4); } else { TEO_QR2(TT, WW, NTV, 6, 4); }
 #define TEO_QR6(TT, WW, NTV) TEO_QR2(TT, WW, NTV, 6, 4)
 #define TEO_QR8(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2, 4); } else { TEO_QR2(TT, WW, NTV, 6, 2); }

@@ -94,12 +94,12 @@ __device__ __forceinline__ u32x4 sk_scale_frag(const u32x4& xv, const u32x4& gv,
 // fragments it feeds to the matrix cores and applies inv_rms in the epilogue -- no separate norm launch, no
 // normalised copy of x.  (g is staged in LDS once per workgroup.)
 template <typename WT, int UNR, bool NT, bool SWIGLU, bool NORM, bool TRACE = false>
-__global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const bf16_t* __restrict__ x, const WT* __restrict__ W,
-                                                                 const float* __restrict__ wscale,
-                                                                 const bf16_t* __restrict__ norm_w, float eps,
-                                                                 const bf16_t* res, void* outv,
-                                                                 int MB, int N, int K, int ldx, int ldo, int ldr, int tiled,
-                                                                 int out_f32, int RT, SkinnyFuse fuse, int sw8) {
+__global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const WT* __restrict__ W, const bf16_t* __restrict__ x,
+                                                                 int MB, int N, int K, int ldx, int tiled, int RT,
+                                                                 const float* __restrict__ wscale, const bf16_t* res,
+                                                                 const bf16_t* __restrict__ norm_w, float eps, void* outv,
+                                                                 int ldo, int ldr, int out_f32, SkinnyFuse fuse, int sw8) {
+    // (argument order: what the first weight / activation requests need sits in the 14 dwords that arrive preloaded in SGPRs)
     constexpr bool F8 = sizeof(WT) == 1;
     constexpr bool F16 = IsF16<WT>::v;                   // WT = f16_t: IEEE binary16 activations, weights and 16-bit outputs (bf16_t / fp8: bfloat16)
     constexpr int KS = F8 ? 64 : 32;                     // k elements per step (one 16-byte chunk per lane)
@@ -606,20 +606,20 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     const int steps_per_wave = K / (w_fp8 ? 64 : 32) / (SK_WAVES / rt);
     const bool unr8 = !swiglu && !norm_w && g_sk_nt && (g_sk_unr == 8 || (g_sk_unr == 0 && steps_per_wave >= 16 && blocks <= 2 * std::max(device_cu_count(), 1)));
     if (unr8) {
-        if (w_fp8) TEO_KLAUNCH((skinny_gemm_kernel<fp8_t, 6, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const fp8_t*)W, wscale,
-                               (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
-        else if (fuse.f16) TEO_KLAUNCH((skinny_gemm_kernel<f16_t, 8, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const f16_t*)W, wscale,
-                               (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
-        else       TEO_KLAUNCH((skinny_gemm_kernel<bf16_t, 8, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)x, (const bf16_t*)W, wscale,
-                               (const bf16_t*)nullptr, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, tiled, of, rt, fuse, sw8);
+        if (w_fp8) TEO_KLAUNCH((skinny_gemm_kernel<fp8_t, 6, true, false, false>), blocks, SK_THREADS, 0, st, (const fp8_t*)W, (const bf16_t*)x, MB, N, K, ldx, tiled, rt,
+                               wscale, (const bf16_t*)res, (const bf16_t*)nullptr, eps, out, ldo, ldr, of, fuse, sw8);
+        else if (fuse.f16) TEO_KLAUNCH((skinny_gemm_kernel<f16_t, 8, true, false, false>), blocks, SK_THREADS, 0, st, (const f16_t*)W, (const bf16_t*)x, MB, N, K, ldx, tiled, rt,
+                               wscale, (const bf16_t*)res, (const bf16_t*)nullptr, eps, out, ldo, ldr, of, fuse, sw8);
+        else       TEO_KLAUNCH((skinny_gemm_kernel<bf16_t, 8, true, false, false>), blocks, SK_THREADS, 0, st, (const bf16_t*)W, (const bf16_t*)x, MB, N, K, ldx, tiled, rt,
+                               wscale, (const bf16_t*)res, (const bf16_t*)nullptr, eps, out, ldo, ldr, of, fuse, sw8);
         note_kernel("skinny_gemm_u8");
         TEO_LAUNCH_CHECK("skinny_gemm");
         return TEO_OK;
     }
 #define TEO_SK(WW, NTV, SW, NM)                                                                            \
     TEO_KLAUNCH((skinny_gemm_kernel<WW, 4, NTV, SW, NM>), blocks, SK_THREADS, dyn, st,                     \
-        (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)norm_w, eps, (const bf16_t*)res, out, MB, N, K, ldx, ldo, ldr, \
-        tiled, of, rt, fuse, sw8)
+        (const WW*)W, (const bf16_t*)x, MB, N, K, ldx, tiled, rt, wscale, (const bf16_t*)res, (const bf16_t*)norm_w, eps, out, ldo, ldr, \
+        of, fuse, sw8)
 #define TEO_SK_N(WW, NTV, SW) if (norm_w) { TEO_SK(WW, NTV, SW, true); } else { TEO_SK(WW, NTV, SW, false); }
 #define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK_N(WW, NTV, true) } else { TEO_SK_N(WW, NTV, false) }
     if (w_fp8)         { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }

@@ -37,11 +37,11 @@ extern "C" int skinny_probe_launch(int mode, const void* x, const void* W, const
     } else {
         const int blocks = ntiles;
         if (w_fp8) {
-            if (sw8) skinny_gemm_kernel<fp8_t, 4, true, true, false, true><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, nullptr, 1e-5f, (const bf16_t*)res, out, MB, N, K, K, ldo, ldo, 1, 0, 1, fuse, 1);
-            else     skinny_gemm_kernel<fp8_t, 4, true, false, false, true><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const fp8_t*)W, wscale, nullptr, 1e-5f, (const bf16_t*)res, out, MB, N, K, K, ldo, ldo, 1, 0, 1, fuse, 0);
+            if (sw8) skinny_gemm_kernel<fp8_t, 4, true, true, false, true><<<blocks, SK_THREADS, 0, st>>>((const fp8_t*)W, (const bf16_t*)x, MB, N, K, K, 1, 1, wscale, (const bf16_t*)res, nullptr, 1e-5f, out, ldo, ldo, 0, fuse, 1);
+            else     skinny_gemm_kernel<fp8_t, 4, true, false, false, true><<<blocks, SK_THREADS, 0, st>>>((const fp8_t*)W, (const bf16_t*)x, MB, N, K, K, 1, 1, wscale, (const bf16_t*)res, nullptr, 1e-5f, out, ldo, ldo, 0, fuse, 0);
         } else {
-            if (sw8) skinny_gemm_kernel<bf16_t, 4, true, true, false, true><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, nullptr, 1e-5f, (const bf16_t*)res, out, MB, N, K, K, ldo, ldo, 1, 0, 1, fuse, 1);
-            else     skinny_gemm_kernel<bf16_t, 4, true, false, false, true><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)x, (const bf16_t*)W, wscale, nullptr, 1e-5f, (const bf16_t*)res, out, MB, N, K, K, ldo, ldo, 1, 0, 1, fuse, 0);
+            if (sw8) skinny_gemm_kernel<bf16_t, 4, true, true, false, true><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)W, (const bf16_t*)x, MB, N, K, K, 1, 1, wscale, (const bf16_t*)res, nullptr, 1e-5f, out, ldo, ldo, 0, fuse, 1);
+            else     skinny_gemm_kernel<bf16_t, 4, true, false, false, true><<<blocks, SK_THREADS, 0, st>>>((const bf16_t*)W, (const bf16_t*)x, MB, N, K, K, 1, 1, wscale, (const bf16_t*)res, nullptr, 1e-5f, out, ldo, ldo, 0, fuse, 0);
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
