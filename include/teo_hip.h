@@ -67,8 +67,8 @@ const char* teo_last_kernel(void);
  *                   (software pipeline inside the wave: -1 auto = causal kernels, 0 one tile at a time, 1 wherever the form exists) --
  *                   same tiles, same arithmetic: bit-identical
  *   decode attn   : "attn_chunk" (keys per decode chunk: 0 auto, 32/64/128/256; fp32 order of the split merge + where P is rounded),
- *                   "attn_whole" (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto, 2 whenever the shape
- *                   allows; bit-identical to the split + combine pair at the same chunk)
+ *                   "attn_whole" (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto = when conversations x
+ *                   heads fill the CUs, 2 whenever the shape allows; bit-identical to the split + combine pair at the same chunk)
  *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible), "skinny_ring"
  *                   (weight tiles in flight of the streaming form: 0 default, 1 one more), "skinny_unr" (tile kernel steps per register
  *                   set: 0 auto, 4, 8) -- bit-identical at K = 4096, fp32 order elsewhere */
