@@ -330,20 +330,22 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const int* __r
 // split (G = 512 / hd) and keeps its loads in flight, the G partial sums of a column meet in LDS -- one or two round trips
 // instead of a dependent chain over all splits.  pb: records of this head, `stride` floats apart; nact <= 256 splits hold keys.
 template <typename T>
-__device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb, int stride, int nact, int hd, T* __restrict__ o_row,
+__device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb, int stride, int nact, int hd_log2, T* __restrict__ o_row,
                                                    float* w /* [256] */, float* red /* [16] */, float* accs /* [512] */) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const bool on = tid < 512;                                              // a larger workgroup: the other waves only join the barriers
-    const int G = 512 / hd;                                                 // hd is a power of two <= 256
-    const int g = on ? tid / hd : 0, d = tid % hd;
+    const int hd = 1 << hd_log2;                                            // hd is a power of two <= 256: shifts, no integer division
+    const int G = 512 >> hd_log2;
+    const int g = on ? tid >> hd_log2 : 0, d = tid & (hd - 1);
     // the first NB splits of this thread are requested together with the split statistics (they do not depend on them): ONE round
-    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split)
+    // trip covers NB * G splits (48 at head_dim 128 = ctx 3072 at 64 keys per split).  32-bit element offsets: a head's records are
+    // at most 256 x 258 floats
     constexpr int NB = 12;
     float v0[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) v0[i] = pb[(long long)min(g + i * G, nact - 1) * stride + 2 + d];
+    for (int i = 0; i < NB; ++i) v0[i] = pb[(unsigned)(min(g + i * G, nact - 1) * stride + 2 + d)];
     float m0 = -INFINITY, l0 = 0.f;
-    if (tid < nact) { m0 = pb[tid * stride]; l0 = pb[tid * stride + 1]; }
+    if (tid < nact) { m0 = pb[(unsigned)(tid * stride)]; l0 = pb[(unsigned)(tid * stride + 1)]; }
     float M = wave_max(m0);
     if (lane == 0 && on) red[wid] = M;
     __syncthreads();
@@ -355,14 +357,22 @@ __device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb,
     __syncthreads();
     const float inv = 1.0f / ((red[8] + red[9]) + (red[10] + red[11]));
     float a = 0.f;
+    // (the product is formed for every slot -- a clamped slot re-reads a valid record -- and a select decides what is added: no branch
+    // per split; adding +0 to the running sum changes nothing)
 #pragma unroll
-    for (int i = 0; i < NB; ++i) a += (g + i * G < nact) ? v0[i] * w[min(g + i * G, 255)] : 0.f;
+    for (int i = 0; i < NB; ++i) {
+        const float t = v0[i] * w[min(g + i * G, 255)];
+        a += (g + i * G < nact) ? t : 0.f;
+    }
     for (int s0 = g + NB * G; s0 < nact; s0 += 8 * G) {
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = pb[(long long)min(s0 + i * G, nact - 1) * stride + 2 + d];
+        for (int i = 0; i < 8; ++i) v[i] = pb[(unsigned)(min(s0 + i * G, nact - 1) * stride + 2 + d)];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a += (s0 + i * G < nact) ? v[i] * w[min(s0 + i * G, 255)] : 0.f;
+        for (int i = 0; i < 8; ++i) {
+            const float t = v[i] * w[min(s0 + i * G, 255)];
+            a += (s0 + i * G < nact) ? t : 0.f;
+        }
     }
     if (on) accs[tid] = a;
     __syncthreads();
@@ -373,22 +383,23 @@ __device__ __forceinline__ void attn_merge_records(const float* __restrict__ pb,
     }
 }
 
-// one workgroup (512 threads) per head
+// one workgroup (512 threads) per head.  chunk and hd are powers of two (host-checked): passed as shifts
 template <typename T>
-__global__ __launch_bounds__(512) void attn_decode_combine_kernel(const float* __restrict__ part, T* __restrict__ o,
-                                                                  const int* __restrict__ d_pos, int hd, int nsplit, int chunk,
+__global__ __launch_bounds__(512) void attn_decode_combine_kernel(const int* __restrict__ d_pos, const float* __restrict__ part,
+                                                                  T* __restrict__ o, int hd_log2, int nsplit, int chunk_log2,
                                                                   long long o_stride) {
     __shared__ float w[256];
     __shared__ float red[16];
     __shared__ float accs[512];
+    const int pos = d_pos[blockIdx.y];                                      // requested first
     const int h = blockIdx.x;
+    const int hd = 1 << hd_log2;
     const int stride = hd + 2;
     part += (long long)blockIdx.y * gridDim.x * nsplit * stride;
     o += (long long)blockIdx.y * o_stride;
-    d_pos += blockIdx.y;
     const float* pb = part + (long long)h * nsplit * stride;
-    const int nact = min(nsplit, (*d_pos + 1 + chunk - 1) / chunk);       // splits that hold keys (<= 256)
-    attn_merge_records<T>(pb, stride, nact, hd, o + h * hd, w, red, accs);
+    const int nact = min(nsplit, (pos + (1 << chunk_log2)) >> chunk_log2);  // splits that hold keys (<= 256)
+    attn_merge_records<T>(pb, stride, nact, hd_log2, o + h * hd, w, red, accs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
 #undef TEO_AW_PV
     __syncthreads();
     float* w = rec + (long long)nact * STRIDE;             // merge scratch behind the records: w[256], red[16], accs[512]
-    attn_merge_records<T>(rec, STRIDE, nact, HD, o + h * HD, w, w + 256, w + 272);
+    attn_merge_records<T>(rec, STRIDE, nact, __builtin_ctz((unsigned)HD), o + h * HD, w, w + 256, w + 272);
 }
 
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch) {
@@ -643,7 +654,8 @@ static void attn_decode_launch(const void* q, void* kc, void* vc, void* vtc, con
 #undef TEO_PART_R
 #undef TEO_PART
     prof_bump(1);
-    TEO_KLAUNCH((attn_decode_combine_kernel<T>), dim3(heads, bt.batch), 512, 0, st, part, (T*)o, d_pos, hd, nsplit, chunk, bt.o_stride);
+    TEO_KLAUNCH((attn_decode_combine_kernel<T>), dim3(heads, bt.batch), 512, 0, st, d_pos, part, (T*)o, __builtin_ctz((unsigned)hd), nsplit,
+                __builtin_ctz((unsigned)chunk), bt.o_stride);
     prof_bump(-1);
 }
 
