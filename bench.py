@@ -508,6 +508,9 @@ def main():
             e["algorithmic_bytes"] = int(alg_bytes[name])
             e["GBps"] = round(alg_bytes[name] / (us * 1e-6) / 1e9, 1)
             e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
+        if name == "attn_decode_combine":
+            # measured with the kernel body removed (profiles/r04_decode_experiments.md, section 5): an EMPTY 32-workgroup kernel reads 4.2 us here
+            e["note"] = "dispatch-timestamp floor: an empty kernel of this grid reads ~4.2 us; by step-time difference the body costs ~1.4 us per launch"
         in_run[name] = e
     pair_us = prof["attn_decode_partial"][1] + prof.get("attn_decode_combine", (0, 0.0))[1]
     in_run["attention_pair"] = {"avg_us": round(pair_us, 2), "algorithmic_bytes": int(alg_bytes["attn_decode_partial"]),
