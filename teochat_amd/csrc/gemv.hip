@@ -527,7 +527,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const WT* __r
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nchunk = K / VE;
     float* red = x_image_end<BfImage<T, WT>::v, VE>(xs, nchunk);
-    const int half = hd >> 1;
+    const int half = hd >> 1, half_log2 = __builtin_ctz((unsigned)hd) - 1;
     const int qk_groups = (H + Hk) * half;              // rotation pairs
     const int ngroups = qk_groups + (Hk * hd) / 2;
     const int nwaves = gridDim.x * GV_WAVES;
@@ -536,8 +536,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const WT* __r
     auto rows_of = [&](int grp, long long (&rows)[R], int& head, int& i0) -> bool {
         const bool qk = grp < qk_groups;
         if (qk) {
-            head = grp / half;
-            i0 = grp % half;
+            head = grp >> half_log2;                     // hd is a power of two (host-checked): no integer division per group
+            i0 = grp & (half - 1);
             rows[0] = (long long)head * hd + i0;
             rows[1] = rows[0] + half;
         } else {
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_qkv_rope_kernel(const WT* __r
                 const int v0 = (grp - qk_groups) * 2;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int hk = (v0 + r) / hd, d = (v0 + r) % hd;
+                    const int hk = (v0 + r) >> (half_log2 + 1), d = (v0 + r) & (hd - 1);
                     T val;
                     Elem<T>::st(&val, acc[r]);
                     vc[((long long)hk * S_max + pos) * hd + d] = val;
@@ -741,7 +741,7 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
                   const float* cs, const float* sn, const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk,
                   int hd, int K, float eps, int dtype, hipStream_t st) {
     const int ve = w_fp8 ? 16 : (dtype == TEO_F32 ? 4 : 8);
-    TEO_CHECK_ARG(K % ve == 0 && hd % 2 == 0, "gemv_qkv_rope: K=%d hd=%d", K, hd);
+    TEO_CHECK_ARG(K % ve == 0 && hd >= 2 && (hd & (hd - 1)) == 0, "gemv_qkv_rope: K=%d hd=%d (head_dim must be a power of two)", K, hd);
     TEO_CHECK_ARG((size_t)(K + 1040) * 4 <= 64 * 1024, "gemv_qkv_rope: K=%d too large for LDS staging", K);
     TEO_CHECK_ARG(!w_fp8 || (dtype == TEO_BF16 && wscale), "gemv_qkv_rope: fp8 weights need bf16 activations and scales");
     const int ngroups = (H + Hk) * (hd / 2) + Hk * hd / 2;

@@ -120,11 +120,13 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const WT* __res
     const bf16_t* gs = reinterpret_cast<const bf16_t*>(sk_dyn) + fg * (sizeof(WT) == 1 ? 16 : 8);
     float ssq = 0.f;
     // the 8 waves of a workgroup = RT row tiles (16 weight rows each) x KSPLIT contiguous K slices
-    const int KSPLIT = SK_WAVES / RT;
-    const int rt = wid / KSPLIT, ks = wid % KSPLIT;
+    // (RT is 1, 2, 4 or 8 -- host-checked: shifts, no integer division in front of the first weight request)
+    const int rt_log2 = __builtin_ctz((unsigned)RT), ks_log2 = __builtin_ctz((unsigned)SK_WAVES) - rt_log2;
+    const int KSPLIT = 1 << ks_log2;
+    const int rt = wid >> ks_log2, ks = wid & (KSPLIT - 1);
     const int n0 = blockIdx.x * 16 * RT;
     const int nsteps = K / KS;
-    const int per = (nsteps + KSPLIT - 1) / KSPLIT;
+    const int per = (nsteps + KSPLIT - 1) >> ks_log2;
     const int s0 = ks * per, s1 = min(s0 + per, nsteps);
 
     // weight addressing.  Row-major [N][K]: a wave instruction touches 16 rows x 64 B.  Tiled (TEO_GEMM_WTILED): the
