@@ -217,3 +217,18 @@ def test_eval_cli_has_the_reference_flags_and_defaults():
     assert E.str_or_none("") is None and E.str_or_none("base") == "base"
     params = inspect.signature(E.eval).parameters
     assert all(k in params for k in a)               # every flag is a keyword of eval(), as eval(**vars(args)) needs
+
+
+def test_every_tune_key_is_documented_in_the_header():
+    """include/teo_hip.h lists the perf-only knobs of teo_tune_set; every key a source file accepts must be named there and every
+    key named there must exist (round-3 review: 'list every key in include/teo_hip.h')."""
+    import glob
+    keys = set()
+    for f in glob.glob(os.path.join(ROOT, "teochat_amd", "csrc", "*.hip")):
+        keys |= set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', open(f).read()))
+    assert len(keys) > 20
+    hdr = open(os.path.join(ROOT, "include", "teo_hip.h")).read()
+    block = hdr[hdr.index("Performance tuning knobs"):hdr.index("int teo_tune_set")]
+    named = set(re.findall(r'"([a-z0-9_]+)"', block))
+    assert keys - named == set(), f"accepted by the library but not documented: {sorted(keys - named)}"
+    assert named - keys == set(), f"documented but not accepted by any source: {sorted(named - keys)}"
