@@ -276,7 +276,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo for plumbing tests")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--rccl-timeout", type=float, default=180.0, help="deadline (s) of the once-per-run RCCL communicator check")
-    ap.add_argument("--tune", action="append", default=[], help="key=value passed to teo_tune_set (perf knobs only)")
+    ap.add_argument("--tune", action="append", default=[], help="key=value set in the engine's teo_tune block (perf knobs only)")
     ap.add_argument("--rope-in-attn", type=int, default=None, choices=[0, 1], help="A/B of the engine option: RoPE + KV append inside the decode attention kernel (1) or in the QKV GEMV epilogue (0, the single-conversation default); same values")
     args = ap.parse_args()
 
@@ -323,7 +323,7 @@ def main():
         eng.set_options(rope_in_attn=bool(args.rope_in_attn))
     for kv in args.tune:
         k_, v_ = kv.split("=")
-        L.check(eng.lib.teo_tune_set(k_.encode(), int(v_)), "teo_tune_set")
+        eng.tune_set(k_, int(v_))                # the engine's own teo_tune block (nothing process-wide)
     frames, ids = synthetic_inputs(T, n_text, model.config.vocab_size, seed=100 * rank if not args.shard_frames else 0,
                                    device=device, dtype=dtype)
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TEO_ABI_VERSION 1
+#define TEO_ABI_VERSION 2 /* 2 (round 5): teo_tune blocks instead of process-wide knobs, `tune` field at the end of the descriptors, teo_sizeof */
 
 typedef void* teo_stream_t; /* hipStream_t */
 
@@ -51,18 +51,30 @@ int teo_version(void);
 const char* teo_last_error(void);
 /* Diagnostics: which kernel family the most recent teo_gemm* / teo_attention call of this thread dispatched to
  * ("gemm_simple", "gemm_mfma_128", "gemm_mfma_128_sk", "gemm_wide", "gemm_wide_sk", "gemm_big", "gemm_big_hybrid", "gemm_fp8_*",
- * "attn_flash32", "attn_simple").  Lets the parity tests state which production kernel they checked. */
+ * "gemm_big_hybrid_cohort", "attn_flash32", "attn_simple").  Lets the parity tests state which production kernel they checked. */
 const char* teo_last_kernel(void);
+/* Size of a struct of this header as the LIBRARY was built with it (0 for an unknown name): a binding checks its own layout against it
+ * at load time -- "teo_vit_desc", "teo_proj_desc", "teo_llama_desc", "teo_decode_state", "teo_decode_batch_state", "teo_attn_args". */
+size_t teo_sizeof(const char* struct_name);
 /* Performance tuning knobs.  PERF-ONLY: every key selects among kernels / geometries that compute the same values (bit-identical
  * unless noted "fp32 order": the fp32 summation order of a reduction may change, nothing else).  Result- or path-selecting options
- * are NOT here: they are fields of the descriptors (teo_llama_desc.prefill_fp8, .rope_in_attn).  The state is process-wide and meant
- * for benchmarks and for tests that force one kernel family; the library's defaults are what ships.  Keys (value 0 / 1 unless said):
+ * are NOT here: they are fields of the descriptors (teo_llama_desc.prefill_fp8, .rope_in_attn).
+ * NO knob is process-wide state (no globals).  Knobs live in a teo_tune block that belongs to its creator
+ * (teo_tune_create / teo_tune_destroy).  The block in effect for a call is
+ *   1. the `tune` field of the descriptor for the descriptor-driven entry points (teo_vit_encode, teo_projector, teo_llama_*), when set
+ *      -- two engines in one process carry two blocks and never see each other's choices;
+ *   2. else the block the CALLING THREAD bound with teo_tune_bind (thread-local; the primitive operators have no descriptor);
+ *   3. else the built-in defaults = what ships.
+ * A block may be read by any number of threads; changing it while another thread runs a call under it is the caller's race.
+ * teo_tune_destroy on a block still bound by ANOTHER thread or named by a live descriptor is a use-after-free of the caller's making.
+ * teo_tune_get(NULL, key, &v) reads the shipped default; teo_tune_keys() lists every key, space separated.  Keys (0 / 1 unless said):
  *   decode GEMV   : "gemv_variant" (-1 default; 0..2, 10..13: row-group geometry; fp32 order), "gemv_nt" (non-temporal weight loads),
  *                   "gemv_max_blocks" (workgroup cap), "gemv_small_k" (x prologue sized to K <= 4096), "gemv_splitk_u" (chunks per thread and step of the split-K GEMV: 0 auto, 1/2/3/4/6), "gemv_splitk_r" (its rows per workgroup: 0 auto, 2/4)
  *   prefill GEMM  : "gemm_bm" (tile rows of the plain kernel: 0 auto, 64, 128), "gemm_depth", "gemm_sk" (stream-K: 0 off, 1 auto, 2 force),
- *                   "gemm_sk_dbg" (timing diagnostics of the hand-off: WRONG results, never set outside tools/), "gemm_wide" (0 off, 1 auto,
- *                   2 force), "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force), "gemm_big_group", "gemm_big_hybrid"
- *                   (0 off, 1 auto, 2 force), "gemm_fp8_wide" (0..3), "gemm_fp8_big" (0..2) -- all bit-identical families
+ *                   "gemm_wide" (0 off, 1 auto, 2 force), "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force),
+ *                   "gemm_big_group", "gemm_big_hybrid" (0 off, 1 auto, 2 force), "gemm_big_cohort" (stream-K part of the hybrid form as
+ *                   XCD-local cohorts: -1 auto, 0 linear ranges, 8 / 16 / 32 workgroups per cohort), "gemm_fp8_wide" (0..3),
+ *                   "gemm_fp8_big" (0..2) -- all bit-identical families
  *   prefill attn  : "flash_order" (causal workgroup order of the flash kernel: 0 heavy-first, 1 second dispatch pass mirrored), "flash_pipe"
  *                   (software pipeline inside the wave: -1 auto = causal kernels, 0 one tile at a time, 1 wherever the form exists) --
  *                   same tiles, same arithmetic: bit-identical
@@ -71,10 +83,16 @@ const char* teo_last_kernel(void);
  *                   heads fill the CUs, 2 whenever the shape allows; bit-identical to the split + combine pair at the same chunk)
  *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible), "skinny_ring"
  *                   (weight tiles in flight of the streaming form: 0 default, 1 one more), "skinny_unr" (tile kernel steps per register
- *                   set: 0 auto, 4, 8) -- bit-identical at K = 4096, fp32 order elsewhere */
-int teo_tune_set(const char* key, int value);
-/* Every knob back to the library default (what ships). */
-int teo_tune_reset(void);
+ *                   set: 0 auto, 4, 8) -- bit-identical at K = 4096, fp32 order elsewhere
+ * teo_tune_set returns TEO_ERR_ARG for an unknown key or a value outside the key's set (message in teo_last_error). */
+typedef struct teo_tune teo_tune;
+teo_tune* teo_tune_create(void);                      /* a block holding the shipped defaults; NULL when out of memory */
+int teo_tune_destroy(teo_tune* tune);                 /* NULL is fine; unbinds it from the calling thread first */
+int teo_tune_set(teo_tune* tune, const char* key, int value);
+int teo_tune_get(const teo_tune* tune, const char* key, int* value);
+int teo_tune_reset(teo_tune* tune);                   /* every key back to the shipped default */
+int teo_tune_bind(const teo_tune* tune);              /* the calling thread's block for calls without a descriptor block; NULL unbinds */
+const char* teo_tune_keys(void);
 /* 1 when the MFMA (fast) kernel would be used for this GEMM, 0 when the generic kernel would. */
 int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags);
 
@@ -299,6 +317,7 @@ typedef struct {
     const void* const* fc1_w; const void* const* fc1_b;
     const void* const* fc2_w; const void* const* fc2_b;
     int keep_cls;   /* feature_select (languagebind/__init__.py:121-129): 0 = 'patch' (drop the CLS row), 1 = 'cls_patch' */
+    const teo_tune* tune; /* performance knobs of this engine (NULL: the calling thread's bound block, else the defaults) */
 } teo_vit_desc;
 
 size_t teo_vit_workspace_bytes(const teo_vit_desc* d, int T);
@@ -312,6 +331,7 @@ typedef struct {
     int in_dim, out_dim, depth; /* depth 1 = linear, 2 = mlp2x_gelu */
     int dtype;
     const void* w[4]; const void* b[4];
+    const teo_tune* tune; /* as teo_vit_desc.tune */
 } teo_proj_desc;
 size_t teo_projector_workspace_bytes(const teo_proj_desc* d, int rows);
 /* build_vision_projector (multimodal_projector/builder.py:33-51) applied to [rows, in_dim]. */
@@ -351,6 +371,7 @@ typedef struct {
                         *    bf16).  Lossy beyond the weight quantisation: selectable, never a default.  0: bf16 / f32 GEMMs */
     int rope_in_attn;  /* single-conversation decode step: 0 = RoPE + KV append in the QKV GEMV epilogue (default), 1 = inside the
                         *    decode attention kernel (same values; the batched step always uses 1) */
+    const teo_tune* tune; /* performance knobs of this engine (as teo_vit_desc.tune); a captured decode graph keeps the choices made at capture */
 } teo_llama_desc;
 
 size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
@@ -479,6 +500,9 @@ int teo_comm_unique_id(void* out_id /* TEO_COMM_ID_BYTES */);
 int teo_ctx_create(int rank, int world_size, const void* unique_id, int device, teo_ctx** out);
 int teo_ctx_destroy(teo_ctx* ctx);
 int teo_ctx_info(const teo_ctx* ctx, int* rank, int* world_size, int* cu_count, size_t* hbm_bytes);
+/* The knob block a context owns (created with it, destroyed with it): the natural home of an engine's knobs when the engine has a
+ * context -- point the descriptors' `tune` at it. */
+teo_tune* teo_ctx_tune(teo_ctx* ctx);
 int teo_allgather_visual(teo_ctx* ctx, const void* d_local, void* d_out, int rows_per_rank, int dim, int dtype,
                          teo_stream_t stream);
 

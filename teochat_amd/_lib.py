@@ -5,6 +5,7 @@ callers get a TeoLibraryError telling them to run `python -c "import __graft_ent
 """
 import ctypes as C
 import os
+import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libteo_hip.so")
@@ -47,12 +48,12 @@ class VitDesc(C.Structure):
                 ("pre_ln_w", C.c_void_p), ("pre_ln_b", C.c_void_p),
                 ("ln1_w", PP), ("ln1_b", PP), ("qkv_w", PP), ("qkv_b", PP), ("out_w", PP), ("out_b", PP),
                 ("ln2_w", PP), ("ln2_b", PP), ("fc1_w", PP), ("fc1_b", PP), ("fc2_w", PP), ("fc2_b", PP),
-                ("keep_cls", C.c_int)]
+                ("keep_cls", C.c_int), ("tune", C.c_void_p)]
 
 
 class ProjDesc(C.Structure):
     _fields_ = [("in_dim", C.c_int), ("out_dim", C.c_int), ("depth", C.c_int), ("dtype", C.c_int),
-                ("w", C.c_void_p * 4), ("b", C.c_void_p * 4)]
+                ("w", C.c_void_p * 4), ("b", C.c_void_p * 4), ("tune", C.c_void_p)]
 
 
 class LlamaDesc(C.Structure):
@@ -65,7 +66,7 @@ class LlamaDesc(C.Structure):
                 ("down_w", PP), ("k_cache", PP), ("v_cache", PP), ("vt_cache", PP),
                 ("qkv_w8", PP), ("qkv_s", PP), ("o_w8", PP), ("o_s", PP), ("gateup_w8", PP), ("gateup_s", PP),
                 ("down_w8", PP), ("down_s", PP), ("lm_head8", C.c_void_p), ("lm_head_s", C.c_void_p),
-                ("prefill_fp8", C.c_int), ("rope_in_attn", C.c_int)]
+                ("prefill_fp8", C.c_int), ("rope_in_attn", C.c_int), ("tune", C.c_void_p)]
 
 
 class DecodeState(C.Structure):
@@ -93,8 +94,14 @@ _SIGS = {
     "teo_version": (C.c_int, []),
     "teo_last_error": (C.c_char_p, []),
     "teo_last_kernel": (C.c_char_p, []),
-    "teo_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
-    "teo_tune_reset": (C.c_int, []),
+    "teo_sizeof": (C.c_size_t, [C.c_char_p]),
+    "teo_tune_create": (C.c_void_p, []),
+    "teo_tune_destroy": (C.c_int, [C.c_void_p]),
+    "teo_tune_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "teo_tune_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "teo_tune_reset": (C.c_int, [C.c_void_p]),
+    "teo_tune_bind": (C.c_int, [C.c_void_p]),
+    "teo_tune_keys": (C.c_char_p, []),
     "teo_gemm_uses_mfma": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "teo_layernorm": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "teo_rmsnorm": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
@@ -162,7 +169,13 @@ _SIGS = {
     "teo_ctx_destroy": (C.c_int, [C.c_void_p]),
     "teo_ctx_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "teo_allgather_visual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "teo_ctx_tune": (C.c_void_p, [C.c_void_p]),
 }
+
+ABI_VERSION = 2            # TEO_ABI_VERSION of include/teo_hip.h this binding was written against
+# (the ctypes mirrors of the header's structs are checked against the library's own sizeof at load: a stale or newer .so must fail
+# THERE, not by reading shifted fields)
+
 
 EXPORTS = tuple(_SIGS.keys())
 _lib = None
@@ -192,10 +205,90 @@ def load():
             raise TeoLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.teo_version() != 1:
-        raise TeoLibraryError(f"ABI version mismatch: library {lib.teo_version()}, binding 1")
+    if lib.teo_version() != ABI_VERSION:
+        raise TeoLibraryError(f"ABI version mismatch: library {lib.teo_version()}, binding {ABI_VERSION}; rebuild {LIB_PATH}")
+    mirrors = {"teo_vit_desc": VitDesc, "teo_proj_desc": ProjDesc, "teo_llama_desc": LlamaDesc, "teo_decode_state": DecodeState,
+               "teo_decode_batch_state": DecodeBatchState, "teo_attn_args": AttnArgs}
+    for name, cls in mirrors.items():
+        want = lib.teo_sizeof(name.encode())
+        if want != C.sizeof(cls):
+            raise TeoLibraryError(f"struct layout mismatch: {name} is {want} bytes in {LIB_PATH}, {C.sizeof(cls)} in this binding; rebuild")
     _lib = lib
     return lib
+
+
+# ---- performance knobs (teo_tune blocks; include/teo_hip.h) -----------------------------------------------------------------------
+class Tune:
+    """One block of performance knobs (teo_tune).  An engine owns one and points its descriptors at it; code that calls the
+    primitive operators binds one to its thread (`bind()`, or the `tuned()` context manager below)."""
+
+    def __init__(self):
+        self._lib = load()
+        self.ptr = self._lib.teo_tune_create()
+        if not self.ptr:
+            raise TeoError("teo_tune_create failed")
+
+    def set(self, key, value):
+        key = key if isinstance(key, bytes) else key.encode()
+        return self._lib.teo_tune_set(self.ptr, key, int(value))
+
+    def get(self, key):
+        key = key if isinstance(key, bytes) else key.encode()
+        v = C.c_int(0)
+        check(self._lib.teo_tune_get(self.ptr, key, C.byref(v)), "teo_tune_get")
+        return v.value
+
+    def reset(self):
+        return self._lib.teo_tune_reset(self.ptr)
+
+    def bind(self):
+        return self._lib.teo_tune_bind(self.ptr)
+
+    def close(self):
+        if self.ptr:
+            self._lib.teo_tune_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_tls = threading.local()
+
+
+def thread_tune():
+    """The calling thread's own block, created and bound on first use (what `tune_set` / `tune_reset` act on)."""
+    t = getattr(_tls, "tune", None)
+    if t is None:
+        t = _tls.tune = Tune()
+        t.bind()
+    return t
+
+
+def tune_set(key, value):
+    """Set a knob in the calling thread's bound block (primitive operators called from this thread see it; engines have their own)."""
+    return thread_tune().set(key, value)
+
+
+def tune_reset():
+    t = getattr(_tls, "tune", None)
+    return t.reset() if t is not None else 0
+
+
+def tune_release():
+    """Unbind and destroy the calling thread's block (tests call this after each test: nothing outlives the test that set it)."""
+    t = getattr(_tls, "tune", None)
+    if t is not None:
+        load().teo_tune_bind(None)
+        t.close()
+        _tls.tune = None
+
+
+def tune_keys():
+    return load().teo_tune_keys().decode().split()
 
 
 def check(rc, what=""):

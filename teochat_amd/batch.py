@@ -79,6 +79,12 @@ class BatchDecoder:
                 for dd in o.slot_desc + [o.desc]:
                     dd.prefill_fp8, dd.rope_in_attn = src.prefill_fp8, src.rope_in_attn
         engine._option_hooks.append(_sync_options)
+
+        def _knob_changed():                      # TeoEngine.tune_set: the captured batched step keeps the choices of its capture
+            o = me()
+            if o is not None:
+                o._drop_graph()
+        engine._tune_hooks.append(_knob_changed)
         # device state
         self.d_token = torch.zeros(B, dtype=torch.int64, device=dev)
         self.d_pos = torch.zeros(B, dtype=torch.int32, device=dev)

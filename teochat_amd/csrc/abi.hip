@@ -1,6 +1,8 @@
 // extern "C" surface of libteo_hip.so (declared in include/teo_hip.h).  Argument validation + dispatch only.
 #include <stdarg.h>
 
+#include <new>
+
 #include "ops.h"
 
 namespace teo {
@@ -27,6 +29,24 @@ int device_cu_count() {
     if (dev >= 0 && dev < 64 && cus > 0) cached[dev] = cus;
     return cus;
 }
+
+int lds_attr_once(const void* kernel, int bytes, unsigned long long* mask, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(mask, __ATOMIC_RELAXED) & bit) return TEO_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", what, bytes, hipGetErrorString(e)); return TEO_ERR_HIP; }
+    __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
+    return TEO_OK;
+}
+
+// ---- performance knobs (tune.h): the block in effect on this thread --------------------------------------------------------------
+static const teo_tune g_tune_defaults;                       // immutable: what ships
+static thread_local const teo_tune* g_tune_bound = nullptr;  // teo_tune_bind / TuneScope
+const teo_tune& tune() { return g_tune_bound ? *g_tune_bound : g_tune_defaults; }
+TuneScope::TuneScope(const teo_tune* t) : prev(g_tune_bound), active(t != nullptr) { if (active) g_tune_bound = t; }
+TuneScope::~TuneScope() { if (active) g_tune_bound = prev; }
 
 int hip_fail(hipError_t e, const char* what) {
     set_error("%s: %s", what, hipGetErrorString(e));
@@ -79,16 +99,55 @@ int teo_version(void) { return TEO_ABI_VERSION; }
 const char* teo_last_error(void) { return g_err; }
 const char* teo_last_kernel(void) { return teo::g_last_kernel; }
 
-int teo_tune_set(const char* key, int value) {
-    if (key && (gemv_tune_set(key, value) == 0 || gemm_tune_set(key, value) == 0 || gemm_wide_tune_set(key, value) == 0 || gemm_big_tune_set(key, value) == 0 || gemm_fp8_tune_set(key, value) == 0 || skinny_tune_set(key, value) == 0 || attn_tune_set(key, value) == 0 || flash_tune_set(key, value) == 0)) return TEO_OK;
-    set_error("teo_tune_set: unknown key");
+teo_tune* teo_tune_create(void) { return new (std::nothrow) teo_tune(); }
+int teo_tune_destroy(teo_tune* t) {
+    if (t && g_tune_bound == t) g_tune_bound = nullptr;       // other threads that bound it must unbind first (contract in the header)
+    delete t;
+    return TEO_OK;
+}
+int teo_tune_set(teo_tune* t, const char* key, int value) {
+    TEO_CHECK_ARG(t != nullptr && key != nullptr, "teo_tune_set: null %s", t ? "key" : "block");
+    const int v = value;
+#define TEO_TUNE_SET(name, def, ok)                                                                       \
+    if (!strcmp(key, #name)) {                                                                            \
+        TEO_CHECK_ARG((ok), "teo_tune_set: %d is not a value of \"%s\"", value, key);                     \
+        t->name = v;                                                                                      \
+        return TEO_OK;                                                                                    \
+    }
+    TEO_TUNE_KEYS(TEO_TUNE_SET)
+#undef TEO_TUNE_SET
+    set_error("teo_tune_set: unknown key \"%s\"", key);
     return TEO_ERR_ARG;
 }
-
-int teo_tune_reset(void) {
-    gemv_tune_reset(); gemm_tune_reset(); gemm_wide_tune_reset(); gemm_big_tune_reset(); gemm_fp8_tune_reset(); skinny_tune_reset();
-    attn_tune_reset(); flash_tune_reset();
+int teo_tune_get(const teo_tune* t, const char* key, int* value) {
+    TEO_CHECK_ARG(key != nullptr && value != nullptr, "teo_tune_get: null argument");
+    const teo_tune& b = t ? *t : g_tune_defaults;              // NULL: the shipped defaults
+#define TEO_TUNE_GET(name, def, ok) if (!strcmp(key, #name)) { *value = b.name; return TEO_OK; }
+    TEO_TUNE_KEYS(TEO_TUNE_GET)
+#undef TEO_TUNE_GET
+    set_error("teo_tune_get: unknown key \"%s\"", key);
+    return TEO_ERR_ARG;
+}
+int teo_tune_reset(teo_tune* t) {
+    TEO_CHECK_ARG(t != nullptr, "teo_tune_reset: null block");
+    *t = teo_tune();
     return TEO_OK;
+}
+int teo_tune_bind(const teo_tune* t) { g_tune_bound = t; return TEO_OK; }
+const char* teo_tune_keys(void) {
+#define TEO_TUNE_NAME(name, def, ok) #name " "
+    return TEO_TUNE_KEYS(TEO_TUNE_NAME);
+#undef TEO_TUNE_NAME
+}
+size_t teo_sizeof(const char* struct_name) {
+    if (!struct_name) return 0;
+    if (!strcmp(struct_name, "teo_vit_desc")) return sizeof(teo_vit_desc);
+    if (!strcmp(struct_name, "teo_proj_desc")) return sizeof(teo_proj_desc);
+    if (!strcmp(struct_name, "teo_llama_desc")) return sizeof(teo_llama_desc);
+    if (!strcmp(struct_name, "teo_decode_state")) return sizeof(teo_decode_state);
+    if (!strcmp(struct_name, "teo_decode_batch_state")) return sizeof(teo_decode_batch_state);
+    if (!strcmp(struct_name, "teo_attn_args")) return sizeof(teo_attn_args);
+    return 0;
 }
 
 int teo_gemm_uses_mfma(int M, int N, int K, int dtype, unsigned flags) {
@@ -281,6 +340,7 @@ size_t teo_vit_workspace_bytes(const teo_vit_desc* d, int T) { return d ? vit_wo
 int teo_vit_encode(const teo_vit_desc* d, const void* px, int T, void* feat, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype);
+    TuneScope tune_scope(d->tune);
     TEO_CHECK_ARG(T >= 0 && d->hidden % d->heads == 0 && d->image % d->patch == 0, "teo_vit_encode: bad config");
     if (T) { NEED(px, "pixels"); NEED(feat, "features"); NEED(ws, "workspace"); }
     return vit_encode(d, px, T, feat, ws, wsb, ST(s));
@@ -290,6 +350,7 @@ size_t teo_projector_workspace_bytes(const teo_proj_desc* d, int rows) { return 
 int teo_projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype);
+    TuneScope tune_scope(d->tune);
     if (rows) { NEED(x, "x"); NEED(y, "y"); }
     return projector(d, x, rows, y, ws, wsb, ST(s));
 }
@@ -299,6 +360,7 @@ int teo_llama_prefill(const teo_llama_desc* d, const void* emb, const int* pos, 
                       float* logits, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype);
+    TuneScope tune_scope(d->tune);
     TEO_CHECK_ARG(S >= 0 && past >= 0, "teo_llama_prefill: S %d past %d", S, past);
     if (S) { NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace"); }
     return llama_prefill(d, emb, pos, S, past, last_only, logits, ws, wsb, ST(s));
@@ -308,6 +370,7 @@ int teo_llama_prefill_batch(const teo_llama_desc* d, const void* emb, const int*
                             int last_only, float* logits, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype); NEED(seq_lens, "seq_lens");
+    TuneScope tune_scope(d->tune);
     TEO_CHECK_ARG(nseq >= 0 && (nseq <= 1 || cache_stride > 0), "teo_llama_prefill_batch: nseq %d cache_stride %lld", nseq, cache_stride);
     if (nseq == 0) return TEO_OK;
     NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace");
@@ -318,6 +381,7 @@ size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d) { return d ? ll
 int teo_llama_decode_step(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
+    TuneScope tune_scope(d->tune);
     NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
     NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
     if (st->do_sample) {
@@ -342,6 +406,7 @@ int teo_llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_stat
                                   teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype);
+    TuneScope tune_scope(d->tune);
     NEED(st->d_token, "d_token"); NEED(st->d_pos, "d_pos"); NEED(st->d_out_tokens, "d_out_tokens");
     NEED(st->d_out_count, "d_out_count"); NEED(st->d_logits, "d_logits");
     if (st->do_sample) {
@@ -355,6 +420,7 @@ int teo_llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_stat
 int teo_llama_decode_begin(const teo_llama_desc* d, const teo_decode_state* st, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED_DT(d->dtype); NEED(st->d_token, "d_token");
+    TuneScope tune_scope(d->tune);
     return llama_decode_begin(d, st, ws, wsb, ST(s));
 }
 
@@ -362,6 +428,7 @@ int teo_llama_decode_graph_create(const teo_llama_desc* d, const teo_decode_stat
                                   teo_stream_t s, teo_graph** out) {
     ENTER();
     NEED(d, "desc"); NEED(st, "state"); NEED(ws, "workspace"); NEED(out, "out"); NEED_DT(d->dtype);
+    TuneScope tune_scope(d->tune);
     TEO_CHECK_ARG(s != nullptr, "teo_llama_decode_graph_create: needs a non-default stream to capture on");
     if (st->do_sample) { const int rc = sampler_check(d->vocab, st->top_k, st->top_p); if (rc != TEO_OK) return rc; }
     return decode_graph_create(d, st, ws, wsb, ST(s), out);
@@ -389,6 +456,7 @@ size_t teo_llama_decode_batch_workspace_bytes(const teo_llama_desc* d, int batch
 int teo_llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch_state* st, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    TuneScope tune_scope(d->tune);
     NEED(ws, "workspace");
     return llama_decode_batch_begin(d, st, ws, wsb, ST(s));
 }
@@ -396,6 +464,7 @@ int teo_llama_decode_batch_begin(const teo_llama_desc* d, const teo_decode_batch
 int teo_llama_decode_batch_step(const teo_llama_desc* d, const teo_decode_batch_state* st, void* ws, size_t wsb, teo_stream_t s) {
     ENTER();
     { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    TuneScope tune_scope(d->tune);
     NEED(ws, "workspace");
     return llama_decode_batch_step(d, st, ws, wsb, ST(s));
 }
@@ -404,6 +473,7 @@ int teo_llama_decode_batch_step_profile(const teo_llama_desc* d, const teo_decod
                                         int* count_out, teo_stream_t s) {
     ENTER();
     { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    TuneScope tune_scope(d->tune);
     NEED(ws, "workspace"); NEED(ms_out, "ms_out"); NEED(count_out, "count_out");
     return llama_decode_batch_step_profile(d, st, ws, wsb, ms_out, count_out, ST(s));
 }
@@ -412,6 +482,7 @@ int teo_llama_decode_batch_graph_create(const teo_llama_desc* d, const teo_decod
                                         teo_stream_t s, teo_graph** out) {
     ENTER();
     { const int rc = check_batch_state(d, st); if (rc != TEO_OK) return rc; }
+    TuneScope tune_scope(d->tune);
     NEED(ws, "workspace"); NEED(out, "out");
     TEO_CHECK_ARG(s != nullptr, "teo_llama_decode_batch_graph_create: needs a non-default stream to capture on");
     return decode_batch_graph_create(d, st, ws, wsb, ST(s), out);

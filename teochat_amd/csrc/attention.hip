@@ -99,16 +99,10 @@ int attention(const teo_attn_args* ap, int dtype, hipStream_t st) {
 // scores: per-row partial dot + xor-shuffle over the LPR lanes; PV: each lane accumulates its 16-byte column slice
 // over its keys, lanes of different rows are summed with two xor-shuffles at the end.  No MFMA: 1 query row.
 // ------------------------------------------------------------------------------------------------
-static int g_dec_chunk = 0;       // keys per workgroup (32 / 64 / 128 / 256); 0 = auto: 64 for one conversation (2.83 vs 2.86 ms/token
+// tune().attn_chunk (default 0): keys per workgroup (32 / 64 / 128 / 256); 0 = auto: 64 for one conversation (2.83 vs 2.86 ms/token
                                   // at 128, 2.87 at 32, 2.94 at 256), 128 for a batched step (4.74 vs 4.79 ms/step at 64)
-static int g_attn_whole = 1;      // batched steps: whole-context kernel (one workgroup per (conversation, head), no combine launch): 0 off, 1 auto
+// tune().attn_whole (default 1): batched steps: whole-context kernel (one workgroup per (conversation, head), no combine launch): 0 off, 1 auto
                                   // (batch * heads >= half the CUs), 2 whenever the shape allows.  Bit-identical to the split + combine pair.
-void attn_tune_reset() { g_dec_chunk = 0; g_attn_whole = 1; }
-int attn_tune_set(const char* key, int value) {
-    if (!strcmp(key, "attn_whole") && value >= 0 && value <= 2) { g_attn_whole = value; return 0; }
-    if (!strcmp(key, "attn_chunk") && (value == 0 || value == 32 || value == 64 || value == 128 || value == 256)) { g_dec_chunk = value; return 0; }
-    return -1;
-}
 
 template <typename T> struct Cvt16;
 template <> struct Cvt16<bf16_t> {
@@ -666,13 +660,8 @@ static int attn_whole_launch_t(const void* q, void* kc, void* vc, void* vtc, con
     dim3 grid(heads, bt.batch);
 #define TEO_AW(CH, RP)                                                                                                          \
     {                                                                                                                           \
-        static bool attr_set = false;                                                                                           \
-        if (!attr_set && lds > 48 * 1024) {                                                                                     \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_whole_kernel<T, LPR, CH, RP, NW>),    \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                          \
-            if (e != hipSuccess) return hip_fail(e, "attn_decode_whole: hipFuncSetAttribute");                                  \
-            attr_set = true;                                                                                                    \
-        }                                                                                                                       \
+        static unsigned long long attr_mask = 0;                                                                                \
+        if (lds > 48 * 1024) if (int e = lds_attr_once(reinterpret_cast<const void*>(&attn_decode_whole_kernel<T, LPR, CH, RP, NW>), 96 * 1024, &attr_mask, "attn_decode_whole")) return e; \
         TEO_KLAUNCH((attn_decode_whole_kernel<T, LPR, CH, RP, NW>), grid, NW * 64, lds, st, (const T*)q, (T*)kc, (T*)vc, (T*)vtc, cs, sn, \
                     (T*)o, d_pos, S_max, heads, kv_heads, scale, bt);                                                           \
     }
@@ -709,7 +698,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
                 float* part, const int* d_pos, int S_max, int heads, int kv_heads, int hd, float scale, int dtype,
                 hipStream_t st, AttnBatch bt) {
     const bool rope = rope_cos != nullptr;
-    int chunk = g_dec_chunk ? g_dec_chunk : (bt.batch > 1 ? 128 : 64);
+    int chunk = tune().attn_chunk ? tune().attn_chunk : (bt.batch > 1 ? 128 : 64);
     const int esz = dtype == TEO_F32 ? 4 : 2;
     const int lpr = hd * esz / 16;
     if (chunk / 4 < 64 / lpr) chunk = 4 * (64 / lpr);          // every wave needs at least one load instruction of keys
@@ -724,7 +713,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
     // wins below that -- B = 4: 30.1 vs 31.8 us, profiles/r04_attn_probe_b4.txt).  Its default chunk is 64 keys (quarter-chunks of 4 load instructions: a 4-slot ring of 64
     // VGPRs; with 128-key chunks the bf16 / head_dim 128 kernel needs more than 256 registers), "attn_chunk" forces another.
     {
-        int cw = g_dec_chunk ? g_dec_chunk : 64;
+        int cw = tune().attn_chunk ? tune().attn_chunk : 64;
         if (cw / 4 < 64 / lpr) cw = 4 * (64 / lpr);
         while (cw < 128 && cdiv(S_max, cw) > 256) cw *= 2;
         const int nsw = cdiv(S_max, cw);
@@ -732,7 +721,7 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
         const size_t lds = ((size_t)8 * cw + (size_t)nsw * (hd + 2) + 784) * sizeof(float);
         const int cus = device_cu_count();
         const bool fits = ni >= 1 && ni <= 8 && (hd & (hd - 1)) == 0 && hd <= 256 && lds <= 96 * 1024 && nsw <= 256 && (cw == 32 || cw == 64 || cw == 128);
-        if (fits && (g_attn_whole == 2 || (g_attn_whole == 1 && bt.batch > 1 && bt.batch * heads >= (cus > 0 ? cus : 256)))) {
+        if (fits && (tune().attn_whole == 2 || (tune().attn_whole == 1 && bt.batch > 1 && bt.batch * heads >= (cus > 0 ? cus : 256)))) {
             const int rcw = attn_whole_launch(q, kc, vc, vtc, rope_cos, rope_sin, o, d_pos, S_max, heads, kv_heads, hd, scale, cw, lpr, dtype, bt, lds, st);
             if (rcw != TEO_ERR_UNSUPPORTED) return rcw;
         }

@@ -94,6 +94,7 @@ struct teo_ctx {
     int cu_count;
     size_t hbm_bytes;
     teo::NcclComm comm;
+    teo_tune tune;          // the context's own block of performance knobs (teo_ctx_tune)
 };
 
 using namespace teo;
@@ -158,6 +159,8 @@ int teo_ctx_info(const teo_ctx* ctx, int* rank, int* world_size, int* cu_count, 
     if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
     return TEO_OK;
 }
+
+teo_tune* teo_ctx_tune(teo_ctx* ctx) { return ctx ? &ctx->tune : nullptr; }
 
 int teo_allgather_visual(teo_ctx* ctx, const void* d_local, void* d_out, int rows_per_rank, int dim, int dtype,
                          teo_stream_t stream) {

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../../include/teo_hip.h"
+#include "tune.h"
 
 namespace teo {
 
@@ -19,6 +20,9 @@ void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 // compute units of the CURRENT device (cached per device id; 0 when the query fails)
 int device_cu_count();
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: set once per (kernel, device); `mask` is the call site's own
+// static word, one bit per device id (a benign race sets it twice)
+int lds_attr_once(const void* kernel, int bytes, unsigned long long* mask, const char* what);
 // diagnostics: name of the kernel family the last dispatching entry point (GEMM / attention) chose -- teo_last_kernel()
 void note_kernel(const char* name);
 

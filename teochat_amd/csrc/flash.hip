@@ -391,23 +391,17 @@ _Pragma("nounroll")
     }
 }
 
-static int g_flash_pipe = -1;      // in-wave pipeline: -1 auto (where the second score buffer fits the register budget), 0 off, 1 on
-static int g_flash_order = 1;      // causal workgroup order: 0 heavy-first, 1 heavy-first with the second dispatch pass mirrored (see the kernel)
-void flash_tune_reset() { g_flash_order = 1; g_flash_pipe = -1; }
-int flash_tune_set(const char* key, int value) {
-    if (!strcmp(key, "flash_order") && value >= 0 && value <= 1) { g_flash_order = value; return 0; }
-    if (!strcmp(key, "flash_pipe") && value >= -1 && value <= 1) { g_flash_pipe = value; return 0; }
-    return -1;
-}
+// tune().flash_pipe (default -1): in-wave pipeline: -1 auto (where the second score buffer fits the register budget), 0 off, 1 on
+// tune().flash_order (default 1): causal workgroup order: 0 heavy-first, 1 heavy-first with the second dispatch pass mirrored (see the kernel)
 
 int attention_flash32(const teo_attn_args& a, hipStream_t st, bool f16) {
     dim3 grid(cdiv(a.q_len, 128) * a.heads * a.batch);
     const int cus = device_cu_count();
-    const int pair_c = (g_flash_order == 1 && a.causal && cus >= 8) ? cus / 8 : 0;
+    const int pair_c = (tune().flash_order == 1 && a.causal && cus >= 8) ? cus / 8 : 0;
     size_t lds = 2 * (size_t)(64 * a.head_dim * 2 + a.head_dim * 128);
     // the in-wave pipeline where its second score buffer fits the 256-register budget of two waves per SIMD (D = 128 non-causal spills)
 #define TEO_FA(DD, CC, PP) { if (f16) attn_flash32_kernel<DD, CC, true, false, PP><<<grid, 256, lds, st>>>(a, pair_c, nullptr); else attn_flash32_kernel<DD, CC, false, false, PP><<<grid, 256, lds, st>>>(a, pair_c, nullptr); }
-    const bool pipe = g_flash_pipe < 0 ? (a.causal != 0) : g_flash_pipe == 1;
+    const bool pipe = tune().flash_pipe < 0 ? (a.causal != 0) : tune().flash_pipe == 1;
     if (!pipe && a.head_dim == 64 && !a.causal) {           // the tower's shape: four tile pairs (64 KB), requests three iterations ahead
         lds = 4 * (size_t)(64 * 64 * 2 + 64 * 128);
         if (f16) attn_flash32_kernel<64, false, true, false, false, 4><<<grid, 256, lds, st>>>(a, pair_c, nullptr);

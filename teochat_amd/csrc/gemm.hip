@@ -22,7 +22,6 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-thread_local bool g_half_f16 = false;   // 16-bit format of the GEMM call being dispatched on this thread (set by gemm())
 
 // ------------------------------------------------------------------------------------------------
 // generic kernel
@@ -397,7 +396,7 @@ template <bool SWIGLU, bool OUT_F32, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                 const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv,
                                                                 int M, int N, int K, int lda, int ldc, int act, int tiles_m,
-                                                                int tiles_n, int per, float* slabs, int* flags, int dbg) {
+                                                                int tiles_n, int per, float* slabs, int* flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -494,7 +493,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
         TEO_SK_SETUP(t_last)
         TEO_SK_ZERO()
         TEO_SK_KLOOP(0, k_end)
-        if (!(dbg & 1))
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -518,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
     }
     // ---- (3) head last: continue the previous range's partial sums in the same k-order
     if (has_head) {
-        if (tid == 0 && !(dbg & 2)) {
+        if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 __builtin_amdgcn_s_sleep(8);
@@ -528,7 +526,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
         }
         __syncthreads();
         const auto src = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)(q - 1) * SK_SLAB_FLOATS, 0, SK_SLAB_FLOATS * 4, 0x00020000);
-        if (dbg & 4) { TEO_SK_ZERO() } else
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -550,10 +547,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_sk_kernel(const bf16_t*
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 constexpr double GEMM_BIG_ROUND_COST = 1.75;  // measured: 100 us per round of 256 x 256 tiles vs 58 us per round of 128 x 256 (gate/up at M = 17344; 8192^3: 195 vs 111)
-static int g_gemm_big = 1;     // 256 x 256 LDS-DMA kernel (gemm_big.hip): 0 off, 1 auto (rounds model), 2 forced
-static int g_gemm_wide = 1;    // wide-tile LDS-DMA kernel (gemm_wide.hip): 0 off, 1 auto, 2 forced wherever its shape constraints hold
-static int g_gemm_sk_dbg = 0;  // timing diagnostics only (wrong results): 1 skip slab stores, 2 skip the flag wait, 4 skip slab loads
-static int g_gemm_sk = 1;      // 1: stream-K kernel when a workspace is given and the static tiling would leave a ragged last round
+// tune().gemm_big (default 1): 256 x 256 LDS-DMA kernel (gemm_big.hip): 0 off, 1 auto (rounds model), 2 forced
+// tune().gemm_wide (default 1): wide-tile LDS-DMA kernel (gemm_wide.hip): 0 off, 1 auto, 2 forced wherever its shape constraints hold
+// tune().gemm_sk (default 1): 1: stream-K kernel when a workspace is given and the static tiling would leave a ragged last round
 constexpr int SK_MAX_GRID = 512;   // 256 CUs x 2 resident workgroups (64 KiB LDS, <= 256 VGPRs each)
 // slabs of every stream-K form share the first GEMM_SK_SLAB_BYTES (512 x 64 KB here, 256 x 128 KB in gemm_wide.hip / gemm_fp8.hip,
 // 256 x 256 KB in gemm_big.hip); the hand-off flags live behind them
@@ -574,18 +570,8 @@ int gemm_sk_workspace_status(const void* ws, int* host_flag, hipStream_t st) {
 static bool sk_grid_fits_device() {
     return device_cu_count() == 256;
 }
-static int g_gemm_depth = 0;   // 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
-static int g_gemm_bm = 0;      // 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
-void gemm_tune_reset() { g_gemm_big = 1; g_gemm_wide = 1; g_gemm_sk_dbg = 0; g_gemm_sk = 1; g_gemm_depth = 0; g_gemm_bm = 0; }
-int gemm_tune_set(const char* key, int value) {
-    if (!strcmp(key, "gemm_bm") && (value == 0 || value == 64 || value == 128)) { g_gemm_bm = value; return 0; }
-    if (!strcmp(key, "gemm_depth")) { g_gemm_depth = value; return 0; }
-    if (!strcmp(key, "gemm_wide")) { g_gemm_wide = value; return 0; }
-    if (!strcmp(key, "gemm_big")) { g_gemm_big = value; return 0; }
-    if (!strcmp(key, "gemm_sk_dbg")) { g_gemm_sk_dbg = value; return 0; }
-    if (!strcmp(key, "gemm_sk")) { g_gemm_sk = value; return 0; }          // 0 off, 1 auto, 2 forced (diagnostics)
-    return -1;
-}
+// tune().gemm_depth (default 0): 0 = auto: 2-deep register prefetch, 1-deep for the SwiGLU epilogue (register budget)
+// tune().gemm_bm (default 0): 0 = auto (by wave quantisation over the resident workgroup slots), 64 or 128
 
 bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned flags, const void* A, const void* W,
                   const void* bias, const void* res, const void* C) {
@@ -598,10 +584,8 @@ bool gemm_mfma_ok(int M, int N, int K, int lda, int ldc, int dtype, unsigned fla
     return al(A, 16) && al(W, 16) && al(bias, 8) && al(res, 8) && al(C, 16);
 }
 
-int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                     int act, bool swiglu, bool of32, hipStream_t st);          // gemm_wide.hip
 int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                        int act, bool of32, void* sk_ws, size_t flags_offset, hipStream_t st);
+                        int act, bool of32, bool f16, void* sk_ws, size_t flags_offset, hipStream_t st);          // gemm_wide.hip
 
 // 128 x 256 tiles on 256 slots (one 8-wave workgroup per CU) against 128 x 128 tiles on 512 slots: rounds of equal-length tiles
 static bool gemm_wide_wins(int M, int N, int K, bool forced) {
@@ -632,7 +616,7 @@ static void launch_simple(const void* A, const void* W, const void* bias, const 
 
 // the 128 x 128 (or 64 x 128) tile kernel, one workgroup per tile
 static int gemm_plain_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                             int act, bool swiglu, bool of32, int bm, hipStream_t st) {
+                             int act, bool swiglu, bool of32, bool f16, int bm, hipStream_t st) {
     const int tiles_n = cdiv(N, BN), tiles_m = cdiv(M, bm);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 4 * TILE_BYTES;
@@ -640,10 +624,10 @@ static int gemm_plain_launch(const void* A, const void* W, const void* bias, con
     gemm_mfma_bf16_kernel<SW, OF, DP, MFV, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                       (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
                                                                       tiles_n)
-#define TEO_GEMM_K(SW, OF, DP, MFV) do { if (g_half_f16) TEO_GEMM_KF(SW, OF, DP, MFV, true); else TEO_GEMM_KF(SW, OF, DP, MFV, false); } while (0)
+#define TEO_GEMM_K(SW, OF, DP, MFV) do { if (f16) TEO_GEMM_KF(SW, OF, DP, MFV, true); else TEO_GEMM_KF(SW, OF, DP, MFV, false); } while (0)
 #define TEO_GEMM_LAUNCH(SW, OF)                                                                                      \
     if (bm == 64) { TEO_GEMM_K(SW, OF, 2, 2); }                                                                       \
-    else if ((g_gemm_depth == 0 && !(SW)) || g_gemm_depth == 2) { TEO_GEMM_K(SW, OF, 2, 4); }                         \
+    else if ((tune().gemm_depth == 0 && !(SW)) || tune().gemm_depth == 2) { TEO_GEMM_K(SW, OF, 2, 4); }                         \
     else { TEO_GEMM_K(SW, OF, 1, 4); }
         if (swiglu) { if (of32) { TEO_GEMM_LAUNCH(true, true) } else { TEO_GEMM_LAUNCH(true, false) } }
         else        { if (of32) { TEO_GEMM_LAUNCH(false, true) } else { TEO_GEMM_LAUNCH(false, false) } }
@@ -664,42 +648,42 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         set_error("teo_gemm: SWIGLU16 needs N %% 32 == 0 and no bias/residual/act");
         return TEO_ERR_ARG;
     }
-    g_half_f16 = dtype == TEO_F16;                           // the 16-bit format of this call, read by the launch helpers of every tile family
+    const bool f16 = dtype == TEO_F16;                       // the 16-bit format of this call, handed to the launch helper of every tile family
     if (gemm_mfma_ok(M, N, K, lda, ldc, dtype, flags, A, W, bias, res, C)) {
         // tile height: 128 rows; 64 rows only for small problems whose 128-row tiling leaves more than half of the 512
         // resident workgroup slots empty (ViT o / fc2: 136 tiles; +7 % there).  Measured at M = 2168: 64-row tiles lose
         // 10-25 % on every LLaMA shape (half the weight reuse per tile), wave quantisation notwithstanding.
         const int tiles_n = cdiv(N, BN);
-        int bm = g_gemm_bm;
+        int bm = tune().gemm_bm;
         if (bm == 0) bm = (cdiv(M, 128) * tiles_n <= 256 && !swiglu) ? 64 : 128;
         const int tiles_m = cdiv(M, bm);
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
         const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = (long long)cdiv(M, 256) * cdiv(N, 256);
-        const bool sk_wide_shape = sk_ws && g_gemm_sk && g_gemm_wide && !swiglu && t_wide_ > 256 && t_wide_ <= 256 + 256 / 6;
+        const bool sk_wide_shape = sk_ws && tune().gemm_sk && tune().gemm_wide && !swiglu && t_wide_ > 256 && t_wide_ <= 256 + 256 / 6;
         // 256 x 256 tiles: a round of them costs GEMM_BIG_ROUND_COST rounds of the 128 x 256 kernel for twice the area (measured
         // 1.45-1.7 us against 0.875 us per K tile); taken when that beats the wide kernel's round count and the chip is filled
         // (with a workspace its hybrid form has no ragged last round: fractional rounds + a hand-off allowance)
         const double big_rounds = (sk_ws && t_big > 256 && t_big % 256 != 0 && gemm_big_hybrid_fits(M, N, K)) ? (double)t_big / 256.0 + 0.12
                                                                                                                  : (double)cdiv(t_big, 256);
-        if (bm == 128 && K >= 2 * BK && (g_gemm_big == 2 || (g_gemm_big == 1 && g_gemm_wide == 1 && t_big >= 224 && !sk_wide_shape &&
+        if (bm == 128 && K >= 2 * BK && (tune().gemm_big == 2 || (tune().gemm_big == 1 && tune().gemm_wide == 1 && t_big >= 224 && !sk_wide_shape &&
                                                                big_rounds * GEMM_BIG_ROUND_COST < (double)cdiv(t_wide_, 256))))
-            return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st, sk_ws, GEMM_SK_SLAB_BYTES);
+            return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, st, sk_ws, GEMM_SK_SLAB_BYTES);
         {   // just over one round of WIDE tiles (272 on 256 CUs: o / down at M = 2168): the stream-K form of the wide kernel
             const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256);
-            if (sk_ws && g_gemm_sk && g_gemm_wide && bm == 128 && !swiglu && K >= 2 * BK && t_wide > 256 &&
-                (g_gemm_sk == 2 || t_wide <= 256 + 256 / 6))
-                return gemm_wide_sk_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, sk_ws, GEMM_SK_SLAB_BYTES, st);
+            if (sk_ws && tune().gemm_sk && tune().gemm_wide && bm == 128 && !swiglu && K >= 2 * BK && t_wide > 256 &&
+                (tune().gemm_sk == 2 || t_wide <= 256 + 256 / 6))
+                return gemm_wide_sk_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, sk_ws, GEMM_SK_SLAB_BYTES, st);
         }
-        if (g_gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, g_gemm_wide == 2))
-            return gemm_wide_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, st);
+        if (tune().gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, tune().gemm_wide == 2))
+            return gemm_wide_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, st);
         // stream-K where it was measured to win: just over ONE round of tiles (544 tiles on 512 slots at M = 2168, N = 4096:
         // o 114 -> 93 us, down 297 -> 250 us).  With several tiles per workgroup the contiguous ranges spread an XCD's
         // concurrent tiles over three times as many W panels as the plain kernel's rolling window does and the L2 misses
         // cost more than the idle tail of the last round saves (qkv, 3.19 rounds: 255 -> 330 us; 1.5 rounds: 118 -> 130 us).
-        if (sk_ws && g_gemm_sk && bm == 128 && nwg > SK_MAX_GRID &&
-            (g_gemm_sk == 2 || (nwg < 2 * SK_MAX_GRID && (nwg % SK_MAX_GRID) <= SK_MAX_GRID / 6))) {
+        if (sk_ws && tune().gemm_sk && bm == 128 && nwg > SK_MAX_GRID &&
+            (tune().gemm_sk == 2 || (nwg < 2 * SK_MAX_GRID && (nwg % SK_MAX_GRID) <= SK_MAX_GRID / 6))) {
             const int nk = K / BK;
             const long long total = (long long)nwg * nk;
             const int per = (int)((total + SK_MAX_GRID - 1) / SK_MAX_GRID);          // >= nk because nwg > SK_MAX_GRID
@@ -708,8 +692,8 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
 #define TEO_SK_LAUNCH_F(SW, OF, FV)                                                                                   \
     gemm_mfma_bf16_sk_kernel<SW, OF, FV><<<SK_MAX_GRID, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,  \
                                                                          (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, \
-                                                                         tiles_n, per, slabs, flg, g_gemm_sk_dbg)
-#define TEO_SK_LAUNCH(SW, OF) do { if (g_half_f16) TEO_SK_LAUNCH_F(SW, OF, true); else TEO_SK_LAUNCH_F(SW, OF, false); } while (0)
+                                                                         tiles_n, per, slabs, flg)
+#define TEO_SK_LAUNCH(SW, OF) do { if (f16) TEO_SK_LAUNCH_F(SW, OF, true); else TEO_SK_LAUNCH_F(SW, OF, false); } while (0)
             if (swiglu) { if (of32) TEO_SK_LAUNCH(true, true); else TEO_SK_LAUNCH(true, false); }
             else { if (of32) TEO_SK_LAUNCH(false, true); else TEO_SK_LAUNCH(false, false); }
 #undef TEO_SK_LAUNCH
@@ -718,7 +702,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
             TEO_LAUNCH_CHECK("gemm_mfma_bf16_sk");
             return TEO_OK;
         }
-        return gemm_plain_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, bm, st);
+        return gemm_plain_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, bm, st);
     }
     if (dtype == TEO_F32) {
         if (out_dtype != TEO_F32) { set_error("teo_gemm: f32 inputs need f32 output"); return TEO_ERR_UNSUPPORTED; }

@@ -41,7 +41,7 @@ template <bool SWIGLU, bool OUT_F32, bool HYBRID, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M,
                                                                int N, int K, int lda, int ldc, int act, int tiles_m, int tiles_n,
-                                                               int group, int dp_rounds, int per, float* slabs, int* flags) {
+                                                               int group, int dp_rounds, int per, float* slabs, int* flags, int cohort) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,11 +50,21 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
     const int nk = K / GB_BK;
     const int q = gb_xcd_remap(blockIdx.x, gridDim.x);
     // segments of this workgroup: [tail piece] [dp_rounds whole tiles] [whole tiles of its stream-K range] [head piece]
+    // The stream-K ranges come in two arrangements.  cohort == 0 (round 2): workgroup q owns the contiguous (tile, k) range
+    // [q per, (q + 1) per) -- neighbours sit at different k of different tiles, nothing of the stream-K part is shared through L2
+    // (its K tiles take up to twice as long as the data-parallel ones once W comes from HBM).  cohort == C (round 5): the
+    // remaining tiles form columns of C tiles (position p = column, tile = p C + slot), workgroup q = (chain q / C, slot q % C);
+    // the C workgroups of a chain link -- neighbours on one XCD after the remap -- all own the SAME (column, k) range and walk it
+    // in step, so they share W panels and A row tiles through their L2 exactly as in a data-parallel round; the hand-off goes
+    // to the same slot of the next link (slab q -> q + C).  Same sequential k-order per tile either way.
     int t_first = 0, k_first = 0, t_last = 0, k_end = nk, has_head = 0, has_tail = 0, n_full = 0, t_full0 = 0, nseg = 1;
     const int sk_tile0 = dp_rounds * 256;
+    const int sk_tiles = tiles_m * tiles_n - sk_tile0;
+    const int slot = cohort ? (q & (cohort - 1)) : 0, pstride = cohort ? cohort : 1;          // position p -> tile sk_tile0 + p * pstride + slot
+    const int pred = q - pstride;
     if (HYBRID) {
-        const long long total = (long long)(tiles_m * tiles_n - sk_tile0) * nk;
-        const long long it0 = (long long)q * per, it1 = min(it0 + per, total);
+        const long long total = cohort ? (long long)((sk_tiles + cohort - 1) / cohort) * nk : (long long)sk_tiles * nk;
+        const long long it0 = (long long)(cohort ? q / cohort : q) * per, it1 = min(it0 + per, total);
         if (it0 < total) {
             t_first = (int)(it0 / nk); k_first = (int)(it0 % nk);
             t_last = (int)((it1 - 1) / nk); k_end = (int)(it1 - (long long)t_last * nk);
@@ -71,10 +81,12 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
         is_tail = has_tail && sgi == 0;
         is_head = has_head && sgi == nseg - 1;
         const int j = sgi - has_tail;                                        // index among the whole tiles
-        if (is_tail) { tile = sk_tile0 + t_last; ke = k_end; }
-        else if (is_head) { tile = sk_tile0 + t_first; kb = k_first; }
-        else if (j < dp_rounds) tile = j * 256 + q;
-        else tile = sk_tile0 + t_full0 + (j - dp_rounds);
+        int pos = -1;
+        if (is_tail) { pos = t_last; ke = k_end; }
+        else if (is_head) { pos = t_first; kb = k_first; }
+        else if (j >= dp_rounds) pos = t_full0 + (j - dp_rounds);
+        tile = pos < 0 ? j * 256 + q : sk_tile0 + pos * pstride + slot;
+        if (tile >= tiles_m * tiles_n) continue;                             // a column's unused slots (both owners skip alike: no hand-off)
     } else {
         tile = q;
     }
@@ -107,14 +119,14 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
     if (HYBRID && is_head) {
         if (tid == 0) {
             int spins = 0;
-            while (__hip_atomic_load(flags + q - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            while (__hip_atomic_load(flags + pred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1 << 24)) { __hip_atomic_store(flags + GEMM_SK_ERR_SLOT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never reached (the producer wrote its slab first thing); a miss is STICKY: teo_gemm_workspace_status
             }
-            __hip_atomic_store(flags + q - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+            __hip_atomic_store(flags + pred, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
         }
         __builtin_amdgcn_s_barrier();
-        const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)(q - 1) * GB_SLAB_FLOATS, 0, GB_SLAB_FLOATS * 4, 0x00020000);
+        const auto sl = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)pred * GB_SLAB_FLOATS, 0, GB_SLAB_FLOATS * 4, 0x00020000);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -245,8 +257,9 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
     }   // segments
 }
 
-static int g_big_group = 0;      // N panels per tile group (0: from the tile grid)
-static int g_big_hybrid = 1;     // data-parallel rounds + stream-K remainder when a workspace is given (1: if it fits MALL, 2: always)
+// tune().gemm_big_group (default 0): N panels per tile group (0: from the tile grid)
+// tune().gemm_big_cohort (default -1): stream-K part in XCD-local cohorts of this many workgroups: -1 auto (16 behind data-parallel rounds, else linear), 0 linear ranges, 8 / 16 / 32
+// tune().gemm_big_hybrid (default 1): data-parallel rounds + stream-K remainder when a workspace is given (1: if it fits MALL, 2: always)
 // ... or there are at most 1.5 tiles per workgroup (a pure stream-K grid whose workgroups mostly stay on one tile: down at M = 4208,
 // 272 tiles, 183 MB: 311 us against 421 us for three ragged rounds of 128 x 256 tiles)
 bool gemm_big_hybrid_fits(int M, int N, int K) {
@@ -257,41 +270,39 @@ bool gemm_big_hybrid_fits(int M, int N, int K) {
     // unshared stream-K part; at M = 4208 (214 MB, 5.7 rounds) the hybrid form loses (712 vs 580 us)
     return bytes <= (160ll << 20) || T <= 384 || (T <= 800 && bytes <= (208ll << 20));
 }
-void gemm_big_tune_reset() { g_big_group = 0; g_big_hybrid = 1; }
-int gemm_big_tune_set(const char* key, int value) {
-    if (!strcmp(key, "gemm_big_group") && value >= 0) { g_big_group = value; return 0; }
-    if (!strcmp(key, "gemm_big_hybrid")) { g_big_hybrid = value; return 0; }
-    return -1;
-}
 
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset) {
+                    int act, bool swiglu, bool of32, bool f16, hipStream_t st, void* sk_ws, size_t flags_offset) {
     const int tiles_m = cdiv(M, GB_BM), tiles_n = cdiv(N, GB_BN);
     const int T = tiles_m * tiles_n, nk = K / GB_BK;
     const size_t lds = 2 * GB_STAGE;
-    const int group = g_big_group ? g_big_group : (tiles_m >= 16 ? 4 : 1);
+    const int group = tune().gemm_big_group ? tune().gemm_big_group : (tiles_m >= 16 ? 4 : 1);
     // hybrid form when the tile count is not a whole number of rounds -- and the operands fit the 256 MB Infinity Cache: the
     // stream-K part has every workgroup at its own (tile, k), nothing is shared through L2, and once A + W no longer sit in MALL its
     // K tiles take twice as long as the data-parallel ones (measured: gate/up at M = 4208, 214 MB: 712 us vs 580; at M = 2168 qkv,
     // 118 MB: 195 vs 203; gemm_big_hybrid = 2 forces it)
-    const bool hybrid = sk_ws && g_big_hybrid && T > 256 && T % 256 != 0 && (g_big_hybrid == 2 || gemm_big_hybrid_fits(M, N, K));
+    const bool hybrid = sk_ws && tune().gemm_big_hybrid && T > 256 && T % 256 != 0 && (tune().gemm_big_hybrid == 2 || gemm_big_hybrid_fits(M, N, K));
     const int dp_rounds = hybrid ? T / 256 - 1 : 0;
-    const int per = hybrid ? (int)(((long long)(T - dp_rounds * 256) * nk + 255) / 256) : 0;
+    // cohort form: columns of `cohort` tiles, 256 / cohort chain links; a link's range must cover a whole tile (per >= nk), else linear.
+    // Measured (tools/bench_kernels.py gemm_cohort, cold weights, us; linear / 8 / 16 / 32): gate/up at M = 2168 (2 rounds + 262 tiles)
+    // 342.9 / 324.9 / 322.1 / 329.4, qkv at M = 4208 (2 + 304) 392.6 / 366.1 / 360.7 / 369.4, gate/up at M = 4208 (4 + 438) 723.6 / 609.1 /
+    // 601.3 / 596.9; with NO data-parallel round in front the linear ranges stay ahead or level (qkv at M = 2168, 432 tiles: 197.6 /
+    // 208.1 / 202.1 / 212.1; gate/up at M = 638, 258 tiles: 117.2 / 123.8 / 126.9 / 135.0; down at M = 4208, 272 tiles: 305.8 / 301.1 /
+    // 295.1 / 308.3) -> auto = 16 behind at least one data-parallel round
+    int cohort = !hybrid ? 0 : (tune().gemm_big_cohort >= 0 ? tune().gemm_big_cohort : (dp_rounds >= 1 ? 16 : 0));
+    if (cohort && cdiv(T - dp_rounds * 256, cohort) < 256 / cohort) cohort = 0;
+    const int per = !hybrid ? 0 : cohort ? cdiv((long long)cdiv(T - dp_rounds * 256, cohort) * nk, 256 / cohort)
+                                         : (int)(((long long)(T - dp_rounds * 256) * nk + 255) / 256);
     float* slabs = (float*)sk_ws;
     int* flg = hybrid ? (int*)((unsigned char*)sk_ws + flags_offset) : nullptr;
-#define TEO_GB_LAUNCH_H(SW, OF, HY) { if (g_half_f16) TEO_GB_LAUNCH_HF(SW, OF, HY, true) else TEO_GB_LAUNCH_HF(SW, OF, HY, false) }
+#define TEO_GB_LAUNCH_H(SW, OF, HY) { if (f16) TEO_GB_LAUNCH_HF(SW, OF, HY, true) else TEO_GB_LAUNCH_HF(SW, OF, HY, false) }
 #define TEO_GB_LAUNCH_HF(SW, OF, HY, FV)                                                                                          \
     {                                                                                                                             \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF, HY, FV>),         \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            if (e != hipSuccess) return hip_fail(e, "gemm_big: hipFuncSetAttribute");                                             \
-            attr_set = true;                                                                                                      \
-        }                                                                                                                         \
+        static unsigned long long attr_mask = 0;                                                                                  \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF, HY, FV>), (int)lds, &attr_mask, "gemm_big")) return e; \
         gemm_mfma_bf16_big_kernel<SW, OF, HY, FV><<<(HY) ? 256 : T, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m,  \
-                                                                               tiles_n, group, dp_rounds, per, slabs, flg);             \
+                                                                               tiles_n, group, dp_rounds, per, slabs, flg, cohort);     \
     }
 #define TEO_GB_LAUNCH(SW, OF) { if (hybrid) TEO_GB_LAUNCH_H(SW, OF, true) else TEO_GB_LAUNCH_H(SW, OF, false) }
     if (swiglu) { if (of32) TEO_GB_LAUNCH(true, true) else TEO_GB_LAUNCH(true, false) }
@@ -299,7 +310,7 @@ int gemm_big_launch(const void* A, const void* W, const void* bias, const void* 
 #undef TEO_GB_LAUNCH
 #undef TEO_GB_LAUNCH_H
 #undef TEO_GB_LAUNCH_HF
-    note_kernel(hybrid ? "gemm_big_hybrid" : "gemm_big");
+    note_kernel(hybrid ? (cohort ? "gemm_big_hybrid_cohort" : "gemm_big_hybrid") : "gemm_big");
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_big");
     return TEO_OK;
 }

@@ -571,15 +571,9 @@ __global__ __launch_bounds__(512) void gemm_mfma_fp8_big_kernel(const unsigned c
     }
 }
 
-static int g_fp8_big = 1;      // 256 x 256 kernel: 0 off, 1 auto (rounds model), 2 forced
+// tune().gemm_fp8_big (default 1): 256 x 256 kernel: 0 off, 1 auto (rounds model), 2 forced
 constexpr double F8_BIG_ROUND_COST = 1.66;   // measured: 58.4 us per round of 256 x 256 tiles vs 35.3 us per round of 128 x 256 (gate/up at M = 17344)
-static int g_fp8_wide = 1;      // 0: 128 x 128 kernel only, 1: by the rounds model, 2: wide wherever K has two tiles
-void gemm_fp8_tune_reset() { g_fp8_big = 1; g_fp8_wide = 1; }
-int gemm_fp8_tune_set(const char* key, int value) {
-    if (!strcmp(key, "gemm_fp8_big")) { g_fp8_big = value; return 0; }
-    if (!strcmp(key, "gemm_fp8_wide")) { g_fp8_wide = value; return 0; }
-    return -1;
-}
+// tune().gemm_fp8_wide (default 1): 0: 128 x 128 kernel only, 1: by the rounds model, 2: wide wherever K has two tiles
 
 bool gemm_fp8_ok(int M, int N, int K, int lda, int ldc, unsigned flags, const void* A, const void* W, const void* res, const void* C) {
     if (M < 1 || N < 1 || K % F8_BK != 0 || lda % 16 != 0 || ldc % 4 != 0 || N % 4 != 0) return false;
@@ -606,22 +600,17 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
         const long long rem = t_plain % 512;
         const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
         const double wide = (double)cdiv(t_wide, 256) * 0.80;   // measured: a wide fp8 round costs ~0.8 of a 128 x 128 round (o: 76 vs 81 us, gate/up 219 vs 272)
-        const bool sk_shape = sk_ws && g_fp8_wide && !swiglu && K >= 2 * F8_BK && t_wide > 256 && (g_fp8_wide == 3 || t_wide <= 256 + 256 / 6);
+        const bool sk_shape = sk_ws && tune().gemm_fp8_wide && !swiglu && K >= 2 * F8_BK && t_wide > 256 && (tune().gemm_fp8_wide == 3 || t_wide <= 256 + 256 / 6);
         const long long t_big = (long long)cdiv(M, F8B_BM) * cdiv(N, F8B_BN);
-        if (K >= 2 * F8_BK && (g_fp8_big == 2 || (g_fp8_big == 1 && g_fp8_wide == 1 && t_big >= 224 && !sk_shape &&
+        if (K >= 2 * F8_BK && (tune().gemm_fp8_big == 2 || (tune().gemm_fp8_big == 1 && tune().gemm_fp8_wide == 1 && t_big >= 224 && !sk_shape &&
                                                   cdiv(t_big, 256) * F8_BIG_ROUND_COST < (double)cdiv(t_wide, 256)))) {
             const int tiles_m = cdiv(M, F8B_BM), tiles_n = cdiv(N, F8B_BN);
             const size_t lds = 2 * F8B_STAGE;
             const int group = tiles_m >= 16 ? 4 : 1;
 #define TEO_F8B_LAUNCH(SW, OF)                                                                                                  \
     {                                                                                                                           \
-        static bool attr_set = false;                                                                                           \
-        if (!attr_set) {                                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_fp8_big_kernel<SW, OF>),                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-            if (e != hipSuccess) return hip_fail(e, "gemm_fp8 big: hipFuncSetAttribute");                                       \
-            attr_set = true;                                                                                                    \
-        }                                                                                                                       \
+        static unsigned long long attr_mask = 0;                                                                                \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_fp8_big_kernel<SW, OF>), (int)lds, &attr_mask, "gemm_fp8 big")) return e; \
         gemm_mfma_fp8_big_kernel<SW, OF><<<tiles_m * tiles_n, 512, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, \
                                                                              w_scale, (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n, group); \
     }
@@ -641,13 +630,8 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
             int* flg = (int*)((unsigned char*)sk_ws + GEMM_SK_SLAB_BYTES);
 #define TEO_F8SK_LAUNCH(OF)                                                                                                     \
     {                                                                                                                           \
-        static bool attr_set = false;                                                                                           \
-        if (!attr_set) {                                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_fp8_wide_sk_kernel<OF>),                \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-            if (e != hipSuccess) return hip_fail(e, "gemm_fp8 wide sk: hipFuncSetAttribute");                                   \
-            attr_set = true;                                                                                                    \
-        }                                                                                                                       \
+        static unsigned long long attr_mask = 0;                                                                                \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_fp8_wide_sk_kernel<OF>), (int)lds, &attr_mask, "gemm_fp8 wide sk")) return e; \
         gemm_mfma_fp8_wide_sk_kernel<OF><<<256, 512, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, w_scale, \
                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n, per, slabs, flg); \
     }
@@ -656,18 +640,13 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
             note_kernel("gemm_fp8_wide_sk"); TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide_sk");
             return TEO_OK;
         }
-        if (K >= 2 * F8_BK && (g_fp8_wide >= 2 || (g_fp8_wide == 1 && t_wide >= 256 && wide < plain))) {
+        if (K >= 2 * F8_BK && (tune().gemm_fp8_wide >= 2 || (tune().gemm_fp8_wide == 1 && t_wide >= 256 && wide < plain))) {
             const int tiles_m = cdiv(M, F8W_BM), tiles_n = cdiv(N, F8W_BN);
             const size_t lds = 3 * F8W_STAGE;
 #define TEO_F8W_LAUNCH(SW, OF)                                                                                                  \
     {                                                                                                                           \
-        static bool attr_set = false;                                                                                           \
-        if (!attr_set) {                                                                                                        \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_fp8_wide_kernel<SW, OF>),               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-            if (e != hipSuccess) return hip_fail(e, "gemm_fp8 wide: hipFuncSetAttribute");                                      \
-            attr_set = true;                                                                                                    \
-        }                                                                                                                       \
+        static unsigned long long attr_mask = 0;                                                                                \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_fp8_wide_kernel<SW, OF>), (int)lds, &attr_mask, "gemm_fp8 wide")) return e; \
         gemm_mfma_fp8_wide_kernel<SW, OF><<<tiles_m * tiles_n, 512, lds, st>>>((const unsigned char*)A8, a_scale, (const unsigned char*)W8, \
                                                                               w_scale, (const bf16_t*)res, C, M, N, K, lda, ldc, tiles_m, tiles_n); \
     }

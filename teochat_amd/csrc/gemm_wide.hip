@@ -29,13 +29,7 @@ constexpr int GW_W_BYTES = GW_BN * GW_BK * 2;            // 32 KiB
 constexpr int GW_STAGE = GW_A_BYTES + GW_W_BYTES;        // 48 KiB
 constexpr int GW_PIECES = GW_STAGE / 1024 / 8;           // 1-KiB DMA pieces per wave per K tile = 6
 
-static int g_wide_sched = 1, g_wide_group = 0;        // group 0: chosen from the tile grid
-void gemm_wide_tune_reset() { g_wide_sched = 1; g_wide_group = 0; }
-int gemm_wide_tune_set(const char* key, int value) {
-    if (!strcmp(key, "gemm_wide_sched")) { g_wide_sched = value; return 0; }
-    if (!strcmp(key, "gemm_wide_group") && value >= 0) { g_wide_group = value; return 0; }
-    return -1;
-}
+// tune().gemm_wide_sched (default 1: the skewed / carried K-loop order), tune().gemm_wide_group (default 0: chosen from the tile grid)
 
 __device__ __forceinline__ int gw_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -392,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
 
 // slabs: 256 x 128 KB (the workspace of gemm_sk_workspace_bytes() holds 512 x 64 KB) + flags behind them
 int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                        int act, bool of32, void* sk_ws, size_t flags_offset, hipStream_t st) {
+                        int act, bool of32, bool f16, void* sk_ws, size_t flags_offset, hipStream_t st) {
     const int tiles_m = cdiv(M, GW_BM), tiles_n = cdiv(N, GW_BN);
     const int nk = K / GW_BK;
     const long long total = (long long)tiles_m * tiles_n * nk;
@@ -401,16 +395,11 @@ int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const vo
     const size_t lds = 3 * GW_STAGE;
     float* slabs = (float*)sk_ws;
     int* flg = (int*)((unsigned char*)sk_ws + flags_offset);
-#define TEO_GWSK_LAUNCH(OF) { if (g_half_f16) TEO_GWSK_LAUNCH_F(OF, true) else TEO_GWSK_LAUNCH_F(OF, false) }
+#define TEO_GWSK_LAUNCH(OF) { if (f16) TEO_GWSK_LAUNCH_F(OF, true) else TEO_GWSK_LAUNCH_F(OF, false) }
 #define TEO_GWSK_LAUNCH_F(OF, FV)                                                                                                 \
     {                                                                                                                             \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_sk_kernel<OF, FV>),             \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            if (e != hipSuccess) return hip_fail(e, "gemm_wide_sk: hipFuncSetAttribute");                                         \
-            attr_set = true;                                                                                                      \
-        }                                                                                                                         \
+        static unsigned long long attr_mask = 0;                                                                                  \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_sk_kernel<OF, FV>), (int)lds, &attr_mask, "gemm_wide_sk")) return e; \
         gemm_mfma_bf16_wide_sk_kernel<OF, FV><<<grid, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,         \
                                                                   (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, \
                                                                   per, slabs, flg);                                               \
@@ -423,26 +412,21 @@ int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const vo
 }
 
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                     int act, bool swiglu, bool of32, hipStream_t st) {
+                     int act, bool swiglu, bool of32, bool f16, hipStream_t st) {
     const int tiles_m = cdiv(M, GW_BM), tiles_n = cdiv(N, GW_BN);
     const int nwg = tiles_m * tiles_n;
     const size_t lds = 3 * GW_STAGE;
-#define TEO_GW_LAUNCH_S(SW, OF, SC) { if (g_half_f16) TEO_GW_LAUNCH_SF(SW, OF, SC, true) else TEO_GW_LAUNCH_SF(SW, OF, SC, false) }
+#define TEO_GW_LAUNCH_S(SW, OF, SC) { if (f16) TEO_GW_LAUNCH_SF(SW, OF, SC, true) else TEO_GW_LAUNCH_SF(SW, OF, SC, false) }
 #define TEO_GW_LAUNCH_SF(SW, OF, SC, FV)                                                                                          \
     {                                                                                                                             \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_kernel<SW, OF, SC, FV>),        \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            if (e != hipSuccess) return hip_fail(e, "gemm_wide: hipFuncSetAttribute");                                            \
-            attr_set = true;                                                                                                      \
-        }                                                                                                                         \
+        static unsigned long long attr_mask = 0;                                                                                  \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_wide_kernel<SW, OF, SC, FV>), (int)lds, &attr_mask, "gemm_wide")) return e; \
         gemm_mfma_bf16_wide_kernel<SW, OF, SC, FV><<<nwg, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,     \
-                                                                      (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, g_wide_group ? g_wide_group : (tiles_m >= 32 ? 4 : 1)); \
+                                                                      (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n, tune().gemm_wide_group ? tune().gemm_wide_group : (tiles_m >= 32 ? 4 : 1)); \
     }
 #define TEO_GW_LAUNCH(SW, OF)                                                                                                     \
     {                                                                                                                             \
-        if (g_wide_sched == 0) TEO_GW_LAUNCH_S(SW, OF, 0)                                                                         \
+        if (tune().gemm_wide_sched == 0) TEO_GW_LAUNCH_S(SW, OF, 0)                                                                         \
         else TEO_GW_LAUNCH_S(SW, OF, 1)                                                                                           \
     }
     if (swiglu) { if (of32) TEO_GW_LAUNCH(true, true) else TEO_GW_LAUNCH(true, false) }

@@ -127,20 +127,7 @@ __device__ __forceinline__ uint4 ld16(const void* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// Tunables (teo_tune_set): non-temporal loads on/off, workgroup cap, variant of the row-group kernel.
-struct GemvTune { int variant = -1; int nt = 1; int max_blocks = 1024; int splitk_u = 0; int splitk_r = 0; int small_k = 1; };
-static GemvTune g_tune;
-void gemv_tune_reset() { g_tune = GemvTune(); }
-int gemv_tune_set(const char* key, int value) {
-    if (!strcmp(key, "gemv_variant")) g_tune.variant = value;
-    else if (!strcmp(key, "gemv_nt")) g_tune.nt = value;
-    else if (!strcmp(key, "gemv_max_blocks")) g_tune.max_blocks = value;
-    else if (!strcmp(key, "gemv_small_k")) g_tune.small_k = value != 0;
-    else if (!strcmp(key, "gemv_splitk_u") && (value >= 0 && value <= 6 && value != 5)) g_tune.splitk_u = value;
-    else if (!strcmp(key, "gemv_splitk_r") && (value == 0 || value == 2 || value == 4)) g_tune.splitk_r = value;
-    else return -1;
-    return 0;
-}
+// Tunables (teo_tune, tune.h): gemv_nt non-temporal loads on/off, gemv_max_blocks workgroup cap, gemv_variant of the row-group kernel, ...
 
 // LDS image of f(x) for weight chunks of VE elements: the lanes of a wave read chunk (cb*64 + lane), so the image is
 // lane-linear per 4-float group -- [cb][g = e/4][lane][4 floats] -- and every ds_read_b128 of a wave is one contiguous
@@ -621,12 +608,12 @@ static int launch_rows(const void* x, const void* W, const float* ws, const void
         return launch_rows<T, TO, WT, R, U, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);   // (short rows: the default prologue)
     const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
     int blocks = cdiv(ngroups, GV_WAVES);
-    if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
+    if (blocks > tune().gemv_max_blocks) blocks = tune().gemv_max_blocks;
     const size_t lds = x_image_bytes<BfImage<T, WT>::v, Vec16<WT>::N>(K);
 #define TEO_GV(NTV, SW)                                                                                              \
     TEO_KLAUNCH((gemv_kernel<T, TO, WT, R, U, PF, NTV, SW, XPT>), blocks, GV_THREADS, lds, st, (const T*)x, (const WT*)W, ws, (const T*)norm_w, \
                 (const T*)res, (TO*)y, N, K, eps)
-    if (g_tune.nt) { if (swiglu) TEO_GV(true, true); else TEO_GV(true, false); }
+    if (tune().gemv_nt) { if (swiglu) TEO_GV(true, true); else TEO_GV(true, false); }
     else           { if (swiglu) TEO_GV(false, true); else TEO_GV(false, false); }
 #undef TEO_GV
     TEO_LAUNCH_CHECK("gemv");
@@ -636,7 +623,7 @@ static int launch_rows(const void* x, const void* W, const float* ws, const void
 template <typename T, typename TO, typename WT, int R, int U>
 static int launch_splitk(const void* x, const void* W, const float* ws, const void* res, void* y, int N, int K, hipStream_t st) {
     const int blocks = cdiv(N, R);
-    if (g_tune.nt)
+    if (tune().gemv_nt)
         TEO_KLAUNCH((gemv_splitk_kernel<T, TO, WT, R, U, true>), blocks, GV_THREADS, 0, st, (const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
     else
         TEO_KLAUNCH((gemv_splitk_kernel<T, TO, WT, R, U, false>), blocks, GV_THREADS, 0, st, (const T*)x, (const WT*)W, ws, (const T*)res, (TO*)y, N, K);
@@ -650,27 +637,27 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
     // few long rows without a fused norm (o / down projections): split-K workgroups, 2 rows each (measured best).
     // U is chosen so that ONE step covers the whole row (256*U chunks): every load of the workgroup is in flight at once
     // instead of 2-3 dependent steps (down projection, K = 11008: 3 steps of U = 2 -> 1 step of U = 6).
-    if (!swiglu && norm_w == nullptr && N <= 8192 && g_tune.variant < 0) {
+    if (!swiglu && norm_w == nullptr && N <= 8192 && tune().gemv_variant < 0) {
         const int nchunk = K / Vec16<WT>::N;
         // round 4 sweep (tools/bench_kernels.py gemv_splitk_sweep -> profiles/r04_gemv_splitk_sweep.txt): a row of <= 256 chunks (fp8 o
         // projection) takes U = 1 -- with U = 2 half of the step's instructions are masked (5.39 -> 4.95 us alone, 5.24 -> 4.72 in
         // the step); 4 rows per workgroup are within noise alone and lose in the step (fp8 down 9.94 -> 10.53 us).  The chunk ->
         // (wave, lane) map and every lane's order of accumulation do not depend on R or U: all forms give the same bits (tested)
-        const int u = g_tune.splitk_u > 0 ? g_tune.splitk_u : (nchunk <= 256 ? 1 : (nchunk <= 512 ? 2 : (nchunk <= 1024 ? 4 : (nchunk <= 1536 ? 6 : 2))));
-        const int r = g_tune.splitk_r > 0 ? g_tune.splitk_r : 2;
+        const int u = tune().gemv_splitk_u > 0 ? tune().gemv_splitk_u : (nchunk <= 256 ? 1 : (nchunk <= 512 ? 2 : (nchunk <= 1024 ? 4 : (nchunk <= 1536 ? 6 : 2))));
+        const int r = tune().gemv_splitk_r > 0 ? tune().gemv_splitk_r : 2;
 #define TEO_SPK(RR, UU) if (r == RR && u == UU) return launch_splitk<T, TO, WT, RR, UU>(x, W, ws, res, y, N, K, st)
         TEO_SPK(2, 1); TEO_SPK(2, 3); TEO_SPK(2, 4); TEO_SPK(2, 6);
         TEO_SPK(4, 1); TEO_SPK(4, 2); TEO_SPK(4, 3); TEO_SPK(4, 4); TEO_SPK(4, 6);
 #undef TEO_SPK
         return launch_splitk<T, TO, WT, 2, 2>(x, W, ws, res, y, N, K, st);
     }
-    switch (g_tune.variant) {          // tuning sweep (tools/bench_kernels.py): R rows x U chunks, prefetch on/off
+    switch (tune().gemv_variant) {          // tuning sweep (tools/bench_kernels.py): R rows x U chunks, prefetch on/off
         case 0: return launch_rows<T, TO, WT, 4, 2, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
         case 1: return launch_rows<T, TO, WT, 2, 4, false>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
         case 2: return launch_rows<T, TO, WT, 2, 8, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
         default: break;
     }
-    const bool small_k = K / Vec16<T>::N <= 2 * GV_THREADS && g_tune.small_k;   // the x prologue fits 2 chunks per thread (stage_x)
+    const bool small_k = K / Vec16<T>::N <= 2 * GV_THREADS && (tune().gemv_small_k != 0);   // the x prologue fits 2 chunks per thread (stage_x)
     // >= 4 KiB contiguous per row per step streams ~7 % faster than 2 KiB; first block prefetched under the prologue.
     // fp8 rows are half as long: 4 rows per wave keep the same bytes in flight per lane
     if constexpr (sizeof(WT) == 1) {
@@ -679,7 +666,7 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
         // prologue the registers are the prologue's and 2 x 2 keeps the occupancy
         if constexpr (IsBf<T>::v) {
             if (small_k) {
-                switch (g_tune.variant) {
+                switch (tune().gemv_variant) {
                     case 11: return launch_rows<T, TO, WT, 4, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
                     case 12: return launch_rows<T, TO, WT, 2, 2, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
                     case 13: return launch_rows<T, TO, WT, 4, 4, true, 2>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
@@ -687,7 +674,7 @@ static int gemv_launch(const void* x, const void* W, const float* ws, const void
                 }
             }
         }
-        switch (g_tune.variant) {
+        switch (tune().gemv_variant) {
             case 10: return launch_rows<T, TO, WT, 2, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
             case 11: return launch_rows<T, TO, WT, 4, 2, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
             case 13: return launch_rows<T, TO, WT, 4, 4, true>(x, W, ws, norm_w, res, y, N, K, eps, swiglu, st);
@@ -746,11 +733,11 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
     TEO_CHECK_ARG(!w_fp8 || (dtype == TEO_BF16 && wscale), "gemv_qkv_rope: fp8 weights need bf16 activations and scales");
     const int ngroups = (H + Hk) * (hd / 2) + Hk * hd / 2;
     int blocks = cdiv(ngroups, GV_WAVES);
-    if (blocks > g_tune.max_blocks) blocks = g_tune.max_blocks;
+    if (blocks > tune().gemv_max_blocks) blocks = tune().gemv_max_blocks;
     const size_t lds = w_fp8 ? xb_lds_bytes<16>(K) : (dtype == TEO_F32 ? xs_lds_bytes<4>(K) : xs_lds_bytes<8>(K));
     // small x prologue (2 register chunks per thread) whenever K allows: fewer VGPRs, more waves per SIMD (see stage_x); fp8 rows then
     // take 4 chunks per step like the row-group kernel (8 KB per wave in flight)
-    const bool small_k = g_tune.small_k && K / (dtype == TEO_F32 ? 4 : 8) <= 2 * GV_THREADS;
+    const bool small_k = (tune().gemv_small_k != 0) && K / (dtype == TEO_F32 ? 4 : 8) <= 2 * GV_THREADS;
     const int uu = (w_fp8 && !small_k) ? 2 : 4;
     const bool pf = K / ve >= 64 * uu;
 #define TEO_QR2(TT, WW, NTV, XP, UU)                                                                                      \
@@ -763,10 +750,10 @@ int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, 
 #define TEO_QR(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2, 4); } else { TEO_QR2(TT, WW, NTV, 6, 4); }
 #define TEO_QR6(TT, WW, NTV) TEO_QR2(TT, WW, NTV, 6, 4)
 #define TEO_QR8(TT, WW, NTV) if (small_k) { TEO_QR2(TT, WW, NTV, 2, 4); } else { TEO_QR2(TT, WW, NTV, 6, 2); }
-    if (w_fp8)                 { if (g_tune.nt) { TEO_QR8(bf16_t, fp8_t, true); } else { TEO_QR8(bf16_t, fp8_t, false); } }
-    else if (dtype == TEO_F32) { if (g_tune.nt) { TEO_QR6(float, float, true); } else { TEO_QR6(float, float, false); } }
-    else if (dtype == TEO_F16) { if (g_tune.nt) { TEO_QR(f16_t, f16_t, true); } else { TEO_QR(f16_t, f16_t, false); } }
-    else                       { if (g_tune.nt) { TEO_QR(bf16_t, bf16_t, true); } else { TEO_QR(bf16_t, bf16_t, false); } }
+    if (w_fp8)                 { if (tune().gemv_nt) { TEO_QR8(bf16_t, fp8_t, true); } else { TEO_QR8(bf16_t, fp8_t, false); } }
+    else if (dtype == TEO_F32) { if (tune().gemv_nt) { TEO_QR6(float, float, true); } else { TEO_QR6(float, float, false); } }
+    else if (dtype == TEO_F16) { if (tune().gemv_nt) { TEO_QR(f16_t, f16_t, true); } else { TEO_QR(f16_t, f16_t, false); } }
+    else                       { if (tune().gemv_nt) { TEO_QR(bf16_t, bf16_t, true); } else { TEO_QR(bf16_t, bf16_t, false); } }
 #undef TEO_QR
 #undef TEO_QR6
 #undef TEO_QR8

@@ -58,15 +58,9 @@ int preprocess_frames(const unsigned char* src, void* out, int T, int H, int W, 
                       int dtype, hipStream_t st, const unsigned char* pad_rgb = nullptr);
 int cross_entropy(const float* logits, long long ld, const long long* labels, float* loss_row, float* out, int rows, int vocab,
                   long long ignore_index, hipStream_t st);
-int gemv_tune_set(const char* key, int value);
-void gemv_tune_reset(); void gemm_tune_reset(); void gemm_wide_tune_reset(); void gemm_big_tune_reset(); void gemm_fp8_tune_reset();
-void skinny_tune_reset(); void attn_tune_reset();
-int gemm_wide_tune_set(const char* key, int value);
-int gemm_big_tune_set(const char* key, int value);
 bool patch_embed_ok(int C, int img, int P, int ldw, int D, int dtype, const void* px, const void* W, const void* out);
 int patch_embed(const void* px, const void* W, void* out, int T, int C, int img, int P, int ldw, int D, hipStream_t st, bool f16 = false);
 bool gemm_big_hybrid_fits(int M, int N, int K);
-int skinny_tune_set(const char* key, int value);
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
 // Producer-side RMSNorm hand-off between the GEMMs of a batched decode step.  A residual-producing GEMM (o / down
 // projection, one row tile per workgroup) also emits xg_out = bf16(h * next_g) and ssq_out[b][workgroup] = its 16
@@ -86,12 +80,11 @@ constexpr int SK_TRACE_SLOTS = 16;
 int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, float eps, const void* res,
                 void* out, int MB, int N, int K, int ldx, int ldo, unsigned flags, int out_dtype, hipStream_t st,
                 SkinnyFuse fuse = SkinnyFuse());
-int gemm_tune_set(const char* key, int value);
-int gemm_fp8_tune_set(const char* key, int value);
+// launch helpers of the tile families; f16: the operands are IEEE binary16 (else bfloat16)
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                    int act, bool swiglu, bool of32, hipStream_t st, void* sk_ws, size_t flags_offset);
+                    int act, bool swiglu, bool of32, bool f16, hipStream_t st, void* sk_ws, size_t flags_offset);
 int gemm_wide_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                     int act, bool swiglu, bool of32, hipStream_t st);
+                     int act, bool swiglu, bool of32, bool f16, hipStream_t st);
 constexpr size_t GEMM_SK_SLAB_BYTES = (size_t)64 << 20;   // slab area of the stream-K workspaces (largest user: 256 x 256 KB)
 constexpr int GEMM_SK_FLAG_INTS = 1024;          // hand-off flags (<= 512 used) + the sticky error word
 constexpr int GEMM_SK_ERR_SLOT = GEMM_SK_FLAG_INTS - 1;   // set to 1 by a hand-off that timed out (results of that GEMM are invalid)
@@ -102,16 +95,12 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
              int lda, int ldc, unsigned flags, int out_dtype, hipStream_t st, void* sk_ws = nullptr);
 int quant_rows_fp8(const void* x, const void* norm_w, void* q, float* s, int M, int K, int ldx, float eps, hipStream_t st);
 int gemm_sk_workspace_init(void* ws, hipStream_t st);
-int attn_tune_set(const char* key, int value);
-int flash_tune_set(const char* key, int value);
-void flash_tune_reset();
 int gemv_qkv_rope(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, void* qout,
                   const float* cs, const float* sn, const int* d_pos, void* kc, void* vc, void* vtc, int S_max, int H, int Hk,
                   int hd, int K, float eps, int dtype, hipStream_t st);
 int gemv_w(const void* x, const void* W, const float* wscale, int w_fp8, const void* norm_w, const void* res, void* y, int N,
            int K, float eps, unsigned flags, int dtype, int out_dtype, hipStream_t st);
 
-extern thread_local bool g_half_f16;      // gemm.hip: true while a TEO_F16 GEMM is being dispatched (selects the F16 instantiation of every tile family)
 inline size_t esize(int dtype) { return dtype == TEO_F32 ? 4 : 2; }
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 

@@ -31,21 +31,12 @@ constexpr int SK_WAVES = 8;
 constexpr int SK_THREADS = SK_WAVES * 64;
 constexpr int SK_TP = 16 * 17;      // padded 16x16 partial tile in LDS: [b][i] at b*17 + i
 
-static int g_sk_tiles = 0;          // 0 = auto
-static int g_sk_nt = 1;
-static int g_sk_stream = 1;         // 0 = never, 1 = auto, 2 = whenever the streaming form is eligible
-static int g_sk_ring = 0;           // streaming form, weight tiles in flight per wave: 0 = default (2 fp8 / 1 bf16: measured best end to end,
+// tune().skinny_tiles (default 0): 0 = auto
+// tune().skinny_nt (default 1): non-temporal weight loads
+// tune().skinny_stream (default 1): 0 = never, 1 = auto, 2 = whenever the streaming form is eligible
+// tune().skinny_ring (default 0): streaming form, weight tiles in flight per wave: 0 = default (2 fp8 / 1 bf16: measured best end to end,
                                     // B = 8 fp8 step 3.455 vs 3.54 ms), 1 = one more (3 / 2)
-static int g_sk_unr = 0;            // tile kernel, steps per register set: 0 = auto (8 for long K slices without SwiGLU / in-kernel norm), 4, 8
-void skinny_tune_reset() { g_sk_tiles = 0; g_sk_nt = 1; g_sk_stream = 1; g_sk_unr = 0; g_sk_ring = 0; }
-int skinny_tune_set(const char* key, int value) {
-    if (!strcmp(key, "skinny_tiles") && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) { g_sk_tiles = value; return 0; }
-    if (!strcmp(key, "skinny_nt")) { g_sk_nt = value != 0; return 0; }
-    if (!strcmp(key, "skinny_stream") && value >= 0 && value <= 2) { g_sk_stream = value; return 0; }
-    if (!strcmp(key, "skinny_ring") && (value == 0 || value == 1)) { g_sk_ring = value; return 0; }
-    if (!strcmp(key, "skinny_unr") && (value == 0 || value == 4 || value == 8)) { g_sk_unr = value; return 0; }
-    return -1;
-}
+// tune().skinny_unr (default 0): tile kernel, steps per register set: 0 = auto (8 for long K slices without SwiGLU / in-kernel norm), 4, 8
 
 // Timeline marks of the probe build (tools/skinny_probe.hip instantiates TRACE = true; the library only TRACE = false):
 // slot s of workgroup blockIdx.x <- the 100 MHz wall clock, written by one lane.
@@ -564,7 +555,7 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
                   "skinny_gemm: the norm hand-off needs a plain bf16 output, next_g and ssq_out");
     TEO_CHECK_ARG(!(fuse.ssq_in && norm_w), "skinny_gemm: ssq_in and norm_w are exclusive");
     TEO_CHECK_ARG(!fuse.ssq_in || fuse.nparts >= 1, "skinny_gemm: nparts %d", fuse.nparts);
-    int rt = g_sk_tiles;
+    int rt = tune().skinny_tiles;
     if (rt == 0 || fuse.xg_out) rt = 1;   // measured: one row tile per workgroup (most waves in flight) wins at every N
     const int sw8 = (flags & TEO_GEMM_SWIGLU8) ? 1 : 0;   // gate/up interleaved in blocks of 8 rows: a pair fits one tile
     if (swiglu && !sw8 && rt < 2) rt = 2; // 16-row interleave: the gate tile and its up tile meet in the epilogue
@@ -573,18 +564,18 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     {
         const int nsteps = K / (w_fp8 ? 64 : 32), ntiles = N / 16;
         const auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-        bool ok = g_sk_stream != 0 && !norm_w && !(flags & TEO_GEMM_SWIGLU16) && (g_sk_tiles == 0 || g_sk_tiles == 1) && N % 16 == 0 &&
+        bool ok = tune().skinny_stream != 0 && !norm_w && !(flags & TEO_GEMM_SWIGLU16) && (tune().skinny_tiles == 0 || tune().skinny_tiles == 1) && N % 16 == 0 &&
                   nsteps <= (w_fp8 ? 64 : 128) && al(x, 16);
         // auto: where it measures faster than one tile per workgroup -- at least two tiles per workgroup, and fp8 weights or more
         // than 8 rows (bf16 at <= 8 rows: a tie, the duplicate activation rows of the tile kernel coalesce)
-        if (ok && g_sk_stream == 1) ok = ntiles >= 512 && (w_fp8 || MB > 8);
+        if (ok && tune().skinny_stream == 1) ok = ntiles >= 512 && (w_fp8 || MB > 8);
         if (ok) {
             const int cus = device_cu_count();
             const int grid = std::max(1, std::min(ntiles, cus > 0 ? cus : 256));
 #define TEO_SS(WW, UN, SP, NSV, SW)                                                                         \
             TEO_KLAUNCH((skinny_stream_kernel<WW, UN, SP, NSV, SW>), grid, SK_THREADS, 0, st, (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
                         out, MB, N, K, ldx, ldo, tiled, of, fuse)
-            if (g_sk_ring == 0) {
+            if (tune().skinny_ring == 0) {
                 if (w_fp8)         { if (sw8) TEO_SS(fp8_t, 8, 1, 2, true); else TEO_SS(fp8_t, 8, 1, 2, false); }
                 else if (fuse.f16) { if (sw8) TEO_SS(f16_t, 8, 2, 2, true); else TEO_SS(f16_t, 8, 2, 2, false); }
                 else               { if (sw8) TEO_SS(bf16_t, 8, 2, 2, true); else TEO_SS(bf16_t, 8, 2, 2, false); }
@@ -606,7 +597,7 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     // (3.2 TB/s, tools/skinny_probe.py); fp8 takes 6 steps (its activation fragments are twice the weights: 8 steps spill); 150-200
     // VGPRs: one workgroup per CU, which is all N = 4096 has anyway
     const int steps_per_wave = K / (w_fp8 ? 64 : 32) / (SK_WAVES / rt);
-    const bool unr8 = !swiglu && !norm_w && g_sk_nt && (g_sk_unr == 8 || (g_sk_unr == 0 && steps_per_wave >= 16 && blocks <= 2 * std::max(device_cu_count(), 1)));
+    const bool unr8 = !swiglu && !norm_w && (tune().skinny_nt != 0) && (tune().skinny_unr == 8 || (tune().skinny_unr == 0 && steps_per_wave >= 16 && blocks <= 2 * std::max(device_cu_count(), 1)));
     if (unr8) {
         if (w_fp8) TEO_KLAUNCH((skinny_gemm_kernel<fp8_t, 6, true, false, false>), blocks, SK_THREADS, 0, st, (const fp8_t*)W, (const bf16_t*)x, MB, N, K, ldx, tiled, rt,
                                wscale, (const bf16_t*)res, (const bf16_t*)nullptr, eps, out, ldo, ldr, of, fuse, sw8);
@@ -624,9 +615,9 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
         of, fuse, sw8)
 #define TEO_SK_N(WW, NTV, SW) if (norm_w) { TEO_SK(WW, NTV, SW, true); } else { TEO_SK(WW, NTV, SW, false); }
 #define TEO_SK_F(WW, NTV) if (swiglu) { TEO_SK_N(WW, NTV, true) } else { TEO_SK_N(WW, NTV, false) }
-    if (w_fp8)         { if (g_sk_nt) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }
+    if (w_fp8)         { if ((tune().skinny_nt != 0)) { TEO_SK_F(fp8_t, true) } else { TEO_SK_F(fp8_t, false) } }
     else if (fuse.f16) { TEO_SK_F(f16_t, true) }              // (non-temporal weight loads only: one instantiation set for the second format)
-    else               { if (g_sk_nt) { TEO_SK_F(bf16_t, true) } else { TEO_SK_F(bf16_t, false) } }
+    else               { if ((tune().skinny_nt != 0)) { TEO_SK_F(bf16_t, true) } else { TEO_SK_F(bf16_t, false) } }
 #undef TEO_SK_F
 #undef TEO_SK_N
 #undef TEO_SK

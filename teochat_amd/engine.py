@@ -112,7 +112,10 @@ class TeoEngine:
         self._phase_depth = 0
         self._pending_status = {}                 # workspace key -> deferred hand-off check (see _check_handoffs)
         self._option_hooks = []                   # callables(desc): keep copies of the LLaMA descriptor in step with set_options
+        self._tune_hooks = []                     # callables(): a knob changed -- captured graphs bake kernel choices in and are dropped
         self._graph = None
+        # performance knobs of THIS engine: a teo_tune block every descriptor points at (include/teo_hip.h); nothing process-wide
+        self.tune = L.Tune()
         self._load_vit(state_dict)
         self._load_projector(state_dict)
         self._load_llama(state_dict)
@@ -179,6 +182,7 @@ class TeoEngine:
             raise ValueError(f"Unexpected select feature: {sf}")        # languagebind/__init__.py:128
         d.keep_cls = 1 if sf == "cls_patch" else 0
         self.vit_tokens = v.num_patches + d.keep_cls                    # rows per frame the tower returns
+        d.tune = self.tune.ptr
         self.vit_desc = d
 
     def _load_projector(self, sd):
@@ -205,6 +209,7 @@ class TeoEngine:
         for j, (w, b) in enumerate(zip(ws, bs)):
             d.w[j], d.b[j] = w.data_ptr(), b.data_ptr()
         self.proj_w = (ws, bs)
+        d.tune = self.tune.ptr
         self.proj_desc = d
 
     def _load_llama(self, sd):
@@ -271,6 +276,7 @@ class TeoEngine:
             d.gateup_w8, d.gateup_s = self._arr(w8["gateup"]), self._arr(s8["gateup"])
             d.down_w8, d.down_s = self._arr(w8["down"]), self._arr(s8["down"])
             d.lm_head8, d.lm_head_s = self.lm_head8.data_ptr(), self.lm_head_s.data_ptr()
+        d.tune = self.tune.ptr
         self.llama_desc = d
 
     def _alloc_decode_state(self, max_new=4096):
@@ -441,25 +447,37 @@ class TeoEngine:
     def prefill_batch(self, embeds_list):
         """Training-shape forward of B independent sequences in ONE pass (teo_llama_prefill_batch, last_only = 0): embeds_list[b]
         is [S_b, D]; the rows are concatenated for the norms / GEMMs, RoPE + causal attention run per sequence on scratch KV slots
-        owned by the engine (allocated on first use, sized [layers, B, Hkv, max_seq, hd] x 3).  Returns fp32 logits
+        owned by the engine (one [B, Hkv, S64, hd] buffer x 3 shared by all layers, grown on demand).  Returns fp32 logits
         [sum(S_b), V], rows in the order of the list.  The single-conversation cache (self.cache_len) is untouched."""
         B = len(embeds_list)
         lens = [int(e.shape[0]) for e in embeds_list]
         if max(lens) > self.max_seq:
             raise ValueError(f"sequence length {max(lens)} exceeds the engine's max_seq {self.max_seq}")
         c = self.cfg
-        Lr, Hk, hd, S = c.num_hidden_layers, c.num_key_value_heads, c.head_dim, self.max_seq
+        Lr, Hk, hd = c.num_hidden_layers, c.num_key_value_heads, c.head_dim
+        # Scratch K / V / V^T for the causal attention of this pass: the forward never reads a layer's keys after that layer, so EVERY
+        # layer's cache pointer aliases ONE [B, Hkv, S64, hd] buffer (S64 = the longest sequence rounded up to the 64-key tile of the
+        # flash kernel), sized by what is asked for, not by the engine's max_seq: 7B at B = 16, S = 4096 is 3 x 0.5 GB instead of 3 x 17 GB
+        S64 = (max(lens) + 63) // 64 * 64
         slot = getattr(self, "_fwd_slots", None)
-        if slot is None or slot["B"] < B:
-            self._fwd_slots = None
-            kv = [torch.zeros(Lr, B, Hk, S, hd, dtype=self.dtype, device=self.device) for _ in range(2)]
-            vt = torch.zeros(Lr, B, Hk, hd, S, dtype=self.dtype, device=self.device)
+        if slot is None or slot["B"] < B or slot["S"] < S64:
+            self._fwd_slots = slot = None
+            kv = [torch.zeros(B, Hk, S64, hd, dtype=self.dtype, device=self.device) for _ in range(2)]
+            vt = torch.zeros(B, Hk, hd, S64, dtype=self.dtype, device=self.device)
             d = L.LlamaDesc.from_buffer_copy(self.llama_desc)
-            d.k_cache = self._arr([kv[0][i, 0] for i in range(Lr)])
-            d.v_cache = self._arr([kv[1][i, 0] for i in range(Lr)])
-            d.vt_cache = self._arr([vt[i, 0] for i in range(Lr)])
-            slot = self._fwd_slots = {"B": B, "k": kv[0], "v": kv[1], "vt": vt, "desc": d}
-            self._option_hooks.append(lambda src, dd=d: (setattr(dd, "prefill_fp8", src.prefill_fp8), setattr(dd, "rope_in_attn", src.rope_in_attn)))
+            d.max_seq = S64
+            d.k_cache = self._arr([kv[0][0]] * Lr)
+            d.v_cache = self._arr([kv[1][0]] * Lr)
+            d.vt_cache = self._arr([vt[0]] * Lr)
+            slot = self._fwd_slots = {"B": B, "S": S64, "k": kv[0], "v": kv[1], "vt": vt, "desc": d}
+
+            def _sync(src, eng=self):                 # ONE hook for whatever descriptor copy is current (a regrow replaces the copy, not the hook)
+                cur = getattr(eng, "_fwd_slots", None)
+                if cur is not None:
+                    cur["desc"].prefill_fp8, cur["desc"].rope_in_attn = src.prefill_fp8, src.rope_in_attn
+            if not getattr(self, "_fwd_hooked", False):
+                self._option_hooks.append(_sync)
+                self._fwd_hooked = True
         d = slot["desc"]
         total = sum(lens)
         with self.phase() as st:
@@ -468,7 +486,7 @@ class TeoEngine:
             self._flush_handoff_checks("prefill")
             ws = self._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d), total))
             arr = (C.c_int * B)(*lens)
-            L.check(self.lib.teo_llama_prefill_batch(C.byref(d), _p(rows), arr, B, slot["k"].stride(1), 0, _p(logits), _p(ws), ws.numel(), st),
+            L.check(self.lib.teo_llama_prefill_batch(C.byref(d), _p(rows), arr, B, slot["k"].stride(0), 0, _p(logits), _p(ws), ws.numel(), st),
                     "teo_llama_prefill_batch")
             sid = C.c_void_p(self.stream.cuda_stream)
             self._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d), total, _p(ws), ws.numel(), C.byref(f), sid),
@@ -523,6 +541,20 @@ class TeoEngine:
             self._drop_graph()                    # the placement is baked into the captured decode step
         for hook in getattr(self, "_option_hooks", []):
             hook(d)
+
+    def tune_set(self, key, value):
+        """A performance knob of THIS engine (teo_tune_set on the engine's own block; keys in include/teo_hip.h).  Captured decode
+        graphs keep the kernel choices of their capture, so they are dropped."""
+        L.check(self.tune.set(key, value), f"teo_tune_set({key!r}, {value})")
+        self._drop_graph()
+        for hook in self._tune_hooks:
+            hook()
+
+    def tune_reset(self):
+        L.check(self.tune.reset(), "teo_tune_reset")
+        self._drop_graph()
+        for hook in self._tune_hooks:
+            hook()
 
     def _drop_graph(self):
         if self._graph is not None:

@@ -36,9 +36,10 @@ def golden_dir():
 
 
 @pytest.fixture(autouse=True)
-def _tune_defaults_after_each_gpu_test(request):
-    """The library's tuning knobs are process-wide: whatever a test forced, the NEXT test runs on the shipped defaults."""
+def _tune_block_of_the_test(request):
+    """Performance knobs are no longer process state (round 5): a test that forces a kernel family does it in the block bound to its own
+    thread (teochat_amd._lib.tune_set).  That block is released when the test ends -- scoping, not a global reset."""
     yield
     if "gpu" in request.keywords and _has_gpu():
         from teochat_amd import _lib
-        _lib.load().teo_tune_reset()
+        _lib.tune_release()

@@ -77,11 +77,11 @@ def test_fp16_gemm_families_and_epilogues(M, N, K):
     outs = []
     for knobs in ({}, {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0}, {"gemm_wide": 2, "gemm_big": 0}, {"gemm_big": 2}, {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2}):
         for k_, v_ in knobs.items():
-            assert lib.teo_tune_set(k_.encode(), v_) == 0
+            assert L.tune_set(k_.encode(), v_) == 0
         C = torch.empty(M, N, dtype=h16, device="cuda")
         L.check(lib.teo_gemm_ws(G.p(dA), G.p(dW), G.p(db), G.p(dr), G.p(C), M, N, K, K, N, 0, 0, L.TEO_F16, L.TEO_F16, G.p(ws), G.stream()), "gemm")
         outs.append((lib.teo_last_kernel().decode(), C.clone()))
-        lib.teo_tune_reset()
+        L.tune_reset()
     assert all(k.startswith("gemm_") and k != "gemm_simple" for k, _ in outs), [k for k, _ in outs]
     for k, C in outs:
         one_ulp(C, R((z + b.double() + r.double()).float()), f"gemm + bias + residual [{k}]", abs_tol=2e-5)
@@ -149,13 +149,13 @@ def test_fp16_decode_attention_split_and_whole(rope):
         dVT = torch.zeros(B, H, d, S, dtype=h16, device="cuda")
         out = torch.zeros(B, H * d, dtype=h16, device="cuda")
         dq = (qkv if rope else qkv[:, :H]).reshape(B, -1).to("cuda", h16).contiguous()
-        assert lib.teo_tune_set(b"attn_whole", whole) == 0 and lib.teo_tune_set(b"attn_chunk", 64) == 0
+        assert L.tune_set(b"attn_whole", whole) == 0 and L.tune_set(b"attn_chunk", 64) == 0
         L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), G.p(dVT) if rope else None, G.p(d_cs) if rope else None,
                                     G.p(d_sn) if rope else None, G.p(out), G.p(part), G.p(pos), S, H, H, d, d ** -0.5, L.TEO_F16, B,
                                     dq.shape[1], H * S * d, H * d, G.stream()), "attn_decode")
         torch.cuda.synchronize()
         outs[whole] = out.clone()
-    lib.teo_tune_reset()
+    L.tune_reset()
     assert torch.equal(outs[2], outs[0])
     for b, n in enumerate(ctx):
         if rope:
@@ -183,10 +183,10 @@ def test_fp16_skinny_gemm_both_forms(MB):
     z = x.double() @ W.double().t()
     outs = {}
     for mode in (0, 2):
-        assert lib.teo_tune_set(b"skinny_stream", mode) == 0
+        assert L.tune_set(b"skinny_stream", mode) == 0
         outs[mode] = (G.gemm_skinny(dx, tile_weights(dW), res=dr, flags=L.GEMM_WTILED, N=N), G.gemm_skinny(dx, dW, flags=L.GEMM_F16, out_dtype=torch.float32))
         assert lib.teo_last_kernel().startswith(b"skinny_stream" if mode else b"skinny_gemm")
-    lib.teo_tune_reset()
+    L.tune_reset()
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
     one_ulp(outs[2][0], R((z + r.double()).float()), "skinny + residual", abs_tol=2e-5)
     torch.testing.assert_close(outs[2][1].cpu(), z.float(), atol=3e-4, rtol=1e-5)

@@ -163,7 +163,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} not exported"
     assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
-    assert L.load().teo_version() == 1
+    m = re.search(r"#define TEO_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "teo_hip.h")).read())
+    assert L.load().teo_version() == int(m.group(1)) == L.ABI_VERSION          # header, library and binding agree (and load() checked sizeof)
 
 
 def test_gate_up_interleave_layout():
@@ -220,15 +221,60 @@ def test_eval_cli_has_the_reference_flags_and_defaults():
 
 
 def test_every_tune_key_is_documented_in_the_header():
-    """include/teo_hip.h lists the perf-only knobs of teo_tune_set; every key a source file accepts must be named there and every
-    key named there must exist (round-3 review: 'list every key in include/teo_hip.h')."""
-    import glob
-    keys = set()
-    for f in glob.glob(os.path.join(ROOT, "teochat_amd", "csrc", "*.hip")):
-        keys |= set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', open(f).read()))
+    """include/teo_hip.h lists the perf-only knobs of a teo_tune block; every key the library accepts (teo_tune_keys(), generated from
+    the one table in csrc/tune.h) must be named there and every key named there must exist (round-3 review: 'list every key')."""
+    table = open(os.path.join(ROOT, "teochat_amd", "csrc", "tune.h")).read()
+    keys = set(re.findall(r"^\s*X\((\w+),", table, flags=re.M))
     assert len(keys) > 20
+    from teochat_amd import _lib as L
+    assert set(L.tune_keys()) == keys
     hdr = open(os.path.join(ROOT, "include", "teo_hip.h")).read()
-    block = hdr[hdr.index("Performance tuning knobs"):hdr.index("int teo_tune_set")]
+    block = hdr[hdr.index("Performance tuning knobs"):hdr.index("typedef struct teo_tune teo_tune;")]
     named = set(re.findall(r'"([a-z0-9_]+)"', block))
     assert keys - named == set(), f"accepted by the library but not documented: {sorted(keys - named)}"
     assert named - keys == set(), f"documented but not accepted by any source: {sorted(named - keys)}"
+
+
+def test_no_process_wide_knob_is_left_in_the_library():
+    """'no globals except an opaque teo_ctx*'.  No .hip file keeps a file-scope mutable int / bool (the knobs live in
+    teo_tune blocks; what remains static is per-device caches and thread-local error / profiling state)."""
+    import glob
+    bad = []
+    for f in glob.glob(os.path.join(ROOT, "teochat_amd", "csrc", "*.hip")):
+        for n, line in enumerate(open(f).read().split("\n"), 1):
+            if re.match(r"^static (int|bool|float|unsigned) g_\w+", line) or re.match(r"^(thread_local )?(int|bool) g_\w+ =", line):
+                bad.append(f"{os.path.basename(f)}:{n}: {line.strip()}")
+    assert bad == [], bad
+
+
+def test_tune_blocks_are_independent_and_validated():
+    """teo_tune blocks (no GPU needed: pure host state): defaults, per-block values, validation of keys and values, reset, and a
+    second thread's bound block does not leak into this thread's."""
+    import ctypes as C
+    import threading
+    from teochat_amd import _lib as L
+    lib = L.load()
+    a, b = L.Tune(), L.Tune()
+    try:
+        assert a.get("gemm_big") == 1 and a.get("gemm_big_cohort") == -1 and a.get("flash_pipe") == -1
+        assert a.set("gemm_big", 2) == 0 and a.get("gemm_big") == 2 and b.get("gemm_big") == 1        # b untouched
+        assert a.set("gemm_big", 7) != 0 and b"not a value" in lib.teo_last_error() and a.get("gemm_big") == 2
+        assert a.set("no_such_key", 1) != 0 and b"unknown key" in lib.teo_last_error()
+        assert a.set("gemm_sk_dbg", 1) != 0                   # the wrong-results diagnostic left the product library in round 5
+        v = C.c_int(-5)
+        assert lib.teo_tune_get(None, b"gemm_big", C.byref(v)) == 0 and v.value == 1                      # NULL block = shipped defaults
+        assert a.reset() == 0 and a.get("gemm_big") == 1
+        seen = {}
+
+        def other():
+            t = L.Tune()
+            t.set("attn_chunk", 128)
+            t.bind()
+            seen["other"] = t.get("attn_chunk")
+            lib.teo_tune_bind(None)
+            t.close()
+        th = threading.Thread(target=other)
+        th.start(); th.join()
+        assert seen["other"] == 128 and a.get("attn_chunk") == 0
+    finally:
+        a.close(); b.close()

@@ -223,10 +223,10 @@ def test_attention_flash_pipeline_and_workgroup_order_do_not_change_a_bit(B, H, 
     vt[..., Sk:] = float("nan")
     outs = {}
     for pipe, order in ((0, 0), (1, 1), (1, 0), (0, 1), (-1, 1)):
-        assert lib.teo_tune_set(b"flash_pipe", pipe) == 0 and lib.teo_tune_set(b"flash_order", order) == 0
+        assert L.tune_set(b"flash_pipe", pipe) == 0 and L.tune_set(b"flash_order", order) == 0
         outs[(pipe, order)] = G.attention(qd, kd, vd, causal, d ** -0.5, vt=vt)
         assert lib.teo_last_kernel() == b"attn_flash32"
-    lib.teo_tune_reset()
+    L.tune_reset()
     base = outs[(0, 0)]
     assert torch.isfinite(base.float()).all()
     for key, o in outs.items():
@@ -550,7 +550,7 @@ def test_gemv_splitk_rows_and_chunks_per_step_do_not_change_a_bit(N, K, fp8):
     try:
         for r in (0, 2, 4):
             for u in (0, 1, 2, 3, 4, 6):
-                assert lib.teo_tune_set(b"gemv_splitk_r", r) == 0 and lib.teo_tune_set(b"gemv_splitk_u", u) == 0
+                assert L.tune_set(b"gemv_splitk_r", r) == 0 and L.tune_set(b"gemv_splitk_u", u) == 0
                 y = torch.empty(N, dtype=torch.float32, device="cuda")
                 if fp8:
                     L.check(lib.teo_gemv_w8(G.p(x), G.p(q_d), G.p(s_d), None, G.p(res), G.p(y), N, K, 1e-5, 0, L.TEO_F32, G.stream()), "gemv_w8")
@@ -558,8 +558,8 @@ def test_gemv_splitk_rows_and_chunks_per_step_do_not_change_a_bit(N, K, fp8):
                     y = G.gemv(x, dW, res=res, out_dtype=torch.float32)
                 outs[(r, u)] = y.cpu()
     finally:
-        lib.teo_tune_set(b"gemv_splitk_r", 0)
-        lib.teo_tune_set(b"gemv_splitk_u", 0)
+        L.tune_set(b"gemv_splitk_r", 0)
+        L.tune_set(b"gemv_splitk_u", 0)
     base = outs[(2, 2)]
     for k_, v in outs.items():
         assert torch.equal(v, base), k_
@@ -600,14 +600,14 @@ def test_gemm_skinny_swiglu_and_tilings(MB, tiles):
     gate, up = G.bf16_round(rnd(Fd, K, seed=2, scale=0.02)), G.bf16_round(rnd(Fd, K, seed=3, scale=0.02))
     gu = G.dev(interleave_gate_up(gate, up), bf)
     dx = G.dev(x, bf)
-    assert G.lib().teo_tune_set(b"skinny_tiles", tiles) == 0
+    assert L.tune_set(b"skinny_tiles", tiles) == 0
     try:
         from teochat_amd.engine import tile_weights
         y = G.gemm_skinny(dx, gu, flags=L.GEMM_SWIGLU16)
         assert torch.equal(G.gemm_skinny(dx, tile_weights(gu), flags=L.GEMM_SWIGLU16 | L.GEMM_WTILED), y)
         yp = G.gemm_skinny(dx, gu, out_dtype=torch.float32).cpu()           # plain product on the interleaved rows
     finally:
-        G.lib().teo_tune_set(b"skinny_tiles", 0)
+        L.tune_set(b"skinny_tiles", 0)
     close_bf16(y, G.bf16_round(F.silu(x @ gate.T) * (x @ up.T)))
     torch.testing.assert_close(yp, x @ interleave_gate_up(gate, up).T, atol=2e-4, rtol=1e-4)
     yg = G.gemm(dx, gu, flags=L.GEMM_SWIGLU16)                              # the prefill GEMM on the same rows
@@ -813,13 +813,13 @@ def test_gemm_skinny_stream_form(MB, fp8, N, K):
     outs = {}
     try:
         for mode in (0, 2):
-            assert G.lib().teo_tune_set(b"skinny_stream", mode) == 0
+            assert L.tune_set(b"skinny_stream", mode) == 0
             outs[mode] = (G.gemm_skinny(dx, dW, scale=scale, out_dtype=torch.float32).cpu(),
                           G.gemm_skinny(dx, dW, scale=scale, res=dr).cpu(),
                           G.gemm_skinny(dx, tile_weights(dW), scale=scale, res=dr, flags=L.GEMM_WTILED, N=N).cpu())
             assert G.lib().teo_last_kernel().startswith(b"skinny_stream" if (mode and N % 16 == 0) else b"skinny_gemm")
     finally:
-        G.lib().teo_tune_set(b"skinny_stream", 1)
+        L.tune_set(b"skinny_stream", 1)
     a, b = outs[0], outs[2]
     assert torch.equal(b[1], b[2])                        # layouts agree within the streaming form
     if same:
@@ -846,11 +846,11 @@ def test_gemm_skinny_stream_swiglu8(MB, fp8):
     outs = {}
     try:
         for mode in (0, 2):
-            assert G.lib().teo_tune_set(b"skinny_stream", mode) == 0
+            assert L.tune_set(b"skinny_stream", mode) == 0
             outs[mode] = (G.gemm_skinny(dx, wt, scale=scale, flags=L.GEMM_SWIGLU8 | L.GEMM_WTILED, out_dtype=torch.float32, N=2 * Fd).cpu(),
                           G.gemm_skinny(dx, wt, scale=scale, flags=L.GEMM_SWIGLU8 | L.GEMM_WTILED, N=2 * Fd).cpu())
     finally:
-        G.lib().teo_tune_set(b"skinny_stream", 1)
+        L.tune_set(b"skinny_stream", 1)
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
     if not fp8:
         torch.testing.assert_close(outs[2][0], F.silu(x @ gate.T) * (x @ up.T), atol=3e-4, rtol=2e-4)
@@ -888,12 +888,12 @@ def test_attn_decode_batched_vs_reference(dtype, H, Hk, d, S, ctx, chunk):
     out = torch.empty(B, H * d, dtype=dtype, device="cuda")
     lib = G.lib()
     part = torch.empty(lib.teo_attn_decode_workspace_bytes(H, d, S, B), dtype=torch.uint8, device="cuda")
-    assert lib.teo_tune_set(b"attn_chunk", chunk) == 0
+    assert L.tune_set(b"attn_chunk", chunk) == 0
     try:
         L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), None, None, None, G.p(out), G.p(part), G.p(pos), S, H, Hk, d,
                                     1.0 / d ** 0.5, G.DT[dtype], B, H * d, Hk * S * d, H * d, G.stream()), "attn_decode")
     finally:
-        lib.teo_tune_set(b"attn_chunk", 0)
+        L.tune_set(b"attn_chunk", 0)
     for b, n in enumerate(ctx):
         ref = _decode_attn_ref(q[b], K[b], V[b], n)
         if dtype == torch.float32:
@@ -943,7 +943,7 @@ def test_attn_decode_whole_context_is_bitwise_the_split_pair(dtype, H, Hk, d, S,
         else:
             dq = qkv[:, :H].reshape(B, -1).to("cuda", dtype).contiguous()
             qs = H * d
-        assert lib.teo_tune_set(b"attn_whole", whole) == 0 and lib.teo_tune_set(b"attn_chunk", cw) == 0
+        assert L.tune_set(b"attn_whole", whole) == 0 and L.tune_set(b"attn_chunk", cw) == 0
         L.check(lib.teo_attn_decode(G.p(dq), G.p(dK), G.p(dV), G.p(dVT) if rope else None, G.p(d_cs) if rope else None,
                                     G.p(d_sn) if rope else None, G.p(out), G.p(part), G.p(pos), S, H, Hk, d, 1.0 / d ** 0.5,
                                     G.DT[dtype], B, qs, Hk * S * d, H * d, G.stream()), "attn_decode")
@@ -1085,7 +1085,7 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra, wide):
     lib = G.lib()
     ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
     L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
-    assert lib.teo_tune_set(b"gemm_wide", 0) == 0
+    assert L.tune_set(b"gemm_wide", 0) == 0
     want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)      # the 128 x 128 kernel, one workgroup per tile
     side = torch.cuda.Stream()
     big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")
@@ -1093,9 +1093,9 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra, wide):
     bad = 0
     # wide = 0: stream-K grid of the 128 x 128 kernel; wide = 1: stream-K grid of the wide-tile LDS-DMA kernel (non-SwiGLU shapes
     # with more than 256 wide tiles; the others fall through to the 128 x 128 form).  Forced: the heuristic only picks ~1 round.
-    assert lib.teo_tune_set(b"gemm_wide", wide) == 0
-    assert lib.teo_tune_set(b"gemm_sk", 2) == 0
-    assert lib.teo_tune_set(b"gemm_big", 0) == 0            # the 256 x 256 hybrid has its own test below
+    assert L.tune_set(b"gemm_wide", wide) == 0
+    assert L.tune_set(b"gemm_sk", 2) == 0
+    assert L.tune_set(b"gemm_big", 0) == 0            # the 256 x 256 hybrid has its own test below
     try:
         for it in range(8):
             if it % 2:
@@ -1105,17 +1105,17 @@ def test_gemm_stream_k_is_bitwise_the_plain_kernel(M, N, K, flags, extra, wide):
             torch.cuda.synchronize()
             bad += int(not torch.equal(got, want))
     finally:
-        lib.teo_tune_set(b"gemm_sk", 1)
-        lib.teo_tune_set(b"gemm_wide", 1)
-        lib.teo_tune_set(b"gemm_big", 1)
+        L.tune_set(b"gemm_sk", 1)
+        L.tune_set(b"gemm_wide", 1)
+        L.tune_set(b"gemm_big", 1)
     assert bad == 0, f"{bad}/8 launches differ from the plain kernel"
     # without a workspace teo_gemm_ws is teo_gemm; tuning the stream-K path off gives the same bits too
     assert torch.equal(_gemm_ws(A, W, None, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)
-    assert lib.teo_tune_set(b"gemm_sk", 0) == 0
+    assert L.tune_set(b"gemm_sk", 0) == 0
     try:
         assert torch.equal(_gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od), want)
     finally:
-        lib.teo_tune_set(b"gemm_sk", 1)
+        L.tune_set(b"gemm_sk", 1)
 
 
 # ---------------------------------------------------------------------------------------------- w8a8 prefill GEMM (fp8 MFMA, X1)
@@ -1164,11 +1164,11 @@ def test_gemm_fp8_mfma_is_exact_against_dequantised_operands(M, N, K):
     try:
         outs = []
         for mode in (0, 2):
-            assert lib.teo_tune_set(b"gemm_fp8_wide", mode) == 0
+            assert L.tune_set(b"gemm_fp8_wide", mode) == 0
             outs.append(_gemm_fp8(A8, dsa, W8, dsw, res=res.cuda(), out_dtype=torch.bfloat16))
         assert K < 256 or torch.equal(outs[0], outs[1])
     finally:
-        lib.teo_tune_set(b"gemm_fp8_wide", 1)
+        L.tune_set(b"gemm_fp8_wide", 1)
 
 
 @pytest.mark.parametrize("M,N,K", [(2168, 4096, 4096), (2168, 4096, 11008), (1100, 2304, 512), (333, 768, 1024)])
@@ -1186,16 +1186,16 @@ def test_gemm_fp8_stream_k_is_bit_identical(M, N, K):
     L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
     try:
         for od in (torch.bfloat16, torch.float32):
-            lib.teo_tune_set(b"gemm_fp8_wide", 0)
+            L.tune_set(b"gemm_fp8_wide", 0)
             want = _gemm_fp8(A8, sa, W8, sw, res=res, out_dtype=od)
-            lib.teo_tune_set(b"gemm_fp8_wide", 3)
+            L.tune_set(b"gemm_fp8_wide", 3)
             for _ in range(3):
                 got = torch.full((M, N), float("nan"), dtype=od, device="cuda")
                 L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(W8), G.p(sw), G.p(res), G.p(got), M, N, K, K, N, 0, G.DT[od], G.p(ws),
                                             G.stream()), "gemm_fp8_ws")
                 assert torch.equal(got, want), (od, (got.float() - want.float()).abs().max().item())
     finally:
-        lib.teo_tune_set(b"gemm_fp8_wide", 1)
+        L.tune_set(b"gemm_fp8_wide", 1)
 
 
 def test_gemm_fp8_swiglu_pairs_gate_and_up_rows():
@@ -1261,14 +1261,14 @@ def test_gemm_wide_tile_kernel_is_bitwise_the_plain_kernel(M, N, K, flags, extra
     od = torch.float32 if "f32out" in extra else bf
     lib = G.lib()
     try:
-        assert lib.teo_tune_set(b"gemm_wide", 0) == 0
+        assert L.tune_set(b"gemm_wide", 0) == 0
         want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
-        assert lib.teo_tune_set(b"gemm_wide", 2) == 0
+        assert L.tune_set(b"gemm_wide", 2) == 0
         for _ in range(3):
             got = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
             assert torch.equal(got, want)
     finally:
-        lib.teo_tune_set(b"gemm_wide", 1)
+        L.tune_set(b"gemm_wide", 1)
 
 
 @pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 12288, 4096, 0, ""), (4208, 2048, 512, L.GEMM_SWIGLU16, ""), (300, 700, 192, 0, "bias_gelu"),
@@ -1289,15 +1289,15 @@ def test_gemm_256x256_kernel_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
     od = torch.float32 if "f32out" in extra else bf
     lib = G.lib()
     try:
-        assert lib.teo_tune_set(b"gemm_big", 0) == 0 and lib.teo_tune_set(b"gemm_wide", 0) == 0
+        assert L.tune_set(b"gemm_big", 0) == 0 and L.tune_set(b"gemm_wide", 0) == 0
         want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
-        assert lib.teo_tune_set(b"gemm_big", 2) == 0
+        assert L.tune_set(b"gemm_big", 2) == 0
         for _ in range(3):
             got = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
             assert torch.equal(got, want)
     finally:
-        lib.teo_tune_set(b"gemm_big", 1)
-        lib.teo_tune_set(b"gemm_wide", 1)
+        L.tune_set(b"gemm_big", 1)
+        L.tune_set(b"gemm_wide", 1)
 
 
 @pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 12288, 4096, 0, ""), (2168, 22016, 4096, L.GEMM_SWIGLU16, ""), (4208, 12288, 512, 0, "res"),
@@ -1325,22 +1325,31 @@ def test_gemm_256x256_hybrid_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
     big = torch.empty(64 * 2 ** 20, dtype=torch.float32, device="cuda")
     big2 = torch.empty_like(big)
     try:
-        assert lib.teo_tune_set(b"gemm_big", 0) == 0 and lib.teo_tune_set(b"gemm_wide", 0) == 0
+        assert L.tune_set(b"gemm_big", 0) == 0 and L.tune_set(b"gemm_wide", 0) == 0
         want = G.gemm(A, W, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
-        assert lib.teo_tune_set(b"gemm_big", 2) == 0 and lib.teo_tune_set(b"gemm_big_hybrid", 2) == 0
-        bad = 0
-        for it in range(6):
-            if it % 2:
-                with torch.cuda.stream(side):
-                    big2.copy_(big)
-            got = _gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
-            torch.cuda.synchronize()
-            bad += int(not torch.equal(got, want))
-        assert bad == 0, f"{bad}/6 launches differ from the plain kernel"
+        assert L.tune_set(b"gemm_big", 2) == 0 and L.tune_set(b"gemm_big_hybrid", 2) == 0
+        # round 5: the stream-K part as XCD-local cohorts (columns of 8 / 16 / 32 tiles walked in step, hand-off to the same slot of the
+        # next chain link) next to the linear ranges (0) and the shipped choice (-1): the same bits from every arrangement
+        for cohort in (-1, 0, 8, 16, 32):
+            assert L.tune_set(b"gemm_big_cohort", cohort) == 0
+            bad = 0
+            for it in range(4):
+                if it % 2:
+                    with torch.cuda.stream(side):
+                        big2.copy_(big)
+                got = _gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
+                torch.cuda.synchronize()
+                bad += int(not torch.equal(got, want))
+            assert bad == 0, f"cohort {cohort}: {bad}/4 launches differ from the plain kernel"
+            assert lib.teo_last_kernel().decode() in ("gemm_big_hybrid", "gemm_big_hybrid_cohort")
+        st = C.c_int(0)
+        L.check(lib.teo_gemm_workspace_status(G.p(ws), C.byref(st), G.stream()), "ws status")
+        assert st.value == 0
     finally:
-        lib.teo_tune_set(b"gemm_big_hybrid", 1)
-        lib.teo_tune_set(b"gemm_big", 1)
-        lib.teo_tune_set(b"gemm_wide", 1)
+        L.tune_set(b"gemm_big_cohort", -1)
+        L.tune_set(b"gemm_big_hybrid", 1)
+        L.tune_set(b"gemm_big", 1)
+        L.tune_set(b"gemm_wide", 1)
 
 
 @pytest.mark.parametrize("M,N,K,swiglu", [(2168, 12288, 4096, False), (4208, 2048, 512, True), (300, 704, 256, False), (257, 512, 128, False),
@@ -1358,15 +1367,15 @@ def test_gemm_fp8_256x256_kernel_is_bitwise_the_plain_fp8_kernel(M, N, K, swiglu
     lib = G.lib()
     try:
         for od in (torch.bfloat16, torch.float32):
-            lib.teo_tune_set(b"gemm_fp8_big", 0); lib.teo_tune_set(b"gemm_fp8_wide", 0)
+            L.tune_set(b"gemm_fp8_big", 0); L.tune_set(b"gemm_fp8_wide", 0)
             want = _gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od)
-            lib.teo_tune_set(b"gemm_fp8_big", 2)
+            L.tune_set(b"gemm_fp8_big", 2)
             for _ in range(2):
                 got = _gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od)
                 assert torch.equal(got, want), (od, (got.float() - want.float()).abs().max().item())
     finally:
-        lib.teo_tune_set(b"gemm_fp8_big", 1)
-        lib.teo_tune_set(b"gemm_fp8_wide", 1)
+        L.tune_set(b"gemm_fp8_big", 1)
+        L.tune_set(b"gemm_fp8_wide", 1)
 
 
 @pytest.mark.parametrize("T,img,P,D", [(2, 224, 14, 1024), (1, 56, 14, 192), (3, 64, 16, 260)])
@@ -1424,11 +1433,11 @@ def test_gemm_dispatch_fuzz_is_bitwise_the_plain_kernel():
         od = torch.float32 if i % 5 == 4 else bf
         try:
             for k_, v_ in ((b"gemm_big", 0), (b"gemm_wide", 0), (b"gemm_sk", 0)):
-                lib.teo_tune_set(k_, v_)
+                L.tune_set(k_, v_)
             want = G.gemm(A, W, res=res, flags=flags, out_dtype=od)
         finally:
             for k_ in (b"gemm_big", b"gemm_wide", b"gemm_sk"):
-                lib.teo_tune_set(k_, 1)
+                L.tune_set(k_, 1)
         got = G.gemm(A, W, res=res, flags=flags, out_dtype=od)
         assert torch.equal(got, want), ("teo_gemm", M, N, K, swiglu)
         got = _gemm_ws(A, W, ws, res=res, flags=flags, out_dtype=od)
@@ -1468,10 +1477,10 @@ def test_gemm_fp8_dispatch_fuzz_is_bitwise_the_plain_fp8_kernel():
         res = None if swiglu or i % 2 else torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
         od = torch.float32 if i % 5 == 4 else torch.bfloat16
         try:
-            lib.teo_tune_set(b"gemm_fp8_big", 0); lib.teo_tune_set(b"gemm_fp8_wide", 0)
+            L.tune_set(b"gemm_fp8_big", 0); L.tune_set(b"gemm_fp8_wide", 0)
             want = _gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od)
         finally:
-            lib.teo_tune_set(b"gemm_fp8_big", 1); lib.teo_tune_set(b"gemm_fp8_wide", 1)
+            L.tune_set(b"gemm_fp8_big", 1); L.tune_set(b"gemm_fp8_wide", 1)
         assert torch.equal(_gemm_fp8(A8, sa, W8, sw, res=res, flags=flags, out_dtype=od), want), ("teo_gemm_fp8", M, N, K, swiglu)
         got = torch.full((M, Nc), float("nan"), dtype=od, device="cuda")
         L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(W8), G.p(sw), G.p(res), G.p(got), M, N, K, K, Nc, flags, G.DT[od], G.p(ws),

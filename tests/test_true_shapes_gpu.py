@@ -116,13 +116,13 @@ def gemm_all_families(gw, A, W, ref, tag, report, families=FAMILIES, **kw):
     for name, knobs in families:
         try:
             for k, v in knobs.items():
-                assert lib.teo_tune_set(k.encode(), v) == 0, k
+                assert L.tune_set(k.encode(), v) == 0, k
             got = gw(A, W, **kw)
             seen.add(lib.teo_last_kernel().decode())
             ulp_check(got, ref, f"{tag} [{name}]", report)
         finally:
             for k, v in DEFAULTS.items():
-                lib.teo_tune_set(k.encode(), v)
+                L.tune_set(k.encode(), v)
     return seen
 
 

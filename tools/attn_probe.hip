@@ -11,6 +11,11 @@ void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(s
 int hip_fail(hipError_t e, const char* what) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return TEO_ERR_HIP; }
 void note_kernel(const char*) {}
 int device_cu_count() { return 256; }
+static teo_tune g_probe_tune;                       // the probe's own knob block (the library keeps these in teo_tune blocks: tune.h)
+const teo_tune& tune() { return g_probe_tune; }
+int lds_attr_once(const void* kernel, int bytes, unsigned long long*, const char*) {
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? TEO_OK : TEO_ERR_HIP;
+}
 bool prof_take(hipEvent_t*, hipEvent_t*) { return false; }
 void prof_class(int) {}
 void prof_bump(int) {}
@@ -28,8 +33,8 @@ extern "C" int attn_probe_launch(int variant, int chunk, int waves, const void* 
     bt.batch = batch; bt.q_stride = q_stride; bt.cache_stride = cache_stride; bt.o_stride = (long long)heads * 128;
     const float scale = 0.08838834764831845f;
     if (variant == 0) {
-        attn_tune_set("attn_whole", 0);
-        attn_tune_set("attn_chunk", chunk);
+        g_probe_tune.attn_whole = 0;
+        g_probe_tune.attn_chunk = chunk;
         return attn_decode(q, kc, vc, vtc, cs, sn, o, part, d_pos, S_max, heads, heads, 128, scale, TEO_BF16, st, bt);
     }
     const int nsw = (S_max + chunk - 1) / chunk;

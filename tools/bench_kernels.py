@@ -56,7 +56,7 @@ def bench_gemv_mall():
     """Infinity-Cache probe: the same weight matrix re-read every launch (resident if it fits 256 MiB) vs a >600 MB rotation."""
     shapes = [("o", 4096, 4096, False, 0), ("qkv", 12288, 4096, True, 0), ("gateup", 22016, 4096, True, L.GEMM_SWIGLU16)]
     for nt in (1, 0):
-        lib.teo_tune_set(b"gemv_nt", nt)
+        L.tune_set(b"gemv_nt", nt)
         for name, N, K, norm, flags in shapes:
             nrot = max(2, int(600e6 // (N * K * 2)))
             Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(nrot)]
@@ -71,7 +71,7 @@ def bench_gemv_mall():
                 us = avg.value * 1e3
                 print(f"mall nt={nt} {name:7s} rot={n:2d} ({N * K * 2 / 1e6:6.1f} MB): {us:7.2f} us {N * K * 2 / us / 1e3:7.1f} GB/s", flush=True)
             del Ws
-    lib.teo_tune_set(b"gemv_nt", 1)
+    L.tune_set(b"gemv_nt", 1)
 
 
 def bench_skinny():
@@ -84,10 +84,10 @@ def bench_skinny():
     if os.environ.get("SK_SHAPES") == "gu":
         shapes = [("gateup", 22016, 4096, L.GEMM_SWIGLU16), ("gu_plain", 22016, 4096, 0)]
     tiled = L.GEMM_WTILED if int(os.environ.get("SK_TILED", "1")) else 0      # tiled and row-major cost the same to set up here
-    lib.teo_tune_set(b"skinny_nt", int(os.environ.get("SK_NT", "1")))
-    lib.teo_tune_set(b"skinny_stream", int(os.environ.get("SK_STREAM", "1")))
-    lib.teo_tune_set(b"skinny_ring", int(os.environ.get("SK_RING", "0")))
-    lib.teo_tune_set(b"skinny_unr", int(os.environ.get("SK_UNR", "0")))
+    L.tune_set(b"skinny_nt", int(os.environ.get("SK_NT", "1")))
+    L.tune_set(b"skinny_stream", int(os.environ.get("SK_STREAM", "1")))
+    L.tune_set(b"skinny_ring", int(os.environ.get("SK_RING", "0")))
+    L.tune_set(b"skinny_unr", int(os.environ.get("SK_UNR", "0")))
     for fp8 in (False, True):
         for name, N, K, flags in shapes:
             wb = 1 if fp8 else 2
@@ -110,14 +110,14 @@ def bench_skinny():
                 for tiles in [int(t) for t in os.environ.get("SK_TILES", "1,2,4,8").split(",")]:
                     if tiles == 1 and (flags & L.GEMM_SWIGLU16):
                         continue
-                    lib.teo_tune_set(b"skinny_tiles", tiles)
+                    L.tune_set(b"skinny_tiles", tiles)
                     avg = C.c_float(0)
                     L.check(SHIM.teo_bench_skinny_chain(x.data_ptr(), pp, pp2, n, nw.data_ptr() if norm else None, y.data_ptr(), MB, N, K, flags | tiled, 10, C.byref(avg),
                                                       G.stream()), "chain")
                     us = avg.value * 1e3
                     line += f"  T{tiles} {us:6.1f}us {N * K * wb / us / 1e3:6.0f}GB/s"
                 print(line, flush=True)
-            lib.teo_tune_set(b"skinny_tiles", 0)
+            L.tune_set(b"skinny_tiles", 0)
             if not fp8:                                   # the prefill GEMM at the same M for comparison
                 x = torch.randn(16, K, device="cuda").to(bf)
                 us = timeit(lambda: [G.gemm(x, w, flags=flags) for w in Ws], iters=5) / len(Ws)
@@ -127,10 +127,10 @@ def bench_skinny():
 
 def bench_gemv_fp8_sweep():
     for v in (10, 11, 12, 13):
-        lib.teo_tune_set(b"gemv_variant", v)
+        L.tune_set(b"gemv_variant", v)
         print("fp8 variant", v, flush=True)
         bench_gemv_fp8()
-    lib.teo_tune_set(b"gemv_variant", -1)
+    L.tune_set(b"gemv_variant", -1)
 
 
 def bench_gemv_splitk_sweep():
@@ -138,13 +138,13 @@ def bench_gemv_splitk_sweep():
     os.environ["GV_SHAPES"] = "splitk"
     for r in (2, 4):
         for u in (1, 2, 3, 4, 6):
-            lib.teo_tune_set(b"gemv_splitk_r", r)
-            lib.teo_tune_set(b"gemv_splitk_u", u)
+            L.tune_set(b"gemv_splitk_r", r)
+            L.tune_set(b"gemv_splitk_u", u)
             print(f"split-K rows {r} chunks {u}", flush=True)
             bench_gemv_fp8()
             bench_gemv()
-    lib.teo_tune_set(b"gemv_splitk_r", 0)
-    lib.teo_tune_set(b"gemv_splitk_u", 0)
+    L.tune_set(b"gemv_splitk_r", 0)
+    L.tune_set(b"gemv_splitk_u", 0)
 
 
 def bench_gemv_fp8():
@@ -179,9 +179,9 @@ def bench_gemv_sweep():
     for maxb in [int(v_) for v_ in os.environ.get("GV_MAXB", "512,768,1024,1376,1536,2048,2752,3072").split(",")]:
         for nt in (1,):
             for v in [int(v_) for v_ in os.environ.get("GV_VARIANTS", "-1").split(",")]:
-                lib.teo_tune_set(b"gemv_variant", v)
-                lib.teo_tune_set(b"gemv_nt", nt)
-                lib.teo_tune_set(b"gemv_max_blocks", maxb)
+                L.tune_set(b"gemv_variant", v)
+                L.tune_set(b"gemv_nt", nt)
+                L.tune_set(b"gemv_max_blocks", maxb)
                 line = f"variant {v:2d} nt={nt} maxb={maxb}:"
                 tot = 0.0
                 for name, N, K, norm, flags in shapes:
@@ -197,7 +197,7 @@ def bench_gemv_sweep():
                     tot += us
                     line += f"  {name} {us:6.1f}us {N * K * 2 / us / 1e3:6.0f}GB/s"
                 print(line + f"  | layer {tot:6.1f}us", flush=True)
-    lib.teo_tune_set(b"gemv_variant", -1)
+    L.tune_set(b"gemv_variant", -1)
 
 
 def bench_gemm():
@@ -209,11 +209,8 @@ def bench_gemm():
               ("down_B8", 17344, 4096, 11008, 0)]
     ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
     L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
-    if os.environ.get("TEO_SK_DBG"):
-        lib.teo_tune_set(b"gemm_sk_dbg", int(os.environ["TEO_SK_DBG"]))
-        shapes = shapes[:2]
     if os.environ.get("TEO_SK_FORCE"):
-        lib.teo_tune_set(b"gemm_sk", 2)
+        L.tune_set(b"gemm_sk", 2)
         shapes = [("sq4096", 4096, 4096, 4096, 0), ("sq8192x4096", 8192, 4096, 4096, 0), ("3072x4096", 3072, 4096, 4096, 0)]
     for name, M, N, K, flags in shapes:
         A = torch.randn(M, K, device="cuda").to(bf)
@@ -245,10 +242,10 @@ def bench_gemm_wide():
         outs = {}
         for _ in range(3):
             for mode in (2, 0):
-                lib.teo_tune_set(b"gemm_wide", mode)
+                L.tune_set(b"gemm_wide", mode)
                 res[mode].append(timeit(lambda: G.gemm(A, W, flags=flags)))
                 outs[mode] = G.gemm(A, W, flags=flags)
-        lib.teo_tune_set(b"gemm_wide", 1)
+        L.tune_set(b"gemm_wide", 1)
         a, b_ = min(res[2]), min(res[0])
         fl = 2.0 * M * N * K
         print(f"gemm {name:9s} M={M} N={N} K={K}: wide {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s | 128x128 {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s"
@@ -267,10 +264,10 @@ def bench_gemm_big():
         outs = {}
         for _ in range(3):
             for mode in (2, 3, 0):
-                lib.teo_tune_set(b"gemm_big", 2 if mode == 2 else (1 if mode == 3 else 0))
+                L.tune_set(b"gemm_big", 2 if mode == 2 else (1 if mode == 3 else 0))
                 res[mode].append(timeit(lambda: G.gemm(A, W, flags=flags)))
                 outs[mode] = G.gemm(A, W, flags=flags)
-        lib.teo_tune_set(b"gemm_big", 2)
+        L.tune_set(b"gemm_big", 2)
         ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
         L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
         Nc = N // 2 if flags else N
@@ -278,13 +275,62 @@ def bench_gemm_big():
         run_ws = lambda: L.check(lib.teo_gemm_ws(G.p(A), G.p(W), None, None, G.p(Cc), M, N, K, K, Nc, 0, flags, L.TEO_BF16, L.TEO_BF16, G.p(ws), G.stream()), "gemm_ws")
         t_h = min(timeit(run_ws) for _ in range(3))
         same_h = bool(torch.equal(Cc, outs[0]))
-        lib.teo_tune_set(b"gemm_big", 1)
+        L.tune_set(b"gemm_big", 1)
         t_auto_ws = min(timeit(run_ws) for _ in range(3))
         a, b_ = min(res[2]), min(res[0])
         fl = 2.0 * M * N * K
         tiles = -(-M // 256) * -(-N // 256)
         print(f"gemm {name:10s} M={M} N={N} K={K}: big {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s ({tiles} tiles = {tiles / 256:.2f} rounds, {a / -(-tiles // 256) / (K // 64) * 1e3:6.0f} ns per K tile) | "
               f"hybrid {t_h:8.1f} us {fl / t_h / 1e6:7.1f} ({'=' if same_h else 'DIFF'}) | auto+ws {t_auto_ws:8.1f} | auto {min(res[3]):8.1f} us | no big {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | bit-identical: {bool(torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]))}", flush=True)
+
+
+def bench_gemm_cohort():
+    """round 5: stream-K ranges of the 256 x 256 hybrid kernel as XCD-local cohorts (gemm_big_cohort = 8 / 16 / 32) vs the linear ranges (0), on cold
+    weights (8 matrices in rotation, as in the layer loop) and interleaved; every form must be bit-identical to the linear one."""
+    shapes = [("qkv", 2168, 12288, 4096, 0, "big"), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16, "big"), ("o", 2168, 4096, 4096, 0, "wide"),
+              ("down", 2168, 4096, 11008, 0, "wide"), ("qkv_T2", 638, 12288, 4096, 0, "big"), ("gateup_T2", 638, 22016, 4096, L.GEMM_SWIGLU16, "big"),
+              ("qkv_T16", 4208, 12288, 4096, 0, "big"), ("gateup_T16", 4208, 22016, 4096, L.GEMM_SWIGLU16, "big"), ("down_T16", 4208, 4096, 11008, 0, "big"),
+              ("o_T16", 4208, 4096, 4096, 0, "big"), ("vit_fc1", 2056, 4096, 1024, 0, "wide")]
+    only = os.environ.get("COHORT_SHAPES")
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    for name, M, N, K, flags, fam in shapes:
+        if only and name not in only.split(","):
+            continue
+        A = torch.randn(M, K, device="cuda").to(bf)
+        Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(8)]
+        Nc = N // 2 if flags else N
+        Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
+        cnt = [0]
+
+        def run():
+            W = Ws[cnt[0] % 8]
+            cnt[0] += 1
+            L.check(lib.teo_gemm_ws(G.p(A), G.p(W), None, None, G.p(Cc), M, N, K, K, Nc, 0, flags, L.TEO_BF16, L.TEO_BF16, G.p(ws), G.stream()), "gemm_ws")
+        variants = [("auto", {}), ("wide_sk", {"gemm_big": 0, "gemm_sk": 2})] + [(f"big{c}", {"gemm_big_cohort": c, "gemm_big": 2, "gemm_big_hybrid": 2}) for c in (0, 8, 16, 32)]
+        res = {v: [] for v, _ in variants}
+        outs, kern = {}, {}
+        for rep in range(3):
+            for v, knobs in variants:
+                L.tune_reset()
+                for k_, val in knobs.items():
+                    assert L.tune_set(k_.encode(), val) == 0, k_
+                res[v].append(timeit(run, iters=16, warm=2))
+                if rep == 0:
+                    cnt[0] = 0
+                    run()
+                    torch.cuda.synchronize()
+                    outs[v] = Cc.clone()
+                    kern[v] = lib.teo_last_kernel().decode()
+        L.tune_reset()
+        fl = 2.0 * M * N * K
+        ref = outs["big0"]
+        line = " | ".join(f"{v} [{kern[v].replace('gemm_', '')}] {min(res[v]):7.1f}{'' if torch.equal(outs[v], ref) else ' DIFF'}" for v, _ in variants)
+        best = min(min(r) for r in res.values())
+        print(f"cohort {name:10s} M={M} N={N} K={K} ({fl / 1e9:6.1f} GF; best {fl / best / 1e6:6.0f} TF/s): {line}", flush=True)
+        st = C.c_int(0)
+        L.check(lib.teo_gemm_workspace_status(G.p(ws), C.byref(st), G.stream()), "ws status")
+        assert st.value == 0, "stream-K hand-off timed out"
 
 
 def bench_gemm_cold():
@@ -342,7 +388,7 @@ def bench_gemm_wide_sched():
     """instruction-order variants of the wide kernel's K loop (gemm_wide_sched), forced wide, plain (non-stream-K) launch."""
     shapes = [("qkv", 2168, 12288, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16), ("sq8192", 8192, 8192, 8192, 0),
               ("qkv_T16", 4208, 12288, 4096, 0)]
-    lib.teo_tune_set(b"gemm_wide", 2)
+    L.tune_set(b"gemm_wide", 2)
     for name, M, N, K, flags in shapes:
         A = torch.randn(M, K, device="cuda").to(bf)
         W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
@@ -350,16 +396,16 @@ def bench_gemm_wide_sched():
         ref = None
         line = f"gemm {name:9s}:"
         for sched, grp in ((0, 1), (1, 1), (1, 4)):
-            lib.teo_tune_set(b"gemm_wide_sched", sched)
-            lib.teo_tune_set(b"gemm_wide_group", grp)
+            L.tune_set(b"gemm_wide_sched", sched)
+            L.tune_set(b"gemm_wide_group", grp)
             t = min(timeit(lambda: G.gemm(A, W, flags=flags)) for _ in range(3))
             out = G.gemm(A, W, flags=flags)
             ref = out if ref is None else ref
             line += f" s{sched}g{grp} {t:7.1f} us {fl / t / 1e6:7.1f} TF ({'=' if torch.equal(out, ref) else 'DIFF'}) |"
         print(line, flush=True)
-    lib.teo_tune_set(b"gemm_wide_sched", 0)
-    lib.teo_tune_set(b"gemm_wide_group", 1)
-    lib.teo_tune_set(b"gemm_wide", 1)
+    L.tune_set(b"gemm_wide_sched", 0)
+    L.tune_set(b"gemm_wide_group", 1)
+    L.tune_set(b"gemm_wide", 1)
 
 
 def bench_gemm_fp8():
@@ -378,17 +424,17 @@ def bench_gemm_fp8():
         t16 = timeit(lambda: G.gemm(A, W, flags=flags))
         run8 = lambda: L.check(lib.teo_gemm_fp8(G.p(A8), G.p(sa), G.p(W8), G.p(sw), None, G.p(Cc), M, N, K, K, Nc, flags, L.TEO_BF16,
                                                  G.stream()), "gemm_fp8")
-        lib.teo_tune_set(b"gemm_fp8_wide", 0)
+        L.tune_set(b"gemm_fp8_wide", 0)
         t8n = timeit(run8)
         c0 = Cc.clone()
-        lib.teo_tune_set(b"gemm_fp8_wide", 2)
+        L.tune_set(b"gemm_fp8_wide", 2)
         t8 = timeit(run8)
         same = bool(torch.equal(c0, Cc))
-        lib.teo_tune_set(b"gemm_fp8_wide", 1)
-        lib.teo_tune_set(b"gemm_fp8_big", 2)
+        L.tune_set(b"gemm_fp8_wide", 1)
+        L.tune_set(b"gemm_fp8_big", 2)
         t8b = timeit(run8)
         same = same and bool(torch.equal(c0, Cc))
-        lib.teo_tune_set(b"gemm_fp8_big", 1)
+        L.tune_set(b"gemm_fp8_big", 1)
         ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
         L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
         tsk = timeit(lambda: L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(W8), G.p(sw), None, G.p(Cc), M, N, K, K, Nc, flags, L.TEO_BF16,
@@ -411,12 +457,12 @@ def bench_attn_prefill():
         res = {}
         for rnd_ in range(3):
             for flash in (1, 0, 2):
-                lib.teo_tune_set(b"flash_order", 1)
-                lib.teo_tune_set(b"flash_pipe", 0 if flash == 2 else -1)
-                lib.teo_tune_set(b"flash_order", 0 if flash == 0 else 1)
+                L.tune_set(b"flash_order", 1)
+                L.tune_set(b"flash_pipe", 0 if flash == 2 else -1)
+                L.tune_set(b"flash_order", 0 if flash == 0 else 1)
                 us = timeit(lambda: G.attention(q, k, v, causal, d ** -0.5, vt=vt))
                 res.setdefault(flash, []).append(us)
-        lib.teo_tune_reset()
+        L.tune_reset()
         a, b_ = min(res[1]), min(res[0])
         print(f"attn prefill B={B} H={H} S={S} d={d} causal={causal}: mirrored {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s | "
               f"heavy-first {b_:8.1f} us {fl / b_ / 1e6:7.1f} TFLOP/s | one tile at a time {min(res[2]):8.1f} us", flush=True)
@@ -436,10 +482,10 @@ def bench_norm():
 
 def bench_gemm_depth():
     for depth in (1, 2):
-        lib.teo_tune_set(b"gemm_depth", depth)
+        L.tune_set(b"gemm_depth", depth)
         print("gemm_depth", depth, flush=True)
         bench_gemm()
-    lib.teo_tune_set(b"gemm_depth", 0)
+    L.tune_set(b"gemm_depth", 0)
 
 
 def bench_gemm_stride():
@@ -455,5 +501,5 @@ def bench_gemm_stride():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_splitk_sweep": bench_gemv_splitk_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_prefetch": bench_gemm_prefetch, "gemm_cold": bench_gemm_cold, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_splitk_sweep": bench_gemv_splitk_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_prefetch": bench_gemm_prefetch, "gemm_cold": bench_gemm_cold, "gemm_cohort": bench_gemm_cohort, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
 

@@ -52,9 +52,9 @@ for M in Ms:
         best = None
         for fam, knobs in FAM:
             for k, v in DEF.items():
-                lib.teo_tune_set(k.encode(), v)
+                L.tune_set(k.encode(), v)
             for k, v in knobs.items():
-                lib.teo_tune_set(k.encode(), v)
+                L.tune_set(k.encode(), v)
             try:
                 run()
                 kern = lib.teo_last_kernel().decode()
@@ -67,5 +67,5 @@ for M in Ms:
             if fam == "auto":
                 auto_t = t
         for k, v in DEF.items():
-            lib.teo_tune_set(k.encode(), v)
+            L.tune_set(k.encode(), v)
         print(line + f"  => best {best[0]} {best[1]:.1f} (auto {auto_t:.1f}, {100 * (auto_t / best[1] - 1):+.1f} %)", flush=True)

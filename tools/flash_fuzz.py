@@ -40,10 +40,10 @@ def main():
         outs = []
         for rep in range(3):
             for pipe, order in ((1, 1), (0, 0), (-1, 1), (1, 0)):
-                lib.teo_tune_set(b"flash_pipe", pipe)
-                lib.teo_tune_set(b"flash_order", order)
+                L.tune_set(b"flash_pipe", pipe)
+                L.tune_set(b"flash_order", order)
                 outs.append(G.attention(q, k, v, causal, d ** -0.5, vt=vt))
-        lib.teo_tune_reset()
+        L.tune_reset()
         torch.cuda.synchronize()
         ref = G.attention(q, k, v, causal, d ** -0.5, force_simple=True)
         same = all(torch.equal(o, outs[0]) for o in outs)

@@ -1,0 +1,440 @@
+// GEMM lab (NOT product code): the 256 x 256 x 64 LDS-DMA kernel of teochat_amd/csrc/gemm_big.hip as a stand-alone executable with
+// K-loop variants selected by a template parameter, A/B-timed interleaved on random data with the weight matrix in rotation (cold,
+// as in the layer loop), every variant compared bit for bit with variant 0, and an in-kernel timeline (s_memtime marks per wave).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_lab.hip -o tools/gemm_lab      Run: tools/gemm_lab [trace]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v, a), __builtin_bit_cast(bf16x8v, b), c, 0, 0, 0);
+}
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int A_BYTES = BM * BK * 2, STAGE = A_BYTES + BN * BK * 2;
+constexpr int PIECES = 8;
+constexpr int TR_MARKS = 10, TR_TILES = 8, TR_T0 = 24;      // marks per K tile, K tiles recorded (from tile TR_T0), per wave of workgroup 0
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+// V: 0 baseline (gemm_big.hip: skewed DMA, carried half)   1 every wave issues its DMA right after the barrier
+//    2 DMA pieces spread over the tile (2 after the barrier, 2 after the first reads, 2 after the first MFMA block, 2 after the second reads)
+//    3 baseline + s_setprio 1 for waves 4-7 (static)        4 all-early + s_setprio 1 around the MFMA blocks
+//    5 all waves late                                        6 no carry: reads h0, MFMA h0, reads h1, MFMA h1 (all early DMA)
+//    7 persistent over tiles with the next tile's first stage requested before the epilogue (plain order otherwise = V1)
+template <int V, bool TRACE>
+__global__ __launch_bounds__(512) void lab_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
+                                                  int K, int tiles_m, int tiles_n, unsigned long long* trace) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / BK;
+    const int ntiles = tiles_m * tiles_n;
+    // V >= 16: bit fields -- skew = V & 3 (0: waves 4-7 early / 0-3 late, 1: all early, 2: waves 0-3 early / 4-7 late),
+    // prio = (V >> 2) & 7 (0 none, 1: s_setprio 1 on waves 4-7, 2: on waves 0-3, 3: prio 2 on waves 4-7, 4: prio 3 on waves 4-7, 5: prio 2 on 4-7 and 1 on 0-3... see below),
+    // lpos = (V >> 5) & 3 (late DMA: 0 after the first MFMA block, 1 in its middle, 2 after the second reads), flag 128
+    constexpr bool BITS = V >= 128;
+    constexpr int SKEW = BITS ? (V & 3) : 0, PRIO = BITS ? ((V >> 2) & 7) : 0, LPOS = BITS ? ((V >> 5) & 3) : 0;
+    if (V == 3 && wid >= 4) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 1 && wid >= 4) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 2 && wid < 4) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 3 && wid >= 4) __builtin_amdgcn_s_setprio(2);
+    if (PRIO == 4 && wid >= 4) __builtin_amdgcn_s_setprio(3);
+#define MARK(KT, I)                                                                                                              \
+    if constexpr (TRACE) {                                                                                                       \
+        if (blockIdx.x == 0 && lane == 0 && (KT) >= TR_T0 && (KT) < TR_T0 + TR_TILES)                                             \
+            trace[(wid * TR_TILES + ((KT) - TR_T0)) * TR_MARKS + (I)] = __builtin_readcyclecounter();                             \
+    }
+    for (int tile = xcd_remap(blockIdx.x, gridDim.x); tile < ntiles; tile += (V == 7 ? (int)gridDim.x : ntiles)) {
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool isA = wid < 4;
+    const bf16_t* base = isA ? A : W;
+    const int row0 = isA ? m0 + wid * 64 : n0 + (wid - 4) * 64;
+    const int rmax = (isA ? M : N) - 1;
+    unsigned off[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        off[j] = (unsigned)min(row0 + j * 8 + rl, rmax) * (unsigned)K + c * 8;
+    }
+    const int lds_piece0 = (isA ? wid * 8 : 32 + (wid - 4) * 8) * 1024;
+#define STAGE_J(KT, ST, J0, J1)                                                                                                  \
+    _Pragma("unroll") for (int j = J0; j < J1; ++j)                                                                             \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[j] + (unsigned)(KT) * BK),  \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * STAGE + lds_piece0 + j * 1024), 16, 0, 0);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(V == 7 && tile != xcd_remap(blockIdx.x, gridDim.x))) { STAGE_J(0, 0, 0, PIECES) }      // V7: later tiles were requested before the previous epilogue
+    const bool late = BITS ? (SKEW == 0 ? wid < 4 : (SKEW == 2 ? wid >= 4 : false)) : (V == 5 ? true : ((V == 0 || V == 3) ? wid < 4 : false));
+    bf16x8 af[8], wf[4], caf[8], cwf[4];
+#define READ(AF, WF, KS)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+        const int rw_ = wn * 64 + i * 16 + fr;                                                                    \
+        WF[i] = *reinterpret_cast<const bf16x8*>(sB + rw_ * 128 + ((((KS) * 4 + fg) ^ (rw_ & 7)) << 4));           \
+    }                                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+        const int ra_ = wm * 128 + i * 16 + fr;                                                                   \
+        AF[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * 128 + ((((KS) * 4 + fg) ^ (ra_ & 7)) << 4));           \
+    }
+#define MFMA(AF, WF) MFMA_R(AF, WF, 0, 4)
+#define MFMA_R(AF, WF, N0, N1)                                                                                    \
+    _Pragma("unroll") for (int ni = N0; ni < N1; ++ni)                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                          \
+            acc[ni][mi] = mfma16(WF[ni], AF[mi], acc[ni][mi]);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        MARK(kt, 0)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        MARK(kt, 1)
+        __builtin_amdgcn_s_barrier();
+        MARK(kt, 2)
+        const bool more = kt + 1 < nk;
+        if (V == 2) { if (more) { STAGE_J(kt + 1, st ^ 1, 0, 2) } }
+        else if (!late && more) { STAGE_J(kt + 1, st ^ 1, 0, PIECES) }
+        __builtin_amdgcn_sched_barrier(0);
+        MARK(kt, 3)
+        const unsigned char* sA = smem + st * STAGE;
+        const unsigned char* sB = sA + A_BYTES;
+        if (V == 6) {
+            READ(af, wf, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA(af, wf)
+            __builtin_amdgcn_sched_barrier(0);
+            READ(caf, cwf, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            MFMA(caf, cwf)
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            READ(af, wf, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            MARK(kt, 4)
+            if (V == 2 && more) { STAGE_J(kt + 1, st ^ 1, 2, 4) }
+            if (V == 4) __builtin_amdgcn_s_setprio(1);
+            if (LPOS == 1) {
+                if (kt > 0) { MFMA_R(caf, cwf, 0, 2) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (late && more) { STAGE_J(kt + 1, st ^ 1, 0, PIECES) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt > 0) { MFMA_R(caf, cwf, 2, 4) }
+            } else {
+                if (kt > 0) { MFMA(caf, cwf) }
+            }
+            if (V == 4) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            MARK(kt, 5)
+            if (V == 2) { if (more) { STAGE_J(kt + 1, st ^ 1, 4, 6) } }
+            else if (LPOS == 0 && late && more) { STAGE_J(kt + 1, st ^ 1, 0, PIECES) }
+            __builtin_amdgcn_sched_barrier(0);
+            MARK(kt, 6)
+            READ(caf, cwf, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (LPOS == 2 && late && more) { STAGE_J(kt + 1, st ^ 1, 0, PIECES) }
+            __builtin_amdgcn_sched_barrier(0);
+            MARK(kt, 7)
+            if (V == 2 && more) { STAGE_J(kt + 1, st ^ 1, 6, 8) }
+            if (V == 4) __builtin_amdgcn_s_setprio(1);
+            MFMA(af, wf)
+            if (V == 4) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            MARK(kt, 8)
+        }
+    }
+    if (V != 6) { MFMA(caf, cwf) }
+    if (V == 7 && tile + (int)gridDim.x < ntiles) {
+        // next tile's first stage: requested now, lands under this tile's epilogue (nk even: stage 0 was last read at K tile nk - 2,
+        // and every wave has passed the barrier of K tile nk - 1 since)
+        const int nt = tile + gridDim.x, ntm = nt % tiles_m, ntn = nt / tiles_m;
+        const int nrow0 = isA ? ntm * BM + wid * 64 : ntn * BN + (wid - 4) * 64;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int rl = lane >> 3, c = (lane & 7) ^ rl;
+            const unsigned o = (unsigned)min(nrow0 + j * 8 + rl, rmax) * (unsigned)K + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o),
+                                             (__attribute__((address_space(3))) void*)(smem + lds_piece0 + j * 1024), 16, 0, 0);
+        }
+    }
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = nw + ni * 16 + fg * 4;
+            if (n >= N) continue;
+            *reinterpret_cast<uint2*>(C + (long long)m * N + n) = make_uint2(pack_bf2(acc[ni][mi][0], acc[ni][mi][1]), pack_bf2(acc[ni][mi][2], acc[ni][mi][3]));
+        }
+    }
+    }
+#undef STAGE_J
+#undef READ
+#undef MFMA
+#undef MFMA_R
+#undef MARK
+}
+
+
+// ---- K step 32, four-stage LDS ring (4 x 32 KB), three steps of DMA lead, one barrier per step --------------------------------------------
+// stage: A 256 rows x 64 B, then W 256 rows x 64 B; 16-byte chunk c (0..3) of row r sits at slot c ^ ((r >> 1) & 3) (conflict-free for the
+// real ds_read_b128 lane groups, searched by script); a 1-KB DMA piece is 16 rows: lane l -> row l >> 2, source chunk (l & 3) ^ ((l >> 3) & 3)
+// P: DMA placement -- 0: one piece after every 8 MFMAs, 1: all four pieces before the MFMA block, 2: after the block
+constexpr int S32 = 32 * 1024;
+template <int P>
+__global__ __launch_bounds__(512) void lab32_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
+                                                    int K, int tiles_m, int tiles_n, unsigned long long* trace) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ns = K / 32;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool isA = wid < 4;
+    const bf16_t* base = isA ? A : W;
+    const int row0 = isA ? m0 + wid * 64 : n0 + (wid - 4) * 64;
+    const int rmax = (isA ? M : N) - 1;
+    unsigned off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = lane >> 2, c = (lane & 3) ^ ((lane >> 3) & 3);
+        off[j] = (unsigned)min(row0 + j * 16 + rl, rmax) * (unsigned)K + c * 8;
+    }
+    const int lds_piece0 = (isA ? wid * 4 : 16 + (wid - 4) * 4) * 1024;
+#define DMA32(S, J)                                                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[J] + (unsigned)(S) * 32),        \
+                                     (__attribute__((address_space(3))) void*)(smem + ((S) & 3) * S32 + lds_piece0 + (J) * 1024), 16, 0, 0);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < 3; ++s0)
+        if (s0 < ns) { DMA32(s0, 0) DMA32(s0, 1) DMA32(s0, 2) DMA32(s0, 3) }
+    bf16x8 xa[8], xw[4], ya[8], yw[4];
+#define READ32(AF, WF, S)                                                                                          \
+    {                                                                                                              \
+        const unsigned char* sA_ = smem + ((S) & 3) * S32;                                                         \
+        const unsigned char* sB_ = sA_ + 16 * 1024;                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            const int rw_ = wn * 64 + i * 16 + fr;                                                                 \
+            WF[i] = *reinterpret_cast<const bf16x8*>(sB_ + rw_ * 64 + ((fg ^ ((rw_ >> 1) & 3)) << 4));              \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                            \
+            const int ra_ = wm * 128 + i * 16 + fr;                                                                \
+            AF[i] = *reinterpret_cast<const bf16x8*>(sA_ + ra_ * 64 + ((fg ^ ((ra_ >> 1) & 3)) << 4));              \
+        }                                                                                                          \
+    }
+#define MFMA32(AF, WF, S, DO)                                                                                      \
+    {                                                                                                              \
+        const bool dma_ = (S) + 3 < ns;                                                                            \
+        if (P == 1 && dma_) { DMA32((S) + 3, 0) DMA32((S) + 3, 1) DMA32((S) + 3, 2) DMA32((S) + 3, 3) }             \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) {                                                         \
+            if (DO) { _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = mfma16(WF[ni], AF[mi], acc[ni][mi]); } \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            if (P == 0 && dma_) { DMA32((S) + 3, ni) }                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }                                                                                                          \
+        if (P == 2 && dma_) { DMA32((S) + 3, 0) DMA32((S) + 3, 1) DMA32((S) + 3, 2) DMA32((S) + 3, 3) }             \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+#define STEP32(S, RA, RW, MA, MW)                                                                                  \
+    {                                                                                                              \
+        if ((S) + 2 < ns) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                              \
+        else if ((S) + 1 < ns) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                         \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        READ32(RA, RW, S)                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        MFMA32(MA, MW, S, (S) > 0)                                                                                 \
+    }
+    // the DMA of step s + 3 goes to stage (s + 3) & 3 == (s - 1) & 3: its readers (step s - 1) all passed this step's barrier with lgkmcnt(0)
+    for (int s2 = 0; s2 < ns; s2 += 2) {
+        STEP32(s2, xa, xw, ya, yw)
+        STEP32(s2 + 1, ya, yw, xa, xw)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = mfma16(yw[ni], ya[mi], acc[ni][mi]);      // step ns - 1 (ns even: read into y)
+#undef DMA32
+#undef READ32
+#undef MFMA32
+#undef STEP32
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = nw + ni * 16 + fg * 4;
+            if (n >= N) continue;
+            *reinterpret_cast<uint2*>(C + (long long)m * N + n) = make_uint2(pack_bf2(acc[ni][mi][0], acc[ni][mi][1]), pack_bf2(acc[ni][mi][2], acc[ni][mi][3]));
+        }
+    }
+}
+template <int P>
+static void launch32(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, unsigned long long* trace, hipStream_t st) {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    const size_t lds = 4 * S32;
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab32_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    lab32_kernel<P><<<tm * tn, 512, lds, st>>>(A, W, C, M, N, K, tm, tn, trace);
+}
+
+static uint64_t rng_state = 88172645463325252ull;
+static inline uint64_t xorshift() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+static bf16_t rnd_bf16(float scale) {
+    const float f = ((float)(xorshift() >> 40) / (float)(1 << 24) * 2.f - 1.f) * scale;
+    unsigned u; memcpy(&u, &f, 4);
+    return (bf16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16);
+}
+
+template <int V>
+static void launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, unsigned long long* trace, hipStream_t st) {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    const size_t lds = 2 * STAGE;
+    static bool set = false;
+    if (!set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_kernel<V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    const int grid = V == 7 ? std::min(tm * tn, 256) : tm * tn;
+    if (trace) lab_kernel<V, true><<<grid, 512, lds, st>>>(A, W, C, M, N, K, tm, tn, trace);
+    else lab_kernel<V, false><<<grid, 512, lds, st>>>(A, W, C, M, N, K, tm, tn, nullptr);
+}
+typedef void (*launch_fn)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int, unsigned long long*, hipStream_t);
+#define BV(SKEW, PRIO, LPOS) (128 + (SKEW) + ((PRIO) << 2) + ((LPOS) << 5))
+static launch_fn LAUNCH[] = {launch<0>, launch<3>, launch<BV(0, 2, 0)>, launch<BV(0, 3, 0)>, launch<BV(0, 4, 0)>, launch<BV(2, 1, 0)>, launch<BV(2, 2, 0)>,
+                             launch32<0>, launch32<1>, launch32<2>};
+static const char* VNAME[] = {"base", "E47p1", "L03p1", "E47p2", "E47p3", "swap+47p1", "swap+03p1", "k32 spread", "k32 before", "k32 after"};
+constexpr int NV = 10;
+
+int main(int argc, char** argv) {
+    const bool do_trace = argc > 1 && !strcmp(argv[1], "trace");
+    struct Shape { const char* name; int M, N, K; };
+    const Shape shapes[] = {{"sq4096", 4096, 4096, 4096}, {"2r 4096x8192x4096", 4096, 8192, 4096}, {"sq8192", 8192, 8192, 8192},
+                            {"qkv2048", 2048, 12288, 4096}, {"gateup2048 (2.69 rounds)", 2048, 22016, 4096}};
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    for (const Shape& s : shapes) {
+        const int M = s.M, N = s.N, K = s.K, NW = 4;
+        std::vector<bf16_t> hA((size_t)M * K), hW((size_t)N * K);
+        for (auto& v : hA) v = rnd_bf16(1.f);
+        for (auto& v : hW) v = rnd_bf16(1.f);
+        bf16_t *dA, *dW[NW], *dC, *dC0;
+        CK(hipMalloc(&dA, hA.size() * 2));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+        for (int i = 0; i < NW; ++i) {
+            CK(hipMalloc(&dW[i], hW.size() * 2));
+            CK(hipMemcpy(dW[i], hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+        }
+        CK(hipMalloc(&dC, (size_t)M * N * 2));
+        CK(hipMalloc(&dC0, (size_t)M * N * 2));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        double best[NV];
+        bool same[NV];
+        for (int v = 0; v < NV; ++v) best[v] = 1e30;
+        std::vector<bf16_t> h0((size_t)M * N), h1((size_t)M * N);
+        for (int rep = 0; rep < 3; ++rep)
+            for (int v = 0; v < NV; ++v) {
+                const int iters = 12;
+                for (int i = 0; i < 2; ++i) LAUNCH[v](dA, dW[i % NW], dC, M, N, K, nullptr, st);
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; ++i) LAUNCH[v](dA, dW[i % NW], dC, M, N, K, nullptr, st);
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                best[v] = std::min(best[v], (double)ms * 1e3 / iters);
+                if (rep == 0) {
+                    CK(hipMemsetAsync(v == 0 ? dC0 : dC, 0, (size_t)M * N * 2, st));
+                    LAUNCH[v](dA, dW[0], v == 0 ? dC0 : dC, M, N, K, nullptr, st);
+                    CK(hipStreamSynchronize(st));
+                    if (v == 0) { CK(hipMemcpy(h0.data(), dC0, h0.size() * 2, hipMemcpyDeviceToHost)); same[0] = true; }
+                    else { CK(hipMemcpy(h1.data(), dC, h1.size() * 2, hipMemcpyDeviceToHost)); same[v] = !memcmp(h0.data(), h1.data(), h0.size() * 2); }
+                }
+            }
+        // spot check of variant 0 against a host dot product (transpose-detecting: A and W are different random matrices)
+        double maxrel = 0;
+        for (int t = 0; t < 64; ++t) {
+            const int m = (int)(xorshift() % M), n = (int)(xorshift() % N);
+            double ref = 0;
+            for (int k = 0; k < K; ++k) {
+                unsigned a = (unsigned)hA[(size_t)m * K + k] << 16, w = (unsigned)hW[(size_t)n * K + k] << 16;
+                float fa, fw; memcpy(&fa, &a, 4); memcpy(&fw, &w, 4);
+                ref += (double)fa * fw;
+            }
+            unsigned g = (unsigned)h0[(size_t)m * N + n] << 16; float fg_; memcpy(&fg_, &g, 4);
+            maxrel = std::max(maxrel, fabs(fg_ - ref) / (fabs(ref) + 1.0));
+        }
+        const double fl = 2.0 * M * N * K;
+        const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+        printf("%-28s (%4d tiles = %.2f rounds, host check %.1e):", s.name, tiles, tiles / 256.0, maxrel);
+        for (int v = 0; v < NV; ++v) printf("  %s %.1f us (%.0f TF)%s", VNAME[v], best[v], fl / best[v] / 1e6, same[v] ? "" : " DIFF");
+        printf("\n");
+        fflush(stdout);
+        if (do_trace && !strcmp(s.name, "sq4096")) {
+            unsigned long long* dT;
+            const size_t nt = 8 * TR_TILES * TR_MARKS;
+            CK(hipMalloc(&dT, nt * 8));
+            for (int v : {0, 1}) {
+                CK(hipMemset(dT, 0, nt * 8));
+                LAUNCH[v](dA, dW[1], dC, M, N, K, dT, st);
+                CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hT(nt);
+                CK(hipMemcpy(hT.data(), dT, nt * 8, hipMemcpyDeviceToHost));
+                printf("trace V%d (cycles since wave 0's first mark; marks: 0 loop top, 1 waitcnt done, 2 past barrier, 3 early DMA issued, 4 reads h0 issued, 5 carried MFMAs issued, 6 late DMA issued, 7 reads h1 issued, 8 MFMAs h0 issued)\n", v);
+                const unsigned long long t0 = hT[0];
+                for (int kt = 0; kt < TR_TILES; ++kt)
+                    for (int w = 0; w < 8; ++w) {
+                        printf("  kt %2d wave %d:", TR_T0 + kt, w);
+                        for (int i = 0; i < 9; ++i) printf(" %6lld", (long long)(hT[(w * TR_TILES + kt) * TR_MARKS + i] - t0));
+                        printf("\n");
+                    }
+            }
+            CK(hipFree(dT));
+        }
+        CK(hipFree(dA)); for (int i = 0; i < NW; ++i) CK(hipFree(dW[i]));
+        CK(hipFree(dC)); CK(hipFree(dC0));
+    }
+    return 0;
+}

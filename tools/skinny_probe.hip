@@ -11,6 +11,11 @@ void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(s
 int hip_fail(hipError_t e, const char* what) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return TEO_ERR_HIP; }
 void note_kernel(const char*) {}
 int device_cu_count() { return 256; }
+static teo_tune g_probe_tune;                       // the probe's own knob block (the library keeps these in teo_tune blocks: tune.h)
+const teo_tune& tune() { return g_probe_tune; }
+int lds_attr_once(const void* kernel, int bytes, unsigned long long*, const char*) {
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? TEO_OK : TEO_ERR_HIP;
+}
 }  // namespace teo
 
 using namespace teo;

@@ -52,9 +52,9 @@ for name, M, N, K, act, with_res in (("vit qkv", 2056, 3072, 1024, 0, False), ("
     line = f"{name:8s} M={M} N={N} K={K} ({2.0 * M * N * K / 1e9:5.1f} GF)"
     ref = None
     for fam, knobs in FAM:
-        lib.teo_tune_reset()
+        L.tune_reset()
         for k, v in knobs.items():
-            lib.teo_tune_set(k.encode(), v)
+            L.tune_set(k.encode(), v)
         try:
             cnt[0] = 0
             run()
@@ -65,5 +65,5 @@ for name, M, N, K, act, with_res in (("vit qkv", 2056, 3072, 1024, 0, False), ("
             line += f" | {fam} [{kern}] {t:5.1f}{'' if torch.equal(out, ref) else ' DIFF'}"
         except Exception as e:  # noqa: BLE001
             line += f" | {fam} err"
-    lib.teo_tune_reset()
+    L.tune_reset()
     print(line, flush=True)
