@@ -188,7 +188,7 @@ def cpu_baseline(T, n_text, n_out, budget_s=240.0, max_layers=None):
                                 "prefill": round(ph["prefill"] * scale_layers, 3),
                                 "decode_per_token": round(ph["decode_per_token"] * scale_layers, 4)},
                     "prefill_tflops": round((2.0 * ph["L"] * 6.476e9 + float(ph["L"]) ** 2 * 262144.0) / 1e12 / (ph["prefill"] * scale_layers), 3),
-                    "decode_weight_stream_GBps": round(6.738e9 * bytes_per_w / (ph["decode_per_token"] * scale_layers) / 1e9, 1)}
+                    "decode_weight_stream_GBps": round(6.607e9 * bytes_per_w / (ph["decode_per_token"] * scale_layers) / 1e9, 1)}
 
         c1 = run(sd, 2, 32, 8)
         c3 = run(sd, T, n_text, 8)
@@ -543,18 +543,35 @@ def main():
     # FETCH_SIZE x2 on gfx950 + WRITE_SIZE); it is NOT measured inside this run: the numbers below are read from the committed
     # summary of those passes (tools/pmc_traffic.sh) and labelled with the file and the commit they were taken at.
     traffic, traffic_src, traffic_all = None, None, None
-    for name in ("r04_pmc_decode_traffic.json", "r03_pmc_decode_traffic.json", "r02_pmc_gemv_gateup.json", "pmc_gemv_gateup.json"):
-        pmc = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(pmc):
+    try:
+        from tools.src_hash import csrc_sha16
+        src_now = csrc_sha16(ROOT)
+    except Exception:  # noqa: BLE001 -- no sources beside the library: nothing can be tied to the kernels that ran
+        src_now = None
+    traffic_note = None
+
+    def pmc_summary(names):
+        """The newest committed PMC summary whose source fingerprint equals that of the kernel sources beside the running library (the
+        summaries are separate rocprofv3 --pmc runs; a kernel change after they were taken must not keep quoting them)."""
+        for name in names:
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                continue
             try:
-                blob = json.load(open(pmc))
-                traffic = blob.get("hbm_bytes_per_launch")
-                traffic_all = blob.get("kernels")
-                traffic_src = {"from_profiles": "profiles/" + name, "commit": blob.get("commit", "see git log of the file"),
-                               "note": "separate rocprofv3 --pmc passes over the same kernels and shapes; not measured in this run"}
+                blob = json.load(open(path))
             except Exception:  # noqa: BLE001
-                traffic = None
-            break
+                continue
+            if src_now is None or blob.get("csrc_sha16") != src_now:
+                return None, name, (f"profiles/{name} was taken on kernel sources {blob.get('csrc_sha16', '(no fingerprint: before round 5)')}, "
+                                    f"the running library's sources are {src_now}: traffic not quoted until tools/pmc_*_traffic.sh is re-run")
+            return blob, name, None
+        return None, None, "no PMC summary under profiles/"
+    blob, name, traffic_note = pmc_summary(("r05_pmc_decode_traffic.json", "r04_pmc_decode_traffic.json"))
+    if blob is not None:
+        traffic = blob.get("hbm_bytes_per_launch")
+        traffic_all = blob.get("kernels")
+        traffic_src = {"from_profiles": "profiles/" + name, "commit": blob.get("commit", "see git log of the file"), "csrc_sha16": blob.get("csrc_sha16"),
+                       "note": "separate rocprofv3 --pmc passes over the same kernels and shapes (same kernel sources: fingerprints equal); not measured in this run"}
     # Two live measurements of the same kernel: (1) its dispatch timestamps inside real decode steps, (2) HIP events around 32 x 5
     # back-to-back launches.  (2) is what `rocprofv3 --kernel-trace --stats` of this command agrees with (its per-kernel averages carry
     # the inter-kernel gap of the replayed graph: they add up to slightly MORE than the step); `achieved` / `frac` use the LONGER of
@@ -567,7 +584,12 @@ def main():
     dom = max(share, key=share.get)
     w_tag = "fp8-e4m3 weights" if args.weights == "fp8" else f"{args.dtype} weights"
     if B > 1:
-        kern_names = {"attn_decode_partial": f"attn_decode_whole_kernel<bf16, 16 lanes per row, 64-key chunks, RoPE + KV append> (batched decode attention: {B} conversations x 32 heads x {ctx_prof} keys)",
+        # which attention form ran: the whole-context kernel has no combine launch in the profiled step (attention.hip takes it when
+        # conversations x heads fill the CUs), the split form carries one
+        whole_ran = "attn_decode_combine" not in prof
+        kern_names = {"attn_decode_partial": (f"attn_decode_whole_kernel<{args.dtype}, 16 lanes per row, 64-key chunks, RoPE + KV append>" if whole_ran
+                                              else f"attn_decode_partial_kernel<{args.dtype}, 128-key chunks, RoPE + KV append> + attn_decode_combine_kernel")
+                                             + f" (batched decode attention: {B} conversations x 32 heads x {ctx_prof} keys)",
                       "gateup_gemv": f"skinny_stream_kernel<{w_tag}, SWIGLU8> (batched decode gate/up + SwiGLU, {B} rows, N=22016 K=4096)",
                       "qkv_rope_gemv": f"skinny_stream_kernel<{w_tag}> (batched decode qkv, {B} rows, N=12288 K=4096)",
                       "down_gemv": f"skinny_gemm_kernel<{w_tag}> (batched decode down + residual, {B} rows, N=4096 K=11008)",
@@ -600,23 +622,21 @@ def main():
         if B > 1:
             # the batched step's own PMC passes exist for config C5's per-GPU shape (8 conversations, fp8 weights: tools/pmc_batch_traffic.sh)
             traffic_all, traffic_src = None, None
-            pmc_b = os.path.join(ROOT, "profiles", "r04_pmc_batch_traffic.json")
-            if B == 8 and args.weights == "fp8" and abs(ctx_prof - 2178) <= 64 and os.path.exists(pmc_b):       # same shape as the PMC passes
-                try:
-                    blob = json.load(open(pmc_b))
+            if B == 8 and args.weights == "fp8" and abs(ctx_prof - 2178) <= 64:       # same shape as the PMC passes
+                blob, name, traffic_note = pmc_summary(("r05_pmc_batch_traffic.json", "r04_pmc_batch_traffic.json"))
+                if blob is not None:
                     key = {"attn_decode_partial": "attn_decode_whole", "gateup_gemv": "gateup_stream_fp8", "qkv_rope_gemv": "qkv_lmhead_stream_fp8",
                            "o_gemv": "o_tile_fp8", "down_gemv": "down_tile_fp8"}.get(dom)
                     traffic_all = blob.get("kernels")
                     traffic = (traffic_all or {}).get(key, {}).get("hbm_bytes_per_launch")
-                    traffic_src = {"from_profiles": "profiles/r04_pmc_batch_traffic.json", "commit": blob.get("commit"),
-                                   "note": "separate rocprofv3 --pmc passes over `bench.py --batch 8 --weights fp8` (ctx 2178); not measured in this run"}
-                except Exception:  # noqa: BLE001
-                    traffic, traffic_all, traffic_src = None, None, None
+                    traffic_src = {"from_profiles": "profiles/" + name, "commit": blob.get("commit"), "csrc_sha16": blob.get("csrc_sha16"),
+                                   "note": "separate rocprofv3 --pmc passes over `bench.py --batch 8 --weights fp8` (ctx 2178), same kernel sources; not measured in this run"}
     achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": kern_names.get(dom, dom),
                 "share_of_profiled_step": round(share[dom] / sum(share.values()), 4),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src if traffic is not None else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src if traffic is not None else ({"note": traffic_note} if traffic_note else None),
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(avg_ms, 5),
                 "measured": ("the longer of: in-run per-launch dispatch timestamps over 8 decode steps x 32 layers after a real prefill (ctx %d); "
                              "HIP events around 32 matrices x 5 back-to-back launches" % ctx_prof) if (dom == "gateup_gemv" and B == 1) else
@@ -631,7 +651,12 @@ def main():
         roofline["traffic_per_kernel"] = traffic_all
     # whole decode step against the HBM roofline (weights + KV per token)
     kv_ctx = Lseq + n_out / 2.0
-    tok_bytes = 6.738e9 * (1 if args.weights == "fp8" else 2) + 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * kv_ctx
+    # weights a decode step actually streams: the layers' four matrices + lm_head (+ the norm vectors, 16-bit).  NOT the embedding table:
+    # a step reads one row of it.  (SURVEY's 6.738e9 counts embed_tokens; rounds 1-4 used it and overstated the step by 1.8 %.)
+    w_params = cfg.num_hidden_layers * (QKVn * Dh + Dh * cfg.num_attention_heads * cfg.head_dim + 2 * Fi * Dh + Dh * Fi) + Vv * Dh
+    norm_bytes = (2 * cfg.num_hidden_layers + 1) * Dh * 2
+    w_tok = w_params * (1 if args.weights == "fp8" else 2) + norm_bytes
+    tok_bytes = w_tok + 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * 2 * kv_ctx
     # the MFMA-bound phases against the dense bf16 peak (algorithmic FLOPs of SURVEY.md section 8d)
     MFMA_PEAK_TFLOPS = 2500.0
     prefill_tf = (2.0 * Lseq * 6.476e9 + 2.0 * 4096 * 32000 + float(Lseq) ** 2 * 262144.0) / 1e12
@@ -642,8 +667,9 @@ def main():
     roofline["decode_step_frac_of_hbm_peak"] = round(tok_bytes / (phases["decode_ms_per_token"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     # t_min = FLOPs_dense / peak_mfma + Bytes_decode / peak_hbm over the whole job; end_to_end_frac = t_min / t_measured.
     # A batched step reads the weights ONCE and every conversation's K / V: bytes per step = weights + B x KV
-    w_tok = 6.738e9 * (1 if args.weights == "fp8" else 2)
     kv_tok = tok_bytes - w_tok
+    roofline["decode_bytes_per_token"] = {"weights_streamed": int(w_tok), "kv_read_plus_append": int(kv_tok),
+                                          "note": "layers + lm_head + norm vectors; embed_tokens is not streamed (one row per token)"}
     step_bytes = w_tok + B * kv_tok
     if B > 1:
         roofline["batched_step_frac_of_hbm_peak"] = round(step_bytes / (phases["batched_decode_ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -674,6 +700,21 @@ def main():
         result["rccl"] = rccl_info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(T, n_text, n_out)
+    elif rank == 0 and world > 1:
+        # measured at N = 1 only (the contract: rank 0, N = 1); an N > 1 line points at the committed N = 1 line instead of carrying null
+        ref_line = None
+        for name in ("r05_bench.json", "r04_bench.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                try:
+                    cb = json.load(open(path)).get("cpu_baseline")
+                    if cb:
+                        ref_line = dict(cb, measured_at="n_gpus = 1", from_profiles="profiles/" + name,
+                                        note="not re-measured in this N > 1 run: the oracle is timed on rank 0 at N = 1 only")
+                        break
+                except Exception:  # noqa: BLE001
+                    pass
+        result["cpu_baseline"] = ref_line
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

@@ -378,10 +378,12 @@ size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
 /* LlamaModel.forward + lm_head over S new positions given inputs_embeds (llava_llama.py:88-99).
  *   d_embeds [S, hidden] (dtype), d_positions int32 [S], past = tokens already in the cache.
  *   logits_rows: 0 -> logits for all S positions [S, vocab] fp32; 1 -> last position only [1, vocab].
- *   d_hidden_out (may be NULL): final-normed hidden states of the rows logits were computed for. */
+ *   d_hidden_states (may be NULL): `output_hidden_states` of the kept forward signature (llava_llama.py:56-69, 88-99) --
+ *   [layers + 1][S][hidden] in the model dtype: snapshot 0 = the input embeddings, l = the residual stream after layer l - 1, the last
+ *   one after the final RMSNorm (what LlamaModel.forward collects: lm_head(hidden_states[-1]) == logits). */
 int teo_llama_prefill(const teo_llama_desc* d, const void* d_embeds, const int* d_positions, int S, int past,
                       int last_only, float* d_logits, void* d_workspace, size_t workspace_bytes,
-                      teo_stream_t stream);
+                      teo_stream_t stream, void* d_hidden_states);
 
 /* Persistent decode state: greedy decode of one sequence with everything (token, position, stop flag) on the device. */
 typedef struct {
@@ -407,7 +409,8 @@ typedef struct {
  * train.py:840-901).  Workspace: teo_llama_prefill_workspace_bytes(d, sum(seq_lens)).  Row for row the results equal
  * teo_llama_prefill's. */
 int teo_llama_prefill_batch(const teo_llama_desc* d, const void* d_embeds, const int* seq_lens, int nseq, long long cache_stride,
-                            int last_only, float* d_logits, void* d_workspace, size_t workspace_bytes, teo_stream_t stream);
+                            int last_only, float* d_logits, void* d_workspace, size_t workspace_bytes, teo_stream_t stream,
+                            void* d_hidden_states /* NULL or [layers + 1][sum(seq_lens)][hidden], as teo_llama_prefill */);
 
 size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d);
 /* Arm a generation: workspace.h <- embed[*d_token] (call once after filling d_token/d_pos; every step's tail then

@@ -102,6 +102,19 @@ def _rounder(rounding):
 K_ORDER = None
 
 
+# Op ORDER of the attention / RoPE arithmetic (round 5, information level only; VERDICT r04 "What's missing" #4).  None = the order of the
+# stack the fixtures were made with (transformers 5.15: scores scaled after q k^T, fp32 softmax statistics, fp32 RoPE angles) and of the
+# kernels.  "tf431" = the reference's PINNED stack (pyproject.toml:17, transformers 4.31.0) as its 16-bit run executes it:
+#   * CLIPAttention (constructed at languagebind/image/modeling_image.py:69; 4.31 modeling_clip.py CLIPAttention.forward): q is scaled
+#     BEFORE q k^T (`self.q_proj(hidden_states) * self.scale`, a rounding of its own), q k^T is a 16-bit bmm output, the softmax runs in
+#     the working dtype (normalised probabilities rounded to 16 bit), P V is a 16-bit bmm output;
+#   * LlamaAttention (4.31 modeling_llama.py): q k^T is a 16-bit matmul output, divided by sqrt(d) (rounded again), softmax in fp32 but
+#     cast back to 16 bit NORMALISED, P V rounded; LlamaRotaryEmbedding keeps cos / sin caches that are cast to the model dtype, and
+#     apply_rotary_pos_emb is three 16-bit ops (q cos, rotate_half(q) sin, their sum).
+# Only meaningful together with rounding="bf16" / "fp16"; in fp32 both orders agree to round-off (asserted by the test that uses it).
+OP_ORDER = None
+
+
 def _lin(x, w):
     """x [..., K] . w[N, K]^T -- every nn.Linear of the path (bias added by the caller)."""
     wt = w.to(x.dtype).t()
@@ -297,6 +310,16 @@ def attention_core(q, k, v, visible, scale, R, mode="exact"):
     B, H, Sq, d = q.shape
     Sk = k.shape[2]
     neg = float("-inf")
+    if mode == "tf431_clip":          # q arrives pre-scaled (and rounded); 16-bit bmm output, softmax output rounded NORMALISED, 16-bit P V
+        s = R(q @ k.transpose(-1, -2))
+        p = R(torch.softmax(s, dim=-1))
+        return R(p @ v)
+    if mode == "tf431_llama":         # 16-bit q k^T, / sqrt(d) rounded, additive mask, fp32 softmax cast back NORMALISED, 16-bit P V
+        s = R(R(q @ k.transpose(-1, -2)) / (1.0 / scale))
+        if visible is not None:
+            s = s.masked_fill(~visible, neg)
+        p = R(torch.softmax(s, dim=-1))
+        return R(p @ v)
     if mode == "exact":
         s = (q @ k.transpose(-1, -2)) * scale
         if visible is not None:
@@ -398,7 +421,10 @@ def vit_attention(x, sd, pre, cfg: VitCfg, R, mode="exact"):
     q = lin("self_attn.q_proj").view(B, N, H, d).transpose(1, 2)
     k = lin("self_attn.k_proj").view(B, N, H, d).transpose(1, 2)
     v = lin("self_attn.v_proj").view(B, N, H, d).transpose(1, 2)
-    o = attention_core(q, k, v, None, d ** -0.5, R, mode)
+    if OP_ORDER == "tf431":
+        o = attention_core(R(q * (d ** -0.5)), k, v, None, 1.0, R, "tf431_clip")
+    else:
+        o = attention_core(q, k, v, None, d ** -0.5, R, mode)
     return R(o.transpose(1, 2).reshape(B, N, D))
 
 
@@ -654,14 +680,19 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, m
     k = R(_lin(n1, sd[pre + "self_attn.k_proj.weight"])).view(B, S, Hk, d).transpose(1, 2)
     v = R(_lin(n1, sd[pre + "self_attn.v_proj.weight"])).view(B, S, Hk, d).transpose(1, 2)
     c, s = cos.unsqueeze(1), sin.unsqueeze(1)
-    q = R(q * c + rotate_half(q) * s)
-    k = R(k * c + rotate_half(k) * s)
+    if OP_ORDER == "tf431":                                                      # 16-bit cos / sin caches, three 16-bit ops
+        c, s = R(c), R(s)
+        q = R(R(q * c) + R(rotate_half(q) * s))
+        k = R(R(k * c) + R(rotate_half(k) * s))
+    else:
+        q = R(q * c + rotate_half(q) * s)
+        k = R(k * c + rotate_half(k) * s)
     kk, vv = cache.append(i, k, v)
     if Hk != H:                                                                  # repeat_kv
         rep = H // Hk
         kk = kk[:, :, None].expand(B, Hk, rep, kk.shape[2], d).reshape(B, H, -1, d)
         vv = vv[:, :, None].expand(B, Hk, rep, vv.shape[2], d).reshape(B, H, -1, d)
-    o = attention_core(q, kk, vv, visible, 1.0 / math.sqrt(d), R, mode)
+    o = attention_core(q, kk, vv, visible, 1.0 / math.sqrt(d), R, "tf431_llama" if OP_ORDER == "tf431" else mode)
     o = R(o.transpose(1, 2).reshape(B, S, D))
     h = R(h + _lin(o, sd[pre + "self_attn.o_proj.weight"]))
     n2 = R(rmsnorm(h, sd[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps))
@@ -702,9 +733,12 @@ def _llama_layer_w8a8(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache
 
 
 def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[KVCache], sd, cfg: LlamaCfg,
-                  rounding=None, last_only=False, return_hidden=False, decode_kernel=False, act_quant=None):
+                  rounding=None, last_only=False, return_hidden=False, decode_kernel=False, act_quant=None, hidden_states=None):
     """LlamaModel + lm_head.  inputs_embeds [B,S,D]; position_ids [B,S] or None (-> past..past+S);
-    attention_mask [B, past+S] of 0/1 or None.  Returns fp logits [B,S,V] (or [B,1,V])."""
+    attention_mask [B, past+S] of 0/1 or None.  Returns fp logits [B,S,V] (or [B,1,V]).
+    hidden_states: a list that receives what LlamaModel.forward collects under output_hidden_states=True (llava_llama.py:56-69 ->
+    tf llama/modeling_llama.py LlamaModel.forward): the input embeddings, the residual stream after every layer but the last, and
+    the final-normed states -- num_hidden_layers + 1 tensors [B,S,D]."""
     R = _rounder(rounding)
     if cache is None:
         cache = KVCache()
@@ -722,7 +756,11 @@ def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[K
         visible = visible & (attention_mask[:, None, None, :T] != 0)
     mode = kernel_attention_mode(rounding, cfg.head_dim, S, decode_kernel)
     for i in range(cfg.num_hidden_layers):
+        if hidden_states is not None:
+            hidden_states.append(h)
         h = llama_layer(h, i, sd, cfg, cos, sin, visible, cache, R, mode, act_quant)
+    if hidden_states is not None:
+        hidden_states.append(R(rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps)))
     if last_only:
         h = h[:, -1:, :]
     hn = R(rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps))
@@ -736,7 +774,7 @@ def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[K
 # H14/H16: multimodal forward and greedy generation
 # --------------------------------------------------------------------------------------
 def mm_forward(input_ids, images: List[torch.Tensor], sd, vcfg: VitCfg, lcfg: LlamaCfg, mm: MMCfg,
-               attention_mask=None, rounding=None, dtype=torch.float32):
+               attention_mask=None, rounding=None, dtype=torch.float32, hidden_states=None):
     """llava_llama.py:56-99 prefill: encode + splice + LLaMA.  images = flat list of [3,H,W]."""
     pix = torch.stack([im.to(dtype) for im in images])                           # llava_arch.py:194
     feats = encode_images(pix, sd, vcfg, mm, rounding)
@@ -744,7 +782,7 @@ def mm_forward(input_ids, images: List[torch.Tensor], sd, vcfg: VitCfg, lcfg: Ll
     emb_w = sd["model.embed_tokens.weight"].to(dtype)
     _, pos, mask, _, embeds, _ = prepare_inputs_labels_for_multimodal(
         input_ids, None, attention_mask, None, None, flat, emb_w, mm)
-    logits, cache = llama_forward(embeds, pos, mask, None, sd, lcfg, rounding)
+    logits, cache = llama_forward(embeds, pos, mask, None, sd, lcfg, rounding, hidden_states=hidden_states)
     return logits, cache, embeds
 
 

@@ -134,7 +134,7 @@ _SIGS = {
     "teo_projector": (C.c_int, [C.POINTER(ProjDesc), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_prefill_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc), C.c_int]),
     "teo_llama_prefill": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "teo_llama_decode_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc)]),
     "teo_llama_decode_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -143,7 +143,7 @@ _SIGS = {
     "teo_llama_decode_graph_create": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t,
                                                 C.c_void_p, C.POINTER(C.c_void_p)]),
     "teo_llama_prefill_batch": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_longlong, C.c_int, C.c_void_p,
-                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "teo_llama_decode_batch_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc), C.c_int]),
     "teo_llama_decode_batch_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_batch_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeBatchState), C.c_void_p, C.c_size_t, C.c_void_p]),

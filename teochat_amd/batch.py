@@ -133,7 +133,7 @@ class BatchDecoder:
             eng._flush_handoff_checks("prefill")
             ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d), S))
             L.check(self.lib.teo_llama_prefill(C.byref(d), _p(e), _p(pos), S, past, 1 if last_only else 0, _p(logits), _p(ws),
-                                               ws.numel(), st), "teo_llama_prefill")
+                                               ws.numel(), st, None), "teo_llama_prefill")
             sid = C.c_void_p(eng.stream.cuda_stream)
             eng._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d), S, _p(ws), ws.numel(), C.byref(f), sid),
                                 "teo_llama_prefill")
@@ -158,7 +158,7 @@ class BatchDecoder:
             ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d0), total))
             arr = (C.c_int * self.B)(*lens)
             L.check(self.lib.teo_llama_prefill_batch(C.byref(d0), _p(rows), arr, self.B, self.k_cache.stride(1), 1,
-                                                     _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill_batch")
+                                                     _p(logits), _p(ws), ws.numel(), st, None), "teo_llama_prefill_batch")
             sid = C.c_void_p(eng.stream.cuda_stream)
             eng._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d0), total, _p(ws), ws.numel(), C.byref(f), sid),
                                 "teo_llama_prefill_batch")

@@ -59,9 +59,9 @@ size_t projector_workspace_bytes(const teo_proj_desc* d, int rows);
 int projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws, size_t ws_bytes, hipStream_t st);
 size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
 int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
-                  float* logits, void* ws, size_t ws_bytes, hipStream_t st);
+                  float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states);
 int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* seq_lens, int nseq, long long cache_stride,
-                        int last_only, float* logits, void* ws, size_t ws_bytes, hipStream_t st);
+                        int last_only, float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states);
 size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
 int llama_decode_step(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, hipStream_t st);
 int llama_decode_step_profile(const teo_llama_desc* d, const teo_decode_state* s, void* ws, size_t ws_bytes, float* ms_out, int* count_out,
@@ -357,24 +357,24 @@ int teo_projector(const teo_proj_desc* d, const void* x, int rows, void* y, void
 
 size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S) { return d ? llama_prefill_workspace_bytes(d, S) : 0; }
 int teo_llama_prefill(const teo_llama_desc* d, const void* emb, const int* pos, int S, int past, int last_only,
-                      float* logits, void* ws, size_t wsb, teo_stream_t s) {
+                      float* logits, void* ws, size_t wsb, teo_stream_t s, void* hidden_states) {
     ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype);
     TuneScope tune_scope(d->tune);
     TEO_CHECK_ARG(S >= 0 && past >= 0, "teo_llama_prefill: S %d past %d", S, past);
     if (S) { NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace"); }
-    return llama_prefill(d, emb, pos, S, past, last_only, logits, ws, wsb, ST(s));
+    return llama_prefill(d, emb, pos, S, past, last_only, logits, ws, wsb, ST(s), hidden_states);
 }
 
 int teo_llama_prefill_batch(const teo_llama_desc* d, const void* emb, const int* seq_lens, int nseq, long long cache_stride,
-                            int last_only, float* logits, void* ws, size_t wsb, teo_stream_t s) {
+                            int last_only, float* logits, void* ws, size_t wsb, teo_stream_t s, void* hidden_states) {
     ENTER();
     NEED(d, "desc"); NEED_DT(d->dtype); NEED(seq_lens, "seq_lens");
     TuneScope tune_scope(d->tune);
     TEO_CHECK_ARG(nseq >= 0 && (nseq <= 1 || cache_stride > 0), "teo_llama_prefill_batch: nseq %d cache_stride %lld", nseq, cache_stride);
     if (nseq == 0) return TEO_OK;
     NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace");
-    return llama_prefill_batch(d, emb, seq_lens, nseq, cache_stride, last_only, logits, ws, wsb, ST(s));
+    return llama_prefill_batch(d, emb, seq_lens, nseq, cache_stride, last_only, logits, ws, wsb, ST(s), hidden_states);
 }
 
 size_t teo_llama_decode_workspace_bytes(const teo_llama_desc* d) { return d ? llama_decode_workspace_bytes(d) : 0; }

@@ -203,8 +203,17 @@ int vit_workspace_status(const teo_vit_desc* d, int T, void* ws, size_t ws_bytes
     return gemm_sk_workspace_status(w.sk, host_flag, st);
 }
 
+// hidden_states (optional, `output_hidden_states` of the kept forward signature, llava_llama.py:56-69): [layers + 1][S][hidden] in the model
+// dtype -- snapshot 0 = the input embeddings, l = the residual stream after layer l - 1, the last one AFTER the final RMSNorm (what
+// LlamaModel.forward collects: lm_head(hidden_states[-1]) == logits)
+static int snapshot_rows(void* hs, int idx, const void* src, int S, int D, size_t e, hipStream_t st) {
+    if (!hs) return TEO_OK;
+    const hipError_t he = hipMemcpyAsync((unsigned char*)hs + (size_t)idx * S * D * e, src, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
+    return he == hipSuccess ? TEO_OK : hip_fail(he, "prefill: hidden-state snapshot");
+}
+
 int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
-                  float* logits, void* ws, size_t ws_bytes, hipStream_t st) {
+                  float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states) {
     if (S == 0) return TEO_OK;
     TEO_CHECK_ARG(past + S <= d->max_seq, "teo_llama_prefill: past %d + S %d exceeds max_seq %d", past, S, d->max_seq);
     const PrefillWs w = prefill_carve(d, S, ws, ws_bytes);
@@ -219,8 +228,10 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
     hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
     TEO_TRY(gemm_sk_workspace_init(w.sk, st));
+    TEO_TRY(snapshot_rows(hidden_states, 0, w.h, S, D, e, st));
     const bool fp8 = prefill_uses_fp8(d);
     for (int l = 0; l < d->layers; ++l) {
+        if (l > 0) TEO_TRY(snapshot_rows(hidden_states, l, w.h, S, D, e, st));         // the residual stream after layer l - 1
         auto attend = [&]() -> int {
         TEO_TRY(rope_kv_append(w.qkv, QKV, positions, d->rope_cos, d->rope_sin, d->k_cache[l], d->v_cache[l],
                                d->vt_cache[l], S, past, nullptr, d->max_seq, H, Hk, hd, dt, st));
@@ -250,10 +261,12 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
         TEO_TRY(gemm(w.act, d->down_w[l], nullptr, w.h, w.h, S, D, F, F, D, TEO_ACT_NONE, 0, dt, dt, st, w.sk));
     }
     if (last_only) {
+        if (hidden_states) TEO_TRY(rmsnorm(w.h, d->final_norm_w, (unsigned char*)hidden_states + (size_t)d->layers * S * D * e, S, D, d->eps, dt, st));
         const void* hl = (const unsigned char*)w.h + (size_t)(S - 1) * D * e;
         return gemv(hl, d->lm_head, d->final_norm_w, nullptr, logits, d->vocab, D, d->eps, 0, dt, TEO_F32, st);
     }
     TEO_TRY(rmsnorm(w.h, d->final_norm_w, w.n, S, D, d->eps, dt, st));
+    TEO_TRY(snapshot_rows(hidden_states, d->layers, w.n, S, D, e, st));
     return gemm(w.n, d->lm_head, nullptr, nullptr, logits, S, d->vocab, D, D, d->vocab, TEO_ACT_NONE, 0, dt, TEO_F32, st, w.sk);
 }
 
@@ -262,7 +275,7 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
 // the causal attention run per sequence on its row block and its own cache slot (slot b = cache pointer + b*cache_stride
 // elements, fresh caches: past = 0).  logits [nseq, vocab]: last position of every sequence.
 int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* seq_lens, int nseq, long long cache_stride,
-                        int last_only, float* logits, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int last_only, float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states) {
     int total = 0;
     for (int b = 0; b < nseq; ++b) {
         TEO_CHECK_ARG(seq_lens[b] >= 1 && seq_lens[b] <= d->max_seq, "teo_llama_prefill_batch: seq_lens[%d] = %d", b, seq_lens[b]);
@@ -281,8 +294,10 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
     hipError_t he = hipMemcpyAsync(w.h, embeds, (size_t)S * D * e, hipMemcpyDeviceToDevice, st);
     if (he != hipSuccess) return hip_fail(he, "prefill copy embeds");
     TEO_TRY(gemm_sk_workspace_init(w.sk, st));
+    TEO_TRY(snapshot_rows(hidden_states, 0, w.h, S, D, e, st));
     const bool fp8 = prefill_uses_fp8(d);
     for (int l = 0; l < d->layers; ++l) {
+        if (l > 0) TEO_TRY(snapshot_rows(hidden_states, l, w.h, S, D, e, st));         // the residual stream after layer l - 1
         auto attend = [&]() -> int {
         int row0 = 0;
         for (int b = 0; b < nseq; ++b) {
@@ -323,8 +338,10 @@ int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* 
     }
     if (!last_only) {                                    // training-shape forward: logits of every row, [sum(seq_lens), vocab]
         TEO_TRY(rmsnorm(w.h, d->final_norm_w, w.n, S, D, d->eps, dt, st));
+        TEO_TRY(snapshot_rows(hidden_states, d->layers, w.n, S, D, e, st));
         return gemm(w.n, d->lm_head, nullptr, nullptr, logits, S, d->vocab, D, D, d->vocab, TEO_ACT_NONE, 0, dt, TEO_F32, st, w.sk);
     }
+    if (hidden_states) TEO_TRY(rmsnorm(w.h, d->final_norm_w, (unsigned char*)hidden_states + (size_t)d->layers * S * D * e, S, D, d->eps, dt, st));
     int row_end = 0;
     for (int b = 0; b < nseq; ++b) {
         row_end += seq_lens[b];

@@ -419,8 +419,10 @@ class TeoEngine:
     def reset_cache(self):
         self.cache_len = 0
 
-    def prefill(self, embeds, positions=None, last_only=False):
-        """embeds [S, D] appended to the cache; returns fp32 logits [S, V] (or [1, V])."""
+    def prefill(self, embeds, positions=None, last_only=False, hidden_states=False):
+        """embeds [S, D] appended to the cache; returns fp32 logits [S, V] (or [1, V]).  With hidden_states: (logits, hs) where hs is
+        [layers + 1, S, D] in the model dtype -- the input embeddings, the residual stream after every layer but the last, and the
+        final-normed states (HF's `output_hidden_states` tuple; llava_llama.py:88-99)."""
         S = embeds.shape[0]
         past = self.cache_len
         if past + S > self.max_seq:
@@ -436,15 +438,16 @@ class TeoEngine:
             need = self.lib.teo_llama_prefill_workspace_bytes(C.byref(self.llama_desc), S)
             self._flush_handoff_checks("prefill")
             ws = self._workspace("prefill", need)
+            hs = torch.empty(self.cfg.num_hidden_layers + 1, S, self.cfg.hidden_size, dtype=self.dtype, device=self.device) if hidden_states else None
             L.check(self.lib.teo_llama_prefill(C.byref(self.llama_desc), _p(e), _p(pos), S, past, 1 if last_only else 0,
-                                               _p(logits), _p(ws), ws.numel(), st), "teo_llama_prefill")
+                                               _p(logits), _p(ws), ws.numel(), st, _p(hs) if hs is not None else None), "teo_llama_prefill")
             sid = C.c_void_p(self.stream.cuda_stream)
             self._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(self.llama_desc), S, _p(ws), ws.numel(),
                                                                                                   C.byref(f), sid), "teo_llama_prefill")
         self.cache_len = past + S
-        return logits
+        return (logits, hs) if hidden_states else logits
 
-    def prefill_batch(self, embeds_list):
+    def prefill_batch(self, embeds_list, hidden_states=False):
         """Training-shape forward of B independent sequences in ONE pass (teo_llama_prefill_batch, last_only = 0): embeds_list[b]
         is [S_b, D]; the rows are concatenated for the norms / GEMMs, RoPE + causal attention run per sequence on scratch KV slots
         owned by the engine (one [B, Hkv, S64, hd] buffer x 3 shared by all layers, grown on demand).  Returns fp32 logits
@@ -486,12 +489,13 @@ class TeoEngine:
             self._flush_handoff_checks("prefill")
             ws = self._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d), total))
             arr = (C.c_int * B)(*lens)
-            L.check(self.lib.teo_llama_prefill_batch(C.byref(d), _p(rows), arr, B, slot["k"].stride(0), 0, _p(logits), _p(ws), ws.numel(), st),
-                    "teo_llama_prefill_batch")
+            hs = torch.empty(c.num_hidden_layers + 1, total, c.hidden_size, dtype=self.dtype, device=self.device) if hidden_states else None
+            L.check(self.lib.teo_llama_prefill_batch(C.byref(d), _p(rows), arr, B, slot["k"].stride(0), 0, _p(logits), _p(ws), ws.numel(), st,
+                                                     _p(hs) if hs is not None else None), "teo_llama_prefill_batch")
             sid = C.c_void_p(self.stream.cuda_stream)
             self._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d), total, _p(ws), ws.numel(), C.byref(f), sid),
                                  "teo_llama_prefill_batch")
-        return logits
+        return (logits, hs) if hidden_states else logits
 
     def sample(self, logits, temperature, top_k, seed, draw, top_p=1.0):
         """One draw of the device sampler (temperature -> top-k -> softmax -> multinomial) from fp32 logits [V]."""

@@ -28,7 +28,7 @@ class CausalLMOutputWithPast(dict):
         self.__dict__ = self
 
     def to_tuple(self):
-        return tuple(v for v in (self.loss, self.logits, self.past_key_values) if v is not None)
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions) if v is not None)
 
 
 class TeoKVCache:
@@ -299,8 +299,9 @@ class LlavaLlamaForCausalLM:
                                                           labels, images)
         if inputs_embeds is None:
             inputs_embeds = self.get_model().embed_tokens(input_ids)
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        if output_attentions:
+            # the flash kernels never materialise the [H, S, S] probability maps; a caller that needs them is outside this path
+            raise NotImplementedError("output_attentions: attention maps are not materialised by the fused attention kernels")
         eng = self.engine
         B, S, _ = inputs_embeds.shape
         if past_key_values is None:
@@ -311,6 +312,10 @@ class LlavaLlamaForCausalLM:
             raise ValueError("the device KV cache holds one sequence; batched continuation is not supported")
         past = eng.cache_len
         logits = torch.zeros(B, S, self.config.vocab_size, dtype=torch.float32, device=eng.device)
+        # output_hidden_states (llava_llama.py:56-69 -> LlamaModel.forward): L + 1 tensors [B, S, D] in the model dtype -- the input
+        # embeddings, the residual stream after each layer but the last, the final-normed states; padded positions stay zero
+        hs_all = (torch.zeros(self.config.num_hidden_layers + 1, B, S, self.config.hidden_size, dtype=eng.dtype, device=eng.device)
+                  if output_hidden_states else None)
         # the rows that exist: right / left padding leaves one contiguous run of real tokens per sample (llava_arch.py:310-329); padded
         # positions keep zero logits -- the reference's values there are never consumed (their labels are IGNORE_INDEX, :320-329)
         spans = []
@@ -339,11 +344,14 @@ class LlavaLlamaForCausalLM:
                     if not torch.equal(pr.to(torch.long).cpu(), torch.arange(hi - lo)):
                         raise ValueError("batched forward supports the default position_ids (0 .. len - 1 per sample) only")
             if live:
-                out = eng.prefill_batch([inputs_embeds[b, spans[b][0]:spans[b][1]] for b in live])
+                out = eng.prefill_batch([inputs_embeds[b, spans[b][0]:spans[b][1]] for b in live], hidden_states=hs_all is not None)
+                out, hs = out if hs_all is not None else (out, None)
                 r0 = 0
                 for b in live:
                     lo, hi = spans[b]
                     logits[b, lo:hi] = out[r0:r0 + hi - lo]
+                    if hs is not None:
+                        hs_all[:, b, lo:hi] = hs[:, r0:r0 + hi - lo]
                     r0 += hi - lo
         elif spans[0] is not None:
             lo, hi = spans[0]
@@ -351,7 +359,11 @@ class LlavaLlamaForCausalLM:
             if position_ids is not None:
                 pr = position_ids[0] if position_ids.dim() == 2 else position_ids
                 pos = pr[lo:hi] if pr.shape[-1] == S else pr
-            logits[0, lo:hi] = eng.prefill(inputs_embeds[0, lo:hi], positions=pos, last_only=False)
+            out = eng.prefill(inputs_embeds[0, lo:hi], positions=pos, last_only=False, hidden_states=hs_all is not None)
+            if hs_all is not None:
+                out, hs = out
+                hs_all[:, 0, lo:hi] = hs
+            logits[0, lo:hi] = out
         loss = None
         if labels is not None:
             # N4: training-shape loss (CrossEntropyLoss over the shifted positions) on the device: row (b, s) pairs
@@ -370,7 +382,8 @@ class LlavaLlamaForCausalLM:
                                                   V, IGNORE_INDEX, st), "teo_cross_entropy")
             loss = out3[0]
         pkv = TeoKVCache(eng) if (use_cache is None or use_cache) and B == 1 else None
-        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv)
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv,
+                                     hidden_states=tuple(hs_all[i] for i in range(hs_all.shape[0])) if hs_all is not None else None)
         if return_dict is False:
             return out.to_tuple()
         return out

@@ -13,6 +13,7 @@ Fixtures (SURVEY.md section 8c list):
                    G8 KeywordsStoppingCriteria truth table
   splice.json      G3 prepare_inputs_labels_for_multimodal index plans / masks / positions / labels
   tinyA.npz/tinyB.npz  G4 ViT features, G5 projector, G6 LLaMA prefill+decode, G7 end-to-end logits
+  hidden_tiny*.npz     `output_hidden_states=True` of the same forward (round 5)
 """
 import ast
 import json
@@ -399,6 +400,33 @@ def gen_numeric(name):
           os.path.getsize(os.path.join(HERE, name + ".npz")) // 1024)
 
 
+def gen_hidden(name):
+    """Round 5: `output_hidden_states=True` of the kept forward signature (llava_llama.py:56-69) -- what the reference's forward returns in
+    `hidden_states` for the G7 inputs and for the batch-of-2 training shape: count, shapes, and 16 evenly spaced rows of every state."""
+    model, sd, (vcfg, lcfg, mm) = build_reference(name)
+    T, n_text = 2, 24
+    frames = O.synthetic_frames(T, vcfg.image_size, seed=0)
+    ids = O.synthetic_prompt_ids(n_text, T, lcfg.vocab_size, seed=1).unsqueeze(0)
+    res = model(input_ids=ids, images=frames, use_cache=True, output_hidden_states=True)
+    hs = torch.stack(list(res.hidden_states))[:, 0]              # [L + 1, S, D]
+    S = hs.shape[1]
+    sel = torch.linspace(0, S - 1, SEL_ROWS).long()
+    out = {"sd_checksum": np.float64(sd_checksum(sd)), "input_ids": ids.numpy(), "T": np.int64(T), "n_states": np.int64(hs.shape[0]),
+           "S": np.int64(S), "sel": sel.numpy(), "hidden_sel": hs[:, sel].numpy(), "hidden_sum_abs": hs.double().abs().sum((1, 2)).numpy(),
+           "logits_from_last": np.float64(float((model.lm_head(hs[-1]) - res.logits[0]).abs().max()))}
+    bids, bmask, blabels, bframes = train_batch(lcfg.vocab_size, vcfg.image_size)
+    rb = model(input_ids=bids, attention_mask=bmask, labels=blabels, images=bframes, output_hidden_states=True)
+    hb = torch.stack(list(rb.hidden_states))                     # [L + 1, 2, W, D]
+    out["batch_hidden_shape"] = np.array(hb.shape, dtype=np.int64)
+    am = model.prepare_inputs_labels_for_multimodal(bids, None, bmask, None, blabels, bframes)[2]      # mask of the spliced rows
+    out["batch_mask"] = am.numpy()
+    rows = [torch.nonzero(am[b]).flatten() for b in range(2)]
+    out["batch_rows0"], out["batch_rows1"] = rows[0][::37].numpy(), rows[1][::37].numpy()
+    out["batch_hidden0"], out["batch_hidden1"] = hb[:, 0, rows[0][::37]].numpy(), hb[:, 1, rows[1][::37]].numpy()
+    np.savez_compressed(os.path.join(HERE, "hidden_" + name + ".npz"), **out)
+    print("hidden", name, tuple(hs.shape), "lm_head(hidden[-1]) - logits:", out["logits_from_last"], "batch", tuple(hb.shape))
+
+
 from tests._tiny import train_batch  # noqa: E402  (shared with the tests that replay the fixture)
 
 
@@ -615,7 +643,7 @@ def gen_detection():
 if __name__ == "__main__":
     assert ref_import.available(), "reference tree required"
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["host", "splice", "numeric", "train", "metrics", "detection"]
+    which = sys.argv[1:] or ["host", "splice", "numeric", "train", "hidden", "metrics", "detection"]
     if "host" in which:
         gen_host()
     if "splice" in which:
@@ -625,6 +653,8 @@ if __name__ == "__main__":
             gen_numeric(nm)
         if "train" in which:
             gen_train(nm)
+        if "hidden" in which:
+            gen_hidden(nm)
     if "metrics" in which:
         gen_metrics()
     if "detection" in which:

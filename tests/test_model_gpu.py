@@ -418,6 +418,52 @@ def test_training_shape_forward_loss_matches_reference(name):
     assert bool(torch.isnan(o2.loss))
 
 
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_output_hidden_states_match_reference(name):
+    """Round 5: forward(output_hidden_states=True) returns what the reference's forward returns -- L + 1 tensors
+    [B, S, D]: input embeddings, the residual stream after each layer but the last, the final-normed states (fixture hidden_*.npz, made
+    by the imported reference) -- for one sample and for the right-padded batch of two; logits are unchanged by the flag;
+    output_attentions stays a documented NotImplementedError."""
+    g = TY.load_npz("hidden_" + name)
+    model, sd = build(name, torch.float32)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs(name)
+    frames = O.synthetic_frames(int(g["T"]), vcfg.image_size, seed=0)
+    ids = torch.from_numpy(g["input_ids"])
+    imgs = [f.to(dev) for f in frames]
+    plain = model(input_ids=ids.to(dev), images=imgs)
+    out = model(input_ids=ids.to(dev), images=imgs, output_hidden_states=True)
+    assert plain.hidden_states is None and torch.equal(plain.logits, out.logits)
+    hs = out.hidden_states
+    assert isinstance(hs, tuple) and len(hs) == int(g["n_states"]) and all(h.shape == (1, int(g["S"]), lcfg.hidden_size) for h in hs)
+    got = torch.stack(hs)[:, 0].cpu()
+    d = float((got[:, torch.from_numpy(g["sel"])] - torch.from_numpy(g["hidden_sel"])).abs().max())
+    print(f"[{name}] hidden states max abs diff vs reference: {d:.2e}")
+    assert d < FP32_TOL
+    np.testing.assert_allclose(got.double().abs().sum((1, 2)).numpy(), g["hidden_sum_abs"], rtol=1e-5)
+    assert len(out.to_tuple()) == len(plain.to_tuple()) + 1
+    # batch of two (one pass over the concatenated rows): real rows equal the reference's, padded rows stay zero
+    bids, bmask, blabels, bframes = TY.train_batch(lcfg.vocab_size, vcfg.image_size)
+    ob = model(input_ids=bids.to(dev), attention_mask=bmask.to(dev), labels=blabels.to(dev), images=[f.to(dev) for f in bframes],
+               output_hidden_states=True)
+    hb = torch.stack(ob.hidden_states).cpu()
+    assert list(hb.shape) == g["batch_hidden_shape"].tolist()
+    for b in range(2):
+        rows = torch.from_numpy(g[f"batch_rows{b}"])
+        db = float((hb[:, b, rows] - torch.from_numpy(g[f"batch_hidden{b}"])).abs().max())
+        assert db < FP32_TOL, (b, db)
+    pad = torch.from_numpy(g["batch_mask"]) == 0
+    assert bool(pad[0].any()) and float(hb[:, 0][:, pad[0]].abs().max()) == 0.0
+    # the last-position-only path (generate's prefill) is not what returns hidden states; bf16 engines return bf16 snapshots
+    m16, _ = build(name, torch.bfloat16)
+    o16 = m16(input_ids=ids.to(dev), images=[f.to(dev, torch.bfloat16) for f in frames], output_hidden_states=True)
+    assert o16.hidden_states[0].dtype == torch.bfloat16
+    rel = float((torch.stack(o16.hidden_states)[:, 0].float().cpu() - got).abs().max()) / float(got.abs().max())
+    assert rel < 3e-2, rel
+    with pytest.raises(NotImplementedError, match="output_attentions"):
+        model(input_ids=ids.to(dev), images=imgs, output_attentions=True)
+
+
 @pytest.mark.parametrize("name", ["tinyA"])
 def test_cls_patch_select_feature(name):
     """feature_select 'cls_patch' (languagebind/__init__.py:125-126): the CLS row stays -> [T, 257, D]; rows 1.. equal the

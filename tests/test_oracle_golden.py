@@ -155,6 +155,27 @@ def test_bf16_boundary_mode_is_close_to_reference_bf16(name):
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_oracle_hidden_states_match_reference(name):
+    """Round 5: `output_hidden_states=True` of the kept forward signature (llava_llama.py:56-69): the reference's tuple (fixture
+    hidden_*.npz made by make_golden.py `hidden`) = input embeddings, residual stream after each layer but the last, final-normed
+    states; the oracle collects the same L + 1 tensors."""
+    g = TY.load_npz("hidden_" + name)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd = TY.state_dict(name)
+    assert abs(TY.sd_checksum(sd) - float(g["sd_checksum"])) < 1e-6 * float(g["sd_checksum"])
+    frames = O.synthetic_frames(int(g["T"]), vcfg.image_size, seed=0)
+    ids = torch.from_numpy(g["input_ids"])
+    hs = []
+    logits, _, _ = O.mm_forward(ids, frames, sd, vcfg, lcfg, mm, hidden_states=hs)
+    assert len(hs) == int(g["n_states"]) == lcfg.num_hidden_layers + 1 and float(g["logits_from_last"]) == 0.0
+    got = torch.stack(hs)[:, 0]
+    assert got.shape[1] == int(g["S"])
+    np.testing.assert_allclose(got[:, torch.from_numpy(g["sel"])].numpy(), g["hidden_sel"], atol=2e-5)
+    np.testing.assert_allclose(got.double().abs().sum((1, 2)).numpy(), g["hidden_sum_abs"], rtol=1e-5)
+    assert float((O._lin(hs[-1], sd["lm_head.weight"]) - logits).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
 def test_oracle_training_shape_loss_matches_reference(name):
     """N4: batch of 2, right padding, labels -> the reference's loss and logits (tests/golden/train_*.npz)."""
     g = TY.load_npz("train_" + name)

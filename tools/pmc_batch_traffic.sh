@@ -2,11 +2,11 @@
 # HBM traffic of the kernels of the BATCHED decode step (config C5 per GPU: 8 conversations, fp8 weights) from PMC counters inside a real
 # bench.py run -- the batched counterpart of tools/pmc_decode_traffic.sh, same recipe (MI355X_MICROARCH.md section HBM: separate rocprofv3
 # --pmc passes with nothing but --kernel-trace beside them, FETCH_SIZE doubled on gfx950, WRITE_SIZE as is, TCC_EA0_RDREQ_sum x 128 B as the
-# cross-check; the program itself follows `--`).  Writes gpurun_out/r04p/r04_pmc_batch_traffic.json.
+# cross-check; the program itself follows `--`).  Writes gpurun_out/r05p/r05_pmc_batch_traffic.json.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 COMMIT=${1:-unknown}
-mkdir -p $ROOT/gpurun_out/r04p
+mkdir -p $ROOT/gpurun_out/r05p
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum; do
   rm -rf /tmp/pmcb8_$C
@@ -32,7 +32,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum"):
     rows = list(cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (c,)))
     raw[c] = {r[0]: (r[1], r[2]) for r in rows}
 out = {"source": "tools/pmc_batch_traffic.sh: three separate rocprofv3 --kernel-trace --pmc passes over `python3 bench.py --steps 1 --warmup 0 --new 12 --no-cpu-baseline --no-graph --batch 8 --weights fp8`",
-       "commit": sys.argv[1], "correction": "gfx950: read bytes = 2 * FETCH_SIZE * 1024 (128-B requests tallied at 64 B) + WRITE_SIZE * 1024; cross-check TCC_EA0_RDREQ_sum * 128 B",
+       "commit": sys.argv[1], "csrc_sha16": __import__("subprocess").check_output(["python3", os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/tools/src_hash.py"]).decode().strip(),
+       "correction": "gfx950: read bytes = 2 * FETCH_SIZE * 1024 (128-B requests tallied at 64 B) + WRITE_SIZE * 1024; cross-check TCC_EA0_RDREQ_sum * 128 B",
        "kernels": {}, "all_teo_kernels": sorted(n[:120] for n in raw.get("FETCH_SIZE", {}) if "teo::" in n and ("skinny" in n or "attn_decode" in n))}
 for key, (match, alg) in KERNELS.items():
     e = {"algorithmic_bytes": alg}
@@ -47,6 +48,6 @@ for key, (match, alg) in KERNELS.items():
         e["error"] = str(ex)
     out["kernels"][key] = e
 out["hbm_bytes_per_launch"] = out["kernels"].get("attn_decode_whole", {}).get("hbm_bytes_per_launch")        # the dominant kernel of this step
-json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r04p/r04_pmc_batch_traffic.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r05p/r05_pmc_batch_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:4000])
 PY

@@ -2,11 +2,11 @@
 # HBM traffic of EVERY kernel of the decode step from PMC counters, inside a real bench.py run (round 3).
 # Collected as MI355X_MICROARCH.md (section HBM) prescribes: separate rocprofv3 --pmc passes (nothing but --kernel-trace beside
 # them), FETCH_SIZE doubled on gfx950 (128-B requests are tallied at 64 B), WRITE_SIZE as is, TCC_EA0_RDREQ_sum x 128 B as the
-# cross-check.  The program itself follows `--` (no wrapper hop).  Writes gpurun_out/r04p/r04_pmc_decode_traffic.json.
+# cross-check.  The program itself follows `--` (no wrapper hop).  Writes gpurun_out/r05p/r05_pmc_decode_traffic.json.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 COMMIT=${1:-unknown}
-mkdir -p $ROOT/gpurun_out/r04p
+mkdir -p $ROOT/gpurun_out/r05p
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum; do
   rm -rf /tmp/pmcd_$C
@@ -33,7 +33,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_RDREQ_sum"):
     rows = list(cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (c,)))
     raw[c] = {r[0]: (r[1], r[2]) for r in rows}
 out = {"source": "tools/pmc_decode_traffic.sh: three separate rocprofv3 --kernel-trace --pmc passes over `python3 bench.py --steps 1 --warmup 0 --new 12 --no-cpu-baseline --no-graph` (rounds 3-4)",
-       "commit": sys.argv[1], "correction": "gfx950: read bytes = 2 * FETCH_SIZE * 1024 (128-B requests tallied at 64 B) + WRITE_SIZE * 1024; cross-check TCC_EA0_RDREQ_sum * 128 B",
+       "commit": sys.argv[1], "csrc_sha16": __import__("subprocess").check_output(["python3", os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/tools/src_hash.py"]).decode().strip(),
+       "correction": "gfx950: read bytes = 2 * FETCH_SIZE * 1024 (128-B requests tallied at 64 B) + WRITE_SIZE * 1024; cross-check TCC_EA0_RDREQ_sum * 128 B",
        "kernels": {}}
 for key, (match, alg) in KERNELS.items():
     e = {"algorithmic_bytes": alg}
@@ -51,6 +52,6 @@ for key, (match, alg) in KERNELS.items():
 gu = out["kernels"].get("gateup_gemv", {})
 out["hbm_bytes_per_launch"] = gu.get("hbm_bytes_per_launch")        # the dominant kernel: bench.py's roofline.traffic
 out["kernel"] = "gemv_kernel<bf16,bf16,R=2,U=4,NT,SWIGLU> N=22016 K=4096 (decode rmsnorm + gate/up + SwiGLU)"
-json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r04p/r04_pmc_decode_traffic.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r05p/r05_pmc_decode_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:3000])
 PY
