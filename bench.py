@@ -301,6 +301,9 @@ def main():
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
+    if os.environ.get("TEO_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        # test hook (tests/test_bench_contract_gpu.py): a rank other than 0 dies -> the launcher must end the job with a non-zero code
+        raise SystemExit(f"rank {rank}: TEO_BENCH_FAIL_RANK set")
     if world > 1 and dist.get_world_size() != args.gpus:
         raise SystemExit(f"{dist.get_world_size()} ranks joined the process group, --gpus says {args.gpus}")
     from teochat_amd import _lib as L
@@ -383,7 +386,21 @@ def main():
     if args.shard_frames:
         # C4: every rank encodes its block of frames; with the nccl backend the gather is the library's RCCL all-gather
         # (teo_allgather_visual, no torch collective on the data path); gloo only for the one-GPU plumbing test
-        model.get_model().image_tower.shard_frames(comm)
+        tower = model.get_model().image_tower
+        tower.shard_frames(comm)
+        # outside the timed region: the gathered features of THIS rank equal the unsharded encode of all T frames bit for bit, in
+        # chronological order (rank order = frame order: `cur_image_idx` consumption, llava_arch.py:284-285) -- on every rank
+        pix_all = torch.stack(frames)
+        feats_sharded = tower(pix_all)
+        feats_whole = eng.vit_features(pix_all).to(pix_all.dtype)
+        shard_ok = bool(torch.equal(feats_sharded, feats_whole))
+        flag = torch.tensor([1 if shard_ok else 0], dtype=torch.int32, device=device if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        from teochat_amd.parallel import frame_partition
+        shard_check = {"frames_per_rank": [c_ for _, c_ in frame_partition(T, world)],
+                       "gathered_equals_unsharded_on_every_rank": bool(int(flag.item()) == 1)}
+        if not shard_check["gathered_equals_unsharded_on_every_rank"]:
+            raise SystemExit("frame-sharded tower: gathered features differ from the unsharded encode")
 
     B = args.batch
     if B > 1:
@@ -695,6 +712,8 @@ def main():
         "phases": phases,
         "roofline": roofline,
     }
+    if args.shard_frames:
+        result["shard_frames_check"] = shard_check
     result["rccl_ranks"] = rccl_info["rccl_ranks"] if rccl_info else (1 if world == 1 else None)
     if rccl_info:
         result["rccl"] = rccl_info

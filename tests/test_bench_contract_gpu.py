@@ -79,7 +79,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]              # only rank 0 prints
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and (d["cpu_baseline"] is None or d["cpu_baseline"]["measured_at"] == "n_gpus = 1")
     assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]      # both ranks' tokens over the max time
     assert "dp2" in d["config"]["parallelism"]
 
@@ -98,6 +98,55 @@ def test_bench_gpus2_without_a_launcher_starts_two_ranks_itself():
     assert d["n_gpus"] == 2 and "dp2" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     assert "rccl_ranks" in d and d["rccl_ranks"] is None        # gloo plumbing run: no RCCL communicator was built
+
+
+def _bench(flags, timeout=1500, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + flags, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    return r, lines
+
+
+def test_bench_eight_ranks_c4_partition_on_one_gpu():
+    """Round 5 (VERDICT r04 "Next round" #5): config C4's REAL partition -- T = 16 frames, 2 frames per rank x 8 ranks, rank order =
+    chronological order (llava_arch.py:284-285 consumes the features in order) -- with all eight ranks on this one GPU (8 bf16 replicas
+    = 8 x 14.2 GB of 288 GB) over gloo; the reference is single-GPU (scripts/eval_teochat.sh:9-10), the split is this build's own.
+    bench.py itself checks, on every rank, that the gathered features equal the unsharded tower's bit for bit.  No scaling number is
+    claimed from this: eight ranks share one GPU."""
+    r, lines = _bench(["--gpus", "8", "--same-gpu", "--dist-backend", "gloo", "--shard-frames", "--frames", "16", "--new", "8",
+                       "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["frames"] == 16 and d["config"]["sequence_len"] == 128 - 16 + 16 * 256
+    assert "frame-sharded" in d["config"]["parallelism"]
+    assert d["shard_frames_check"] == {"frames_per_rank": [2] * 8, "gathered_equals_unsharded_on_every_rank": True}
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]          # ONE conversation: the ranks replicate the LLM
+    assert d["cpu_baseline"] is None or d["cpu_baseline"].get("measured_at") == "n_gpus = 1"
+
+
+def test_bench_eight_data_parallel_ranks_on_one_gpu():
+    """The driver's SCALE form at N = 8 (`python bench.py --gpus 8`, conversation-level data parallel, weak scaling) as far as one GPU
+    can take it: eight ranks, eight different conversations, barrier + max-over-ranks time, whole-job value, and the N = 1 cpu_baseline
+    carried by reference instead of null."""
+    r, lines = _bench(["--gpus", "8", "--same-gpu", "--dist-backend", "gloo", "--batch", "1", "--frames", "2", "--prompt", "32", "--new", "8",
+                       "--steps", "1", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "dp8" in d["config"]["parallelism"]
+    assert abs(d["value"] - 8 * 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]      # all ranks' tokens over the slowest rank's time
+    cb = d["cpu_baseline"]
+    assert cb is not None and cb["measured_at"] == "n_gpus = 1" and cb["value"] > 0 and cb["from_profiles"].startswith("profiles/")
+
+
+def test_a_failing_rank_fails_the_whole_bench():
+    """rank != 0 dying must surface in the exit code of `python bench.py --gpus N` (the launcher ends the job); no JSON line is printed."""
+    r, lines = _bench(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--frames", "2", "--prompt", "32", "--new", "8", "--steps", "1",
+                       "--warmup", "0", "--no-cpu-baseline"], timeout=900, extra_env={"TEO_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not lines, r.stdout[-1000:]
 
 
 def test_bench_refuses_more_ranks_than_gpus():

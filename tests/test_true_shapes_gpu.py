@@ -31,9 +31,25 @@ from teochat_amd.engine import interleave_gate_up, rope_tables
 from tests import _gpu as G
 
 pytestmark = pytest.mark.gpu
-bf = torch.bfloat16
+bf = torch.bfloat16          # the 16-bit format under test: the `fmt` fixture below switches it (and FMT) to IEEE half for the fp16 legs
 DEV = "cuda:0"
 N_LAYERS_DEEP = 3            # (b): LLaMA layers at full width
+# round 5 (VERDICT r04 "Next round" #2): every test of this file runs in BOTH 16-bit formats -- bfloat16 and the reference's own
+# inference type, IEEE binary16 (model/builder.py:104-105, eval/inference.py:53).  name = the oracle's rounding mode, mant = mantissa
+# bits incl. the hidden one (what one ulp is), dt = the C ABI's dtype code
+_FORMATS = {"bf16": dict(name="bf16", dtype=torch.bfloat16, mant=8, dt=L.TEO_BF16), "fp16": dict(name="fp16", dtype=torch.float16, mant=11, dt=L.TEO_F16)}
+FMT = dict(_FORMATS["bf16"])
+
+
+@pytest.fixture(params=["bf16", "fp16"])
+def fmt(request):
+    global bf
+    old = dict(FMT), bf
+    FMT.clear(); FMT.update(_FORMATS[request.param])
+    bf = FMT["dtype"]
+    yield request.param
+    FMT.clear(); FMT.update(old[0])
+    bf = old[1]
 
 
 def R(t):
@@ -59,7 +75,7 @@ def ulp_check(got, ref, tag, report, kernel=True, abs_tol=FP32_SUM_ABS):
     ulps."""
     got = got.float().cpu().reshape(ref.shape)
     d = (got - ref).abs()
-    ulp = G.ulp16(ref)
+    ulp = G.ulp16(ref, FMT['mant'])
     if torch.is_tensor(abs_tol):
         abs_tol = abs_tol.float().reshape(ref.shape)
     bad = int((d > ulp + abs_tol).sum())
@@ -75,7 +91,7 @@ def attn_p_noise(q, k, v, visible, scale):
     scores to bf16 before the PV product, each at its own 1-ulp-different value, so an output moves by up to
     2^-8 * sum_j p_j |v_j| whatever its own magnitude (outputs of late causal rows are sums of ~2000 terms that largely cancel).
     Returned in the layout attention_core returns ([B, H, S, d])."""
-    return (2.0 ** -8) * O.attention_core(q, k, v.abs(), visible, scale, lambda t: t, "exact")
+    return (2.0 ** -FMT['mant']) * O.attention_core(q, k, v.abs(), visible, scale, lambda t: t, "exact")
 
 
 def _rand(shape, gen, std=1.0):
@@ -127,7 +143,7 @@ def gemm_all_families(gw, A, W, ref, tag, report, families=FAMILIES, **kw):
 
 
 # ------------------------------------------------------------------------------------------------------------ (a) LLaMA
-def test_llama_layer_walk_at_7b_shapes():
+def test_llama_layer_walk_at_7b_shapes(fmt):
     _threads()
     t0 = time.perf_counter()
     report = []
@@ -161,7 +177,7 @@ def test_llama_layer_walk_at_7b_shapes():
     vc, vtc = torch.zeros_like(kc), torch.zeros(H, hd, S_max, dtype=bf, device=DEV)
     d_pos, d_cs, d_sn = pos.int().to(DEV), cs.to(DEV), sn.to(DEV)
     L.check(G.lib().teo_rope_kv_append(G.p(d_qkv), 3 * D, G.p(d_pos), G.p(d_cs), G.p(d_sn), G.p(kc), G.p(vc), G.p(vtc), S, 0, S_max,
-                                       H, H, hd, L.TEO_BF16, G.stream()), "rope")
+                                       H, H, hd, FMT['dt'], G.stream()), "rope")
     ulp_check(d_qkv[:, :D].reshape(S, H, hd), qr, "RoPE q", report, kernel=False)
     ulp_check(kc[:, :S].transpose(0, 1), kr, "RoPE k -> K cache", report, kernel=False)
     assert torch.equal(vc[:, :S].transpose(0, 1).cpu().float(), v), "V cache rows"
@@ -177,7 +193,7 @@ def test_llama_layer_walk_at_7b_shapes():
     a.q_hs, a.q_rs, a.k_hs, a.k_rs, a.v_hs, a.v_rs = hd, D, S_max * hd, hd, S_max * hd, hd
     a.vt_hs, a.vt_rs, a.o_rs = hd * S_max, S_max, D
     a.batch, a.heads, a.kv_heads, a.head_dim, a.q_len, a.kv_len, a.causal, a.scale = 1, H, H, hd, S, S, 1, 1 / math.sqrt(hd)
-    L.check(G.lib().teo_attention(C.byref(a), L.TEO_BF16, G.stream()), "attn")
+    L.check(G.lib().teo_attention(C.byref(a), FMT['dt'], G.stream()), "attn")
     assert G.lib().teo_last_kernel() == b"attn_flash32"
     ulp_check(o_k, o_ref, "causal flash attention L=2168 H=32 d=128", report,
               abs_tol=attn_p_noise(qq, kk, vv, vis, 1 / math.sqrt(hd)).transpose(1, 2).reshape(S, D) + FP32_SUM_ABS)
@@ -214,7 +230,7 @@ def test_llama_layer_walk_at_7b_shapes():
     posd = torch.tensor([n_keys - 1], dtype=torch.int32, device=DEV)
     d_qd = G.dev(qd.reshape(D), bf)
     L.check(lib.teo_attn_decode(G.p(d_qd), G.p(kc), G.p(vc), None, None, None, G.p(out), G.p(part), G.p(posd), S_max, H,
-                                H, hd, 1.0 / math.sqrt(hd), L.TEO_BF16, 1, D, H * S_max * hd, D, G.stream()), "attn_decode")
+                                H, hd, 1.0 / math.sqrt(hd), FMT['dt'], 1, D, H * S_max * hd, D, G.stream()), "attn_decode")
     o_dec = R(O.attention_core(qd[None, :, None, :], kk, vv, None, 1 / math.sqrt(hd), R, "split64")[0, :, 0].reshape(D))
     ulp_check(out, o_dec, "decode attention ctx=2168 (split-KV + combine)", report, kernel=False,
               abs_tol=attn_p_noise(qd[None, :, None, :], kk, vv, None, 1 / math.sqrt(hd))[0, :, 0].reshape(D) + FP32_SUM_ABS)
@@ -227,12 +243,12 @@ def test_llama_layer_walk_at_7b_shapes():
     err = float((lg.cpu().double() - want).abs().max()) / float(want.abs().max())
     report.append(f"  {'decode GEMV rmsnorm + lm_head (fp32 logits) N=32000':<58s} max|d|/max|logit| {err:.2e}")
     assert err < 1e-5
-    print("\n[7B-shape LLaMA layer walk, every kernel fed the oracle's input]\n" + "\n".join(report)
+    print(f"\n[7B-shape LLaMA layer walk in {fmt}, every kernel fed the oracle's input]\n" + "\n".join(report)
           + f"\n  wall {time.perf_counter() - t0:.1f} s")
 
 
 # ------------------------------------------------------------------------------------------------------------ (a) ViT + projector
-def test_vit_layer_and_projector_walk_at_vit_l14_shapes():
+def test_vit_layer_and_projector_walk_at_vit_l14_shapes(fmt):
     _threads()
     t0 = time.perf_counter()
     report = []
@@ -250,7 +266,7 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes():
     pw_pad[:, :588] = pw.reshape(D, 588)
     d_out = torch.empty(T * 256, D, dtype=bf, device=DEV)
     d_px, d_pw = G.dev(px, bf), G.dev(pw_pad, bf)            # (device operands are kept in variables: a temporary would be freed,
-    L.check(lib.teo_patch_embed(G.p(d_px), G.p(d_pw), G.p(d_out), T, 3, 224, 14, 640, D, L.TEO_BF16, G.stream()),   # and its block reused, before the launch)
+    L.check(lib.teo_patch_embed(G.p(d_px), G.p(d_pw), G.p(d_out), T, 3, 224, 14, 640, D, FMT['dt'], G.stream()),   # and its block reused, before the launch)
             "patch_embed")
     assert lib.teo_last_kernel() == b"patch_embed_mfma"
     ulp_check(d_out, patches, "patch embedding (fused gather + MFMA) K=588", report)
@@ -262,7 +278,7 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes():
     d_h0 = torch.empty(T * N, D, dtype=bf, device=DEV)
     dv = [G.dev(t, bf) for t in (patches, cls, posw, g0, b0)]
     L.check(lib.teo_vit_embed_ln(G.p(dv[0]), G.p(dv[1]), G.p(dv[2]), G.p(dv[3]), G.p(dv[4]),
-                                 G.p(d_h0), T, 256, D, 1e-5, L.TEO_BF16, G.stream()), "vit_embed_ln")
+                                 G.p(d_h0), T, 256, D, 1e-5, FMT['dt'], G.stream()), "vit_embed_ln")
     ulp_check(d_h0, h0, "CLS + position embedding + pre-LayerNorm", report, kernel=False)
     # one encoder layer at M = T * 257 = 2056
     h = _rand((T * N, D), gen)
@@ -305,7 +321,7 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes():
                       bias=G.dev(pb0, bf), act=L.ACT_GELU_ERF)
     outp = R(mid @ p2.t() + pb2)
     gemm_all_families(gw, G.dev(mid, bf), G.dev(p2, bf), outp, "projector.2 + bias 4096->4096", report, families=fam, bias=G.dev(pb2, bf))
-    print("\n[ViT-L/14 layer + projector walk at T=8, every kernel fed the oracle's input]\n" + "\n".join(report)
+    print(f"\n[ViT-L/14 layer + projector walk at T=8 in {fmt}, every kernel fed the oracle's input]\n" + "\n".join(report)
           + f"\n  wall {time.perf_counter() - t0:.1f} s")
 
 
@@ -335,7 +351,7 @@ def _stats(got, ref):
 
 
 @pytest.mark.parametrize("T,n_out,tag", [(2, 128, "C2"), (8, 256, "C3")])
-def test_c2_c3_prefill_and_decode_against_the_oracle_at_full_width(T, n_out, tag):
+def test_c2_c3_prefill_and_decode_against_the_oracle_at_full_width(T, n_out, tag, fmt):
     """ViT-L/14 (23 layers) + projector + splice + LLaMA at 7B width, N_LAYERS_DEEP layers: prefill logits of EVERY position and 8
     teacher-forced decode steps against the oracle, bf16 and fp32."""
     _threads()
@@ -376,32 +392,37 @@ def test_c2_c3_prefill_and_decode_against_the_oracle_at_full_width(T, n_out, tag
     # ---- bf16 engine vs the boundary-rounded oracle
     g_pre, g_dec = gpu_run(m16, bf)
     assert g_pre.shape == (Lseq, 32000)
-    o_pre, o_dec = oracle_run("bf16", torch.float32)
+    o_pre, o_dec = oracle_run(FMT["name"], torch.float32)
     mx, p99, med, sc = _stats(g_pre, o_pre)
     dmx, dp99, dmed, _ = _stats(g_dec, o_dec)
     agree = float((g_pre.argmax(-1) == o_pre.argmax(-1)).float().mean())
-    print(f"\n[{tag} bf16, {N_LAYERS_DEEP} LLaMA layers at 7B width, L={Lseq}] prefill logits vs oracle(bf16 boundaries), |d|/max|logit| "
+    print(f"\n[{tag} {fmt}, {N_LAYERS_DEEP} LLaMA layers at 7B width, L={Lseq}] prefill logits vs oracle({fmt} boundaries), |d|/max|logit| "
           f"(max|logit| {sc:.2f}): max {mx:.2e}  p99 {p99:.2e}  median {med:.2e};  argmax agreement {agree * 100:.1f} % of {Lseq} rows;  "
           f"8 teacher-forced decode steps: max {dmx:.2e}  p99 {dp99:.2e}  median {dmed:.2e}")
     # bars = measured + ~35 % (round 3, MI355X: C2 max 2.26e-2 / p99 8.9e-3 / median 2.1e-3, decode steps 1.05e-2; C3 2.21e-2 / 8.1e-3 /
     # 2.0e-3, decode 8.5e-3).  This is rounding noise, not error: every kernel is within 1 ulp of the oracle on every element
     # (the walks above), ~0.05-0.3 % of a kernel's outputs land on the other side of a bf16 rounding boundary, and 26 layers x ~8
     # kernels of such flips random-walk to a per-logit sigma of ~3e-3 of max|logit| -- the max over 7e7 logits is a 5.7-sigma event.
-    assert mx < 3e-2 and p99 < 1.2e-2 and med < 3e-3 and dmx < 1.5e-2
+    # fp16 (round 5, three more mantissa bits; measured on MI355X: see BASELINE.md section 4): the same statement an order of magnitude
+    # lower -- and the format in which north_star's 1e-3 is met by the p99 and the median, though not by the maximum over 2e7-7e7 logits
+    bars = {"bf16": (3e-2, 1.2e-2, 3e-3, 1.5e-2), "fp16": (4e-3, 1.6e-3, 4e-4, 2.5e-3)}[fmt]
+    assert mx < bars[0] and p99 < bars[1] and med < bars[2] and dmx < bars[3], (mx, p99, med, dmx)
     # ---- the control (tests/test_noise_floor.py): the oracle against ITSELF with only the fp32 summation order of its Linear layers
     # changed (K in 8 chunks, descending, vs the single matmul above) -- the HIP path may differ from the oracle by at most 1.5x what
     # the oracle differs from itself by, statistic by statistic.  That is a parity statement, not a regression guard.
     try:
         O.K_ORDER = (8, True)
-        s_pre, _, _ = O.mm_forward(ids, frames, sd, vcfg, lcfg, mm, None, "bf16", torch.float32)
+        s_pre, _, _ = O.mm_forward(ids, frames, sd, vcfg, lcfg, mm, None, FMT["name"], torch.float32)
     finally:
         O.K_ORDER = None
     smx, sp99, smed, _ = _stats(s_pre[0], o_pre)
-    print(f"[{tag} bf16] oracle vs itself (K order changed, nothing else): max {smx:.2e}  p99 {sp99:.2e}  median {smed:.2e};  "
+    print(f"[{tag} {fmt}] oracle vs itself (K order changed, nothing else): max {smx:.2e}  p99 {sp99:.2e}  median {smed:.2e};  "
           f"HIP / self: max {mx / smx:.2f}x  p99 {p99 / sp99:.2f}x  median {med / smed:.2f}x")
     assert mx <= 1.5 * smx and p99 <= 1.5 * sp99 and med <= 1.5 * smed, (mx, smx, p99, sp99, med, smed)
     del m16
     torch.cuda.empty_cache()
+    if fmt != "bf16":
+        return                                                       # the fp32 leg below does not depend on the 16-bit format: run once
     # ---- fp32 engine (same bf16-valued weights) vs the oracle in fp64: north_star's 1e-5
     m32, _, _ = _full_width_model(N_LAYERS_DEEP, torch.float32, Lseq + n_out + 8, sd=sd_dev)
     g_pre, g_dec = gpu_run(m32, torch.float32)
@@ -497,7 +518,7 @@ def test_w8a8_prefill_layer_walk_at_7b_shapes():
         out = torch.empty(S, Nc, dtype=bf, device=DEV)
         d_res = G.dev(res, bf) if res is not None else None
         L.check(lib.teo_gemm_fp8_ws(G.p(A8), G.p(sa), G.p(q8.to(DEV)), G.p(sw.to(DEV)), G.p(d_res), G.p(out), S, N, x.shape[1], x.shape[1], Nc,
-                                    flags, L.TEO_BF16, G.p(gw.ws), G.stream()), "gemm_fp8_ws")
+                                    flags, FMT['dt'], G.p(gw.ws), G.stream()), "gemm_fp8_ws")
         kern = lib.teo_last_kernel().decode()
         return x_dq, Wdq, out, same, kern
 
@@ -506,7 +527,7 @@ def test_w8a8_prefill_layer_walk_at_7b_shapes():
         DESIGN.md section 5; an fp32 FMA chain would need 1e-7) -- `sum_abs` is that bound per element, computed from the operands"""
         got = out.float().cpu()
         d = (got - ref).abs()
-        ulp = G.ulp16(ref)
+        ulp = G.ulp16(ref, FMT['mant'])
         bad = int((d > ulp + sum_abs + FP32_SUM_ABS).sum())
         worst = float((d / ulp).max())
         report.append(f"  {tag:<44s} kernel={kern:<18s} quantiser bytes equal {same * 100:7.3f} %  worst {worst:5.2f} ulp  beyond 1 ulp + 3e-5 sum|a||w|: {bad} of {d.numel()}")

@@ -318,6 +318,105 @@ static void launch32(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, 
     lab32_kernel<P><<<tm * tn, 512, lds, st>>>(A, W, C, M, N, K, tm, tn, trace);
 }
 
+// ---- narrow tile: BM (64 / 128) x 128 x 64, 4 waves (2 x 2), LDS-DMA ring of NS stages, one barrier per K tile -- for the few-tiles / long-K and
+// short-K problems of the ViT tower (fc2 / out_proj run on 64 x 128 register-staged tiles today: 0.78 us per K step, latency-bound) --------------
+template <int TBM, int NS, int SCHED>
+__global__ __launch_bounds__(256) void lab_narrow_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* __restrict__ C, int M, int N,
+                                                         int K, int tiles_m, int tiles_n) {
+    constexpr int TBN = 128;
+    constexpr int A_B = TBM * 128, STG = A_B + TBN * 128;            // bytes: 128-byte rows (64 k)
+    constexpr int NP = STG / 1024 / 4;                                // 1-KiB pieces per wave per K tile (6 for 64 x 128, 8 for 128 x 128)
+    constexpr int MI = TBM / 32;                                      // 16-row A fragments per wave (wave tile TBM/2 x 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / 64;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const bf16_t* src[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int g = wid * NP + j;                                   // piece g: 8 rows; g < TBM / 8: A rows, else W rows
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        if (g < TBM / 8) src[j] = A + (long long)min(m0 + g * 8 + rl, M - 1) * K + c * 8;
+        else src[j] = W + (long long)min(n0 + (g - TBM / 8) * 8 + rl, N - 1) * K + c * 8;
+    }
+#define NSTAGE(KT, ST)                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < NP; ++j)                                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long long)(KT) * 64),        \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * STG + (wid * NP + j) * 1024), 16, 0, 0);
+    f32x4 acc[4][MI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nk) { NSTAGE(s0, s0) }
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of tile kt landed (NS - 2 later tiles may still fly), then everybody's; stage (kt - 1) % NS is free
+        const int ahead = min(nk - 1 - kt, NS - 2);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int stn = (st + NS - 1) % NS;                           // stage of tile kt + NS - 1 == the one tile kt - 1 used
+        if (SCHED == 0 && kt + NS - 1 < nk) { NSTAGE(kt + NS - 1, stn) }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* sA = smem + st * STG;
+        const unsigned char* sB = sA + A_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MI], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rw_ = wn * 64 + i * 16 + fr;
+                wf[i] = *reinterpret_cast<const bf16x8*>(sB + rw_ * 128 + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ra_ = wm * (TBM / 2) + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(sA + ra_ * 128 + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
+            }
+            if (SCHED == 1 && ks == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + NS - 1 < nk) { NSTAGE(kt + NS - 1, stn) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
+        }
+        st = st + 1 == NS ? 0 : st + 1;
+    }
+#undef NSTAGE
+    const int mw = m0 + wm * (TBM / 2), nw = n0 + wn * 64;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = nw + ni * 16 + fg * 4;
+            if (n >= N) continue;
+            *reinterpret_cast<uint2*>(C + (long long)m * N + n) = make_uint2(pack_bf2(acc[ni][mi][0], acc[ni][mi][1]), pack_bf2(acc[ni][mi][2], acc[ni][mi][3]));
+        }
+    }
+}
+template <int TBM, int NS, int SCHED>
+static void launch_narrow(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, unsigned long long*, hipStream_t st) {
+    const int tm = (M + TBM - 1) / TBM, tn = (N + 127) / 128;
+    const size_t lds = (size_t)NS * (TBM * 128 + 128 * 128);
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_narrow_kernel<TBM, NS, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    lab_narrow_kernel<TBM, NS, SCHED><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn);
+}
+
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint64_t xorshift() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 static bf16_t rnd_bf16(float scale) {
@@ -343,18 +442,25 @@ static void launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, in
 typedef void (*launch_fn)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int, unsigned long long*, hipStream_t);
 #define BV(SKEW, PRIO, LPOS) (128 + (SKEW) + ((PRIO) << 2) + ((LPOS) << 5))
 static launch_fn LAUNCH[] = {launch<0>, launch<3>, launch<BV(0, 2, 0)>, launch<BV(0, 3, 0)>, launch<BV(0, 4, 0)>, launch<BV(2, 1, 0)>, launch<BV(2, 2, 0)>,
-                             launch32<0>, launch32<1>, launch32<2>};
-static const char* VNAME[] = {"base", "E47p1", "L03p1", "E47p2", "E47p3", "swap+47p1", "swap+03p1", "k32 spread", "k32 before", "k32 after"};
-constexpr int NV = 10;
+                             launch_narrow<64, 3, 0>, launch_narrow<64, 3, 1>, launch_narrow<64, 4, 0>, launch_narrow<64, 2, 0>, launch_narrow<128, 2, 0>, launch_narrow<128, 3, 0>, launch_narrow<128, 3, 1>};
+static const char* VNAME[] = {"big", "E47p1", "L03p1", "E47p2", "E47p3", "swap+47p1", "swap+03p1", "n64 s3", "n64 s3 mid", "n64 s4", "n64 s2", "n128 s2", "n128 s3", "n128 s3 mid"};
+constexpr int NV = 14;
 
 int main(int argc, char** argv) {
     const bool do_trace = argc > 1 && !strcmp(argv[1], "trace");
     struct Shape { const char* name; int M, N, K; };
-    const Shape shapes[] = {{"sq4096", 4096, 4096, 4096}, {"2r 4096x8192x4096", 4096, 8192, 4096}, {"sq8192", 8192, 8192, 8192},
-                            {"qkv2048", 2048, 12288, 4096}, {"gateup2048 (2.69 rounds)", 2048, 22016, 4096}};
+    const bool narrow = argc > 1 && !strcmp(argv[1], "narrow");
+    const Shape shapes_big[] = {{"sq4096", 4096, 4096, 4096}, {"2r 4096x8192x4096", 4096, 8192, 4096}, {"sq8192", 8192, 8192, 8192},
+                                {"qkv2048", 2048, 12288, 4096}, {"gateup2048 (2.69 rounds)", 2048, 22016, 4096}};
+    const Shape shapes_narrow[] = {{"vit fc2", 2056, 1024, 4096}, {"vit out", 2056, 1024, 1024}, {"vit fc1", 2056, 4096, 1024}, {"vit qkv", 2056, 3072, 1024},
+                                   {"proj1", 2048, 4096, 1024}, {"proj2", 2048, 4096, 4096}, {"llama o (M=2168)", 2168, 4096, 4096}};
+    const Shape* shapes_p = narrow ? shapes_narrow : shapes_big;
+    const int n_shapes = narrow ? 7 : 5;
+    const int v_lo = narrow ? 7 : 0, v_hi = narrow ? 14 : 7;
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    for (const Shape& s : shapes) {
+    for (int si = 0; si < n_shapes; ++si) {
+        const Shape& s = shapes_p[si];
         const int M = s.M, N = s.N, K = s.K, NW = 4;
         std::vector<bf16_t> hA((size_t)M * K), hW((size_t)N * K);
         for (auto& v : hA) v = rnd_bf16(1.f);
@@ -372,10 +478,10 @@ int main(int argc, char** argv) {
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         double best[NV];
         bool same[NV];
-        for (int v = 0; v < NV; ++v) best[v] = 1e30;
+        for (int v = 0; v < NV; ++v) { best[v] = 1e30; same[v] = true; }
         std::vector<bf16_t> h0((size_t)M * N), h1((size_t)M * N);
         for (int rep = 0; rep < 3; ++rep)
-            for (int v = 0; v < NV; ++v) {
+            for (int v = v_lo; v < v_hi; ++v) {
                 const int iters = 12;
                 for (int i = 0; i < 2; ++i) LAUNCH[v](dA, dW[i % NW], dC, M, N, K, nullptr, st);
                 CK(hipEventRecord(e0, st));
@@ -386,10 +492,10 @@ int main(int argc, char** argv) {
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 best[v] = std::min(best[v], (double)ms * 1e3 / iters);
                 if (rep == 0) {
-                    CK(hipMemsetAsync(v == 0 ? dC0 : dC, 0, (size_t)M * N * 2, st));
-                    LAUNCH[v](dA, dW[0], v == 0 ? dC0 : dC, M, N, K, nullptr, st);
+                    CK(hipMemsetAsync(v == v_lo ? dC0 : dC, 0, (size_t)M * N * 2, st));
+                    LAUNCH[v](dA, dW[0], v == v_lo ? dC0 : dC, M, N, K, nullptr, st);
                     CK(hipStreamSynchronize(st));
-                    if (v == 0) { CK(hipMemcpy(h0.data(), dC0, h0.size() * 2, hipMemcpyDeviceToHost)); same[0] = true; }
+                    if (v == v_lo) { CK(hipMemcpy(h0.data(), dC0, h0.size() * 2, hipMemcpyDeviceToHost)); same[v] = true; }
                     else { CK(hipMemcpy(h1.data(), dC, h1.size() * 2, hipMemcpyDeviceToHost)); same[v] = !memcmp(h0.data(), h1.data(), h0.size() * 2); }
                 }
             }
@@ -409,7 +515,7 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * M * N * K;
         const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
         printf("%-28s (%4d tiles = %.2f rounds, host check %.1e):", s.name, tiles, tiles / 256.0, maxrel);
-        for (int v = 0; v < NV; ++v) printf("  %s %.1f us (%.0f TF)%s", VNAME[v], best[v], fl / best[v] / 1e6, same[v] ? "" : " DIFF");
+        for (int v = v_lo; v < v_hi; ++v) printf("  %s %.1f us (%.0f TF)%s", VNAME[v], best[v], fl / best[v] / 1e6, same[v] ? "" : " DIFF");
         printf("\n");
         fflush(stdout);
         if (do_trace && !strcmp(s.name, "sq4096")) {
