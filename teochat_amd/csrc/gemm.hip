@@ -594,6 +594,9 @@ static bool gemm_wide_wins(int M, int N, int K, bool forced) {
     if (forced) return true;
     // not enough tiles to fill the chip once (240 at M = 638, N = 12288: 57 vs 79 us); with a short K loop (K <= 1024: the tower's
     // qkv at M = 2056, 204 wide tiles) the single round of wide tiles wins from 192 on (23.9 vs 29.6 us, tools/vit_gemm_probe.py)
+    // a long K loop on half a round of wide tiles still beats a whole round of 128 x 128 ones (the tower's fc2 at T = 16: M = 4112, N = 1024,
+    // K = 4096, 132 wide tiles: 52.6 us against 61-65 us on either 128 x 128 kernel; tools/vit_gemm_probe.py, round 5)
+    if (K >= 4096 && t_wide >= 128 && t_wide <= 256) return true;
     if (t_wide < 208 && !(K <= 1024 && t_wide >= 192)) return false;
     // cost in rounds of the plain kernel; its ragged last round runs faster when it leaves one workgroup per CU (x 0.66, measured)
     const long long rem = t_plain % 512;
@@ -660,8 +663,20 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const int nwg = tiles_m * tiles_n;
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
+        // narrow LDS-DMA tiles (gemm_narrow.hip, round 5): forced here; the automatic rule sits below, after the families it competes with
+        if (tune().gemm_narrow == 2 && !swiglu)
+            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, tune().gemm_narrow_bm == 128 ? 128 : 64, st);
+        // automatic: wherever the 64-row register-staged kernel was the choice (few tiles: the tower's out_proj / fc2, every tower GEMM and
+        // the LLaMA o / down projections of config C2) the 64 x 128 LDS-DMA tile runs instead -- tools/vit_gemm_probe.py (round 5, us):
+        // fc2 47.1 -> 36.5, out_proj 17.2 -> 14.6 (T = 8); at T = 2: fc2 42.6 -> 32.6, fc1 23.0 -> 18.6, LLaMA o 60.8 -> 39.2, down 148 -> 93
+        if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && bm == 64)
+            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, st);
         const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = (long long)cdiv(M, 256) * cdiv(N, 256);
-        const bool sk_wide_shape = sk_ws && tune().gemm_sk && tune().gemm_wide && !swiglu && t_wide_ > 256 && t_wide_ <= 256 + 256 / 6;
+        // just over one round of wide tiles -- or, for a short K loop (K <= 1024: the tower's fc1 at T = 16, 528 tiles), just over two:
+        // there a ragged third round costs a third of the launch (wide 86.7 us, its stream-K form 65.5; tools/vit_gemm_probe.py, round 5)
+        const long long sk_wide_max = K <= 1024 ? 2 * 256 + 256 / 6 : 256 + 256 / 6;
+        const bool sk_wide_fit = t_wide_ > 256 && t_wide_ <= sk_wide_max && (t_wide_ % 256) != 0 && (t_wide_ % 256) <= 256 / 6;
+        const bool sk_wide_shape = sk_ws && tune().gemm_sk && tune().gemm_wide && !swiglu && sk_wide_fit;
         // 256 x 256 tiles: a round of them costs GEMM_BIG_ROUND_COST rounds of the 128 x 256 kernel for twice the area (measured
         // 1.45-1.7 us against 0.875 us per K tile); taken when that beats the wide kernel's round count and the chip is filled
         // (with a workspace its hybrid form has no ragged last round: fractional rounds + a hand-off allowance)
@@ -673,7 +688,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         {   // just over one round of WIDE tiles (272 on 256 CUs: o / down at M = 2168): the stream-K form of the wide kernel
             const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256);
             if (sk_ws && tune().gemm_sk && tune().gemm_wide && bm == 128 && !swiglu && K >= 2 * BK && t_wide > 256 &&
-                (tune().gemm_sk == 2 || t_wide <= 256 + 256 / 6))
+                (tune().gemm_sk == 2 || sk_wide_fit))
                 return gemm_wide_sk_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, sk_ws, GEMM_SK_SLAB_BYTES, st);
         }
         if (tune().gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, tune().gemm_wide == 2))
@@ -702,6 +717,10 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
             TEO_LAUNCH_CHECK("gemm_mfma_bf16_sk");
             return TEO_OK;
         }
+        // what no other family took: the 128 x 128 LDS-DMA tile instead of the register-staged one (the tower's fc2 / out_proj at T = 16:
+        // 75.5 -> 59.0 us, 25.8 -> 23.8); the register-staged kernel keeps the SwiGLU epilogue and stays the reference form of the tests
+        if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && bm == 128 && !swiglu)
+            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 128, st);
         return gemm_plain_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, bm, st);
     }
     if (dtype == TEO_F32) {

@@ -12,6 +12,7 @@
 // ring is latency-bound at ~1.1 us per 64 KB), fragment reads alone 81.  A second barrier per K tile that frees the stage early
 // (1.5 tiles of DMA lead) makes the DMA alone faster (106 us) and the kernel slower (246 us): not kept.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "ops.h"
 
 namespace teo {
@@ -198,61 +199,11 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
         }
     }
 
-    // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3 (as the other MFMA kernels)
-    const int mw = m0 + wm * 128, nw = n0 + wn * 64;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int m = mw + mi * 16 + fr;
-        if (m >= M) continue;
-        if (SWIGLU) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ni += 2) {
-                const int ng = nw + ni * 16 + fg * 4;
-                if (ng >= N) continue;
-                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
-                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
-            }
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = nw + ni * 16 + fg * 4;
-                if (n >= N) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
-                if (n + 3 < N) {
-                    if (bias) {
-                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
-                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
-                    }
-                    if (act != TEO_ACT_NONE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
-                    }
-                    if (res) {
-                        const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += h_lo<F16>(q.x); o[1] += h_hi<F16>(q.x);
-                        o[2] += h_lo<F16>(q.y); o[3] += h_hi<F16>(q.y);
-                    }
-                    if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
-                } else {
-                    for (int r = 0; r < 4 && n + r < N; ++r) {
-                        float v = o[r];
-                        if (bias) v += h2f<F16>(bias[n + r]);
-                        v = act_apply(v, act);
-                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
-                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
-                    }
-                }
-            }
-        }
+    // epilogue (gemm_epilogue.h); the bias is fetched here, not ahead of the K loop: this kernel has no registers to spare
+    {
+        uint2 bv[4];
+        gemm_bias_load<4>(SWIGLU ? nullptr : bias, n0 + wn * 64, fg, N, bv);
+        gemm_epilogue<4, 8, 1, SWIGLU, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * 128, n0 + wn * 64, fr, fg);
     }
     }   // segments
 }

@@ -16,6 +16,7 @@
 // wave-linear: 1 KB = 8 rows per instruction), which keeps every 128-byte row a single coalesced request.
 // Same k-order per output element as the plain kernel -> bit-identical results (tests/test_kernels_gpu.py).
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "ops.h"
 
 namespace teo {
@@ -131,6 +132,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long long)(KT) * GW_BK), \
                                          (__attribute__((address_space(3))) void*)(smem + (ST) * GW_STAGE + (wid * GW_PIECES + j) * 1024), 16, 0, 0);
 
+    uint2 bv[4];                                         // bias of the lane's columns: requested now, used after the K loop (gemm_epilogue.h)
+    gemm_bias_load<4>(SWIGLU ? nullptr : bias, n0 + wn * 64, fg, N, bv);
     gw_f32x4 acc[4][4];   // [ni][mi]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -175,62 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_kernel(const bf16_
 #undef TEO_GW_STAGE
     if (sched != 0 && nk > 0) gw_flush<F16>(acc, caf, cwf);
 
-    // epilogue: lane holds C[m = mw + mi*16 + fr][n = nw + ni*16 + fg*4 + r], r = 0..3 (as gemm_mfma_bf16_kernel)
-    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = mw + mi * 16 + fr;
-        if (m >= M) continue;
-        if (SWIGLU) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ni += 2) {
-                const int ng = nw + ni * 16 + fg * 4;
-                if (ng >= N) continue;
-                const int oc = (nw >> 1) + (ni >> 1) * 16 + fg * 4;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu(acc[ni][mi][r]) * acc[ni + 1][mi][r];
-                if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + oc) = make_float4(o[0], o[1], o[2], o[3]);
-                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + oc) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
-            }
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = nw + ni * 16 + fg * 4;
-                if (n >= N) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
-                if (n + 3 < N) {
-                    if (bias) {
-                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
-                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
-                    }
-                    if (act != TEO_ACT_NONE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
-                    }
-                    if (res) {
-                        const uint2 q = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += h_lo<F16>(q.x); o[1] += h_hi<F16>(q.x);
-                        o[2] += h_lo<F16>(q.y); o[3] += h_hi<F16>(q.y);
-                    }
-                    if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
-                } else {
-                    for (int r = 0; r < 4 && n + r < N; ++r) {
-                        float v = o[r];
-                        if (bias) v += h2f<F16>(bias[n + r]);
-                        v = act_apply(v, act);
-                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
-                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<4, 4, 2, SWIGLU, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * 64, n0 + wn * 64, fr, fg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -308,6 +256,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (gw_f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        // bias of the lane's columns (segments that end in an epilogue): requested ahead of the K loop (gemm_epilogue.h)
+        uint2 bv[4];
+        gemm_bias_load<4>(bias, n0 + wn * 64, fg, N, bv);
         // the ring is primed AFTER the slab loads were issued: vmcnt retires loads in order, so the counted waits below still
         // mean "this wave's pieces of tile kt have landed" (the 16 slab loads of a head segment are older and retire first)
         TEO_GW_STAGE(kb, 0)
@@ -340,47 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mfma_bf16_wide_sk_kernel(const bf
             continue;
         }
         // epilogue (no SwiGLU in this form: it serves the N = hidden layers, o and down)
-        const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = mw + mi * 16 + fr;
-            if (m >= M) continue;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = nw + ni * 16 + fg * 4;
-                if (n >= N) continue;
-                float o[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[ni][mi][r];
-                if (n + 3 < N) {
-                    if (bias) {
-                        const uint2 b = *reinterpret_cast<const uint2*>(bias + n);
-                        o[0] += h_lo<F16>(b.x); o[1] += h_hi<F16>(b.x);
-                        o[2] += h_lo<F16>(b.y); o[3] += h_hi<F16>(b.y);
-                    }
-                    if (act != TEO_ACT_NONE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = act_apply(o[r], act);
-                    }
-                    if (res) {
-                        const uint2 qv = *reinterpret_cast<const uint2*>(res + (long long)m * ldc + n);
-                        o[0] += h_lo<F16>(qv.x); o[1] += h_hi<F16>(qv.x);
-                        o[2] += h_lo<F16>(qv.y); o[3] += h_hi<F16>(qv.y);
-                    }
-                    if (OUT_F32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + (long long)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (long long)m * ldc + n) = make_uint2(pack_h2<F16>(o[0], o[1]), pack_h2<F16>(o[2], o[3]));
-                } else {
-                    for (int r = 0; r < 4 && n + r < N; ++r) {
-                        float v = o[r];
-                        if (bias) v += h2f<F16>(bias[n + r]);
-                        v = act_apply(v, act);
-                        if (res) v += h2f<F16>(res[(long long)m * ldc + n + r]);
-                        if (OUT_F32) reinterpret_cast<float*>(Cv)[(long long)m * ldc + n + r] = v;
-                        else reinterpret_cast<bf16_t*>(Cv)[(long long)m * ldc + n + r] = f2h<F16>(v);
-                    }
-                }
-            }
-        }
+        gemm_epilogue<4, 4, 2, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * 64, n0 + wn * 64, fr, fg);
     }
 }
 

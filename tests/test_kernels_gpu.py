@@ -1271,6 +1271,34 @@ def test_gemm_wide_tile_kernel_is_bitwise_the_plain_kernel(M, N, K, flags, extra
         L.tune_set(b"gemm_wide", 1)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,extra", [(2056, 1024, 4096, "bias_res"), (2056, 1024, 1024, "bias_res"), (2056, 4096, 1024, "bias_gelu"),
+                                         (300, 700, 192, "bias_quick"), (129, 260, 128, "res"), (1000, 1024, 2048, "f32out"), (65, 132, 64, ""),
+                                         (514, 3072, 1024, "bias")])
+def test_gemm_narrow_tiles_are_bitwise_the_plain_kernel(M, N, K, extra, dt):
+    """gemm_narrow.hip (round 5: 64 x 128 and 128 x 128 tiles, 4 waves, LDS-DMA ring of 3 / 2 stages, two workgroups per CU) against the
+    register-staged kernel: same LDS image, same fragment reads, same k-ascending MFMA chain -> BIT-identical in both 16-bit formats, incl.
+    the tower's real shapes (fc2 / out_proj / fc1 at M = 2056), ragged M / N edges, K of one / two / three tiles and every epilogue."""
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    A = torch.randn(M, K, generator=g).to(dt).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).to(dt).cuda() if "bias" in extra else None
+    res = torch.randn(M, N, generator=g).to(dt).cuda() if "res" in extra else None
+    act = L.ACT_GELU_ERF if "gelu" in extra else (L.ACT_QUICK_GELU if "quick" in extra else L.ACT_NONE)
+    od = torch.float32 if "f32out" in extra else dt
+    lib = G.lib()
+    assert L.tune_set(b"gemm_narrow", 0) == 0 and L.tune_set(b"gemm_big", 0) == 0 and L.tune_set(b"gemm_wide", 0) == 0
+    want = G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
+    assert lib.teo_last_kernel().decode() in ("gemm_mfma_64", "gemm_mfma_128")
+    assert L.tune_set(b"gemm_narrow", 2) == 0
+    for bm in (64, 128):
+        assert L.tune_set(b"gemm_narrow_bm", bm) == 0
+        for _ in range(3):
+            got = G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
+            assert lib.teo_last_kernel().decode() == f"gemm_narrow_{bm}"
+            assert torch.equal(got, want), (bm, float((got.float() - want.float()).abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 12288, 4096, 0, ""), (4208, 2048, 512, L.GEMM_SWIGLU16, ""), (300, 700, 192, 0, "bias_gelu"),
                                                (129, 260, 128, 0, "res"), (1000, 1024, 2048, 0, "f32out"), (257, 512, 128, 0, ""),
                                                (2056, 4096, 1024, 0, "bias_res"), (4096, 1024, 1024, 0, "group")])

@@ -117,13 +117,15 @@ class GemmWs:
 
 # forced tile families (tune knobs are perf-only; every family must agree with the oracle, not merely with each other)
 FAMILIES = (("production dispatch", {}),
-            ("128x128 tile", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0}),
-            ("128x128 stream-K", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2}),
+            ("128x128 tile", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0}),
+            ("128x128 stream-K", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2, "gemm_narrow": 0}),
+            ("64x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 64}),           # round 5 (SwiGLU GEMMs have no such form: they fall
+            ("128x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 128}),         # through to the production dispatch under these knobs)
             ("128x256 tile", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0}),
             ("128x256 stream-K", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}),
             ("256x256 tile", {"gemm_big": 2, "gemm_big_hybrid": 0}),
             ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2}))
-DEFAULTS = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1}
+DEFAULTS = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1, "gemm_narrow": 1, "gemm_narrow_bm": 0}
 
 
 def gemm_all_families(gw, A, W, ref, tag, report, families=FAMILIES, **kw):
@@ -163,7 +165,7 @@ def test_llama_layer_walk_at_7b_shapes(fmt):
     qkv = R(n1 @ Wqkv.t())
     d_n1, d_Wqkv = G.dev(n1, bf), G.dev(Wqkv, bf)
     seen = gemm_all_families(gw, d_n1, d_Wqkv, qkv, "qkv GEMM M=2168 N=12288 K=4096", report)
-    assert {"gemm_mfma_128", "gemm_wide", "gemm_big"} <= seen, seen
+    assert {"gemm_mfma_128", "gemm_wide", "gemm_big", "gemm_narrow_64", "gemm_narrow_128"} <= seen, seen
     # RoPE + KV append
     pos = torch.arange(S)
     c, s_ = O.rope_cos_sin(pos, hd, 10000.0, torch.float32)
@@ -289,7 +291,8 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes(fmt):
     ulp_check(G.layernorm(G.dev(h, bf), G.dev(ln["1"][0], bf), G.dev(ln["1"][1], bf), 1e-5), ln1, "LayerNorm", report, kernel=False)
     Wqkv = torch.cat([w["q"], w["k"], w["v"]], 0)
     qkv = R(ln1 @ Wqkv.t() + b["qkv"])
-    fam = [f for f in FAMILIES if f[0] in ("production dispatch", "128x128 tile", "128x256 tile", "256x256 tile")]
+    fam = [f for f in FAMILIES if f[0] in ("production dispatch", "128x128 tile", "128x256 tile", "256x256 tile", "64x128 LDS-DMA", "128x128 LDS-DMA")]
+    fam.sort(key=lambda f: ("production dispatch", "128x128 tile", "64x128 LDS-DMA", "128x128 LDS-DMA", "128x256 tile", "256x256 tile").index(f[0]))
     gemm_all_families(gw, G.dev(ln1, bf), G.dev(Wqkv, bf), qkv, "qkv GEMM + bias M=2056 N=3072 K=1024", report, families=fam, bias=G.dev(b["qkv"], bf))
     q, k, v = (qkv[:, i * D:(i + 1) * D].view(T, N, H, hd).transpose(1, 2) for i in range(3))
     o_ref = R(O.attention_core(q, k, v, None, hd ** -0.5, R, "flash64").transpose(1, 2).reshape(T * N, D))
@@ -300,7 +303,7 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes(fmt):
               abs_tol=attn_p_noise(q, k, v, None, hd ** -0.5).transpose(1, 2).reshape(T * N, D) + FP32_SUM_ABS)
     h1 = R(h + o_ref @ w["o"].t() + b["o"])
     gemm_all_families(gw, G.dev(o_ref, bf), G.dev(w["o"], bf), h1, "out_proj + bias + residual N=1024 K=1024", report,
-                      families=fam[:2], bias=G.dev(b["o"], bf), res=G.dev(h, bf))
+                      families=fam[:4], bias=G.dev(b["o"], bf), res=G.dev(h, bf))
     ln2 = R(F.layer_norm(h1, (D,), ln["2"][0], ln["2"][1], 1e-5))
     m = R(F.gelu(ln2 @ w["fc1"].t() + b["fc1"]))
     gemm_all_families(gw, G.dev(ln2, bf), G.dev(w["fc1"], bf), m, "fc1 + bias + GELU(erf) N=4096", report, families=fam,
@@ -310,7 +313,7 @@ def test_vit_layer_and_projector_walk_at_vit_l14_shapes(fmt):
     gemm_all_families(gw, G.dev(ln2, bf), G.dev(w["fc1"], bf), mq, "fc1 + bias + quick_gelu N=4096", report, families=fam[:1],
                       bias=G.dev(b["fc1"], bf), act=L.ACT_QUICK_GELU)
     h2 = R(h1 + m @ w["fc2"].t() + b["fc2"])
-    gemm_all_families(gw, G.dev(m, bf), G.dev(w["fc2"], bf), h2, "fc2 + bias + residual K=4096", report, families=fam[:2],
+    gemm_all_families(gw, G.dev(m, bf), G.dev(w["fc2"], bf), h2, "fc2 + bias + residual K=4096", report, families=fam[:4],
                       bias=G.dev(b["fc2"], bf), res=G.dev(h1, bf))
     # projector mlp2x_gelu on the T * 256 visual tokens
     feats = _rand((T * 256, D), gen)
