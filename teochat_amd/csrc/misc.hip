@@ -54,11 +54,13 @@ template <bool F16>
 __global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(bf16_t* __restrict__ qkv, int ld, const int* __restrict__ positions,
                                                                  const float* __restrict__ cs, const float* __restrict__ sn,
                                                                  bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int past,
-                                                                 int S_max, int heads, int kv_heads, int hd) {
+                                                                 int S_max, int heads, int kv_heads, int hd, int copy_v) {
+    // copy_v == 0 (round 5): the V rows are appended by vt_append_vec_kernel, which has them in hand for the V^T scatter anyway -- V is
+    // read once per layer instead of twice
     const int s = blockIdx.x, half = hd >> 1, tph = half >> 3;
     const int t = blockIdx.y * 256 + threadIdx.x;
     const int hh = t / tph, i0 = (t % tph) * 8;
-    if (hh >= heads + 2 * kv_heads) return;
+    if (hh >= heads + (copy_v ? 2 : 1) * kv_heads) return;
     const int pos = positions ? positions[s] : past + s;
     const int slot = past + s;
     bf16_t* x = qkv + (long long)s * ld + hh * hd;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void vt_append_kernel(const T* __restrict__ qk
 // Positions >= S inside the last 8-position store chunk are written as zeros (slots past the sequence end, rewritten by
 // whoever appends there).  Needs (past + s0) % 8 == 0 for the aligned 16-byte stores.
 __global__ __launch_bounds__(256) void vt_append_vec_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ vtc, int S,
-                                                            int past, int S_max, int v_off, int hd) {
+                                                            int past, int S_max, int v_off, int hd, bf16_t* __restrict__ vc) {
     __shared__ bf16_t tile[64][136];                       // row stride 272 B: 16-byte aligned rows, column reads spread over banks
     const int s0 = blockIdx.x * 64, hk = blockIdx.y;
     for (int d0 = 0; d0 < hd; d0 += 128) {
@@ -122,7 +124,10 @@ __global__ __launch_bounds__(256) void vt_append_vec_kernel(const bf16_t* __rest
         for (int id = threadIdx.x; id < 64 * nc; id += 256) {
             const int r = id / nc, c = id % nc;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (s0 + r < S) v = *reinterpret_cast<const uint4*>(qkv + (long long)(s0 + r) * ld + v_off + hk * hd + d0 + c * 8);
+            if (s0 + r < S) {
+                v = *reinterpret_cast<const uint4*>(qkv + (long long)(s0 + r) * ld + v_off + hk * hd + d0 + c * 8);
+                if (vc) *reinterpret_cast<uint4*>(vc + ((long long)hk * S_max + past + s0 + r) * hd + d0 + c * 8) = v;      // the V cache row (rope kernel: copy_v = 0)
+            }
             *reinterpret_cast<uint4*>(&tile[r][c * 8]) = v;
         }
         __syncthreads();
@@ -158,14 +163,18 @@ int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, con
         const bool vec = hd % 16 == 0 && ld % 8 == 0 && d_past == nullptr && wvt == 0 &&
                          ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(kc) | reinterpret_cast<uintptr_t>(vc) |
                            reinterpret_cast<uintptr_t>(cs) | reinterpret_cast<uintptr_t>(sn)) & 15) == 0;
+        // the 16-byte V^T kernel also appends the V rows (it reads them for the transpose anyway): the rope kernel then leaves V alone
+        const bool vvec = tiled_vt && hd % 8 == 0 && ld % 8 == 0 && past % 8 == 0 && S_max % 8 == 0 &&
+                          ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(vtc)) & 15) == 0;
+        const bool v_by_vt = vec && vvec && (reinterpret_cast<uintptr_t>(vc) & 15) == 0;
         if (vec) {
-            const int nthr = (heads + 2 * kv_heads) * (hd / 16);
+            const int nthr = (heads + (v_by_vt ? 1 : 2) * kv_heads) * (hd / 16);
             if (dtype == TEO_F16)
                 rope_kv_append_vec_kernel<true><<<dim3(S, cdiv(nthr, 256)), 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
-                                                                                          (bf16_t*)vc, past, S_max, heads, kv_heads, hd);
+                                                                                          (bf16_t*)vc, past, S_max, heads, kv_heads, hd, v_by_vt ? 0 : 1);
             else
                 rope_kv_append_vec_kernel<false><<<dim3(S, cdiv(nthr, 256)), 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc,
-                                                                                           (bf16_t*)vc, past, S_max, heads, kv_heads, hd);
+                                                                                           (bf16_t*)vc, past, S_max, heads, kv_heads, hd, v_by_vt ? 0 : 1);
         } else if (dtype == TEO_F16) {
             rope_kv_append_kernel<f16_t><<<grid, threads, 0, st>>>((f16_t*)qkv, ld, positions, cs, sn, (f16_t*)kc,
                                                                    (f16_t*)vc, (f16_t*)vtc, past, d_past, S_max, heads,
@@ -176,11 +185,9 @@ int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, con
                                                                     kv_heads, hd, wvt);
         }
         if (tiled_vt) {
-            const bool vvec = hd % 8 == 0 && ld % 8 == 0 && past % 8 == 0 && S_max % 8 == 0 &&
-                              ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(vtc)) & 15) == 0;
             if (vvec)
                 vt_append_vec_kernel<<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const bf16_t*)qkv, ld, (bf16_t*)vtc, S, past, S_max,
-                                                                                  (heads + kv_heads) * hd, hd);
+                                                                                  (heads + kv_heads) * hd, hd, v_by_vt ? (bf16_t*)vc : nullptr);
             else
                 vt_append_kernel<bf16_t><<<dim3(cdiv(S, 64), kv_heads), 256, 0, st>>>((const bf16_t*)qkv, ld, (bf16_t*)vtc, S,
                                                                                       past, S_max, (heads + kv_heads) * hd, hd);

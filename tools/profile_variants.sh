@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/profile_variants.sh  -> gpurun_out/r04p/bench_<variant>_kernel_stats.md
+# usage (on the GPU box): bash tools/profile_variants.sh  -> gpurun_out/r05p/bench_<variant>_kernel_stats.md
 # rocprofv3 kernel summaries of the other north-star shapes (the default C3 one is made by tools/refresh_profiles.sh).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r04p
+OUT=$ROOT/gpurun_out/r05p
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 prof() { name=$1; shift; rm -rf /tmp/prof_$name

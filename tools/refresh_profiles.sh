@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/refresh_profiles.sh   -> gpurun_out/r04p/{bench*.json, kernel_stats.md}
-# The bench lines and the rocprofv3 kernel summary that profiles/r04_* are copied from.
+# usage (on the GPU box): bash tools/refresh_profiles.sh   -> gpurun_out/r05p/{bench*.json, kernel_stats.md}
+# The bench lines and the rocprofv3 kernel summary that profiles/r05_* are copied from.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r04p
+OUT=$ROOT/gpurun_out/r05p
 mkdir -p $OUT
 cd $ROOT
 timeout 900 python3 bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
