@@ -467,6 +467,35 @@ def test_output_hidden_states_match_reference(name):
         model(input_ids=ids.to(dev), images=imgs, output_attentions=True)
 
 
+def test_batched_forward_scratch_is_sized_by_the_request_and_shared_by_all_layers():
+    """the B > 1 training-shape forward keeps scratch K / V / V^T for its causal attention.  It is ONE [B, Hkv, S64, hd] buffer per
+    kind, aliased by every layer (the forward never reads a layer's keys after that layer) and sized by the longest sequence of the call
+    rounded to the flash kernel's 64-key tile -- not [layers, B, Hkv, max_seq, hd]; regrowing it registers no second option hook; and the
+    logits equal the per-sample forwards bit for bit."""
+    model, _ = build("tinyB", torch.bfloat16)
+    eng, dev = model.engine, model.device
+    vcfg, lcfg, mm = TY.cfgs("tinyB")
+    g = torch.Generator().manual_seed(9)
+    seqs = [torch.randn(n, lcfg.hidden_size, generator=g).to(torch.bfloat16).to(dev) for n in (70, 33, 130)]
+    hooks0 = len(eng._option_hooks)
+    out = eng.prefill_batch(seqs[:2])
+    slot = eng._fwd_slots
+    assert tuple(slot["k"].shape) == (2, lcfg.num_key_value_heads, 128, lcfg.head_dim) and tuple(slot["vt"].shape) == (2, lcfg.num_key_value_heads, lcfg.head_dim, 128)
+    assert slot["desc"].max_seq == 128 and len(eng._option_hooks) == hooks0 + 1
+    out3 = eng.prefill_batch(seqs)                           # more rows AND a longer sequence: the buffers regrow, the hook does not
+    assert tuple(eng._fwd_slots["k"].shape) == (3, lcfg.num_key_value_heads, 192, lcfg.head_dim) and len(eng._option_hooks) == hooks0 + 1
+    assert torch.equal(out3[:103], out)                      # the first two sequences' rows are what the B = 2 call gave
+    r0 = 0
+    for e in seqs:
+        eng.reset_cache()
+        one = eng.prefill(e, last_only=False)
+        assert torch.equal(out3[r0:r0 + e.shape[0]], one)
+        r0 += e.shape[0]
+    eng.set_options(rope_in_attn=True)                       # the one hook keeps the CURRENT descriptor copy in step
+    assert eng._fwd_slots["desc"].rope_in_attn == 1
+    eng.set_options(rope_in_attn=False)
+
+
 @pytest.mark.parametrize("name", ["tinyA"])
 def test_cls_patch_select_feature(name):
     """feature_select 'cls_patch' (languagebind/__init__.py:125-126): the CLS row stays -> [T, 257, D]; rows 1.. equal the
