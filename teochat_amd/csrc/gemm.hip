@@ -672,6 +672,16 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && bm == 64)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, st);
         const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = (long long)cdiv(M, 256) * cdiv(N, 256);
+        // 256 x 160 tiles on four waves (gemm_quad.hip, round 5): forced, or -- automatic, and only while no other family is forced -- where
+        // the problem is ONE round of them but more than one round of 128 x 256 tiles: M = 2056 .. 2304 against N = 4096 (272 wide tiles,
+        // 234 of these).  tools/gemm_lab.hip w4n / bench_kernels.py yardstick, no epilogue (us): LLaMA o 78 -> 66, down 174 -> 159, the tower's
+        // fc1 31 -> 24; with the real epilogues (tools/vit_gemm_probe.py): o 79.8 -> 71.1, down 188.5 -> 168.7 .. 177.8 -- but fc1 43.2 -> 51.3:
+        // one wave per SIMD walks 160 erf evaluations per lane as 80 KB of straight-line code, so the rule leaves activations to the 8-wave tiles
+        if (!swiglu && (tune().gemm_quad == 2 ||
+                        (tune().gemm_quad == 1 && tune().gemm_bm == 0 && tune().gemm_wide == 1 && tune().gemm_big == 1 && tune().gemm_sk == 1 &&
+                         act == TEO_ACT_NONE && K >= 8 * BK && t_wide_ > 256 &&
+                         (long long)cdiv(M, 256) * cdiv(N, 160) <= std::min(device_cu_count(), 256))))
+            return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);
         // just over one round of wide tiles -- or, for a short K loop (K <= 1024: the tower's fc1 at T = 16, 528 tiles), just over two:
         // there a ragged third round costs a third of the launch (wide 86.7 us, its stream-K form 65.5; tools/vit_gemm_probe.py, round 5)
         const long long sk_wide_max = K <= 1024 ? 2 * 256 + 256 / 6 : 256 + 256 / 6;

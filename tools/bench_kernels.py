@@ -497,9 +497,57 @@ def bench_gemm_stride():
         us = timeit(lambda: G.gemm(A, W))
         print(f"gemm M={M} N={N} K={K}: {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s", flush=True)
 
+def bench_yardstick():
+    """NOT a product path: what the vendor libraries reach on this box at the same shapes (torch.matmul -> hipBLASLt / rocBLAS,
+    scaled_dot_product_attention -> the bundled flash kernels), next to the library's own kernels in the same process.  A yardstick for
+    the MFMA phases: the product cannot use them (every tile family here is bit-identical to every other, the library kernels are not, and
+    the fused epilogues / S^T layouts are the library's own), but they say what a tuned kernel of that shape gets out of the chip."""
+    import torch.nn.functional as F
+    shapes = [("qkv", 2168, 12288, 4096, 0), ("o", 2168, 4096, 4096, 0), ("gateup", 2168, 22016, 4096, L.GEMM_SWIGLU16),
+              ("down", 2168, 4096, 11008, 0), ("vit_qkv", 2056, 3072, 1024, 0), ("vit_fc1", 2056, 4096, 1024, 0),
+              ("vit_fc2", 2056, 1024, 4096, 0), ("qkv_C2", 638, 12288, 4096, 0), ("gateup_C2", 638, 22016, 4096, L.GEMM_SWIGLU16),
+              ("qkv_T16", 4208, 12288, 4096, 0), ("sq8192", 8192, 8192, 8192, 0)]
+    ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws init")
+    for name, M, N, K, flags in shapes:
+        n = max(2, int(600e6 // (N * K * 2)))          # weights in rotation: > the 256 MB Infinity Cache, as in a real prefill
+        A = torch.randn(M, K, device="cuda").to(bf)
+        Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(n)]
+        Nc = N // 2 if flags else N
+        Cc = torch.empty(M, Nc, dtype=bf, device="cuda")
+        Cl = torch.empty(M, N, dtype=bf, device="cuda")
+        it = [0]
+
+        def ours():
+            w = Ws[it[0] % n]; it[0] += 1
+            L.check(lib.teo_gemm_ws(G.p(A), G.p(w), None, None, G.p(Cc), M, N, K, K, Nc, 0, flags, L.TEO_BF16, L.TEO_BF16, G.p(ws), G.stream()), "gemm")
+
+        def theirs():
+            w = Ws[it[0] % n]; it[0] += 1
+            torch.matmul(A, w.t(), out=Cl)
+        a = min(timeit(ours, iters=4 * n) for _ in range(3))
+        b = min(timeit(theirs, iters=4 * n) for _ in range(3))
+        fl = 2.0 * M * N * K
+        print(f"yardstick gemm {name:9s} M={M} N={N} K={K}: this library{' (+SwiGLU)' if flags else ''} {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s | "
+              f"torch.matmul {b:8.1f} us {fl / b / 1e6:7.1f} TFLOP/s | ratio {a / b:5.2f}", flush=True)
+        del Ws
+    for (B, H, S, d, causal) in [(1, 32, 2168, 128, True), (1, 32, 4208, 128, True), (8, 16, 257, 64, False), (1, 32, 638, 128, True)]:
+        q = torch.randn(B, H, S, d, device="cuda").to(bf)
+        k = torch.randn(B, H, S, d, device="cuda").to(bf)
+        v = torch.randn(B, H, S, d, device="cuda").to(bf)
+        vt = G.make_vt(v)
+        fl = 4.0 * B * H * S * S * d * (0.5 if causal else 1.0)
+        a = min(timeit(lambda: G.attention(q, k, v, causal, d ** -0.5, vt=vt)) for _ in range(3))
+        try:
+            b = min(timeit(lambda: F.scaled_dot_product_attention(q, k, v, is_causal=causal)) for _ in range(3))
+            theirs = f"{b:8.1f} us {fl / b / 1e6:7.1f} TFLOP/s | ratio {a / b:5.2f}"
+        except Exception as e:  # noqa: BLE001
+            theirs = f"unavailable ({type(e).__name__})"
+        print(f"yardstick attention B={B} H={H} S={S} d={d} causal={causal}: this library {a:8.1f} us {fl / a / 1e6:7.1f} TFLOP/s | torch SDPA {theirs}", flush=True)
+
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemv", "gemm", "attn_prefill", "norm"]
     for w in which:
-        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_splitk_sweep": bench_gemv_splitk_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_prefetch": bench_gemm_prefetch, "gemm_cold": bench_gemm_cold, "gemm_cohort": bench_gemm_cohort, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm}[w]()
+        {"gemv": bench_gemv, "gemv_mall": bench_gemv_mall, "skinny": bench_skinny, "gemv_fp8": bench_gemv_fp8, "gemv_fp8_sweep": bench_gemv_fp8_sweep, "gemv_splitk_sweep": bench_gemv_splitk_sweep, "gemv_sweep": bench_gemv_sweep, "gemm_stride": bench_gemm_stride, "gemm_depth": bench_gemm_depth, "gemm": bench_gemm, "gemm_fp8": bench_gemm_fp8, "gemm_wide": bench_gemm_wide, "gemm_big": bench_gemm_big, "gemm_prefetch": bench_gemm_prefetch, "gemm_cold": bench_gemm_cold, "gemm_cohort": bench_gemm_cohort, "gemm_wide_sched": bench_gemm_wide_sched, "attn_prefill": bench_attn_prefill, "norm": bench_norm, "yardstick": bench_yardstick}[w]()
 

@@ -417,6 +417,403 @@ static void launch_narrow(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, in
     lab_narrow_kernel<TBM, NS, SCHED><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn);
 }
 
+// ---- 4 waves, one per SIMD: 256 x 256 x 64 tile, wave tile 128 x 128 (acc = 256 registers per lane, the whole 512-register file is the wave's) ------
+// What the vendor library's hand-written kernels do at these shapes (profiles/r05_library_yardstick.txt: MT256x256x64, 256 threads, 130 KB LDS).
+// Per K tile a wave reads 32 KB of fragments (8 waves of 128 x 64: 24 KB each = 192 KB per workgroup against 128 KB here) and issues 16 DMA
+// pieces.  Two phases per K tile, ONE barrier:   A: MFMA k-half 0 (X) || ds_read k-half 1 -> Y
+//                                               -- lgkmcnt(0) (my reads of this stage are done), vmcnt(0) (my pieces of tile kt + 1 landed), barrier --
+//                                               B: DMA tile kt + 2 -> this stage || ds_read k-half 0 of tile kt + 1 -> X || MFMA k-half 1 (Y)
+// P: 0 = the compiler orders each phase; 1 = sched_group_barrier pattern (1 DS read : 4 MFMA; phase B: 1 DMA : 1 DS read : 4 MFMA);
+//    2 = pattern with the DMA pieces first in phase B
+template <int P>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lab_w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                                           bf16_t* __restrict__ C, int M, int N, int K, int tiles_m,
+                                                                                           int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / BK;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    // DMA: 64 pieces per stage (32 of A rows, 32 of W rows, 8 rows each); wave w brings pieces 16 w .. 16 w + 15 (waves 0, 1: A; 2, 3: W)
+    const bool isA = wid < 2;
+    const bf16_t* base = isA ? A : W;
+    const int row0 = isA ? m0 + wid * 128 : n0 + (wid - 2) * 128;
+    const int rmax = (isA ? M : N) - 1;
+    unsigned off[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        off[j] = (unsigned)min(row0 + j * 8 + rl, rmax) * (unsigned)K + c * 8;
+    }
+    const int lds_piece0 = wid * 16 * 1024;
+#define W4_STAGE(KT, ST)                                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j)                                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[j] + (unsigned)(KT) * BK),  \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * STAGE + lds_piece0 + j * 1024), 16, 0, 0);
+    f32x4 acc[8][8];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 xa[8], xw[8], ya[8], yw[8];
+#define W4_READ(AF, WF, ST, KS)                                                                                   \
+    {                                                                                                             \
+        const unsigned char* sA_ = smem + (ST) * STAGE;                                                           \
+        const unsigned char* sB_ = sA_ + A_BYTES;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                           \
+            const int rw_ = wn * 128 + i * 16 + fr;                                                               \
+            WF[i] = *reinterpret_cast<const bf16x8*>(sB_ + rw_ * 128 + ((((KS) * 4 + fg) ^ (rw_ & 7)) << 4));      \
+        }                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                           \
+            const int ra_ = wm * 128 + i * 16 + fr;                                                               \
+            AF[i] = *reinterpret_cast<const bf16x8*>(sA_ + ra_ * 128 + ((((KS) * 4 + fg) ^ (ra_ & 7)) << 4));      \
+        }                                                                                                         \
+    }
+#define W4_MFMA(AF, WF)                                                                                           \
+    _Pragma("unroll") for (int ni = 0; ni < 8; ++ni)                                                              \
+        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi)                                                          \
+            acc[ni][mi] = mfma16(WF[ni], AF[mi], acc[ni][mi]);
+    W4_STAGE(0, 0)
+    if (nk > 1) { W4_STAGE(1, 1) }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    W4_READ(xa, xw, 0, 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        W4_READ(ya, yw, st, 1)
+        W4_MFMA(xa, xw)
+        if (P >= 1) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) { W4_STAGE(kt + 2, st) }
+        if (P == 2) __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) { W4_READ(xa, xw, st ^ 1, 0) }
+        W4_MFMA(ya, yw)
+        if (P == 1) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+        if (P == 2) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+    }
+#undef W4_STAGE
+#undef W4_READ
+#undef W4_MFMA
+    const int mw = m0 + wm * 128, nw = n0 + wn * 128;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            const int n = nw + ni * 16 + fg * 4;
+            if (n >= N) continue;
+            *reinterpret_cast<uint2*>(C + (long long)m * N + n) = make_uint2(pack_bf2(acc[ni][mi][0], acc[ni][mi][1]), pack_bf2(acc[ni][mi][2], acc[ni][mi][3]));
+        }
+    }
+}
+
+template <int P>
+static void launch_w4(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, unsigned long long*, hipStream_t st) {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    const size_t lds = 2 * STAGE;
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_w4_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    lab_w4_kernel<P><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn);
+}
+
+// ---- the same 4-wave structure with the accumulators pinned to the 256 AGPRs (inline-asm MFMA, "+a") and the phases interleaved by hand --------
+// (the builtin form above lets the register allocator shuffle accumulators between AGPRs and VGPRs: ~1000 v_accvgpr moves per K tile)
+// volatile asm keeps source order against the LDS reads and the DMA builtins, so the source order below IS the issue order:
+// phase A: 16 x { 1 ds_read_b128 (Y), 4 MFMA (X) }      phase B: 16 x { [1 DMA piece,] 1 ds_read_b128 (X of the next tile), 4 MFMA (Y) }
+// Q: 0 = DMA pieces interleaved one per group; 1 = all 16 pieces right after the barrier; 2 = two per group in the first 8 groups
+__device__ __forceinline__ void mfma_a(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int Q, bool TRACE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lab_w4a_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                                            bf16_t* __restrict__ C, int M, int N, int K, int tiles_m,
+                                                                                            int tiles_n, unsigned long long* trace) {
+    // marks go to LDS (a global store would sit in the vmcnt queue the K loop waits on) and are copied out after the loop
+    __shared__ unsigned long long marks[TRACE ? 4 * TR_TILES * TR_MARKS : 1];
+#define WA_MARK(KT, I)                                                                                                           \
+    if constexpr (TRACE) {                                                                                                       \
+        if (blockIdx.x == 0 && lane == 0 && (KT) >= TR_T0 && (KT) < TR_T0 + TR_TILES)                                             \
+            marks[(wid * TR_TILES + ((KT) - TR_T0)) * TR_MARKS + (I)] = __builtin_readcyclecounter();                             \
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / BK;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bool isA = wid < 2;
+    const bf16_t* base = isA ? A : W;
+    const int row0 = isA ? m0 + wid * 128 : n0 + (wid - 2) * 128;
+    const int rmax = (isA ? M : N) - 1;
+    unsigned off[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        off[j] = (unsigned)min(row0 + j * 8 + rl, rmax) * (unsigned)K + c * 8;
+    }
+    const int lds_piece0 = wid * 16 * 1024;
+#define WA_PIECE(KT, ST, J)                                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[J] + (unsigned)(KT) * BK),      \
+                                     (__attribute__((address_space(3))) void*)(smem + (ST) * STAGE + lds_piece0 + (J) * 1024), 16, 0, 0);
+    f32x4 acc[8][8];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[16], yf[16];      // [0..7]: W fragments (rows wn * 128 + i * 16 + fr), [8..15]: A fragments
+    // fragment g of k-half KS of stage ST
+    const int rw0 = wn * 128 + fr, ra0 = wm * 128 + fr;
+#define WA_READ(F, ST, KS, G)                                                                                     \
+    {                                                                                                             \
+        const int r_ = ((G) < 8 ? rw0 : ra0) + ((G) & 7) * 16;                                                    \
+        F[G] = *reinterpret_cast<const bf16x8*>(smem + (ST) * STAGE + ((G) < 8 ? A_BYTES : 0) + r_ * 128 + ((((KS) * 4 + fg) ^ (r_ & 7)) << 4)); \
+    }
+    // MFMA group g (0..15) of a phase: 4 MFMAs.  Reads arrive in the order W0..W7, A0..A7; group g of the NEXT phase must only need fragments
+    // whose reads were issued early: order the 64 (ni, mi) pairs so that pair p uses W[ni], A[mi] with max(ni, mi) non-decreasing
+#define WA_MFMA4(F, G)                                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                            \
+        constexpr int dummy_ = 0; (void)dummy_;                                                                   \
+        const int p_ = (G) * 4 + q_;                                                                              \
+        const int ni_ = p_ >> 3, mi_ = p_ & 7;                                                                    \
+        mfma_a(acc[ni_][mi_], F[ni_], F[8 + mi_]);                                                                \
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { WA_PIECE(0, 0, j) }
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { WA_PIECE(1, 1, j) }
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { WA_READ(xf, 0, 0, g) }
+#define WA_KTILE(KT, MORE2, MORE1)                                                                                \
+    {                                                                                                             \
+        const int st = (KT) & 1;                                                                                  \
+        WA_MARK(KT, 0)                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                          \
+            WA_MFMA4(xf, g)                                                                                       \
+            if (Q < 3) { WA_READ(yf, st, 1, (g + 8) & 15) }                                                       \
+            else if (g < 8) { WA_READ(yf, st, 1, (2 * g + 8) & 15) WA_READ(yf, st, 1, (2 * g + 9) & 15) }         \
+        }                                                                                                         \
+        WA_MARK(KT, 1)                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                               \
+        WA_MARK(KT, 2)                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        WA_MARK(KT, 3)                                                                                            \
+        if (Q == 1 && MORE2) {                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) { WA_PIECE((KT) + 2, st, j) }                          \
+        }                                                                                                         \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                          \
+            WA_MFMA4(yf, g)                                                                                       \
+            if (Q == 0 && MORE2) { WA_PIECE((KT) + 2, st, g) }                                                    \
+            if (Q == 2 && MORE2 && g < 8) { WA_PIECE((KT) + 2, st, 2 * g) WA_PIECE((KT) + 2, st, 2 * g + 1) }     \
+            if (Q == 3 && MORE2 && g < 8) { WA_PIECE((KT) + 2, st, 2 * g) WA_PIECE((KT) + 2, st, 2 * g + 1) }     \
+            if (Q == 4 && MORE2 && g >= 8) { WA_PIECE((KT) + 2, st, 2 * g - 16) WA_PIECE((KT) + 2, st, 2 * g - 15) } \
+            if (Q == 5 && MORE2) { WA_PIECE((KT) + 2, st, g) }                                                    \
+            if (Q < 3) { if (MORE1) { WA_READ(xf, st ^ 1, 0, (g + 8) & 15) } }                                    \
+            else if (MORE1 && g < 8) { WA_READ(xf, st ^ 1, 0, (2 * g + 8) & 15) WA_READ(xf, st ^ 1, 0, (2 * g + 9) & 15) } \
+        }                                                                                                         \
+        WA_MARK(KT, 4)                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the X fragments landed long ago: tells the compiler's wait pass so */ \
+    }
+    // read order within a phase: A0..A7 then W0..W7 (MFMA group g needs every A fragment but only W[g / 2])
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) WA_KTILE(kt, true, true)
+    if (kt + 1 < nk) { WA_KTILE(kt, false, true) ++kt; }
+    WA_KTILE(kt, false, false)
+#undef WA_KTILE
+#undef WA_MARK
+    if constexpr (TRACE) {
+        if (blockIdx.x == 0 && lane == 0)
+            for (int i = 0; i < TR_TILES * TR_MARKS; ++i) trace[wid * TR_TILES * TR_MARKS + i] = marks[wid * TR_TILES * TR_MARKS + i];
+    }
+#undef WA_PIECE
+#undef WA_READ
+#undef WA_MFMA4
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const int mw = m0 + wm * 128, nw = n0 + wn * 128;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            const int n = nw + ni * 16 + fg * 4;
+            if (n >= N) continue;
+            *reinterpret_cast<uint2*>(C + (long long)m * N + n) = make_uint2(pack_bf2(acc[ni][mi][0], acc[ni][mi][1]), pack_bf2(acc[ni][mi][2], acc[ni][mi][3]));
+        }
+    }
+}
+
+template <int Q>
+static void launch_w4a(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, unsigned long long* trace, hipStream_t st) {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    const size_t lds = 2 * STAGE;
+    static bool set = false;
+    if (!set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_w4a_kernel<Q, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_w4a_kernel<Q, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set = true;
+    }
+    if (trace) lab_w4a_kernel<Q, true><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn, trace);
+    else lab_w4a_kernel<Q, false><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn, nullptr);
+}
+
+// ---- 4 waves, tile 256 x (32 NI) x 64, ring of NS stages: the vendor library's answer for the shapes that miss a whole round of 256 x 256 or 128 x 256
+// tiles (profiles/r05_library_yardstick.txt: MT256x160 for the tower's fc1, MT160x256 for LLaMA's o / down) -- one round of <= 256 workgroups.
+// NI = 5: 256 x 160, stage 52 KB, NS = 3 (156 KB).  Same phases as lab_w4a_kernel; at the boundary of K tile kt the pieces of tile kt + 1 must
+// have landed and those of kt + 2 .. kt + NS - 1 may fly: vmcnt((NS - 2) * NPW).
+template <int NI, int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lab_w4n_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                                            bf16_t* __restrict__ C, int M, int N, int K, int tiles_m,
+                                                                                            int tiles_n) {
+    constexpr int TN = 32 * NI, STG = (256 + TN) * 128, PT = 32 + 4 * NI, NPW = PT / 4;
+    static_assert(PT % 4 == 0, "pieces split evenly over the four waves");
+    constexpr int G = NI * 2;                    // MFMA groups of 4 per phase
+    constexpr int R = 8 + NI;                    // fragment reads per phase
+    constexpr int PPG = (NPW + G - 1) / G;       // DMA pieces per group
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk = K / BK;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = tile % tiles_m, tn = tile / tiles_m;
+    const int m0 = tm * 256, n0 = tn * TN;
+    const bf16_t* src[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int p = wid * NPW + j;             // piece of the stage: < 32 -> A rows 8 p .., else W rows 8 (p - 32) ..
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        src[j] = p < 32 ? A + (size_t)min(m0 + p * 8 + rl, M - 1) * K + c * 8 : W + (size_t)min(n0 + (p - 32) * 8 + rl, N - 1) * K + c * 8;
+    }
+    const int lds_piece0 = wid * NPW * 1024;
+#define WN_PIECE(KT, ST, J)                                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[J] + (size_t)(KT) * BK),               \
+                                     (__attribute__((address_space(3))) void*)(smem + (ST) * STG + lds_piece0 + (J) * 1024), 16, 0, 0);
+    f32x4 acc[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[16], yf[16];                       // [0 .. NI - 1]: W fragments, [8 .. 15]: A fragments
+    const int rw0 = wn * (NI * 16) + fr, ra0 = wm * 128 + fr;
+    // read r of a phase: r < 8 -> A fragment r, else W fragment r - 8
+#define WN_READ(F, ST, KS, RI)                                                                                    \
+    {                                                                                                             \
+        const int isw_ = (RI) >= 8;                                                                               \
+        const int r_ = (isw_ ? rw0 + ((RI) - 8) * 16 : ra0 + (RI) * 16);                                          \
+        F[isw_ ? (RI) - 8 : 8 + (RI)] = *reinterpret_cast<const bf16x8*>(smem + (ST) * STG + (isw_ ? 256 * 128 : 0) + r_ * 128 + ((((KS) * 4 + fg) ^ (r_ & 7)) << 4)); \
+    }
+#define WN_MFMA4(F, GI)                                                                                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                            \
+        const int p_ = (GI) * 4 + q_;                                                                             \
+        const int ni_ = p_ >> 3, mi_ = p_ & 7;                                                                    \
+        mfma_a(acc[ni_][mi_], F[ni_], F[8 + mi_]);                                                                \
+    }
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+        if (t < nk) {
+#pragma unroll
+            for (int j = 0; j < NPW; ++j) { WN_PIECE(t, t, j) }
+        }
+    if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int r = 0; r < R; ++r) { WN_READ(xf, 0, 0, r) }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int st = 0;
+#define WN_KTILE(MORE, MORE1)                                                                                     \
+    {                                                                                                             \
+        const int stn = st + 1 == NS ? 0 : st + 1;                                                                \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                           \
+            WN_MFMA4(xf, g)                                                                                       \
+            if (2 * g < R) { WN_READ(yf, st, 1, 2 * g) }                                                          \
+            if (2 * g + 1 < R) { WN_READ(yf, st, 1, 2 * g + 1) }                                                  \
+        }                                                                                                         \
+        if (MORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NPW) : "memory");                \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                           \
+            WN_MFMA4(yf, g)                                                                                       \
+            _Pragma("unroll") for (int t = 0; t < PPG; ++t)                                                       \
+                if (g * PPG + t < NPW && MORE) { WN_PIECE(kt + NS, st, g * PPG + t) }                             \
+            if (MORE1) {                                                                                          \
+                if (2 * g < R) { WN_READ(xf, stn, 0, 2 * g) }                                                     \
+                if (2 * g + 1 < R) { WN_READ(xf, stn, 0, 2 * g + 1) }                                             \
+            }                                                                                                     \
+        }                                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+        st = stn;                                                                                                 \
+    }
+    int kt = 0;
+    for (; kt + NS < nk; ++kt) WN_KTILE(true, true)
+    for (; kt + 1 < nk; ++kt) WN_KTILE(false, true)
+    WN_KTILE(false, false)
+#undef WN_KTILE
+#undef WN_PIECE
+#undef WN_READ
+#undef WN_MFMA4
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const int mw = m0 + wm * 128, nw = n0 + wn * (NI * 16);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = mw + mi * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = nw + ni * 16 + fg * 4;
+            if (n >= N) continue;
+            *reinterpret_cast<uint2*>(C + (long long)m * N + n) = make_uint2(pack_bf2(acc[ni][mi][0], acc[ni][mi][1]), pack_bf2(acc[ni][mi][2], acc[ni][mi][3]));
+        }
+    }
+}
+
+template <int NI, int NS>
+static void launch_w4n(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, unsigned long long*, hipStream_t st) {
+    constexpr int TN = 32 * NI;
+    const int tm = (M + 255) / 256, tn = (N + TN - 1) / TN;
+    const size_t lds = (size_t)NS * (256 + TN) * 128;
+    static bool set = false;
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_w4n_kernel<NI, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    lab_w4n_kernel<NI, NS><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn);
+}
+
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint64_t xorshift() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
 static bf16_t rnd_bf16(float scale) {
@@ -442,9 +839,11 @@ static void launch(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, in
 typedef void (*launch_fn)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int, unsigned long long*, hipStream_t);
 #define BV(SKEW, PRIO, LPOS) (128 + (SKEW) + ((PRIO) << 2) + ((LPOS) << 5))
 static launch_fn LAUNCH[] = {launch<0>, launch<3>, launch<BV(0, 2, 0)>, launch<BV(0, 3, 0)>, launch<BV(0, 4, 0)>, launch<BV(2, 1, 0)>, launch<BV(2, 2, 0)>,
-                             launch_narrow<64, 3, 0>, launch_narrow<64, 3, 1>, launch_narrow<64, 4, 0>, launch_narrow<64, 2, 0>, launch_narrow<128, 2, 0>, launch_narrow<128, 3, 0>, launch_narrow<128, 3, 1>};
-static const char* VNAME[] = {"big", "E47p1", "L03p1", "E47p2", "E47p3", "swap+47p1", "swap+03p1", "n64 s3", "n64 s3 mid", "n64 s4", "n64 s2", "n128 s2", "n128 s3", "n128 s3 mid"};
-constexpr int NV = 14;
+                             launch_narrow<64, 3, 0>, launch_narrow<64, 3, 1>, launch_narrow<64, 4, 0>, launch_narrow<64, 2, 0>, launch_narrow<128, 2, 0>, launch_narrow<128, 3, 0>, launch_narrow<128, 3, 1>,
+                             launch_w4<0>, launch_w4<1>, launch_w4<2>, launch_w4a<0>, launch_w4a<1>, launch_w4a<2>, launch_w4a<3>, launch_w4a<4>, launch_w4a<5>,
+                             launch_w4n<5, 3>, launch_w4n<5, 2>, launch_w4n<4, 3>, launch_w4n<6, 2>, launch_w4n<8, 2>};
+static const char* VNAME[] = {"big", "E47p1", "L03p1", "E47p2", "E47p3", "swap+47p1", "swap+03p1", "n64 s3", "n64 s3 mid", "n64 s4", "n64 s2", "n128 s2", "n128 s3", "n128 s3 mid", "w4", "w4 pattern", "w4 dma-first", "w4 agpr", "w4 agpr dma-early", "w4 agpr dma-2x8", "w4 r2 dma 2x8 first half", "w4 r2 dma 2x8 second half", "w4 r2 dma 1x16", "256x160 s3", "256x160 s2", "256x128 s3", "256x192 s2", "256x256 s2"};
+constexpr int NV = 28;
 
 int main(int argc, char** argv) {
     const bool do_trace = argc > 1 && !strcmp(argv[1], "trace");
@@ -453,10 +852,18 @@ int main(int argc, char** argv) {
     const Shape shapes_big[] = {{"sq4096", 4096, 4096, 4096}, {"2r 4096x8192x4096", 4096, 8192, 4096}, {"sq8192", 8192, 8192, 8192},
                                 {"qkv2048", 2048, 12288, 4096}, {"gateup2048 (2.69 rounds)", 2048, 22016, 4096}};
     const Shape shapes_narrow[] = {{"vit fc2", 2056, 1024, 4096}, {"vit out", 2056, 1024, 1024}, {"vit fc1", 2056, 4096, 1024}, {"vit qkv", 2056, 3072, 1024},
-                                   {"proj1", 2048, 4096, 1024}, {"proj2", 2048, 4096, 4096}, {"llama o (M=2168)", 2168, 4096, 4096}};
-    const Shape* shapes_p = narrow ? shapes_narrow : shapes_big;
-    const int n_shapes = narrow ? 7 : 5;
-    const int v_lo = narrow ? 7 : 0, v_hi = narrow ? 14 : 7;
+                                   {"proj1", 2048, 4096, 1024}, {"proj2", 2048, 4096, 4096}, {"llama o (M=2168)", 2168, 4096, 4096},
+                                   {"llama down (M=2168)", 2168, 4096, 11008}};
+    const Shape* shapes_p = (narrow || (argc > 1 && !strcmp(argv[1], "w4n"))) ? shapes_narrow : shapes_big;
+    const int n_shapes = (narrow || (argc > 1 && !strcmp(argv[1], "w4n"))) ? 8 : 5;
+    const bool w4 = argc > 1 && !strcmp(argv[1], "w4");
+    std::vector<int> vs;                                   // variants of this mode; the first is the bitwise reference
+    if (narrow) for (int v = 7; v < 14; ++v) vs.push_back(v);
+    else if (w4) vs = {0, 17, 20, 21, 22};
+    const bool w4n = argc > 1 && !strcmp(argv[1], "w4n");
+    if (w4n) vs = {11, 0, 23, 24, 25, 26, 27};
+    else for (int v = 0; v < 7; ++v) vs.push_back(v);
+    const int v_lo = vs[0];
     hipStream_t st;
     CK(hipStreamCreate(&st));
     for (int si = 0; si < n_shapes; ++si) {
@@ -481,7 +888,7 @@ int main(int argc, char** argv) {
         for (int v = 0; v < NV; ++v) { best[v] = 1e30; same[v] = true; }
         std::vector<bf16_t> h0((size_t)M * N), h1((size_t)M * N);
         for (int rep = 0; rep < 3; ++rep)
-            for (int v = v_lo; v < v_hi; ++v) {
+            for (int v : vs) {
                 const int iters = 12;
                 for (int i = 0; i < 2; ++i) LAUNCH[v](dA, dW[i % NW], dC, M, N, K, nullptr, st);
                 CK(hipEventRecord(e0, st));
@@ -515,9 +922,30 @@ int main(int argc, char** argv) {
         const double fl = 2.0 * M * N * K;
         const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
         printf("%-28s (%4d tiles = %.2f rounds, host check %.1e):", s.name, tiles, tiles / 256.0, maxrel);
-        for (int v = v_lo; v < v_hi; ++v) printf("  %s %.1f us (%.0f TF)%s", VNAME[v], best[v], fl / best[v] / 1e6, same[v] ? "" : " DIFF");
+        for (int v : vs) printf("  %s %.1f us (%.0f TF)%s", VNAME[v], best[v], fl / best[v] / 1e6, same[v] ? "" : " DIFF");
         printf("\n");
         fflush(stdout);
+        if (w4 && argc > 2 && !strcmp(argv[2], "trace") && !strcmp(s.name, "sq4096")) {
+            unsigned long long* dT;
+            const size_t nt = 8 * TR_TILES * TR_MARKS;
+            CK(hipMalloc(&dT, nt * 8));
+            for (int v : {20, 21}) {
+                CK(hipMemset(dT, 0, nt * 8));
+                LAUNCH[v](dA, dW[1], dC, M, N, K, dT, st);
+                CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hT(nt);
+                CK(hipMemcpy(hT.data(), dT, nt * 8, hipMemcpyDeviceToHost));
+                printf("trace %s (cycles since wave 0's first mark; marks: 0 K-tile top, 1 phase A issued (64 MFMA + 16 reads), 2 waits done, 3 past the barrier, 4 phase B issued (64 MFMA + 16 reads + DMA))\n", VNAME[v]);
+                const unsigned long long t0 = hT[0];
+                for (int kt = 0; kt < TR_TILES; ++kt)
+                    for (int w = 0; w < 4; ++w) {
+                        printf("  kt %2d wave %d:", TR_T0 + kt, w);
+                        for (int i = 0; i < 5; ++i) printf(" %6lld", (long long)(hT[(w * TR_TILES + kt) * TR_MARKS + i] - t0));
+                        printf("\n");
+                    }
+            }
+            CK(hipFree(dT));
+        }
         if (do_trace && !strcmp(s.name, "sq4096")) {
             unsigned long long* dT;
             const size_t nt = 8 * TR_TILES * TR_MARKS;

@@ -83,7 +83,7 @@ def main():
                 rel = lambda col: (t[:, col][t[:, col] > 0] - e0)
                 row = {"wgs": int(used.sum()), "entry_last": rel(0).max()}
                 if mode == 0:
-                    row.update(first_w=rel(1).mean(), loop_done_mean=rel(2).mean(), loop_done_max=rel(2).max(), end_mean=rel(4).mean(), end_max=rel(4).max())
+                    row.update(first_w=rel(1).mean(), loop_done_mean=rel(2).mean(), loop_done_max=rel(2).max(), all_waves_done_mean=rel(3).mean(), all_waves_done_max=rel(3).max(), end_mean=rel(4).mean(), end_max=rel(4).max())
                     end = t[:, 4].max()
                 else:
                     ends = []
