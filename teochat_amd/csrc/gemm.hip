@@ -676,7 +676,8 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         // the problem is ONE round of them but more than one round of 128 x 256 tiles: M = 2056 .. 2304 against N = 4096 (272 wide tiles,
         // 234 of these).  tools/gemm_lab.hip w4n / bench_kernels.py yardstick, no epilogue (us): LLaMA o 78 -> 66, down 174 -> 159, the tower's
         // fc1 31 -> 24; with the real epilogues (tools/vit_gemm_probe.py): o 79.8 -> 71.1, down 188.5 -> 168.7 .. 177.8 -- but fc1 43.2 -> 51.3:
-        // one wave per SIMD walks 160 erf evaluations per lane as 80 KB of straight-line code, so the rule leaves activations to the 8-wave tiles
+        // one wave per SIMD issues the 160 erf evaluations of a lane alone (no second wave to alternate VALU slots with; the same epilogue as a
+        // rolled loop through LDS measured the same), so the rule leaves GEMMs with an activation to the 8-wave tiles
         if (!swiglu && (tune().gemm_quad == 2 ||
                         (tune().gemm_quad == 1 && tune().gemm_bm == 0 && tune().gemm_wide == 1 && tune().gemm_big == 1 && tune().gemm_sk == 1 &&
                          act == TEO_ACT_NONE && K >= 8 * BK && t_wide_ > 256 &&

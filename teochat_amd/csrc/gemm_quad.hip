@@ -141,6 +141,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the asm MFMAs are invisible to hipcc's hazard recognizer: cover the last results' write-back before the epilogue reads the AGPRs
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
+    // (measured and not kept: the same epilogue through LDS -- 64 rows x 80 columns of f32 per wave parked in the free ring, read back as whole
+    // rows by a rolled loop, 8-byte stores covering a row's 160 contiguous bytes: bit-identical, o 73.1 -> 89.8 us, down 175.9 -> 187.2, fc1 + GELU
+    // 51.2 -> 52.2.  The activation's cost here is VALU issue with ONE wave per SIMD, not code size: 160 erf per lane, no second wave to
+    // alternate with -- which is why the dispatch leaves GEMMs with an activation to the 8-wave tiles.)
     gemm_epilogue<NI, 8, 4, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * 128, n0 + wn * (NI * 16), fr, fg);
 }
 
