@@ -665,7 +665,8 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const bool of32 = out_dtype == TEO_F32;
         // narrow LDS-DMA tiles (gemm_narrow.hip, round 5): forced here; the automatic rule sits below, after the families it competes with
         if (tune().gemm_narrow == 2 && !swiglu)
-            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, tune().gemm_narrow_bm == 128 ? 128 : 64, st);
+            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16,
+                                      tune().gemm_narrow_bm == 128 ? 128 : (tune().gemm_narrow_bm == 256 ? 256 : 64), st);
         // automatic: wherever the 64-row register-staged kernel was the choice (few tiles: the tower's out_proj / fc2, every tower GEMM and
         // the LLaMA o / down projections of config C2) the 64 x 128 LDS-DMA tile runs instead -- tools/vit_gemm_probe.py (round 5, us):
         // fc2 47.1 -> 36.5, out_proj 17.2 -> 14.6 (T = 8); at T = 2: fc2 42.6 -> 32.6, fc1 23.0 -> 18.6, LLaMA o 60.8 -> 39.2, down 148 -> 93
@@ -678,11 +679,13 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         // fc1 31 -> 24; with the real epilogues (tools/vit_gemm_probe.py): o 79.8 -> 71.1, down 188.5 -> 168.7 .. 177.8 -- but fc1 43.2 -> 51.3:
         // one wave per SIMD issues the 160 erf evaluations of a lane alone (no second wave to alternate VALU slots with; the same epilogue as a
         // rolled loop through LDS measured the same), so the rule leaves GEMMs with an activation to the 8-wave tiles
-        if (!swiglu && (tune().gemm_quad == 2 ||
-                        (tune().gemm_quad == 1 && tune().gemm_bm == 0 && tune().gemm_wide == 1 && tune().gemm_big == 1 && tune().gemm_sk == 1 &&
-                         act == TEO_ACT_NONE && K >= 8 * BK && t_wide_ > 256 &&
-                         (long long)cdiv(M, 256) * cdiv(N, 160) <= std::min(device_cu_count(), 256))))
+        // -- those run the same 256 x 160 tile on EIGHT waves (gemm_narrow.hip, bm = 256): fc1 + GELU 43 -> see profiles/r05_gemm_experiments.md 6b
+        const bool one_round_160 = !swiglu && tune().gemm_quad == 1 && tune().gemm_bm == 0 && tune().gemm_wide == 1 && tune().gemm_big == 1 &&
+                                   tune().gemm_sk == 1 && tune().gemm_narrow == 1 && K >= 8 * BK && t_wide_ > 256 &&
+                                   (long long)cdiv(M, 256) * cdiv(N, 160) <= std::min(device_cu_count(), 256);
+        if (!swiglu && (tune().gemm_quad == 2 || (one_round_160 && act == TEO_ACT_NONE)))
             return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);
+        if (one_round_160) return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 256, st);
         // just over one round of wide tiles -- or, for a short K loop (K <= 1024: the tower's fc1 at T = 16, 528 tiles), just over two:
         // there a ragged third round costs a third of the launch (wide 86.7 us, its stream-K form 65.5; tools/vit_gemm_probe.py, round 5)
         const long long sk_wide_max = K <= 1024 ? 2 * 256 + 256 / 6 : 256 + 256 / 6;

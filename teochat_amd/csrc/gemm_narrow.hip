@@ -1,4 +1,5 @@
-// Narrow-tile form of the 16-bit MFMA GEMM (round 5): TBM (64 or 128) x 128 x 64 workgroup tile, 4 waves (2 x 2) of (TBM / 2) x 64,
+// Narrow-tile form of the 16-bit MFMA GEMM (round 5): TBM (64 or 128) x 128 x 64 workgroup tile, 4 waves (2 x 2) of (TBM / 2) x 64
+// (and, late in the round, the same K loop on a 256 x 160 tile with 8 waves: see the template's comment),
 // operands brought in by LDS-DMA (global_load_lds_dwordx4) into a ring of NS stages, ONE barrier per K tile -- the K loop of the
 // 128 x 256 kernel (gemm_wide.hip) on a tile small enough for problems that have FEW tiles (the ViT tower: M = 2056, N = 1024 ->
 // 136 tiles of 128 x 128) or a SHORT K loop (K = 1024: 16 K tiles, prologue and epilogue as long as the loop).
@@ -20,7 +21,7 @@ namespace teo {
 typedef __attribute__((ext_vector_type(8))) short gn_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float gn_f32x4;
 
-constexpr int GN_BN = 128, GN_BK = 64;
+constexpr int GN_BK = 64;
 
 __device__ __forceinline__ int gn_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -28,42 +29,50 @@ __device__ __forceinline__ int gn_xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <int TBM, int NS, bool OUT_F32, bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_narrow_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+// TBM x TBN tile, WM x WN waves of (TBM / WM) x (TBN / WN); NS stages.  Shipped: 64 x 128 and 128 x 128 on 2 x 2 waves (two workgroups per
+// CU), and -- round 5, late -- 256 x 160 on 4 x 2 waves (one workgroup per CU, 3 x 52 KB): the ONE-round tile of M = 2056 .. 2304 against
+// N = 4096 (gemm_quad.hip) for the GEMMs that carry an activation, whose epilogue wants two waves per SIMD (the tower's fc1 + GELU)
+template <int TBM, int TBN, int WM, int WN, int NS, bool OUT_F32, bool F16>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mfma_bf16_narrow_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                      const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M,
                                                                      int N, int K, int lda, int ldc, int act, int tiles_m, int tiles_n) {
-    constexpr int A_BYTES = TBM * GN_BK * 2, STAGE = A_BYTES + GN_BN * GN_BK * 2;
-    constexpr int NP = STAGE / 1024 / 4;          // 1-KiB DMA pieces per wave per K tile: 6 (64 x 128) or 8 (128 x 128)
-    constexpr int MI = TBM / 32;                  // 16-row A fragments per wave
+    constexpr int NW = WM * WN;
+    constexpr int A_BYTES = TBM * GN_BK * 2, STAGE = A_BYTES + TBN * GN_BK * 2;
+    constexpr int PT = STAGE / 1024;              // 1-KiB DMA pieces per K tile (8 rows each): TBM / 8 of A, then TBN / 8 of W
+    constexpr int NP = (PT + NW - 1) / NW;        // pieces per wave: 6 (64 x 128), 8 (128 x 128), 7 (256 x 160: 56 slots for 52 pieces -- the
+                                                  // last wave brings piece 51 five times, to the same LDS bytes: +8 % L2 reads, one wait count)
+    constexpr int MI = TBM / WM / 16, NI = TBN / WN / 16;      // 16-row A / W fragments per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int fr = lane & 15, fg = lane >> 4;
     const int nk = K / GN_BK;
     const int tile = gn_xcd_remap(blockIdx.x, gridDim.x);      // m fastest: the workgroups an XCD runs together share a W panel
     const int tm = tile % tiles_m, tn = tile / tiles_m;
-    const int m0 = tm * TBM, n0 = tn * GN_BN;
+    const int m0 = tm * TBM, n0 = tn * TBN;
 
-    // DMA pieces of this wave: piece g = wid * NP + j covers 8 rows (g < TBM / 8: A rows, else W rows); lane l brings row (l >> 3) of
-    // the piece, logical chunk (l & 7) ^ (l >> 3), to LDS byte g * 1024 + l * 16 of the stage
+    // DMA pieces of this wave: piece g = min(wid * NP + j, PT - 1) covers 8 rows (g < TBM / 8: A rows, else W rows); lane l brings row
+    // (l >> 3) of the piece, logical chunk (l & 7) ^ (l >> 3), to LDS byte g * 1024 + l * 16 of the stage
     const bf16_t* src[NP];
+    int gofs[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const int g = wid * NP + j;
+        const int g = min(wid * NP + j, PT - 1);
         const int rl = lane >> 3, c = (lane & 7) ^ rl;
         if (g < TBM / 8) src[j] = A + (long long)min(m0 + g * 8 + rl, M - 1) * lda + c * 8;
         else src[j] = W + (long long)min(n0 + (g - TBM / 8) * 8 + rl, N - 1) * K + c * 8;
+        gofs[j] = g * 1024;                       // (wave-uniform)
     }
 #define TEO_GN_STAGE(KT, ST)                                                                                                   \
     _Pragma("unroll") for (int j = 0; j < NP; ++j)                                                                             \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (long long)(KT) * GN_BK),   \
-                                         (__attribute__((address_space(3))) void*)(smem + (ST) * STAGE + (wid * NP + j) * 1024), 16, 0, 0);
-    uint2 bv[4];                                  // the lane's bias values: requested now, used after the K loop (gemm_epilogue.h)
-    gemm_bias_load<4>(bias, n0 + wn * 64, fg, N, bv);
-    gn_f32x4 acc[4][MI];   // [ni][mi]
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * STAGE + gofs[j]), 16, 0, 0);
+    uint2 bv[NI];                                 // the lane's bias values: requested now, used after the K loop (gemm_epilogue.h)
+    gemm_bias_load<NI>(bias, n0 + wn * (NI * 16), fg, N, bv);
+    gn_f32x4 acc[NI][MI];   // [ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = (gn_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -84,19 +93,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_narrow_kernel(const bf1
         const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            gn_bf16x8 af[MI], wf[4];
+            gn_bf16x8 af[MI], wf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rw_ = wn * 64 + i * 16 + fr;
+            for (int i = 0; i < NI; ++i) {
+                const int rw_ = wn * (NI * 16) + i * 16 + fr;
                 wf[i] = *reinterpret_cast<const gn_bf16x8*>(sB + rw_ * 128 + (((ks * 4 + fg) ^ (rw_ & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int ra_ = wm * (TBM / 2) + i * 16 + fr;
+                const int ra_ = wm * (MI * 16) + i * 16 + fr;
                 af[i] = *reinterpret_cast<const gn_bf16x8*>(sA + ra_ * 128 + (((ks * 4 + fg) ^ (ra_ & 7)) << 4));
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = mfma16<F16>(wf[ni], af[mi], acc[ni][mi]);
         }
@@ -105,30 +114,31 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_bf16_narrow_kernel(const bf1
 #undef TEO_GN_STAGE
     static_assert(NS == 2 || NS == 3, "the counted wait above allows one later tile in flight");
 
-    gemm_epilogue<4, MI, MI, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (TBM / 2), n0 + wn * 64, fr, fg);
+    gemm_epilogue<NI, MI, MI, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (MI * 16), n0 + wn * (NI * 16), fr, fg);
 }
 
-// bm: 64 -> 64 x 128 tiles, 3 stages (72 KB: two workgroups per CU); 128 -> 128 x 128 tiles, 2 stages (64 KB: two per CU).  No SwiGLU
-// form (the shapes this family serves carry bias / activation / residual epilogues)
+// bm: 64 -> 64 x 128 tiles, 3 stages (72 KB: two workgroups per CU); 128 -> 128 x 128 tiles, 2 stages (64 KB: two per CU); 256 -> 256 x 160
+// tiles on 8 waves, 3 stages (156 KB: one per CU).  No SwiGLU form (the shapes this family serves carry bias / activation / residual epilogues)
 int gemm_narrow_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                        int act, bool of32, bool f16, int bm, hipStream_t st) {
-    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, GN_BN);
+    const int bn = bm == 256 ? 160 : 128;
+    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
     const int nwg = tiles_m * tiles_n;
-#define TEO_GN_LAUNCH_T(TBM, NS, OF, FV)                                                                                          \
+#define TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, FV)                                                                             \
     {                                                                                                                             \
-        constexpr size_t lds = (size_t)(NS) * ((TBM) * GN_BK * 2 + GN_BN * GN_BK * 2);                                            \
+        constexpr size_t lds = (size_t)(NS) * ((TBM) * GN_BK * 2 + (TBN) * GN_BK * 2);                                            \
         static unsigned long long attr_mask = 0;                                                                                  \
-        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_narrow_kernel<TBM, NS, OF, FV>), (int)lds, &attr_mask, "gemm_narrow")) return e; \
-        gemm_mfma_bf16_narrow_kernel<TBM, NS, OF, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,  \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_narrow_kernel<TBM, TBN, WM, WN, NS, OF, FV>), (int)lds, &attr_mask, "gemm_narrow")) return e; \
+        gemm_mfma_bf16_narrow_kernel<TBM, TBN, WM, WN, NS, OF, FV><<<nwg, (WM) * (WN) * 64, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias,  \
                                                                           (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
     }
-#define TEO_GN_LAUNCH_F(TBM, NS, OF) { if (f16) TEO_GN_LAUNCH_T(TBM, NS, OF, true) else TEO_GN_LAUNCH_T(TBM, NS, OF, false) }
-#define TEO_GN_LAUNCH(TBM, NS) { if (of32) TEO_GN_LAUNCH_F(TBM, NS, true) else TEO_GN_LAUNCH_F(TBM, NS, false) }
-    if (bm == 64) TEO_GN_LAUNCH(64, 3) else TEO_GN_LAUNCH(128, 2)
+#define TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, OF) { if (f16) TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, true) else TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, false) }
+#define TEO_GN_LAUNCH(TBM, TBN, WM, WN, NS) { if (of32) TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, true) else TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, false) }
+    if (bm == 64) TEO_GN_LAUNCH(64, 128, 2, 2, 3) else if (bm == 256) TEO_GN_LAUNCH(256, 160, 4, 2, 3) else TEO_GN_LAUNCH(128, 128, 2, 2, 2)
 #undef TEO_GN_LAUNCH
 #undef TEO_GN_LAUNCH_F
 #undef TEO_GN_LAUNCH_T
-    note_kernel(bm == 64 ? "gemm_narrow_64" : "gemm_narrow_128");
+    note_kernel(bm == 64 ? "gemm_narrow_64" : (bm == 256 ? "gemm_narrow_256x160" : "gemm_narrow_128"));
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_narrow");
     return TEO_OK;
 }

@@ -122,6 +122,7 @@ FAMILIES = (("production dispatch", {}),
             ("64x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 64}),           # round 5 (SwiGLU GEMMs have no such form: they fall
             ("128x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 128}),         # through to the production dispatch under these knobs)
             ("256x160 four waves", {"gemm_quad": 2}),
+            ("256x160 eight waves", {"gemm_narrow": 2, "gemm_narrow_bm": 256}),
             ("128x256 tile", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0}),
             ("128x256 stream-K", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}),
             ("256x256 tile", {"gemm_big": 2, "gemm_big_hybrid": 0}),
