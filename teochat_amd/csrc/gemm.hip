@@ -667,13 +667,14 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         if (tune().gemm_narrow == 2 && !swiglu)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16,
                                       tune().gemm_narrow_bm == 128 ? 128 : (tune().gemm_narrow_bm == 256 ? 256 : 64), st);
+        if (tune().gemm_quad == 2 && !swiglu) return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);      // forced (its rule: below)
         // automatic: wherever the 64-row register-staged kernel was the choice (few tiles: the tower's out_proj / fc2, every tower GEMM and
         // the LLaMA o / down projections of config C2) the 64 x 128 LDS-DMA tile runs instead -- tools/vit_gemm_probe.py (round 5, us):
         // fc2 47.1 -> 36.5, out_proj 17.2 -> 14.6 (T = 8); at T = 2: fc2 42.6 -> 32.6, fc1 23.0 -> 18.6, LLaMA o 60.8 -> 39.2, down 148 -> 93
         if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && bm == 64)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, st);
         const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = (long long)cdiv(M, 256) * cdiv(N, 256);
-        // 256 x 160 tiles on four waves (gemm_quad.hip, round 5): forced, or -- automatic, and only while no other family is forced -- where
+        // 256 x 160 tiles on four waves (gemm_quad.hip, round 5): automatic, and only while no other family is forced, where
         // the problem is ONE round of them but more than one round of 128 x 256 tiles: M = 2056 .. 2304 against N = 4096 (272 wide tiles,
         // 234 of these).  tools/gemm_lab.hip w4n / bench_kernels.py yardstick, no epilogue (us): LLaMA o 78 -> 66, down 174 -> 159, the tower's
         // fc1 31 -> 24; with the real epilogues (tools/vit_gemm_probe.py): o 79.8 -> 71.1, down 188.5 -> 168.7 .. 177.8 -- but fc1 43.2 -> 51.3:
@@ -683,7 +684,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const bool one_round_160 = !swiglu && tune().gemm_quad == 1 && tune().gemm_bm == 0 && tune().gemm_wide == 1 && tune().gemm_big == 1 &&
                                    tune().gemm_sk == 1 && tune().gemm_narrow == 1 && K >= 8 * BK && t_wide_ > 256 &&
                                    (long long)cdiv(M, 256) * cdiv(N, 160) <= std::min(device_cu_count(), 256);
-        if (!swiglu && (tune().gemm_quad == 2 || (one_round_160 && act == TEO_ACT_NONE)))
+        if (one_round_160 && act == TEO_ACT_NONE)
             return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);
         if (one_round_160) return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 256, st);
         // just over one round of wide tiles -- or, for a short K loop (K <= 1024: the tower's fc1 at T = 16, 528 tiles), just over two:
