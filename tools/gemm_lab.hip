@@ -696,7 +696,7 @@ static void launch_w4a(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N
 // tiles (profiles/r05_library_yardstick.txt: MT256x160 for the tower's fc1, MT160x256 for LLaMA's o / down) -- one round of <= 256 workgroups.
 // NI = 5: 256 x 160, stage 52 KB, NS = 3 (156 KB).  Same phases as lab_w4a_kernel; at the boundary of K tile kt the pieces of tile kt + 1 must
 // have landed and those of kt + 2 .. kt + NS - 1 may fly: vmcnt((NS - 2) * NPW).
-template <int NI, int NS>
+template <int NI, int NS, bool SADDR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void lab_w4n_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                                             bf16_t* __restrict__ C, int M, int N, int K, int tiles_m,
                                                                                             int tiles_n) {
@@ -722,9 +722,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         src[j] = p < 32 ? A + (size_t)min(m0 + p * 8 + rl, M - 1) * K + c * 8 : W + (size_t)min(n0 + (p - 32) * 8 + rl, N - 1) * K + c * 8;
     }
     const int lds_piece0 = wid * NPW * 1024;
+    // SADDR: address = uniform base (SGPR pair, advanced by the K tile with scalar adds) + 32-bit per-lane byte offset (loop-invariant VGPR):
+    // no 64-bit VALU add per piece and K tile
+    const char* pbase[NPW];
+    unsigned voff[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int p = wid * NPW + j;
+        const int rl = lane >> 3, c = (lane & 7) ^ rl;
+        pbase[j] = p < 32 ? reinterpret_cast<const char*>(A) : reinterpret_cast<const char*>(W);
+        voff[j] = p < 32 ? ((unsigned)min(m0 + p * 8 + rl, M - 1) * (unsigned)K + c * 8) * 2u : ((unsigned)min(n0 + (p - 32) * 8 + rl, N - 1) * (unsigned)K + c * 8) * 2u;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)               // (the buffer builtins do not exist in the host pass)
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, 0x7fffffff, 0x00020000);
+#define WN_BUF(KT, ST, J)                                                                                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((wid * NPW + (J)) < 32 ? rsA : rsW,                                              \
+                                                 (__attribute__((address_space(3))) void*)(smem + (ST) * STG + lds_piece0 + (J) * 1024), 16, voff[J], \
+                                                 (KT) * (BK * 2), 0, 0);
+#else
+#define WN_BUF(KT, ST, J)
+#endif
 #define WN_PIECE(KT, ST, J)                                                                                                      \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[J] + (size_t)(KT) * BK),               \
-                                     (__attribute__((address_space(3))) void*)(smem + (ST) * STG + lds_piece0 + (J) * 1024), 16, 0, 0);
+    if constexpr (SADDR) { WN_BUF(KT, ST, J) }                                                                                   \
+    else                                                                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[J] + (size_t)(KT) * BK),           \
+                                         (__attribute__((address_space(3))) void*)(smem + (ST) * STG + lds_piece0 + (J) * 1024), 16, 0, 0);
     f32x4 acc[NI][8];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -787,6 +810,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     WN_KTILE(false, false)
 #undef WN_KTILE
 #undef WN_PIECE
+#undef WN_BUF
 #undef WN_READ
 #undef WN_MFMA4
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -804,14 +828,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
-template <int NI, int NS>
+template <int NI, int NS, bool SADDR = false>
 static void launch_w4n(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, int K, unsigned long long*, hipStream_t st) {
     constexpr int TN = 32 * NI;
     const int tm = (M + 255) / 256, tn = (N + TN - 1) / TN;
     const size_t lds = (size_t)NS * (256 + TN) * 128;
     static bool set = false;
-    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_w4n_kernel<NI, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
-    lab_w4n_kernel<NI, NS><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn);
+    if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_w4n_kernel<NI, NS, SADDR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+    lab_w4n_kernel<NI, NS, SADDR><<<tm * tn, 256, lds, st>>>(A, W, C, M, N, K, tm, tn);
 }
 
 static uint64_t rng_state = 88172645463325252ull;
@@ -841,9 +865,9 @@ typedef void (*launch_fn)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int, 
 static launch_fn LAUNCH[] = {launch<0>, launch<3>, launch<BV(0, 2, 0)>, launch<BV(0, 3, 0)>, launch<BV(0, 4, 0)>, launch<BV(2, 1, 0)>, launch<BV(2, 2, 0)>,
                              launch_narrow<64, 3, 0>, launch_narrow<64, 3, 1>, launch_narrow<64, 4, 0>, launch_narrow<64, 2, 0>, launch_narrow<128, 2, 0>, launch_narrow<128, 3, 0>, launch_narrow<128, 3, 1>,
                              launch_w4<0>, launch_w4<1>, launch_w4<2>, launch_w4a<0>, launch_w4a<1>, launch_w4a<2>, launch_w4a<3>, launch_w4a<4>, launch_w4a<5>,
-                             launch_w4n<5, 3>, launch_w4n<5, 2>, launch_w4n<4, 3>, launch_w4n<6, 2>, launch_w4n<8, 2>};
-static const char* VNAME[] = {"big", "E47p1", "L03p1", "E47p2", "E47p3", "swap+47p1", "swap+03p1", "n64 s3", "n64 s3 mid", "n64 s4", "n64 s2", "n128 s2", "n128 s3", "n128 s3 mid", "w4", "w4 pattern", "w4 dma-first", "w4 agpr", "w4 agpr dma-early", "w4 agpr dma-2x8", "w4 r2 dma 2x8 first half", "w4 r2 dma 2x8 second half", "w4 r2 dma 1x16", "256x160 s3", "256x160 s2", "256x128 s3", "256x192 s2", "256x256 s2"};
-constexpr int NV = 28;
+                             launch_w4n<5, 3>, launch_w4n<5, 2>, launch_w4n<4, 3>, launch_w4n<6, 2>, launch_w4n<8, 2>, launch_w4n<5, 3, true>};
+static const char* VNAME[] = {"big", "E47p1", "L03p1", "E47p2", "E47p3", "swap+47p1", "swap+03p1", "n64 s3", "n64 s3 mid", "n64 s4", "n64 s2", "n128 s2", "n128 s3", "n128 s3 mid", "w4", "w4 pattern", "w4 dma-first", "w4 agpr", "w4 agpr dma-early", "w4 agpr dma-2x8", "w4 r2 dma 2x8 first half", "w4 r2 dma 2x8 second half", "w4 r2 dma 1x16", "256x160 s3", "256x160 s2", "256x128 s3", "256x192 s2", "256x256 s2", "256x160 s3 saddr"};
+constexpr int NV = 29;
 
 int main(int argc, char** argv) {
     const bool do_trace = argc > 1 && !strcmp(argv[1], "trace");
@@ -861,7 +885,7 @@ int main(int argc, char** argv) {
     if (narrow) for (int v = 7; v < 14; ++v) vs.push_back(v);
     else if (w4) vs = {0, 17, 20, 21, 22};
     const bool w4n = argc > 1 && !strcmp(argv[1], "w4n");
-    if (w4n) vs = {11, 0, 23, 24, 25, 26, 27};
+    if (w4n) vs = {11, 0, 23, 28, 24};
     else for (int v = 0; v < 7; ++v) vs.push_back(v);
     const int v_lo = vs[0];
     hipStream_t st;
