@@ -51,7 +51,7 @@ int teo_version(void);
 const char* teo_last_error(void);
 /* Diagnostics: which kernel family the most recent teo_gemm* / teo_attention call of this thread dispatched to
  * ("gemm_simple", "gemm_mfma_128", "gemm_mfma_128_sk", "gemm_wide", "gemm_wide_sk", "gemm_big", "gemm_big_hybrid", "gemm_fp8_*",
- * "gemm_big_hybrid_cohort", "gemm_narrow_64", "gemm_narrow_128", "gemm_narrow_256x160", "gemm_quad_160", "attn_flash32", "attn_simple").  Lets the parity tests state which production kernel they checked. */
+ * "gemm_big_hybrid_cohort", "gemm_narrow_64", "gemm_narrow_128", "gemm_quad_160", "gemm_quad_160_w4", "attn_flash32", "attn_simple").  Lets the parity tests state which production kernel they checked. */
 const char* teo_last_kernel(void);
 /* Size of a struct of this header as the LIBRARY was built with it (0 for an unknown name): a binding checks its own layout against it
  * at load time -- "teo_vit_desc", "teo_proj_desc", "teo_llama_desc", "teo_decode_state", "teo_decode_batch_state", "teo_attn_args". */
@@ -74,8 +74,9 @@ size_t teo_sizeof(const char* struct_name);
  *                   "gemm_wide" (0 off, 1 auto, 2 force), "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force),
  *                   "gemm_big_group", "gemm_big_hybrid" (0 off, 1 auto, 2 force), "gemm_big_cohort" (stream-K part of the hybrid form as
  *                   XCD-local cohorts: -1 auto, 0 linear ranges, 8 / 16 / 32 workgroups per cohort), "gemm_narrow" (64 / 128 x 128 LDS-DMA
- *                   tiles for few-tile / short-K shapes: 0 off, 1 auto, 2 force), "gemm_narrow_bm" (its tile rows: 0 auto, 64, 128, 256 = the 256 x 160 tile on eight waves),
- *                   "gemm_quad" (256 x 160 tiles on four waves, one per SIMD, for problems that are one round of them: 0 off, 1 auto, 2 force), "gemm_fp8_wide" (0..3),
+ *                   tiles for few-tile / short-K shapes: 0 off, 1 auto, 2 force), "gemm_narrow_bm" (its tile rows: 0 auto, 64, 128),
+ *                   "gemm_quad" (256 x 160 tiles, hand-scheduled K loop with the accumulators in AGPRs, for problems that are one round of them: 0 off, 1 auto,
+ *                   2 force), "gemm_quad_waves" (8: two waves per SIMD, the default; 4: one wave per SIMD with the whole register file), "gemm_fp8_wide" (0..3),
  *                   "gemm_fp8_big" (0..2) -- all bit-identical families
  *   prefill attn  : "flash_order" (causal workgroup order of the flash kernel: 0 heavy-first, 1 second dispatch pass mirrored), "flash_pipe"
  *                   (software pipeline inside the wave: -1 auto = causal kernels, 0 one tile at a time, 1 wherever the form exists) --

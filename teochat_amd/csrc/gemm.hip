@@ -665,8 +665,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const bool of32 = out_dtype == TEO_F32;
         // narrow LDS-DMA tiles (gemm_narrow.hip, round 5): forced here; the automatic rule sits below, after the families it competes with
         if (tune().gemm_narrow == 2 && !swiglu)
-            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16,
-                                      tune().gemm_narrow_bm == 128 ? 128 : (tune().gemm_narrow_bm == 256 ? 256 : 64), st);
+            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, tune().gemm_narrow_bm == 128 ? 128 : 64, st);
         if (tune().gemm_quad == 2 && !swiglu) return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);      // forced (its rule: below)
         // automatic: wherever the 64-row register-staged kernel was the choice (few tiles: the tower's out_proj / fc2, every tower GEMM and
         // the LLaMA o / down projections of config C2) the 64 x 128 LDS-DMA tile runs instead -- tools/vit_gemm_probe.py (round 5, us):
@@ -674,19 +673,14 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && bm == 64)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, st);
         const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = (long long)cdiv(M, 256) * cdiv(N, 256);
-        // 256 x 160 tiles on four waves (gemm_quad.hip, round 5): automatic, and only while no other family is forced, where
-        // the problem is ONE round of them but more than one round of 128 x 256 tiles: M = 2056 .. 2304 against N = 4096 (272 wide tiles,
-        // 234 of these).  tools/gemm_lab.hip w4n / bench_kernels.py yardstick, no epilogue (us): LLaMA o 78 -> 66, down 174 -> 159, the tower's
-        // fc1 31 -> 24; with the real epilogues (tools/vit_gemm_probe.py): o 79.8 -> 71.1, down 188.5 -> 168.7 .. 177.8 -- but fc1 43.2 -> 51.3:
-        // one wave per SIMD issues the 160 erf evaluations of a lane alone (no second wave to alternate VALU slots with; the same epilogue as a
-        // rolled loop through LDS measured the same), so the rule leaves GEMMs with an activation to the 8-wave tiles
-        // -- those run the same 256 x 160 tile on EIGHT waves (gemm_narrow.hip, bm = 256): fc1 + GELU 43 -> see profiles/r05_gemm_experiments.md 6b
+        // 256 x 160 tiles (gemm_quad.hip, round 5): automatic, and only while no other family is forced, where the problem is ONE round of
+        // them but more than one round of 128 x 256 tiles: M = 2056 .. 2304 against N = 4096 (272 wide tiles, 234 of these): LLaMA o / down at
+        // config C3, the tower's fc1.  tools/vit_gemm_probe.py (us, real epilogues): o 79.7 -> 71.3, down 178.6 -> 170.7, fc1 + GELU 39.5 -> 34.2
+        // on the eight-wave form (the default); the four-wave form (one wave per SIMD) ties it on o / down and loses 17 us on fc1 + GELU
         const bool one_round_160 = !swiglu && tune().gemm_quad == 1 && tune().gemm_bm == 0 && tune().gemm_wide == 1 && tune().gemm_big == 1 &&
                                    tune().gemm_sk == 1 && tune().gemm_narrow == 1 && K >= 8 * BK && t_wide_ > 256 &&
                                    (long long)cdiv(M, 256) * cdiv(N, 160) <= std::min(device_cu_count(), 256);
-        if (one_round_160 && act == TEO_ACT_NONE)
-            return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);
-        if (one_round_160) return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 256, st);
+        if (one_round_160) return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);
         // just over one round of wide tiles -- or, for a short K loop (K <= 1024: the tower's fc1 at T = 16, 528 tiles), just over two:
         // there a ragged third round costs a third of the launch (wide 86.7 us, its stream-K form 65.5; tools/vit_gemm_probe.py, round 5)
         const long long sk_wide_max = K <= 1024 ? 2 * 256 + 256 / 6 : 256 + 256 / 6;

@@ -1,5 +1,5 @@
 // Narrow-tile form of the 16-bit MFMA GEMM (round 5): TBM (64 or 128) x 128 x 64 workgroup tile, 4 waves (2 x 2) of (TBM / 2) x 64
-// (and, late in the round, the same K loop on a 256 x 160 tile with 8 waves: see the template's comment),
+// (tile and wave layout are template parameters: see the template's comment),
 // operands brought in by LDS-DMA (global_load_lds_dwordx4) into a ring of NS stages, ONE barrier per K tile -- the K loop of the
 // 128 x 256 kernel (gemm_wide.hip) on a tile small enough for problems that have FEW tiles (the ViT tower: M = 2056, N = 1024 ->
 // 136 tiles of 128 x 128) or a SHORT K loop (K = 1024: 16 K tiles, prologue and epilogue as long as the loop).
@@ -30,8 +30,8 @@ __device__ __forceinline__ int gn_xcd_remap(int bid, int nwg) {
 }
 
 // TBM x TBN tile, WM x WN waves of (TBM / WM) x (TBN / WN); NS stages.  Shipped: 64 x 128 and 128 x 128 on 2 x 2 waves (two workgroups per
-// CU), and -- round 5, late -- 256 x 160 on 4 x 2 waves (one workgroup per CU, 3 x 52 KB): the ONE-round tile of M = 2056 .. 2304 against
-// N = 4096 (gemm_quad.hip) for the GEMMs that carry an activation, whose epilogue wants two waves per SIMD (the tower's fc1 + GELU)
+// CU).  (Measured late in round 5 and not kept: 256 x 160 on 4 x 2 waves, 3 stages -- the hand-scheduled form of that tile is gemm_quad.hip,
+// 1-12 us ahead -- and 128 x 160 on 2 x 2 waves with two workgroups per CU: profiles/r05_gemm_experiments.md 6b.)
 template <int TBM, int TBN, int WM, int WN, int NS, bool OUT_F32, bool F16>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mfma_bf16_narrow_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                      const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M,
@@ -117,11 +117,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mfm
     gemm_epilogue<NI, MI, MI, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (MI * 16), n0 + wn * (NI * 16), fr, fg);
 }
 
-// bm: 64 -> 64 x 128 tiles, 3 stages (72 KB: two workgroups per CU); 128 -> 128 x 128 tiles, 2 stages (64 KB: two per CU); 256 -> 256 x 160
-// tiles on 8 waves, 3 stages (156 KB: one per CU).  No SwiGLU form (the shapes this family serves carry bias / activation / residual epilogues)
+// bm: 64 -> 64 x 128 tiles, 3 stages (72 KB: two workgroups per CU); 128 -> 128 x 128 tiles, 2 stages (64 KB: two per CU).
+// No SwiGLU form (the shapes this family serves carry bias / activation / residual epilogues)
 int gemm_narrow_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                        int act, bool of32, bool f16, int bm, hipStream_t st) {
-    const int bn = bm == 256 ? 160 : 128;
+    const int bn = 128;
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
     const int nwg = tiles_m * tiles_n;
 #define TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, FV)                                                                             \
@@ -134,11 +134,11 @@ int gemm_narrow_launch(const void* A, const void* W, const void* bias, const voi
     }
 #define TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, OF) { if (f16) TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, true) else TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, false) }
 #define TEO_GN_LAUNCH(TBM, TBN, WM, WN, NS) { if (of32) TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, true) else TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, false) }
-    if (bm == 64) TEO_GN_LAUNCH(64, 128, 2, 2, 3) else if (bm == 256) TEO_GN_LAUNCH(256, 160, 4, 2, 3) else TEO_GN_LAUNCH(128, 128, 2, 2, 2)
+    if (bm == 64) TEO_GN_LAUNCH(64, 128, 2, 2, 3) else TEO_GN_LAUNCH(128, 128, 2, 2, 2)
 #undef TEO_GN_LAUNCH
 #undef TEO_GN_LAUNCH_F
 #undef TEO_GN_LAUNCH_T
-    note_kernel(bm == 64 ? "gemm_narrow_64" : (bm == 256 ? "gemm_narrow_256x160" : "gemm_narrow_128"));
+    note_kernel(bm == 64 ? "gemm_narrow_64" : "gemm_narrow_128");
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_narrow");
     return TEO_OK;
 }

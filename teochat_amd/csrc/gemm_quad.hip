@@ -1,23 +1,27 @@
-// Four-wave form of the 16-bit MFMA GEMM (round 5, late): 256 x 160 x 64 workgroup tile, 4 waves (2 x 2) of 128 x 80, ONE wave per SIMD
-// with the accumulators pinned to the AGPR half of its 512-register file, operands by LDS-DMA into a ring of 3 stages (3 x 52 KB).
+// Hand-scheduled form of the 16-bit MFMA GEMM on a 256 x 160 x 64 workgroup tile (round 5, late): operands by LDS-DMA into a ring of 3 stages
+// (3 x 52 KB), accumulators pinned to AGPRs, the K loop's issue order written out.  Two wave layouts of the same loop:
+//   WM = 4 (default): EIGHT waves (4 x 2) of 64 x 80, two per SIMD -- 80 accumulator registers, 40 MFMAs + 7 DMA pieces + 18 reads per K tile and wave;
+//   WM = 2: FOUR waves (2 x 2) of 128 x 80, ONE per SIMD with the whole 512-register file -- 160 accumulator registers, 80 + 13 + 26.
 //
 // Why this shape: M = 2056 .. 2304 rows against N = 4096 (LLaMA o / down at config C3, the tower's fc1) is 272 tiles of 128 x 256 -- one
 // round of the 256 CUs plus a ragged sixteenth -- and 144 of 256 x 256, which leaves 112 CUs idle.  256 x 160 tiles make it 9 x 26 = 234
 // workgroups: ONE round, 91 % of the CUs busy, and the tile is still large enough to amortise its operand traffic.  It is the tile the
 // vendor library picks for the same shapes (profiles/r05_library_yardstick.txt: MT256x160 / MT160x256, 256 threads); measured here
-// (tools/gemm_lab.hip `w4n`, profiles/r05_gemm_lab_w4n.txt, cold weights): o 66 us against 78 (128 x 256 stream-K) and the library's 71,
-// down 159 against 174 / 169, fc1 24 against 31 / 22.  A 2-stage ring loses 28 % on down (K = 11008 from HBM): the third stage is the point.
+// (tools/gemm_lab.hip `w4n`, profiles/r05_gemm_lab_w4n.txt, four waves, no epilogue, cold weights): o 66 us against 78 (128 x 256 stream-K)
+// and the library's 71, down 159 against 174 / 169, fc1 24 against 31 / 22.  A 2-stage ring loses 28 % on down (K = 11008 from HBM): the
+// third stage is the point.  With the real epilogues (tools/vit_gemm_probe.py): o 79.7 -> 71.3 (8 waves) / 72.4 (4), down 178.6 -> 170.7 / 170.0,
+// fc1 + GELU 39.5 -> 34.2 / 51.1 -- one wave per SIMD issues the 160 erf evaluations of a lane alone, two alternate; hence the default.
 //
 // K tile = two phases, ONE barrier:
 //     A: MFMA k-half 0 (fragments X) || ds_read k-half 1 -> Y
 //        -- lgkmcnt(0): my reads of this stage are done; vmcnt: my pieces of tile kt + 1 have landed (tile kt + 2 may fly) -- s_barrier --
 //     B: MFMA k-half 1 (Y) || DMA of tile kt + 3 into the stage just released || ds_read k-half 0 of tile kt + 1 -> X
-// The MFMAs are inline asm with "+a" accumulators: with the builtin the register allocator moves accumulators between AGPRs and VGPRs
-// (~1000 v_accvgpr moves per K tile at 256 x 256); as volatile asm they also keep SOURCE order against the LDS reads and the DMA builtins, so
-// the interleave below (4 MFMAs, then the group's DMA pieces and two reads) is the issue order.  hipcc still places the s_waitcnt for the
-// fragment registers itself (it sees the asm operands); the explicit lgkmcnt(0) at the end of a K tile sits where nothing is outstanding.
-// Same LDS image (128-byte rows, 16-byte chunk c of row r at c ^ (r & 7), applied through the DMA source address), same fragment
-// reads and the same k-ascending MFMA chain per output element as every other tile family -> bit-identical results (tested).
+// The MFMAs are inline asm with "+a" accumulators: with the builtin and 160+ accumulators the register allocator moves them between AGPRs
+// and VGPRs (~1000 v_accvgpr moves per K tile at 256 x 256); as volatile asm they also keep SOURCE order against the LDS reads and the DMA
+// builtins, so the interleave below (4 MFMAs, then the group's DMA pieces and two reads) is the issue order.  hipcc still places the
+// s_waitcnt for the fragment registers itself (it sees the asm operands); the explicit lgkmcnt(0) at the end of a K tile sits where nothing
+// is outstanding.  Same LDS image (128-byte rows, 16-byte chunk c of row r at c ^ (r & 7), applied through the DMA source address), same
+// fragment reads and the same k-ascending MFMA chain per output element as every other tile family -> bit-identical results (tested).
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "ops.h"
@@ -37,14 +41,16 @@ template <bool F16> __device__ __forceinline__ void gq_mfma(teo_f32x4& c, const 
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-template <int NI, int NS, bool OUT_F32, bool F16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_mfma_bf16_quad_kernel(
+// WM: waves along M (2: four waves of 128 x 16 NI, one per SIMD; 4: EIGHT waves of 64 x 16 NI, two per SIMD)
+template <int NI, int NS, int WM, bool OUT_F32, bool F16>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2, WM / 2))) void gemm_mfma_bf16_quad_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M, int N, int K,
     int lda, int ldc, int act, int tiles_m, int tiles_n) {
-    constexpr int TN = 32 * NI, STG = (GQ_BM + TN) * 128, PT = 32 + 4 * NI, NPW = PT / 4;
-    static_assert(PT % 4 == 0 && NS >= 2, "pieces split evenly over the four waves");
-    constexpr int G = NI * 2;                    // MFMA groups of 4 per phase (NI x 8 fragment pairs)
-    constexpr int R = 8 + NI;                    // fragment reads per phase
+    constexpr int NW = WM * 2, MI = 16 / WM;     // waves; 16-row A fragments per wave (8 or 4)
+    constexpr int TN = 32 * NI, STG = (GQ_BM + TN) * 128, PT = 32 + 4 * NI, NPW = (PT + NW - 1) / NW;
+    static_assert(NS >= 2 && (NI * MI) % 4 == 0, "MFMA groups of four");
+    constexpr int G = NI * MI / 4;               // MFMA groups of 4 per phase (NI x MI fragment pairs)
+    constexpr int R = MI + NI;                   // fragment reads per phase
     constexpr int PPG = (NPW + G - 1) / G;       // DMA pieces per group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,35 +67,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bf16_t* src[NPW];
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-        const int p = wid * NPW + j;
+        const int p = min(wid * NPW + j, PT - 1);   // (eight waves: 56 slots for 52 pieces -- the last wave brings piece 51 again, same bytes)
         const int rl = lane >> 3, c = (lane & 7) ^ rl;
         src[j] = p < 32 ? A + (long long)min(m0 + p * 8 + rl, M - 1) * lda + c * 8 : W + (long long)min(n0 + (p - 32) * 8 + rl, N - 1) * K + c * 8;
     }
-    const int lds_piece0 = wid * NPW * 1024;
 #define TEO_GQ_PIECE(KT, ST, J)                                                                                                  \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[J] + (long long)(KT) * GQ_BK),         \
-                                     (__attribute__((address_space(3))) void*)(smem + (ST) * STG + lds_piece0 + (J) * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + (ST) * STG + min(wid * NPW + (J), PT - 1) * 1024), 16, 0, 0);
     uint2 bv[NI];                                 // the lane's bias values: requested now, used after the K loop (gemm_epilogue.h)
     gemm_bias_load<NI>(bias, n0 + wn * (NI * 16), fg, N, bv);
-    teo_f32x4 acc[NI][8];   // [ni][mi]
+    teo_f32x4 acc[NI][MI];   // [ni][mi]
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (teo_f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = (teo_f32x4){0.f, 0.f, 0.f, 0.f};
     teo_h16x8 xf[16], yf[16];                    // [0 .. NI - 1]: W fragments, [8 .. 15]: A fragments
-    const int rw0 = wn * (NI * 16) + fr, ra0 = wm * 128 + fr;
-    // read RI of a phase: RI < 8 -> A fragment RI, else W fragment RI - 8 (every MFMA group needs all eight A fragments, group g only W[g / 2])
+    const int rw0 = wn * (NI * 16) + fr, ra0 = wm * (MI * 16) + fr;
+    // read RI of a phase: RI < MI -> A fragment RI, else W fragment RI - MI (the first MFMA groups need every A fragment, group g only W[4 g / MI])
 #define TEO_GQ_READ(F, ST, KS, RI)                                                                                \
     {                                                                                                             \
-        const int isw_ = (RI) >= 8;                                                                               \
-        const int r_ = (isw_ ? rw0 + ((RI) - 8) * 16 : ra0 + (RI) * 16);                                          \
-        F[isw_ ? (RI) - 8 : 8 + (RI)] =                                                                           \
+        const int isw_ = (RI) >= MI;                                                                              \
+        const int r_ = (isw_ ? rw0 + ((RI) - MI) * 16 : ra0 + (RI) * 16);                                         \
+        F[isw_ ? (RI) - MI : 8 + (RI)] =                                                                          \
             *reinterpret_cast<const teo_h16x8*>(smem + (ST) * STG + (isw_ ? GQ_BM * 128 : 0) + r_ * 128 + ((((KS) * 4 + fg) ^ (r_ & 7)) << 4)); \
     }
 #define TEO_GQ_MFMA4(F, GI)                                                                                       \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                            \
         const int p_ = (GI) * 4 + q_;                                                                             \
-        const int ni_ = p_ >> 3, mi_ = p_ & 7;                                                                    \
+        const int ni_ = p_ / MI, mi_ = p_ % MI;                                                                   \
         gq_mfma<F16>(acc[ni_][mi_], F[ni_], F[8 + mi_]);                                                          \
     }
 #pragma unroll
@@ -144,29 +149,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (measured and not kept: the same epilogue through LDS -- 64 rows x 80 columns of f32 per wave parked in the free ring, read back as whole
     // rows by a rolled loop, 8-byte stores covering a row's 160 contiguous bytes: bit-identical, o 73.1 -> 89.8 us, down 175.9 -> 187.2, fc1 + GELU
     // 51.2 -> 52.2.  The activation's cost here is VALU issue with ONE wave per SIMD, not code size: 160 erf per lane, no second wave to
-    // alternate with -- which is why the dispatch leaves GEMMs with an activation to the 8-wave tiles.)
-    gemm_epilogue<NI, 8, 4, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * 128, n0 + wn * (NI * 16), fr, fg);
+    // alternate with -- which is why the eight-wave layout is the default.)
+    gemm_epilogue<NI, MI, 4, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (MI * 16), n0 + wn * (NI * 16), fr, fg);
 }
 
-// 256 x 160 tiles, 3 stages (156 KB: one workgroup per CU).  No SwiGLU form (gate / up run several rounds: the 256 x 256 hybrid's shapes)
+// 256 x 160 tiles, 3 stages (156 KB: one workgroup per CU), eight or four waves (tune().gemm_quad_waves).  No SwiGLU form (gate / up run
+// several rounds: the 256 x 256 hybrid's shapes)
 int gemm_quad_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool of32, bool f16, hipStream_t st) {
+    const bool eight = tune().gemm_quad_waves != 4;          // default: eight waves (two per SIMD); 4: one wave per SIMD, 128 x 80 each
     constexpr int NI = 5, NS = 3, TN = 32 * NI;
     const int tiles_m = cdiv(M, GQ_BM), tiles_n = cdiv(N, TN);
     const int nwg = tiles_m * tiles_n;
     constexpr size_t lds = (size_t)NS * (GQ_BM + TN) * 128;
-#define TEO_GQ_LAUNCH_T(OF, FV)                                                                                                   \
+#define TEO_GQ_LAUNCH_W(OF, FV, WMV)                                                                                              \
     {                                                                                                                             \
         static unsigned long long attr_mask = 0;                                                                                  \
-        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<NI, NS, OF, FV>), (int)lds, &attr_mask, "gemm_quad")) return e; \
-        gemm_mfma_bf16_quad_kernel<NI, NS, OF, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<NI, NS, WMV, OF, FV>), (int)lds, &attr_mask, "gemm_quad")) return e; \
+        gemm_mfma_bf16_quad_kernel<NI, NS, WMV, OF, FV><<<nwg, (WMV) * 128, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                           (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
     }
+#define TEO_GQ_LAUNCH_T(OF, FV) { if (eight) TEO_GQ_LAUNCH_W(OF, FV, 4) else TEO_GQ_LAUNCH_W(OF, FV, 2) }
 #define TEO_GQ_LAUNCH_F(OF) { if (f16) TEO_GQ_LAUNCH_T(OF, true) else TEO_GQ_LAUNCH_T(OF, false) }
     if (of32) TEO_GQ_LAUNCH_F(true) else TEO_GQ_LAUNCH_F(false)
 #undef TEO_GQ_LAUNCH_F
 #undef TEO_GQ_LAUNCH_T
-    note_kernel("gemm_quad_160");
+#undef TEO_GQ_LAUNCH_W
+    note_kernel(eight ? "gemm_quad_160" : "gemm_quad_160_w4");
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_quad");
     return TEO_OK;
 }

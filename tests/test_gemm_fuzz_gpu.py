@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 PLAIN = {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}
 FORCED = (("64x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 64}, "gemm_narrow_64"),
           ("128x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 128}, "gemm_narrow_128"),
-          ("256x160 eight waves", {"gemm_narrow": 2, "gemm_narrow_bm": 256}, "gemm_narrow_256x160"),
-          ("256x160 four waves", {"gemm_quad": 2}, "gemm_quad_160"),
+          ("256x160 eight waves", {"gemm_quad": 2}, "gemm_quad_160"),
+          ("256x160 four waves", {"gemm_quad": 2, "gemm_quad_waves": 4}, "gemm_quad_160_w4"),
           ("128x256", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}, "gemm_wide"),      # (both need
           ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}, "gemm_big"),                 # K >= 128)
           ("64-row register-staged", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 64}, "gemm_mfma_64"),
@@ -80,4 +80,4 @@ def test_every_tile_family_is_bitwise_the_plain_kernel_on_random_shapes(seed, dt
                 assert ran == kernel, (name, ran, M, N, K)
             assert torch.equal(got, want), (name, ran, M, N, K, extra, float((got.float() - want.float()).abs().max()))
     L.tune_reset()
-    assert {"gemm_narrow_64", "gemm_narrow_128", "gemm_narrow_256x160", "gemm_quad_160", "gemm_wide", "gemm_big", "gemm_mfma_64"} <= seen
+    assert {"gemm_narrow_64", "gemm_narrow_128", "gemm_quad_160", "gemm_quad_160_w4", "gemm_wide", "gemm_big", "gemm_mfma_64"} <= seen

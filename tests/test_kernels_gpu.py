@@ -1291,11 +1291,11 @@ def test_gemm_narrow_tiles_are_bitwise_the_plain_kernel(M, N, K, extra, dt):
     want = G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
     assert lib.teo_last_kernel().decode() in ("gemm_mfma_64", "gemm_mfma_128")
     assert L.tune_set(b"gemm_narrow", 2) == 0
-    for bm in (64, 128, 256):                              # 256: the 256 x 160 tile on eight waves (4 x 2), three stages, one workgroup per CU
+    for bm in (64, 128):
         assert L.tune_set(b"gemm_narrow_bm", bm) == 0
         for _ in range(3):
             got = G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
-            assert lib.teo_last_kernel().decode() == ("gemm_narrow_256x160" if bm == 256 else f"gemm_narrow_{bm}")
+            assert lib.teo_last_kernel().decode() == f"gemm_narrow_{bm}"
             assert torch.equal(got, want), (bm, float((got.float() - want.float()).abs().max()))
 
 
@@ -1304,11 +1304,12 @@ def test_gemm_narrow_tiles_are_bitwise_the_plain_kernel(M, N, K, extra, dt):
                                          (300, 700, 192, "bias_quick"), (129, 260, 128, "res"), (1000, 1024, 2048, "f32out"), (65, 132, 64, ""),
                                          (257, 164, 256, "bias_res"), (514, 3072, 320, "bias")])
 def test_gemm_quad_tiles_are_bitwise_the_plain_kernel(M, N, K, extra, dt):
-    """gemm_quad.hip (round 5: 256 x 160 tiles, four waves of 128 x 80 -- one per SIMD, accumulators pinned to AGPRs by inline-asm MFMAs --
-    three-stage LDS-DMA ring, one barrier per K tile) against the register-staged kernel: same LDS image, same fragment reads, same k-ascending
-    MFMA chain -> BIT-identical in both 16-bit formats, at the shapes it is dispatched for (LLaMA o / down at M = 2168, the tower's fc1), at
-    ragged M / N edges (N not a multiple of 160, of 16; M = 1 row over a tile), K of one .. five tiles (ring shorter than / equal to / longer
-    than the loop) and with every epilogue.  The production dispatch picks it for the first two shapes by itself."""
+    """gemm_quad.hip (round 5: 256 x 160 tiles, accumulators pinned to AGPRs by inline-asm MFMAs, hand-written issue order, three-stage
+    LDS-DMA ring, one barrier per K tile; eight waves of 64 x 80 -- the default -- or four of 128 x 80, one per SIMD) against the
+    register-staged kernel: same LDS image, same fragment reads, same k-ascending MFMA chain -> BIT-identical in both 16-bit formats and
+    both wave layouts, at the shapes it is dispatched for (LLaMA o / down at M = 2168, the tower's fc1), at ragged M / N edges (N not a
+    multiple of 160, of 16; M = 1 row over a tile), K of one .. five tiles (ring shorter than / equal to / longer than the loop) and with
+    every epilogue.  The production dispatch picks it for the first four shapes by itself."""
     g = torch.Generator().manual_seed(M + 7 * N + K)
     A = torch.randn(M, K, generator=g).to(dt).cuda()
     W = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
@@ -1319,17 +1320,17 @@ def test_gemm_quad_tiles_are_bitwise_the_plain_kernel(M, N, K, extra, dt):
     lib = G.lib()
     if M >= 2056 and N == 4096:
         G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
-        # one round of 256 x 160 tiles, more than one of 128 x 256: the dispatch's own choice -- on four waves, or on eight when an
-        # activation rides in the epilogue (gemm_narrow.hip, bm = 256)
-        assert lib.teo_last_kernel().decode() == ("gemm_quad_160" if act == L.ACT_NONE else "gemm_narrow_256x160")
+        assert lib.teo_last_kernel().decode() == "gemm_quad_160"           # one round of 256 x 160 tiles, more than one of 128 x 256
     assert L.tune_set(b"gemm_narrow", 0) == 0 and L.tune_set(b"gemm_big", 0) == 0 and L.tune_set(b"gemm_wide", 0) == 0
     want = G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
     assert lib.teo_last_kernel().decode() in ("gemm_mfma_64", "gemm_mfma_128")
     assert L.tune_set(b"gemm_quad", 2) == 0
-    for _ in range(3):
-        got = G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
-        assert lib.teo_last_kernel().decode() == "gemm_quad_160"
-        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    for waves, name in ((8, "gemm_quad_160"), (4, "gemm_quad_160_w4")):
+        assert L.tune_set(b"gemm_quad_waves", waves) == 0
+        for _ in range(3):
+            got = G.gemm(A, W, bias=bias, res=res, act=act, out_dtype=od)
+            assert lib.teo_last_kernel().decode() == name
+            assert torch.equal(got, want), (waves, float((got.float() - want.float()).abs().max()))
 
 
 @pytest.mark.parametrize("M,N,K,flags,extra", [(2168, 12288, 4096, 0, ""), (4208, 2048, 512, L.GEMM_SWIGLU16, ""), (300, 700, 192, 0, "bias_gelu"),

@@ -121,13 +121,13 @@ FAMILIES = (("production dispatch", {}),
             ("128x128 stream-K", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2, "gemm_narrow": 0}),
             ("64x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 64}),           # round 5 (SwiGLU GEMMs have no such form: they fall
             ("128x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 128}),         # through to the production dispatch under these knobs)
-            ("256x160 four waves", {"gemm_quad": 2}),
-            ("256x160 eight waves", {"gemm_narrow": 2, "gemm_narrow_bm": 256}),
+            ("256x160 eight waves", {"gemm_quad": 2}),
+            ("256x160 four waves", {"gemm_quad": 2, "gemm_quad_waves": 4}),
             ("128x256 tile", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0}),
             ("128x256 stream-K", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}),
             ("256x256 tile", {"gemm_big": 2, "gemm_big_hybrid": 0}),
             ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2}))
-DEFAULTS = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1, "gemm_narrow": 1, "gemm_narrow_bm": 0, "gemm_quad": 1}
+DEFAULTS = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1, "gemm_narrow": 1, "gemm_narrow_bm": 0, "gemm_quad": 1, "gemm_quad_waves": 8}
 
 
 def gemm_all_families(gw, A, W, ref, tag, report, families=FAMILIES, **kw):
@@ -205,7 +205,7 @@ def test_llama_layer_walk_at_7b_shapes(fmt):
     h1 = R(h + o_ref @ w["o"].t())
     d_o, d_Wo, d_h = G.dev(o_ref, bf), G.dev(w["o"], bf), G.dev(h, bf)
     seen = gemm_all_families(gw, d_o, d_Wo, h1, "o GEMM + residual N=4096 K=4096", report, res=d_h)
-    assert {"gemm_mfma_128_sk", "gemm_wide_sk", "gemm_quad_160"} <= seen, seen     # (production dispatch: the 256 x 160 four-wave tile)
+    assert {"gemm_mfma_128_sk", "gemm_wide_sk", "gemm_quad_160"} <= seen, seen     # (production dispatch: the hand-scheduled 256 x 160 tile)
     # post norm, gate/up with SwiGLU epilogue, down + residual
     n2 = R(O.rmsnorm(h1, g_post, 1e-5))
     act = R(F.silu(n2 @ w["gate"].t()) * (n2 @ w["up"].t()))

@@ -19,7 +19,7 @@ FAM = (("auto", {}), ("plain", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0}),
        ("128x256 sk", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}), ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0}),
        ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2}),
        ("narrow 64", {"gemm_narrow": 2, "gemm_narrow_bm": 64}), ("narrow 128", {"gemm_narrow": 2, "gemm_narrow_bm": 128}), ("no narrow", {"gemm_narrow": 0}),
-       ("quad 256x160", {"gemm_quad": 2}), ("8 waves 256x160", {"gemm_narrow": 2, "gemm_narrow_bm": 256}), ("no quad", {"gemm_quad": 0}))
+       ("quad 256x160", {"gemm_quad": 2}), ("quad 256x160 four waves", {"gemm_quad": 2, "gemm_quad_waves": 4}), ("no quad", {"gemm_quad": 0}))
 ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
 L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws")
 
