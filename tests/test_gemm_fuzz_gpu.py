@@ -3,6 +3,7 @@
 is tested at the model's shapes elsewhere; here it is fuzzed over ragged M / N (one row over a tile, N not a multiple of any tile width),
 short and long K (one K tile .. more than any ring), strided A (lda > K), every epilogue and both 16-bit formats, for the eight forced
 families incl. the two 256 x 160 forms of round 5.  The reference leg (plain 128 x 128 tile) is itself checked against fp64 on a sample."""
+import os
 import random
 
 import pytest
@@ -39,7 +40,7 @@ def _case(rng):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TEO_FUZZ_SEEDS", "6"))))       # soak: TEO_FUZZ_SEEDS=60 (profiles/r05_gemm_fuzz_soak.txt)
 def test_every_tile_family_is_bitwise_the_plain_kernel_on_random_shapes(seed, dt):
     rng = random.Random(1000 * seed + (dt == torch.float16))
     lib = G.lib()
