@@ -355,6 +355,46 @@ def _stats(got, ref):
     return float(d.max()) / scale, float(d.kthvalue(k99).values) / scale, float(d.median()) / scale, scale
 
 
+def test_tile_family_knobs_do_not_change_one_bit_of_the_c3_forward_at_full_width():
+    """The kernel-level claim (every GEMM tile family is bit-identical to every other: tests/test_kernels_gpu.py, test_gemm_fuzz_gpu.py)
+    at the level a caller sees: the ViT-L/14 tower (23 layers, T = 8) + projector and a two-layer LLaMA prefill at 7B width, L = 2168 --
+    the shapes at which the dispatch picks the 256 x 160 hand-scheduled tile, the 256 x 256 hybrid, the narrow tiles and the 128 x 256
+    tile by itself -- give the SAME BITS (visual features and the logits of every position) whichever families an engine's tune block
+    allows.  A performance knob is a performance knob."""
+    _threads()
+    m16, sd_dev, cfg = _full_width_model(2, bf, 2304)
+    eng = m16.engine
+    lib = G.lib()
+    g = torch.Generator().manual_seed(17)
+    pixels = torch.randn(8, 3, 224, 224, generator=g).to(bf).to(DEV)
+    embeds = (torch.randn(2168, cfg.hidden_size, generator=g) * 0.5).to(bf).to(DEV)
+
+    def run():
+        eng.reset_cache()
+        feats = eng.encode_images(pixels)
+        return feats.clone(), eng.prefill(embeds).clone()
+
+    f0, l0 = run()
+    assert torch.isfinite(l0).all() and l0.shape == (2168, cfg.vocab_size)
+    variants = (("no 256x160 tile", {"gemm_quad": 0}), ("256x160 on four waves", {"gemm_quad_waves": 4}),
+                ("no 256x256 tile", {"gemm_big": 0}), ("no stream-K / hybrid forms", {"gemm_sk": 0, "gemm_big_hybrid": 0}),
+                ("no LDS-DMA narrow tiles", {"gemm_narrow": 0}),
+                ("register-staged 128x128 tile only", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}))
+    for name, knobs in variants:
+        eng.tune_reset()
+        for k, v in knobs.items():
+            eng.tune_set(k, v)
+        f1, l1 = run()
+        assert torch.equal(f1, f0), (name, float((f1.float() - f0.float()).abs().max()))
+        assert torch.equal(l1, l0), (name, float((l1 - l0).abs().max()))
+    eng.tune_reset()
+    # and the default dispatch did use the new tile at these shapes
+    A = torch.randn(2168, 4096, generator=g).to(bf).to(DEV)
+    W = (torch.randn(4096, 4096, generator=g) * 0.02).to(bf).to(DEV)
+    G.gemm(A, W, res=A)
+    assert lib.teo_last_kernel().decode() == "gemm_quad_160"
+
+
 @pytest.mark.parametrize("T,n_out,tag", [(2, 128, "C2"), (8, 256, "C3")])
 def test_c2_c3_prefill_and_decode_against_the_oracle_at_full_width(T, n_out, tag, fmt):
     """ViT-L/14 (23 layers) + projector + splice + LLaMA at 7B width, N_LAYERS_DEEP layers: prefill logits of EVERY position and 8
