@@ -786,6 +786,39 @@ def mm_forward(input_ids, images: List[torch.Tensor], sd, vcfg: VitCfg, lcfg: Ll
     return logits, cache, embeds
 
 
+def logit_stats(a, b):
+    """(max, p99, median) of |a - b| as fractions of max|b|."""
+    d = (a.double() - b.double()).abs().flatten()
+    scale = float(b.abs().max())
+    k99 = max(1, int(0.99 * d.numel()))
+    return float(d.max()) / scale, float(d.kthvalue(k99).values) / scale, float(d.median()) / scale
+
+
+SELF_DIFF_ORDERS = ((8, False), (8, True), (4, True), (2, False))
+
+
+def self_difference(input_ids, images, sd, vcfg: VitCfg, lcfg: LlamaCfg, mm: MMCfg, rounding, base=None):
+    """The 16-bit noise floor of THIS configuration, measured (test infrastructure; tests/test_noise_floor.py is the demonstration at
+    7B width): the oracle's prefill logits under `rounding`, re-run with only the fp32 summation order of its Linear layers changed
+    (K_ORDER: K in 8 / 4 / 2 chunks, ascending or descending) -- same weights, same rounding points.  Returns (max, p99, median) of
+    the pairwise differences between the runs (and `base`, the plain single-matmul run, if given) as fractions of max|logit|: the
+    LARGEST of the pairs for the max statistic (a maximum over a few 10^5 logits is itself noisy), the mean of the pairs for p99 and
+    median.  A kernel path that differs from the oracle by rounding only lands at ~1 x these numbers; the parity tests assert
+    <= 1.25 x."""
+    global K_ORDER
+    runs = [] if base is None else [base]
+    try:
+        for order in SELF_DIFF_ORDERS:
+            K_ORDER = order
+            lg, _, _ = mm_forward(input_ids, images, sd, vcfg, lcfg, mm, None, rounding, torch.float32)
+            runs.append(lg[0])
+    finally:
+        K_ORDER = None
+    st = [logit_stats(runs[i], runs[j]) for i in range(len(runs)) for j in range(i + 1, len(runs))]
+    n = float(len(st))
+    return max(x[0] for x in st), sum(x[1] for x in st) / n, sum(x[2] for x in st) / n
+
+
 def training_loss(input_ids, attention_mask, labels, images, sd, vcfg: VitCfg, lcfg: LlamaCfg, mm: MMCfg):
     """Training-shape forward with labels: llava_llama.py:56-99 -> LlamaForCausalLM loss = CrossEntropyLoss over the
     shifted positions of the SPLICED sequence (labels come back from prepare_inputs_labels_for_multimodal with

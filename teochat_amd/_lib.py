@@ -228,9 +228,18 @@ class Tune:
         if not self.ptr:
             raise TeoError("teo_tune_create failed")
 
-    def set(self, key, value):
+    def try_set(self, key, value):
+        """The raw status of teo_tune_set (0, or TEO_ERR_ARG for an unknown key / a value outside the knob's set): for callers that
+        test the rejection itself."""
         key = key if isinstance(key, bytes) else key.encode()
         return self._lib.teo_tune_set(self.ptr, key, int(value))
+
+    def set(self, key, value):
+        """Set a knob; raises TeoError when the library rejects the key or the value -- a sweep must never report the default
+        dispatch under the label of a knob that was silently dropped.  Returns 0."""
+        rc = self.try_set(key, value)
+        check(rc, f"teo_tune_set({key!r}, {value})")
+        return rc
 
     def get(self, key):
         key = key if isinstance(key, bytes) else key.encode()
@@ -239,7 +248,9 @@ class Tune:
         return v.value
 
     def reset(self):
-        return self._lib.teo_tune_reset(self.ptr)
+        rc = self._lib.teo_tune_reset(self.ptr)
+        check(rc, "teo_tune_reset")
+        return rc
 
     def bind(self):
         return self._lib.teo_tune_bind(self.ptr)
@@ -269,7 +280,8 @@ def thread_tune():
 
 
 def tune_set(key, value):
-    """Set a knob in the calling thread's bound block (primitive operators called from this thread see it; engines have their own)."""
+    """Set a knob in the calling thread's bound block (primitive operators called from this thread see it; engines have their own).
+    Raises TeoError on an unknown key or a rejected value (`Tune.try_set` is the non-raising form)."""
     return thread_tune().set(key, value)
 
 

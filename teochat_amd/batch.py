@@ -23,6 +23,7 @@ class BatchDecoder:
         if not 1 <= batch <= L.MAX_DECODE_BATCH:
             raise ValueError(f"batch {batch} outside 1..{L.MAX_DECODE_BATCH}")
         self.eng, self.B, self.lib = engine, int(batch), engine.lib
+        self.tune = engine.tune                   # the descriptor copies below carry its raw pointer: keep the block alive as long as they live
         self.max_new = int(max_new)
         c = engine.cfg
         dev, dt = engine.device, engine.dtype
@@ -107,6 +108,7 @@ class BatchDecoder:
         self.state = s
         self._graph = None
         self._steps_done = 0
+        self._armed = False
 
     def _arr(self, tensors):
         arr, pp = L.ptr_array([t.data_ptr() for t in tensors])
@@ -116,6 +118,7 @@ class BatchDecoder:
     # ------------------------------------------------------------------ prefill (one conversation at a time)
     def reset(self):
         self.cache_len = [0] * self.B
+        self._armed = False
 
     def prefill(self, slot, embeds, last_only=True):
         """Append embeds [S, D] to conversation `slot`; returns fp32 logits ([1, V] with last_only)."""
@@ -140,9 +143,11 @@ class BatchDecoder:
         self.cache_len[slot] = past + S
         return logits
 
-    def prefill_all(self, embeds_list):
+    def prefill_all(self, embeds_list, last_only=True, hidden_states=False):
         """Prefill every slot at once from fresh caches: embeds_list[b] is [S_b, D].  The rows are concatenated so norms
-        and GEMMs run over sum(S_b) rows (teo_llama_prefill_batch).  Returns fp32 logits [B, V] (last positions)."""
+        and GEMMs run over sum(S_b) rows (teo_llama_prefill_batch).  Returns fp32 logits [B, V] (last positions), or with
+        last_only=False [sum(S_b), V] (every position, rows in the order of the list: what a forward() that keeps its cache
+        returns); hidden_states=True additionally returns the [layers + 1, sum(S_b), D] residual-stream snapshots."""
         eng = self.eng
         if len(embeds_list) != self.B:
             raise ValueError(f"need {self.B} sequences")
@@ -152,18 +157,22 @@ class BatchDecoder:
         total = sum(lens)
         with eng.phase() as st:
             rows = torch.cat([e.to(device=eng.device, dtype=eng.dtype) for e in embeds_list], dim=0).contiguous()
-            logits = torch.empty(self.B, eng.cfg.vocab_size, dtype=torch.float32, device=eng.device)
+            logits = torch.empty(self.B if last_only else total, eng.cfg.vocab_size, dtype=torch.float32, device=eng.device)
+            hs = (torch.empty(eng.cfg.num_hidden_layers + 1, total, eng.cfg.hidden_size, dtype=eng.dtype, device=eng.device)
+                  if hidden_states else None)
             eng._flush_handoff_checks("prefill")
             d0 = self.slot_desc[0]
             ws = eng._workspace("prefill", self.lib.teo_llama_prefill_workspace_bytes(C.byref(d0), total))
             arr = (C.c_int * self.B)(*lens)
-            L.check(self.lib.teo_llama_prefill_batch(C.byref(d0), _p(rows), arr, self.B, self.k_cache.stride(1), 1,
-                                                     _p(logits), _p(ws), ws.numel(), st, None), "teo_llama_prefill_batch")
+            L.check(self.lib.teo_llama_prefill_batch(C.byref(d0), _p(rows), arr, self.B, self.k_cache.stride(1), 1 if last_only else 0,
+                                                     _p(logits), _p(ws), ws.numel(), st, _p(hs) if hs is not None else None),
+                    "teo_llama_prefill_batch")
             sid = C.c_void_p(eng.stream.cuda_stream)
             eng._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(d0), total, _p(ws), ws.numel(), C.byref(f), sid),
                                 "teo_llama_prefill_batch")
         self.cache_len = list(lens)
-        return logits
+        self._armed = False
+        return (logits, hs) if hidden_states else logits
 
     # ------------------------------------------------------------------ decode
     def _workspace(self):
@@ -249,6 +258,31 @@ class BatchDecoder:
         self.cache_len = [x + n for x in self.cache_len]
         self._steps_done += n
         return {name: (cnt[k] // n, tot[k] / cnt[k] * 1e3) for k, name in enumerate(names) if cnt[k]}
+
+    def forward_step(self, tokens):
+        """One batched step fed with CALLER-chosen tokens (the continuation of LlavaLlamaForCausalLM.forward(past_key_values=...) at
+        B > 1, llava_arch.py:154-163): conversation b takes tokens[b] at position cache_len[b], its K / V rows are appended, and the
+        fp32 logits [B, V] of that position are returned.  The device loop's own pick (the tail kernel's argmax) is overwritten by
+        the next call's tokens, so greedy streams driven from here equal generate_batch()'s token for token."""
+        toks = [int(t) for t in (tokens.view(-1).tolist() if torch.is_tensor(tokens) else tokens)]
+        if len(toks) != self.B:
+            raise ValueError(f"need {self.B} tokens")
+        s = self.state
+        fresh = (not getattr(self, "_armed", False)) or self._steps_done + 1 > self.max_new \
+            or (s.n_stop_ids, s.do_sample) != (0, 0)
+        if fresh:
+            self.begin(toks)                       # greedy, no device stop: positions from cache_len, counters zeroed
+            self._armed = True
+        else:
+            with self.eng.phase():
+                self.d_token.copy_(torch.tensor(toks, dtype=torch.int64))
+                self.d_stop.zero_()
+            ws = self._workspace()                 # (the step reads the token's embedding row itself: teo_llama_decode_batch_begin
+            with self.eng.phase() as st:           #  re-embeds d_token)
+                L.check(self.lib.teo_llama_decode_batch_begin(C.byref(self.desc), C.byref(self.state), _p(ws), ws.numel(), st),
+                        "teo_llama_decode_batch_begin")
+        self.steps(1, use_graph=True)
+        return self.d_logits.clone()
 
     def generated(self):
         """[B, steps] int64: the tokens produced by the steps so far (the first token of each conversation excluded)."""

@@ -464,15 +464,18 @@ class TeoEngine:
         S64 = (max(lens) + 63) // 64 * 64
         slot = getattr(self, "_fwd_slots", None)
         if slot is None or slot["B"] < B or slot["S"] < S64:
+            # regrow to the maximum of the old and the new shape (alternating (B = 4, S = 64) / (B = 2, S = 128) calls must not
+            # reallocate every time); the pointer arrays of the slot live in the slot, not in the engine-lifetime `_keep` list, so a
+            # regrow frees the old ones, and the slot holds the Tune object its descriptor copy points at
+            Bn, Sn = (B, S64) if slot is None else (max(slot["B"], B), max(slot["S"], S64))
             self._fwd_slots = slot = None
-            kv = [torch.zeros(B, Hk, S64, hd, dtype=self.dtype, device=self.device) for _ in range(2)]
-            vt = torch.zeros(B, Hk, hd, S64, dtype=self.dtype, device=self.device)
+            kv = [torch.zeros(Bn, Hk, Sn, hd, dtype=self.dtype, device=self.device) for _ in range(2)]
+            vt = torch.zeros(Bn, Hk, hd, Sn, dtype=self.dtype, device=self.device)
             d = L.LlamaDesc.from_buffer_copy(self.llama_desc)
-            d.max_seq = S64
-            d.k_cache = self._arr([kv[0][0]] * Lr)
-            d.v_cache = self._arr([kv[1][0]] * Lr)
-            d.vt_cache = self._arr([vt[0]] * Lr)
-            slot = self._fwd_slots = {"B": B, "S": S64, "k": kv[0], "v": kv[1], "vt": vt, "desc": d}
+            d.max_seq = Sn
+            arrs = [L.ptr_array([t.data_ptr()] * Lr) for t in (kv[0][0], kv[1][0], vt[0])]
+            d.k_cache, d.v_cache, d.vt_cache = arrs[0][1], arrs[1][1], arrs[2][1]
+            slot = self._fwd_slots = {"B": Bn, "S": Sn, "k": kv[0], "v": kv[1], "vt": vt, "desc": d, "arrs": arrs, "tune": self.tune}
 
             def _sync(src, eng=self):                 # ONE hook for whatever descriptor copy is current (a regrow replaces the copy, not the hook)
                 cur = getattr(eng, "_fwd_slots", None)
@@ -549,13 +552,13 @@ class TeoEngine:
     def tune_set(self, key, value):
         """A performance knob of THIS engine (teo_tune_set on the engine's own block; keys in include/teo_hip.h).  Captured decode
         graphs keep the kernel choices of their capture, so they are dropped."""
-        L.check(self.tune.set(key, value), f"teo_tune_set({key!r}, {value})")
+        self.tune.set(key, value)                 # raises TeoError on an unknown key / rejected value
         self._drop_graph()
         for hook in self._tune_hooks:
             hook()
 
     def tune_reset(self):
-        L.check(self.tune.reset(), "teo_tune_reset")
+        self.tune.reset()
         self._drop_graph()
         for hook in self._tune_hooks:
             hook()

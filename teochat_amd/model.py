@@ -50,6 +50,27 @@ class TeoKVCache:
         return (shape, shape)
 
 
+class TeoBatchKVCache:
+    """Handle to the per-conversation device KV caches of a batched forward (the BatchDecoder's slots): what
+    forward(input_ids [B, S], use_cache=True) returns at B > 1 and what forward(input_ids [B, 1], past_key_values=...) continues.
+    `[-1][-1].shape[-2]` reports the longest cached sequence (the legacy tuple cache of a padded batch has that length,
+    llava_arch.py:156)."""
+
+    def __init__(self, engine, decoder):
+        self.engine, self.decoder = engine, decoder
+
+    def get_seq_length(self):
+        return max(self.decoder.cache_len)
+
+    def __len__(self):
+        return self.engine.cfg.num_hidden_layers
+
+    def __getitem__(self, i):
+        c = self.engine.cfg
+        shape = SimpleNamespace(shape=(self.decoder.B, c.num_key_value_heads, max(self.decoder.cache_len), c.head_dim))
+        return (shape, shape)
+
+
 class TeoImageTower:
     """The tower object `get_image_tower()` returns (LanguageBindImageTower surface, languagebind/__init__.py:94-173)."""
 
@@ -293,6 +314,18 @@ class LlavaLlamaForCausalLM:
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
                 return_dict=None):
+        """LlavaLlamaForCausalLM.forward (llava_llama.py:56-99), same arguments in the same order.
+
+        Contract where it differs from the reference (also in INTEGRATION.md):
+          * PADDED positions (attention_mask == 0) are never computed: their `logits` rows and, with `output_hidden_states`, their rows
+            in ALL L + 1 hidden-state tensors are ZERO, at B = 1 and at B > 1 alike.  The reference's LlamaModel returns the (masked)
+            activations it computed there; a consumer that pools over the full [B, S, D] tensor without applying the attention mask
+            gets different values.  Real positions equal the reference's (tests/golden/hidden_*.npz).
+          * `output_attentions` raises NotImplementedError (the fused attention kernels never materialise the maps).
+          * B > 1: `use_cache=True` (explicit) keeps one device cache per conversation and returns a TeoBatchKVCache; the next call
+            takes it with input_ids [B, 1] (one batched decode step, every row at its own true next position).  With use_cache
+            left None (the training-shape forward) nothing is kept and `past_key_values` is None.
+        """
         if inputs_embeds is None:
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = \
                 self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
@@ -304,13 +337,20 @@ class LlavaLlamaForCausalLM:
             raise NotImplementedError("output_attentions: attention maps are not materialised by the fused attention kernels")
         eng = self.engine
         B, S, _ = inputs_embeds.shape
+        if isinstance(past_key_values, TeoBatchKVCache):
+            # batched continuation (HF generate over a batch re-enters forward with the cache and ONE new token per row,
+            # llava_arch.py:154-163): one batched decode step over the BatchDecoder's slots
+            return self._forward_batch_step(input_ids, past_key_values, labels, output_hidden_states, return_dict, B, S)
         if past_key_values is None:
             eng.reset_cache()
         elif not isinstance(past_key_values, TeoKVCache) or past_key_values.engine is not eng:
-            raise ValueError("past_key_values must be the TeoKVCache returned by this model")
+            raise ValueError("past_key_values must be the cache object returned by this model")
         if B > 1 and past_key_values is not None:
-            raise ValueError("the device KV cache holds one sequence; batched continuation is not supported")
+            raise ValueError("a one-sequence TeoKVCache cannot continue a batch: pass the TeoBatchKVCache that the batched forward returned")
         past = eng.cache_len
+        # B > 1 with use_cache=True (explicitly: the training-shape forward leaves it None and keeps nothing): the prompts are
+        # prefilled INTO the batch decoder's per-conversation cache slots and the returned TeoBatchKVCache continues them
+        keep_batch = B > 1 and use_cache is True
         logits = torch.zeros(B, S, self.config.vocab_size, dtype=torch.float32, device=eng.device)
         # output_hidden_states (llava_llama.py:56-69 -> LlamaModel.forward): L + 1 tensors [B, S, D] in the model dtype -- the input
         # embeddings, the residual stream after each layer but the last, the final-normed states; padded positions stay zero
@@ -343,8 +383,16 @@ class LlavaLlamaForCausalLM:
                     pr = pr[lo:hi] if pr.shape[-1] == S else pr
                     if not torch.equal(pr.to(torch.long).cpu(), torch.arange(hi - lo)):
                         raise ValueError("batched forward supports the default position_ids (0 .. len - 1 per sample) only")
+            if keep_batch and len(live) != B:
+                raise ValueError("use_cache=True at B > 1 needs at least one real token in every row")
             if live:
-                out = eng.prefill_batch([inputs_embeds[b, spans[b][0]:spans[b][1]] for b in live], hidden_states=hs_all is not None)
+                seqs = [inputs_embeds[b, spans[b][0]:spans[b][1]] for b in live]
+                if keep_batch:
+                    dec = self.batch_decoder(B, 64)
+                    dec.reset()
+                    out = dec.prefill_all(seqs, last_only=False, hidden_states=hs_all is not None)
+                else:
+                    out = eng.prefill_batch(seqs, hidden_states=hs_all is not None)
                 out, hs = out if hs_all is not None else (out, None)
                 r0 = 0
                 for b in live:
@@ -364,29 +412,56 @@ class LlavaLlamaForCausalLM:
                 out, hs = out
                 hs_all[:, 0, lo:hi] = hs
             logits[0, lo:hi] = out
+        pkv = TeoKVCache(eng) if (use_cache is None or use_cache) and B == 1 else None
+        if keep_batch:
+            pkv = TeoBatchKVCache(eng, self._batch_decoder)
+        return self._forward_result(logits, labels, pkv, hs_all, return_dict)
+
+    def _forward_result(self, logits, labels, pkv, hs_all, return_dict):
+        eng = self.engine
         loss = None
         if labels is not None:
-            # N4: training-shape loss (CrossEntropyLoss over the shifted positions) on the device: row (b, s) pairs
-            # logits[b, s] with labels[b, s + 1]; the last position of every sample is ignored
-            V = self.config.vocab_size
-            lab = labels.to(device=logits.device, dtype=torch.int64)
-            if bool(((lab != IGNORE_INDEX) & ((lab < 0) | (lab >= V))).any()):
-                raise IndexError("Target out of bounds")                    # what torch's cross_entropy reports
-            shifted = torch.cat([lab[:, 1:], torch.full_like(lab[:, :1], IGNORE_INDEX)], dim=1).reshape(-1).contiguous()
-            rows = shifted.numel()
-            loss_row = torch.empty(rows, dtype=torch.float32, device=logits.device)
-            out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
-            with eng.phase() as st:
-                lg = logits.reshape(rows, V)
-                L.check(eng.lib.teo_cross_entropy(lg.data_ptr(), V, shifted.data_ptr(), loss_row.data_ptr(), out3.data_ptr(), rows,
-                                                  V, IGNORE_INDEX, st), "teo_cross_entropy")
-            loss = out3[0]
-        pkv = TeoKVCache(eng) if (use_cache is None or use_cache) and B == 1 else None
+            loss = self._shifted_loss(logits, labels)
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv,
                                      hidden_states=tuple(hs_all[i] for i in range(hs_all.shape[0])) if hs_all is not None else None)
         if return_dict is False:
             return out.to_tuple()
         return out
+
+    def _shifted_loss(self, logits, labels):
+        """N4: training-shape loss (CrossEntropyLoss over the shifted positions) on the device: row (b, s) pairs logits[b, s] with
+        labels[b, s + 1]; the last position of every sample is ignored."""
+        eng = self.engine
+        V = self.config.vocab_size
+        lab = labels.to(device=logits.device, dtype=torch.int64)
+        if bool(((lab != IGNORE_INDEX) & ((lab < 0) | (lab >= V))).any()):
+            raise IndexError("Target out of bounds")                    # what torch's cross_entropy reports
+        shifted = torch.cat([lab[:, 1:], torch.full_like(lab[:, :1], IGNORE_INDEX)], dim=1).reshape(-1).contiguous()
+        rows = shifted.numel()
+        loss_row = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+        with eng.phase() as st:
+            lg = logits.reshape(rows, V)
+            L.check(eng.lib.teo_cross_entropy(lg.data_ptr(), V, shifted.data_ptr(), loss_row.data_ptr(), out3.data_ptr(), rows,
+                                              V, IGNORE_INDEX, st), "teo_cross_entropy")
+        return out3[0]
+
+    def _forward_batch_step(self, input_ids, cache, labels, output_hidden_states, return_dict, B, S):
+        """forward(input_ids [B, 1], past_key_values=TeoBatchKVCache): conversation b's new token at ITS OWN next position
+        (cache_len[b]); logits [B, 1, V] and the same cache object.  Positions: the reference derives them from the text-level
+        attention_mask (sum(mask) - 1, llava_arch.py:157-162), which equals the true next position only when no row of the batch is
+        padded; here every row continues at its true length whatever the mask says (stated in INTEGRATION.md)."""
+        eng = self.engine
+        if cache.engine is not eng or cache.decoder is not getattr(self, "_batch_decoder", None):
+            raise ValueError("past_key_values must be the TeoBatchKVCache returned by this model's last batched forward")
+        if S != 1 or input_ids is None:
+            raise ValueError("batched continuation takes ONE new token id per conversation (input_ids [B, 1])")
+        if B != cache.decoder.B:
+            raise ValueError(f"the cache holds {cache.decoder.B} conversations, input_ids has {B} rows")
+        if output_hidden_states:
+            raise NotImplementedError("output_hidden_states on a batched decode step (the fused step keeps no per-layer snapshots)")
+        logits = cache.decoder.forward_step(input_ids[:, 0]).view(B, 1, -1)
+        return self._forward_result(logits, labels, cache, None, return_dict)
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
         images = kwargs.pop("images", None)

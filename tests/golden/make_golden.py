@@ -54,6 +54,11 @@ TINY = {
 
 TINY_STD = 0.08   # large enough that attention is peaked and greedy tokens vary at tiny dims
 
+# round 6: tinyC (anchored successor cycle: a greedy stream with 8 distinct tokens) is defined once, in tests/_tiny.py
+from tests import _tiny as TY  # noqa: E402
+TINY["tinyC"] = TY.TINY["tinyC"]
+assert all(TY.TINY[k] == TINY[k] for k in TINY) and TY.TINY_STD == TINY_STD
+
 
 def cfgs(name):
     t = TINY[name]
@@ -124,6 +129,8 @@ def build_reference(name):
     model = LL.LlavaLlamaForCausalLM(cfg)
     model.eval()
     sd = O.make_state_dict(vcfg, lcfg, mm, seed=2, std=TINY_STD)
+    if TINY[name].get("anchors"):
+        sd = TY.apply_anchors(sd, TINY[name]["anchors"], TINY_STD)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
     bad = [k for k in missing if "post_layernorm" not in k and "inv_freq" not in k and "position_ids" not in k]
@@ -316,7 +323,7 @@ def gen_numeric(name):
     model, sd, (vcfg, lcfg, mm) = build_reference(name)
     T, n_text, n_new = 2, 24, 8
     frames = O.synthetic_frames(T, vcfg.image_size, seed=0)
-    ids = O.synthetic_prompt_ids(n_text, T, lcfg.vocab_size, seed=1).unsqueeze(0)
+    ids = TY.prompt_ids(name, n_text, T, lcfg.vocab_size, seed=1).unsqueeze(0)      # == O.synthetic_prompt_ids for tinyA / tinyB
     out = {"sd_checksum": np.float64(sd_checksum(sd)), "input_ids": ids.numpy(), "T": np.int64(T),
            "frames_checksum": np.float64(float(sum(f.double().abs().sum() for f in frames)))}
 
@@ -651,6 +658,8 @@ if __name__ == "__main__":
     for nm in TINY:
         if "numeric" in which:
             gen_numeric(nm)
+        if nm == "tinyC":                     # the anchored config exists for its token stream: G4-G7 only
+            continue
         if "train" in which:
             gen_train(nm)
         if "hidden" in which:

@@ -39,7 +39,7 @@ def conversations(name, n, vocab):
     return g, convs
 
 
-@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+@pytest.mark.parametrize("name", ["tinyA", "tinyB", "tinyC"])
 def test_batched_decode_fp32_equals_single_and_reference(name):
     model, sd = build(name, torch.float32)
     dev = model.device
@@ -224,3 +224,64 @@ def test_prefill_all_equals_per_slot_prefill(name, dtype):
         n = int(e.shape[0])
         assert torch.equal(dec.k_cache[:, b, :, :n], k1[:, b, :, :n]) and torch.equal(dec.v_cache[:, b, :, :n], v1[:, b, :, :n])
         assert torch.equal(dec.vt_cache[:, b, :, :, :n], vt1[:, b, :, :, :n])
+
+
+@pytest.mark.parametrize("name,dtype", [("tinyA", torch.float32), ("tinyB", torch.float32), ("tinyB", torch.bfloat16)])
+def test_forward_api_batched_continuation_equals_generate_batch(name, dtype):
+    """An HF-style batched generate loop written against the reference API -- forward(input_ids [B, W], attention_mask, images,
+    use_cache=True), then forward(input_ids [B, 1], past_key_values=<returned cache>) per step (llava_arch.py:154-163,
+    llava_llama.py:101-108) -- produces generate_batch()'s greedy streams token for token, for conversations of different lengths
+    (right-padded rows); the step logits equal the batched device loop's bit for bit (same kernels, same caches)."""
+    model, sd = build(name, dtype)
+    dev = model.device
+    vcfg, lcfg, mm = TY.cfgs(name)
+    g, convs = conversations(name, 4, lcfg.vocab_size)
+    n_new = 6
+    ids_list = [ids.to(dev) for ids, _ in convs]
+    frames_list = [[f.to(dev, dtype=dtype) for f in fr] for _, fr in convs]
+    want = model.generate_batch(ids_list, frames_list, do_sample=False, max_new_tokens=n_new, eos_token_id=None)
+    want_new = [w[ids_list[b].numel():].tolist() for b, w in enumerate(want)]
+    dec = model._batch_decoder
+    want_last_logits = dec.d_logits.clone()
+
+    B = len(convs)
+    W = max(int(i.numel()) for i in ids_list)
+    ids_p = torch.zeros(B, W, dtype=torch.long, device=dev)
+    mask = torch.zeros(B, W, dtype=torch.long, device=dev)
+    for b, i in enumerate(ids_list):
+        ids_p[b, :i.numel()] = i
+        mask[b, :i.numel()] = 1
+    flat = [f for fr in frames_list for f in fr]
+    out = model(input_ids=ids_p, attention_mask=mask, images=flat, use_cache=True)
+    from teochat_amd.model import TeoBatchKVCache
+    pkv = out.past_key_values
+    assert isinstance(pkv, TeoBatchKVCache) and out.logits.shape[0] == B
+    # last REAL position of every (right-padded) row
+    (_, _, new_mask, _, _, _) = model.prepare_inputs_labels_for_multimodal(ids_p, None, mask, None, None, flat)
+    last = [int(torch.nonzero(new_mask[b].to(torch.bool)).flatten()[-1]) for b in range(B)]
+    assert list(pkv.decoder.cache_len) == [l + 1 for l in last] and pkv[-1][-1].shape[-2] == max(last) + 1
+    # fp32: the loop picks its own tokens (what HF's greedy loop does).  bf16: the prompt logits come from the all-position lm_head
+    # GEMM here and from the last-row form in generate_batch (another fp32 summation order), so a near-tie may pick another token;
+    # the loop is teacher-forced with generate_batch's stream there and the statement is the bit-equality of the step logits below
+    own = dtype == torch.float32
+    toks = [[int(out.logits[b, last[b]].argmax()) if own else want_new[b][0]] for b in range(B)]
+    for step in range(n_new - 1):
+        nxt = torch.tensor([[t[-1]] for t in toks], dtype=torch.long, device=dev)
+        mask = torch.cat([mask, torch.ones(B, 1, dtype=mask.dtype, device=dev)], dim=1)
+        _in = model.prepare_inputs_for_generation(nxt, past_key_values=pkv, images=flat, attention_mask=mask, use_cache=True)
+        out = model(**_in)
+        assert out.logits.shape == (B, 1, lcfg.vocab_size) and out.past_key_values is pkv
+        for b in range(B):
+            toks[b].append(int(out.logits[b, 0].argmax()) if own else want_new[b][step + 1])
+    assert toks == want_new
+    # the loop's last step consumed token n_new - 2 of every stream, as generate_batch's last device step did: same logits, bit for bit
+    assert torch.equal(out.logits[:, 0], want_last_logits)
+    # errors: a one-sequence cache cannot continue a batch, and more than one new token per row is not a decode step
+    one = model(input_ids=ids_list[0].view(1, -1), images=frames_list[0], use_cache=True).past_key_values
+    with pytest.raises(ValueError):
+        model(input_ids=nxt, past_key_values=one, attention_mask=mask)
+    out2 = model(input_ids=ids_p, attention_mask=mask[:, :W], images=flat, use_cache=True)
+    with pytest.raises(ValueError):
+        model(input_ids=torch.cat([nxt, nxt], dim=1), past_key_values=out2.past_key_values, attention_mask=mask)
+    # the training-shape forward (use_cache left None) keeps nothing
+    assert model(input_ids=ids_p, attention_mask=mask[:, :W], images=flat).past_key_values is None

@@ -222,6 +222,12 @@ def test_fp16_tiny_models_against_the_oracle_fp16_mode(name):
         imgs = [f.to("cuda:0", dtype=dt) for f in frames]
         out = model(input_ids=ids.cuda(), images=imgs)
         errs[rounding] = float((out.logits[0].cpu().float() - want[0]).abs().max()) / float(want[0].abs().max())
+        # the bar: the oracle's own self-difference at these rounding points, computed here (tests/test_model_gpu.py SELF_DIFF_FACTOR)
+        floor = O.self_difference(ids, frames, sdr, vcfg, lcfg, mm, rounding, base=want[0])
+        mine = O.logit_stats(out.logits[0].cpu().float(), want[0])
+        print(f"\n[{name}] {rounding} HIP vs oracle max / p99 / median {mine[0]:.2e} / {mine[1]:.2e} / {mine[2]:.2e}; oracle vs itself "
+              f"{floor[0]:.2e} / {floor[1]:.2e} / {floor[2]:.2e}")
+        assert all(m <= 1.25 * f for m, f in zip(mine, floor)), (rounding, mine, floor)
         if dt == h16:
             ref_tokens, _, _ = O.greedy_generate(ids, frames, sdr, vcfg, lcfg, mm, max_new_tokens=4, rounding="fp16")
             gen = model.generate(input_ids=ids.cuda(), images=imgs, do_sample=False, max_new_tokens=4, eos_token_id=None)
@@ -232,5 +238,4 @@ def test_fp16_tiny_models_against_the_oracle_fp16_mode(name):
             both = model.generate_batch([ids[0].cuda(), ids[0].cuda()], [imgs, imgs], do_sample=False, max_new_tokens=4, eos_token_id=None)
             assert both[0].tolist() == both[1].tolist() and len(both[0]) >= 4
     print(f"\n[{name}] end-to-end logits vs the oracle at the same rounding points, max|d| / max|logit|: fp16 {errs['fp16']:.2e}   bf16 {errs['bf16']:.2e}")
-    assert errs["fp16"] < FP16_REL
     assert errs["fp16"] < 0.5 * errs["bf16"]            # 3 more mantissa bits: well below the bf16 drift (expected ~1/8)

@@ -81,7 +81,7 @@ def test_splice_plans_bit_exact():
     assert r[0].tolist() == p["input_ids"] and all(x is None for x in r[1:])
 
 
-@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+@pytest.mark.parametrize("name", ["tinyA", "tinyB", "tinyC"])
 def test_numeric_fixtures(name):
     g = TY.load_npz(name)
     vcfg, lcfg, mm = TY.cfgs(name)
@@ -91,7 +91,12 @@ def test_numeric_fixtures(name):
     frames = O.synthetic_frames(T, vcfg.image_size, seed=0)
     assert abs(float(sum(f.double().abs().sum() for f in frames)) - float(g["frames_checksum"])) < 1e-3
     ids = torch.from_numpy(g["input_ids"])
-    assert torch.equal(ids[0], O.synthetic_prompt_ids(ids.shape[1], T, lcfg.vocab_size, seed=1))
+    assert torch.equal(ids[0], TY.prompt_ids(name, ids.shape[1], T, lcfg.vocab_size, seed=1))
+    if name == "tinyC":
+        # the anchored config exists for its token stream: the REFERENCE's greedy stream (the fixture) is varied -- at least 6
+        # distinct tokens in 8 steps, with a context-decided jump off the anchors' +1 walk
+        gt = g["greedy_tokens"].tolist()
+        assert len(set(gt)) >= 6 and any(b != a + 1 for a, b in zip(gt, gt[1:]))
     pix = torch.stack(frames)
 
     # G4 ViT
@@ -190,7 +195,7 @@ def test_oracle_training_shape_loss_matches_reference(name):
     np.testing.assert_allclose(logits[0, -1].numpy(), g["logits_last_valid"][0], atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+@pytest.mark.parametrize("name", ["tinyA", "tinyB", "tinyC"])
 def test_kernel_emulating_attention_modes_are_pinned(name, monkeypatch):
     """The bf16 parity chain compares the HIP kernels with the oracle's `flash64` (MFMA flash kernel: 64-key tiles,
     running max, exp2) and `split128` (decode kernel: independent key chunks + combine) attention modes.  Pin those modes
