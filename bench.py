@@ -18,9 +18,12 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
-import torch
+_T_PROCESS_START = time.perf_counter()      # before `import torch`: setup_s below is what a rank spends before it can take its first step
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -235,7 +238,51 @@ def cpu_baseline(T, n_text, n_out, budget_s=240.0, max_layers=None):
                                              for k, v in c1.items() if k != "L"}},
         }
         out["wall_s"] = round(time.perf_counter() - t_start, 1)
+        # `value` is ONE box's host: the gpurun boxes grant 16 of 256 hardware threads and differ among themselves.  The same leg as
+        # the committed lines of earlier rounds measured it (profiles/r0N_bench.json, the driver's BENCH_r0N.json; round 1 timed a 2-layer
+        # sample with 256 threads and is not comparable), so that the number is not read as a constant:
+        seen = []
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "BENCH_r0*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r0*_bench.json"))):
+            try:
+                blob = json.load(open(path))
+                cb = (blob.get("parsed") or blob).get("cpu_baseline") or {}
+                if cb.get("value", 0) > 0.5:
+                    seen.append((round(float(cb["value"]), 3), os.path.relpath(path, ROOT)))
+            except Exception:  # noqa: BLE001
+                pass
+        vals = [v for v, _ in seen] + [out["value"]]
+        out["range_across_boxes"] = {"tokens_per_s": [min(vals), max(vals)], "n_boxes": len(vals),
+                                     "from": [f"{n}: {v}" for v, n in seen] + [f"this run: {out['value']}"],
+                                     "note": "same sample and method on every box (rounds 2-6); the spread is the hosts' (16 granted CPUs of a 2 x 64-core EPYC 9575F)"}
     return out
+
+
+class Deadline:
+    """A hard deadline around one collective / rendezvous step of an N > 1 run: if the block has not finished after `seconds`, the rank
+    says which step hung and leaves with exit code 3 -- the launcher then ends the job with a non-zero code and no JSON line, instead
+    of the driver's clock running out on a silent hang.  (An exit, never an exec: this process holds the GPU.)"""
+
+    def __init__(self, seconds, what, rank):
+        self.seconds, self.what, self.rank, self.timer = float(seconds), what, rank, None
+
+    def _fire(self):
+        sys.stderr.write(f"bench.py: rank {self.rank}: '{self.what}' did not finish within {self.seconds:.0f} s -- a rank is missing or the "
+                         f"fabric is stuck; exiting with code 3\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *a):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
 
 
 def spawn_ranks(args):
@@ -276,6 +323,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on real multi-GPU nodes; gloo for plumbing tests")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing test: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--rccl-timeout", type=float, default=180.0, help="deadline (s) of the once-per-run RCCL communicator check")
+    ap.add_argument("--collective-timeout", type=float, default=900.0, help="N > 1: hard deadline (s) of every rendezvous / barrier / reduction of the "
+                    "run, the timed region's barriers included; a rank that hits it exits with code 3 (0 = no deadline)")
     ap.add_argument("--tune", action="append", default=[], help="key=value set in the engine's teo_tune block (perf knobs only)")
     ap.add_argument("--rope-in-attn", type=int, default=None, choices=[0, 1], help="A/B of the engine option: RoPE + KV append inside the decode attention kernel (1) or in the QKV GEMV epilogue (0, the single-conversation default); same values")
     args = ap.parse_args()
@@ -294,12 +343,24 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     import torch.distributed as dist
+    import datetime
+    deadline = lambda what: Deadline(args.collective_timeout if world > 1 else 0, what, rank)      # noqa: E731
+    host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        pg_timeout = datetime.timedelta(seconds=max(args.collective_timeout, 60.0))
+        with deadline("init_process_group"):
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device), timeout=pg_timeout)
+            else:
+                dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=pg_timeout)
+        # host-side exchanges (the communicator's unique id, the per-rank statistics of the line) go over their OWN gloo group: they
+        # never touch the GPU and never interleave with the timed region's barrier / reductions on the default group
+        with deadline("new_group(gloo)"):
+            try:
+                host_group = dist.new_group(backend="gloo", timeout=pg_timeout)
+            except Exception:  # noqa: BLE001 -- no gloo in this build: the default group carries the host objects too
+                host_group = None
 
     if os.environ.get("TEO_BENCH_FAIL_RANK") == str(rank) and world > 1:
         # test hook (tests/test_bench_contract_gpu.py): a rank other than 0 dies -> the launcher must end the job with a non-zero code
@@ -329,6 +390,10 @@ def main():
         eng.tune_set(k_, int(v_))                # the engine's own teo_tune block (nothing process-wide)
     frames, ids = synthetic_inputs(T, n_text, model.config.vocab_size, seed=100 * rank if not args.shard_frames else 0,
                                    device=device, dtype=dtype)
+    torch.cuda.synchronize()
+    # process start -> model resident and inputs on the device.  The synthetic weights are seed-generated ON this rank's GPU
+    # (teochat_amd/synthetic.py: a device generator, no host copy of the 14 GB), so N ranks do not compete for the job's CPUs here
+    setup_s = time.perf_counter() - _T_PROCESS_START
 
     # The library's own RCCL communicator (teo_ctx_create over all ranks): the data path of the frame-sharded tower, and for the
     # data-parallel replicas a once-per-run proof that N ranks really hold one communicator over xGMI (`rccl_ranks` below) plus
@@ -340,10 +405,7 @@ def main():
         box = {}
         # the check's host-side exchange (the communicator's unique id) runs on its OWN gloo group: if the helper thread is still inside
         # it at the deadline, the timed region's barrier / all_reduce on the default group stay ordered across ranks
-        try:
-            chk_group = dist.new_group(backend="gloo")
-        except Exception:  # noqa: BLE001 -- no gloo on this build: the default group carries the id (the round-3 behaviour)
-            chk_group = None
+        chk_group = host_group
 
         def rccl_check():
             # runs on a helper thread with a deadline: a communicator that never forms (a rank missing, a fabric fault) must not
@@ -395,12 +457,37 @@ def main():
         feats_whole = eng.vit_features(pix_all).to(pix_all.dtype)
         shard_ok = bool(torch.equal(feats_sharded, feats_whole))
         flag = torch.tensor([1 if shard_ok else 0], dtype=torch.int32, device=device if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        with deadline("all_reduce(MIN) of the shard-frames check"):
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         from teochat_amd.parallel import frame_partition
         shard_check = {"frames_per_rank": [c_ for _, c_ in frame_partition(T, world)],
                        "gathered_equals_unsharded_on_every_rank": bool(int(flag.item()) == 1)}
         if not shard_check["gathered_equals_unsharded_on_every_rank"]:
             raise SystemExit("frame-sharded tower: gathered features differ from the unsharded encode")
+        # what the split buys, read off one line (outside the timed region; this rank's wall clock, median of 5 after a warm-up):
+        # the whole tower on one GPU, the sharded call (local block + gather + reassembly), its local encode alone, the gather alone
+        import statistics
+
+        def _ms(fn, reps=5):
+            fn(); torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                with deadline("shard-frames timing barrier"):
+                    dist.barrier()
+                t_ = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t_) * 1e3)
+            return statistics.median(ts)
+        s_, c_ = frame_partition(T, world)[rank]
+        cmax = max(c__ for _, c__ in frame_partition(T, world))
+        NVt, Dvt = feats_whole.shape[1], feats_whole.shape[2]
+        send_t = torch.zeros(cmax * NVt, Dvt, dtype=feats_whole.dtype, device=device)
+        recv_t = torch.empty(world * cmax * NVt, Dvt, dtype=feats_whole.dtype, device=device)
+        gather = (lambda: comm.all_gather_rows(send_t, recv_t)) if comm is not None else (lambda: dist.all_gather_into_tensor(recv_t, send_t))
+        shard_times = {"tower_ms_unsharded": round(_ms(lambda: eng.vit_features(pix_all)), 3),
+                       "tower_ms_sharded": round(_ms(lambda: tower(pix_all)), 3),
+                       "local_encode_ms": round(_ms(lambda: eng.vit_features(pix_all[s_:s_ + max(c_, 1)])), 3),
+                       "gather_ms": round(_ms(gather), 3), "gather_bytes_per_rank": int(send_t.numel() * send_t.element_size()),
+                       "gather_via": "teo_allgather_visual (RCCL)" if comm is not None else f"torch.distributed {args.dist_backend}",
+                       "note": "rank 0's clock; every timed call starts behind a barrier"}
 
     B = args.batch
     if B > 1:
@@ -419,9 +506,13 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            with deadline("barrier of the timed region"):
+                dist.barrier()
             torch.cuda.synchronize()
 
+    if os.environ.get("TEO_BENCH_STALL_RANK") == str(rank) and world > 1:
+        # test hook (tests/test_bench_contract_gpu.py): this rank never reaches the barrier -> the others' deadline must end the job
+        time.sleep(10 * max(args.collective_timeout, 1.0))
     for _ in range(args.warmup):
         out = step()
     sync()
@@ -430,11 +521,21 @@ def main():
         out = step()
     sync()
     dt = time.perf_counter() - t0
+    dt_own = dt
     assert out.shape[1] == n_text + n_out
     tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        with deadline("all_reduce(MAX) of the step time"):
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # every rank's own clock and setup time, gathered on the host group (N > 1): the line shows the spread and names the straggler
+    per_rank = None
+    if world > 1:
+        mine = {"rank": rank, "seconds": dt_own, "setup_s": setup_s}
+        box = [None] * world
+        with deadline("all_gather_object of the per-rank statistics"):
+            dist.all_gather_object(box, mine, group=host_group)
+        per_rank = sorted(box, key=lambda e: e["rank"])
     convs = args.steps * (1 if args.shard_frames else world) * B
     value = convs * n_out / dt
 
@@ -712,8 +813,19 @@ def main():
         "phases": phases,
         "roofline": roofline,
     }
+    result["setup_s"] = round(setup_s, 2)
+    if per_rank is not None:
+        own_tokens = args.steps * B * n_out          # what ONE rank generated in its own `seconds` (the sharded-tower run: the same conversation on every rank)
+        vals = [own_tokens / e["seconds"] for e in per_rank]
+        slow = max(range(world), key=lambda r_: per_rank[r_]["seconds"])
+        result["per_rank"] = {"tokens_per_s": [round(v, 2) for v in vals], "ms_per_step": [round(e["seconds"] / args.steps * 1e3, 2) for e in per_rank],
+                              "setup_s": [round(e["setup_s"], 2) for e in per_rank],
+                              "min_tokens_per_s": round(min(vals), 2), "max_tokens_per_s": round(max(vals), 2), "straggler_rank": slow,
+                              "spread": round(max(vals) / min(vals) - 1.0, 4),
+                              "note": "each rank's own clock between the two barriers of the timed region; `value` uses the slowest rank's"}
     if args.shard_frames:
         result["shard_frames_check"] = shard_check
+        result["shard_frames"] = shard_times
     result["rccl_ranks"] = rccl_info["rccl_ranks"] if rccl_info else (1 if world == 1 else None)
     if rccl_info:
         result["rccl"] = rccl_info
@@ -743,7 +855,8 @@ def main():
         if stuck:
             sys.stdout.flush()
             os._exit(0)
-        dist.destroy_process_group()
+        with deadline("destroy_process_group"):
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

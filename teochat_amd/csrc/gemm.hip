@@ -683,16 +683,25 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         if (one_round_160) return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);
         // just over one round of wide tiles -- or, for a short K loop (K <= 1024: the tower's fc1 at T = 16, 528 tiles), just over two:
         // there a ragged third round costs a third of the launch (wide 86.7 us, its stream-K form 65.5; tools/vit_gemm_probe.py, round 5)
-        const long long sk_wide_max = K <= 1024 ? 2 * 256 + 256 / 6 : 256 + 256 / 6;
-        const bool sk_wide_fit = t_wide_ > 256 && t_wide_ <= sk_wide_max && (t_wide_ % 256) != 0 && (t_wide_ % 256) <= 256 / 6;
+        // round 6 (tools/shape_sweep.py, tools/dispatch_probe.py over M = 767 .. 3328): with a LONG K loop (K >= 2048: the LLaMA shapes) the
+        // stream-K form keeps winning up to 1.375 tiles per workgroup -- o / down at M = 2305 .. 2816 (304 .. 352 wide tiles) 86-97 / 208-242 us
+        // against 113-136 / 298-343 us on the 128 x 128 tiles the rounds model fell back to, qkv at M = 769 .. 896 (336 tiles) 93-95 vs 128-132
+        const long long sk_wide_rem = K >= 2048 ? 96 : 256 / 6;
+        const long long sk_wide_max = K <= 1024 ? 2 * 256 + 256 / 6 : 256 + sk_wide_rem;
+        const bool sk_wide_fit = t_wide_ > 256 && t_wide_ <= sk_wide_max && (t_wide_ % 256) != 0 && (t_wide_ % 256) <= sk_wide_rem;
         const bool sk_wide_shape = sk_ws && tune().gemm_sk && tune().gemm_wide && !swiglu && sk_wide_fit;
         // 256 x 256 tiles: a round of them costs GEMM_BIG_ROUND_COST rounds of the 128 x 256 kernel for twice the area (measured
         // 1.45-1.7 us against 0.875 us per K tile); taken when that beats the wide kernel's round count and the chip is filled
         // (with a workspace its hybrid form has no ragged last round: fractional rounds + a hand-off allowance)
         const double big_rounds = (sk_ws && t_big > 256 && t_big % 256 != 0 && gemm_big_hybrid_fits(M, N, K)) ? (double)t_big / 256.0 + 0.12
                                                                                                                  : (double)cdiv(t_big, 256);
-        if (bm == 128 && K >= 2 * BK && (tune().gemm_big == 2 || (tune().gemm_big == 1 && tune().gemm_wide == 1 && t_big >= 224 && !sk_wide_shape &&
-                                                               big_rounds * GEMM_BIG_ROUND_COST < (double)cdiv(t_wide_, 256))))
+        // round 6: three quarters of a round of 256 x 256 tiles already beats the alternatives when the K loop is long (K >= 2048): qkv at
+        // M = 897 .. 1024 (192 tiles) 97-99 us vs 137-139 on 128 x 128 tiles, o / down at M = 2817 .. 3328 (192 / 208 tiles) 102-108 / 252-257 vs
+        // 122-142 / 300-365; and at EQUAL modelled cost the 256 x 256 tile is the one that measures ahead (gate/up at M = 2305 .. 2560: four
+        // rounds of them 393 us, seven rounds of 128 x 256 tiles 434-443) -- hence <=
+        const long long t_big_min = K >= 2048 ? 192 : 224;
+        if (bm == 128 && K >= 2 * BK && (tune().gemm_big == 2 || (tune().gemm_big == 1 && tune().gemm_wide == 1 && t_big >= t_big_min && !sk_wide_shape &&
+                                                               big_rounds * GEMM_BIG_ROUND_COST <= (double)cdiv(t_wide_, 256))))
             return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, st, sk_ws, GEMM_SK_SLAB_BYTES);
         {   // just over one round of WIDE tiles (272 on 256 CUs: o / down at M = 2168): the stream-K form of the wide kernel
             const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256);

@@ -119,6 +119,11 @@ template <typename T> struct Is16 { static constexpr bool v = IsBf<T>::v || IsF1
 // slower than the unpack + FMA pairs it replaces), so bf16 weights keep the fp32 image.  The split-K kernel reads x from
 // global memory as bf16 and uses v_dot2c for both (down projection 16.6 -> 15.6 us).
 template <typename T, typename WT> struct BfImage { static constexpr bool v = IsBf<T>::v && sizeof(WT) == 1; };
+// Round 6, IEEE half weights in the row-group kernel (gate/up, lm_head): the fp32 image costs 8 v_cvt_f32_f16 (four of them SDWA forms,
+// with their s_nop hazards) + 4 v_pk_fma_f32 + the register moves that pair them per 8 weights -- 20 VALU instructions where bfloat16
+// needs 16 (shift / mask unpack) -- and measured 1.2-2.6 % behind bf16 whatever the data (tools/fp16_probe.py).  The 16-bit image +
+// v_dot2_f32_f16 is 4 instructions and one ds_read_b128 per 8 weights.  (The QKV + RoPE kernel keeps the fp32 image: it ties there.)
+template <typename T, typename WT> struct RowsImage16 { static constexpr bool v = BfImage<T, WT>::v || (IsF16<T>::v && IsF16<WT>::v); };
 
 template <bool NT>
 __device__ __forceinline__ uint4 ld16(const void* p) {
@@ -208,7 +213,8 @@ __device__ __forceinline__ void stage_x(const T* __restrict__ x, const T* __rest
                 }
                 if constexpr (XB) {          // bf16 image: the raw row, or the rounded normalised values repacked
                     uint4 o = xr[i];
-                    if (norm_w) o = make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+                    if (norm_w) o = make_uint4(pack_h2<IsF16<T>::v>(f[0], f[1]), pack_h2<IsF16<T>::v>(f[2], f[3]), pack_h2<IsF16<T>::v>(f[4], f[5]),
+                                               pack_h2<IsF16<T>::v>(f[6], f[7]));
                     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(xs) + xb_off<VE>(c * VX)) = o;
                 } else {
 #pragma unroll
@@ -244,7 +250,8 @@ __device__ __forceinline__ void stage_x(const T* __restrict__ x, const T* __rest
                     Vec16<T>::cvt(*p4, v);
 #pragma unroll
                     for (int e = 0; e < VX; ++e) v[e] = v[e] * rr * f[e];
-                    *p4 = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                    *p4 = make_uint4(pack_h2<IsF16<T>::v>(v[0], v[1]), pack_h2<IsF16<T>::v>(v[2], v[3]), pack_h2<IsF16<T>::v>(v[4], v[5]),
+                                     pack_h2<IsF16<T>::v>(v[6], v[7]));
                 } else {
 #pragma unroll
                     for (int e = 0; e < VX; e += 4) {
@@ -275,11 +282,11 @@ __device__ __forceinline__ void issue_block(uint4 (&w)[U][R], const WT* const (&
         }
     }
 }
-template <typename T, typename WT, int R, int U, bool FULL>
+template <typename T, typename WT, int R, int U, bool FULL, bool XB16 = BfImage<T, WT>::v>
 __device__ __forceinline__ void consume_block(const uint4 (&w)[U][R], const float* xs, int c0, int lane, int nchunk,
                                               float (&acc)[R]) {
     constexpr int VE = Vec16<WT>::N;
-    if constexpr (BfImage<T, WT>::v) {
+    if constexpr (XB16) {
         // one accumulator per (row, chunk): v_dot2c chains of 4 instead of 4 U (the instruction accumulates in place, so
         // a single accumulator per row serialises the whole step)
         float part[U][R];
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     constexpr int STEP = 64 * U;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nchunk = K / VE;                    // 16-byte weight chunks per row
-    float* red = x_image_end<BfImage<T, WT>::v, VE>(xs, nchunk);
+    float* red = x_image_end<RowsImage16<T, WT>::v, VE>(xs, nchunk);
     const int nwaves = gridDim.x * GV_WAVES;
     const int ngroups = SWIGLU ? (N / 2 + (R / 2) - 1) / (R / 2) : (N + R - 1) / R;
 
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
     int grp = blockIdx.x * GV_WAVES + wid;
     // PF (host guarantees nchunk >= STEP): NO branch around the prefetch -- at a control-flow merge hipcc waits vmcnt(0),
     // which would drain the weights before the prologue.  Waves past the last group prefetch a clamped (valid) row.
-    stage_x<T, VE, BfImage<T, WT>::v, XPT>(x, norm_w, xs, red, K, eps, [&]() {
+    stage_x<T, VE, RowsImage16<T, WT>::v, XPT>(x, norm_w, xs, red, K, eps, [&]() {
         if (PF) {
             const int gp = min(grp, ngroups - 1);
             const WT* rowp[R];
@@ -377,15 +384,15 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const T* __restrict__ 
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
         int c0 = 0;
-        if (have) { consume_block<T, WT, R, U, true>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
+        if (have) { consume_block<T, WT, R, U, true, RowsImage16<T, WT>::v>(wa, xs, 0, lane, nchunk, acc); c0 = STEP; have = false; }
         const int cfull = (nchunk / STEP) * STEP;          // steady state: no bounds checks, no exec masking
         for (; c0 < cfull; c0 += STEP) {
             issue_block<WT, R, U, NT, true>(wa, rowp, c0, lane, nchunk);
-            consume_block<T, WT, R, U, true>(wa, xs, c0, lane, nchunk, acc);
+            consume_block<T, WT, R, U, true, RowsImage16<T, WT>::v>(wa, xs, c0, lane, nchunk, acc);
         }
         if (c0 < nchunk) {
             issue_block<WT, R, U, NT, false>(wa, rowp, c0, lane, nchunk);
-            consume_block<T, WT, R, U, false>(wa, xs, c0, lane, nchunk, acc);
+            consume_block<T, WT, R, U, false, RowsImage16<T, WT>::v>(wa, xs, c0, lane, nchunk, acc);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
@@ -609,7 +616,7 @@ static int launch_rows(const void* x, const void* W, const float* ws, const void
     const int ngroups = swiglu ? cdiv(N / 2, R / 2) : cdiv(N, R);
     int blocks = cdiv(ngroups, GV_WAVES);
     if (blocks > tune().gemv_max_blocks) blocks = tune().gemv_max_blocks;
-    const size_t lds = x_image_bytes<BfImage<T, WT>::v, Vec16<WT>::N>(K);
+    const size_t lds = x_image_bytes<RowsImage16<T, WT>::v, Vec16<WT>::N>(K);
 #define TEO_GV(NTV, SW)                                                                                              \
     TEO_KLAUNCH((gemv_kernel<T, TO, WT, R, U, PF, NTV, SW, XPT>), blocks, GV_THREADS, lds, st, (const T*)x, (const WT*)W, ws, (const T*)norm_w, \
                 (const T*)res, (TO*)y, N, K, eps)

@@ -37,6 +37,8 @@ constexpr int SK_TP = 16 * 17;      // padded 16x16 partial tile in LDS: [b][i] 
 // tune().skinny_ring (default 0): streaming form, weight tiles in flight per wave: 0 = default (2 fp8 / 1 bf16: measured best end to end,
                                     // B = 8 fp8 step 3.455 vs 3.54 ms), 1 = one more (3 / 2)
 // tune().skinny_unr (default 0): tile kernel, steps per register set: 0 = auto (8 for long K slices without SwiGLU / in-kernel norm), 4, 8
+// tune().skinny_waves (default 0): tile kernel, waves per workgroup: 0 = auto, 8, 16 (16: K split 16 ways; plain / residual epilogues, one row tile per workgroup)
+// tune().skinny_grid (default 0): streaming form, persistent workgroups per CU: 0 = auto (1), 1, 2, 3
 
 // Timeline marks of the probe build (tools/skinny_probe.hip instantiates TRACE = true; the library only TRACE = false):
 // slot s of workgroup blockIdx.x <- the 100 MHz wall clock, written by one lane.
@@ -84,8 +86,8 @@ __device__ __forceinline__ u32x4 sk_scale_frag(const u32x4& xv, const u32x4& gv,
 // per-row factor 1/rms commutes with the GEMM, so the kernel streams x once, accumulates sum(x^2) from the very
 // fragments it feeds to the matrix cores and applies inv_rms in the epilogue -- no separate norm launch, no
 // normalised copy of x.  (g is staged in LDS once per workgroup.)
-template <typename WT, int UNR, bool NT, bool SWIGLU, bool NORM, bool TRACE = false>
-__global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const WT* __restrict__ W, const bf16_t* __restrict__ x,
+template <typename WT, int UNR, bool NT, bool SWIGLU, bool NORM, bool TRACE = false, int WV = SK_WAVES>
+__global__ __launch_bounds__(WV * 64) void skinny_gemm_kernel(const WT* __restrict__ W, const bf16_t* __restrict__ x,
                                                                  int MB, int N, int K, int ldx, int tiled, int RT,
                                                                  const float* __restrict__ wscale, const bf16_t* res,
                                                                  const bf16_t* __restrict__ norm_w, float eps, void* outv,
@@ -96,15 +98,18 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const WT* __res
     constexpr int KS = F8 ? 64 : 32;                     // k elements per step (one 16-byte chunk per lane)
     constexpr int CH = F8 ? 16 : 8;                      // k elements per lane chunk
     constexpr int XL = F8 ? 2 : 1;                       // 16-byte activation loads per step
-    __shared__ float red[SK_WAVES][SK_TP];
-    __shared__ float ssq_part[SK_WAVES][16];
+    // WV waves per workgroup: 8, or 16 (round 6: the one-tile-per-CU launches -- o / down -- split K over twice as many waves, i.e.
+    // twice the weight requests of a CU in flight from the first cycle; `skinny_waves`)
+    constexpr int WG_THREADS = WV * 64;
+    __shared__ float red[WV][SK_TP];
+    __shared__ float ssq_part[WV][16];
     __shared__ float inv_s[16];
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_dyn[];      // NORM: g[K] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     if (wid == 0) sk_mark<TRACE>(fuse, 0);
     if (NORM) {
-        for (int i = tid; i < K / 8; i += SK_THREADS)
+        for (int i = tid; i < K / 8; i += WG_THREADS)
             reinterpret_cast<u32x4*>(sk_dyn)[i] = reinterpret_cast<const u32x4*>(norm_w)[i];
         __syncthreads();
     }
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const WT* __res
     float ssq = 0.f;
     // the 8 waves of a workgroup = RT row tiles (16 weight rows each) x KSPLIT contiguous K slices
     // (RT is 1, 2, 4 or 8 -- host-checked: shifts, no integer division in front of the first weight request)
-    const int rt_log2 = __builtin_ctz((unsigned)RT), ks_log2 = __builtin_ctz((unsigned)SK_WAVES) - rt_log2;
+    const int rt_log2 = __builtin_ctz((unsigned)RT), ks_log2 = __builtin_ctz((unsigned)WV) - rt_log2;
     const int KSPLIT = 1 << ks_log2;
     const int rt = wid >> ks_log2, ks = wid & (KSPLIT - 1);
     const int n0 = blockIdx.x * 16 * RT;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const WT* __res
         }                                                                                                      \
     }
 
-    // producer-side RMSNorm (SkinnyFuse): wave w owns rows w and w + 8; the first 256 partial sums of both rows are REQUESTED
+    // producer-side RMSNorm (SkinnyFuse): wave w owns rows w and w + WV (WV = waves of the workgroup: 8 -> two rows each, 16 -> one); the first 256 partial sums of both rows are REQUESTED
     // here (unconditional, clamped; a dummy source when the launch takes no partials) and summed by TEO_SK_SSQ_REDUCE after the
     // wave's first weights are in flight -- they are the oldest entries of the in-order vmcnt queue, so waiting for them waits for
     // nothing else
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_gemm_kernel(const WT* __res
         const int ssq_on_ = fuse.ssq_in ? 1 : 0, ssq_n_ = fuse.ssq_in ? fuse.nparts : 1; \
         float ssq_a0_[4], ssq_a1_[4]; \
         { \
-            const long long r0_ = (long long)min(wid, MB - 1) * ssq_n_ * ssq_on_, r1_ = (long long)min(wid + 8, MB - 1) * ssq_n_ * ssq_on_; \
+            const long long r0_ = (long long)min(wid, MB - 1) * ssq_n_ * ssq_on_, r1_ = (long long)min(wid + WV, MB - 1) * ssq_n_ * ssq_on_; \
 _Pragma("unroll") \
             for (int i = 0; i < 4; ++i) { \
                 const int p_ = min(lane + 64 * i, ssq_n_ - 1) * ssq_on_; \
@@ -228,14 +233,14 @@ _Pragma("unroll") \
             if (ssq_n_ > 256) {                                         /* more than 256 partials (hidden > 4096): the rare tail */ \
                 for (int p0 = 256 + lane; p0 < fuse.nparts; p0 += 64) { \
                     sq0 += fuse.ssq_in[(long long)min(wid, MB - 1) * fuse.nparts + p0]; \
-                    sq1 += fuse.ssq_in[(long long)min(wid + 8, MB - 1) * fuse.nparts + p0]; \
+                    sq1 += fuse.ssq_in[(long long)min(wid + WV, MB - 1) * fuse.nparts + p0]; \
                 } \
             } \
             sq0 = wave_sum(sq0); \
             sq1 = wave_sum(sq1); \
             if (lane == 0) { \
                 if (wid < MB) inv_s[wid] = rsqrtf(fabsf(sq0) / (float)K + fuse.eps); \
-                if (wid + 8 < MB) inv_s[wid + 8] = rsqrtf(fabsf(sq1) / (float)K + fuse.eps); \
+                if (wid + WV < MB) inv_s[wid + WV] = rsqrtf(fabsf(sq1) / (float)K + fuse.eps); \
             } \
         }
 
@@ -276,7 +281,7 @@ _Pragma("unroll") \
     const int OUTC = SWIGLU ? 8 * RT : 16 * RT;          // output columns of this workgroup
     float emit_v = 0.f;
     bool emit_ok = false;
-    for (int o = tid; o < 16 * OUTC; o += SK_THREADS) {
+    for (int o = tid; o < 16 * OUTC; o += WG_THREADS) {
         const int b = o / OUTC, c = o % OUTC;
         if (b >= MB) break;
         const bool first = o == tid;                     // this thread's prefetched operands apply
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_stream_kernel(const bf16_t*
     constexpr bool F16 = IsF16<WT>::v;
     constexpr int KS = F8 ? 64 : 32, CH = F8 ? 16 : 8, XL = F8 ? 2 : 1;
     constexpr int PER = UNR * SPT;                       // steps of one wave per tile
+    constexpr int WV = SK_WAVES;
     static_assert(NS % SPT == 0 && NS >= 2, "the ring holds whole tiles");
     __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][SS_TP];
     __shared__ float inv_s[16];
@@ -571,7 +577,8 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
         if (ok && tune().skinny_stream == 1) ok = ntiles >= 512 && (w_fp8 || MB > 8);
         if (ok) {
             const int cus = device_cu_count();
-            const int grid = std::max(1, std::min(ntiles, cus > 0 ? cus : 256));
+            const int per_cu = tune().skinny_grid > 0 ? tune().skinny_grid : 1;
+            const int grid = std::max(1, std::min(ntiles, per_cu * (cus > 0 ? cus : 256)));
 #define TEO_SS(WW, UN, SP, NSV, SW)                                                                         \
             TEO_KLAUNCH((skinny_stream_kernel<WW, UN, SP, NSV, SW>), grid, SK_THREADS, 0, st, (const bf16_t*)x, (const WW*)W, wscale, (const bf16_t*)res, \
                         out, MB, N, K, ldx, ldo, tiled, of, fuse)
@@ -596,6 +603,27 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
     // activation loads in flight per wave instead of 8 -- the launch is latency-bound with 64 KB of weights per CU in flight
     // (3.2 TB/s, tools/skinny_probe.py); fp8 takes 6 steps (its activation fragments are twice the weights: 8 steps spill); 150-200
     // VGPRs: one workgroup per CU, which is all N = 4096 has anyway
+    // 16 waves per workgroup (round 6): the launches with about one 16-row tile per CU (o, down: N = 4096 -> 256 workgroups) are bound by
+    // how many weight requests a CU has in flight, not by its waves' arithmetic -- 16 K slices put twice the requests out from the first cycle
+    {
+        const int steps16 = K / (w_fp8 ? 64 : 32) / 16;
+        const bool w16 = !swiglu && !norm_w && rt == 1 && (tune().skinny_nt != 0) && steps16 >= 2 &&
+                         (tune().skinny_waves == 16 || (tune().skinny_waves == 0 && false));
+        if (w16) {
+#define TEO_SK16(WW, UN)                                                                                    \
+            TEO_KLAUNCH((skinny_gemm_kernel<WW, UN, true, false, false, false, 16>), blocks, 1024, 0, st, (const WW*)W, (const bf16_t*)x, MB, N, K, ldx,  \
+                        tiled, rt, wscale, (const bf16_t*)res, (const bf16_t*)nullptr, eps, out, ldo, ldr, of, fuse, sw8)
+            // steps per register set: two sets cover the wave's whole K slice where the registers allow (every request of the launch out at once)
+            const int un = steps16 <= 4 ? 2 : (steps16 <= 8 ? 4 : 6);
+            if (w_fp8)         { if (un == 2) TEO_SK16(fp8_t, 2); else if (un == 4) TEO_SK16(fp8_t, 4); else TEO_SK16(fp8_t, 6); }
+            else if (fuse.f16) { if (un == 2) TEO_SK16(f16_t, 2); else if (un == 4) TEO_SK16(f16_t, 4); else TEO_SK16(f16_t, 6); }
+            else               { if (un == 2) TEO_SK16(bf16_t, 2); else if (un == 4) TEO_SK16(bf16_t, 4); else TEO_SK16(bf16_t, 6); }
+#undef TEO_SK16
+            note_kernel("skinny_gemm_w16");
+            TEO_LAUNCH_CHECK("skinny_gemm");
+            return TEO_OK;
+        }
+    }
     const int steps_per_wave = K / (w_fp8 ? 64 : 32) / (SK_WAVES / rt);
     const bool unr8 = !swiglu && !norm_w && (tune().skinny_nt != 0) && (tune().skinny_unr == 8 || (tune().skinny_unr == 0 && steps_per_wave >= 16 && blocks <= 2 * std::max(device_cu_count(), 1)));
     if (unr8) {

@@ -36,7 +36,9 @@
     X(skinny_nt, 1, true)                                                                                    \
     X(skinny_stream, 1, (v >= 0 && v <= 2))                                                                  \
     X(skinny_ring, 0, (v == 0 || v == 1))                                                                    \
-    X(skinny_unr, 0, (v == 0 || v == 4 || v == 8))
+    X(skinny_unr, 0, (v == 0 || v == 4 || v == 8))                                                           \
+    X(skinny_waves, 0, (v == 0 || v == 8 || v == 16))                                                        \
+    X(skinny_grid, 0, (v >= 0 && v <= 3))
 
 struct teo_tune {
 #define TEO_TUNE_FIELD(name, def, ok) int name = def;

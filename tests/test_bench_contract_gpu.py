@@ -123,6 +123,12 @@ def test_bench_eight_ranks_c4_partition_on_one_gpu():
     assert "frame-sharded" in d["config"]["parallelism"]
     assert d["shard_frames_check"] == {"frames_per_rank": [2] * 8, "gathered_equals_unsharded_on_every_rank": True}
     assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]          # ONE conversation: the ranks replicate the LLM
+    # round 6: what the split buys is read off the line -- the whole tower, the sharded call, its local block and the gather, each timed
+    sf = d["shard_frames"]
+    for k in ("tower_ms_unsharded", "tower_ms_sharded", "local_encode_ms", "gather_ms"):
+        assert sf[k] > 0, k
+    assert sf["gather_bytes_per_rank"] == 2 * 256 * 1024 * 2 and "gloo" in sf["gather_via"]        # 2 frames x 256 tokens x 1024 x bf16 = 1 MiB per rank
+    _check_per_rank(d, 8, 8)
     assert d["cpu_baseline"] is None or d["cpu_baseline"].get("measured_at") == "n_gpus = 1"
 
 
@@ -139,6 +145,35 @@ def test_bench_eight_data_parallel_ranks_on_one_gpu():
     assert abs(d["value"] - 8 * 8 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]      # all ranks' tokens over the slowest rank's time
     cb = d["cpu_baseline"]
     assert cb is not None and cb["measured_at"] == "n_gpus = 1" and cb["value"] > 0 and cb["from_profiles"].startswith("profiles/")
+    _check_per_rank(d, 8, 8)
+    # first contact with 8 ranks must not be a setup cliff: the synthetic weights are seed-generated on each rank's GPU, so eight ranks
+    # SHARING one GPU (and the job's CPUs) get ready within 2 x the time one rank needs alone (+ 20 s of launcher / rendezvous slack)
+    r1, l1 = _bench(["--gpus", "1", "--frames", "2", "--prompt", "32", "--new", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(l1[0])["setup_s"]
+    print(f"setup_s: one rank {one:.1f} s; eight ranks on one GPU {d['per_rank']['setup_s']}")
+    assert max(d["per_rank"]["setup_s"]) <= 2.0 * one + 20.0, (one, d["per_rank"]["setup_s"])
+
+
+def _check_per_rank(d, world, tokens_per_rank_step):
+    """Round 6 (VERDICT r05 "Next round" #5b): an N > 1 line carries every rank's own clock, the spread and the straggler."""
+    pr = d["per_rank"]
+    assert len(pr["tokens_per_s"]) == len(pr["ms_per_step"]) == len(pr["setup_s"]) == world
+    assert pr["min_tokens_per_s"] == min(pr["tokens_per_s"]) and pr["max_tokens_per_s"] == max(pr["tokens_per_s"])
+    assert 0 <= pr["straggler_rank"] < world and pr["ms_per_step"][pr["straggler_rank"]] == max(pr["ms_per_step"])
+    assert abs(max(pr["ms_per_step"]) - d["ms_per_step"]) < 0.02 * d["ms_per_step"]          # `value` is made of the slowest rank's time
+    assert all(v > 0 for v in pr["setup_s"]) and d["setup_s"] > 0
+
+
+def test_a_hung_collective_ends_the_job_with_a_nonzero_code():
+    """Round 6 (VERDICT r05 "Next round" #5d): every rendezvous / barrier / reduction of an N > 1 run sits under a hard deadline.  Rank 1
+    stalls before the timed region's barrier (test hook); rank 0 must not wait for ever: it leaves with code 3, the launcher ends the job
+    with a non-zero code and no JSON line."""
+    r, lines = _bench(["--gpus", "2", "--same-gpu", "--dist-backend", "gloo", "--frames", "2", "--prompt", "32", "--new", "8", "--steps", "1",
+                       "--warmup", "0", "--no-cpu-baseline", "--collective-timeout", "45"], timeout=900, extra_env={"TEO_BENCH_STALL_RANK": "1"})
+    assert r.returncode != 0
+    assert not lines, r.stdout[-1000:]
+    assert "did not finish within" in r.stderr
 
 
 def test_a_failing_rank_fails_the_whole_bench():

@@ -638,6 +638,40 @@ def test_gemm_skinny_fp8_weights(MB, N, K, swiglu):
     torch.testing.assert_close(y8.cpu(), ref, atol=3e-4, rtol=2e-4)
 
 
+@pytest.mark.parametrize("MB", [1, 8, 16])
+@pytest.mark.parametrize("N,K,fp8", [(4096, 4096, True), (4096, 11008, True), (4096, 4096, False), (4096, 11008, False), (320, 128, False), (64, 2048, True)])
+def test_gemm_skinny_sixteen_waves(MB, N, K, fp8):
+    """Round 6: the tile kernel with 16 waves per workgroup (K split 16 ways, `skinny_waves` = 16) computes the same products with
+    another fp32 partition of K: fp32 output within the accumulation-order tolerance of the 8-wave kernel and of the fp64 product,
+    residual epilogue and the norm hand-off (xg_out / ssq partials are produced by the same code) unchanged in form."""
+    from teochat_amd.engine import quantize_fp8_rows, tile_weights
+    bf = torch.bfloat16
+    W = G.bf16_round(rnd(N, K, seed=2, scale=0.02))
+    x = G.bf16_round(rnd(MB, K, seed=1))
+    res = G.bf16_round(rnd(MB, N, seed=3))
+    dx, dr = G.dev(x, bf), G.dev(res, bf)
+    scale = None
+    if fp8:
+        q, s_, dq = quantize_fp8_rows(W.to(bf))
+        W, dW, scale = dq.float(), tile_weights(q.cuda()), s_.cuda()
+    else:
+        dW = tile_weights(G.dev(W, bf))
+    y8 = G.gemm_skinny(dx, dW, scale=scale, flags=L.GEMM_WTILED, out_dtype=torch.float32, N=N)
+    assert G.lib().teo_last_kernel().decode() in ("skinny_gemm", "skinny_gemm_u8")
+    assert L.tune_set(b"skinny_waves", 16) == 0
+    try:
+        y16 = G.gemm_skinny(dx, dW, scale=scale, flags=L.GEMM_WTILED, out_dtype=torch.float32, N=N)
+        took16 = G.lib().teo_last_kernel().decode() == "skinny_gemm_w16"
+        yr = G.gemm_skinny(dx, dW, scale=scale, res=dr, flags=L.GEMM_WTILED, N=N)
+    finally:
+        L.tune_set(b"skinny_waves", 0)
+    assert took16 == (K // (64 if fp8 else 32) // 16 >= 2)
+    ref = (x.double() @ W.double().T).float()
+    torch.testing.assert_close(y16.cpu(), ref, atol=3e-4, rtol=2e-4)
+    torch.testing.assert_close(y16, y8, atol=3e-4, rtol=2e-4)
+    close_bf16(yr, G.bf16_round(ref + res))
+
+
 def test_gemm_skinny_rejects_unsupported():
     x = torch.zeros(2, 48, dtype=torch.bfloat16, device="cuda")
     W = torch.zeros(16, 48, dtype=torch.bfloat16, device="cuda")

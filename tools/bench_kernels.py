@@ -88,6 +88,8 @@ def bench_skinny():
     L.tune_set(b"skinny_stream", int(os.environ.get("SK_STREAM", "1")))
     L.tune_set(b"skinny_ring", int(os.environ.get("SK_RING", "0")))
     L.tune_set(b"skinny_unr", int(os.environ.get("SK_UNR", "0")))
+    L.tune_set(b"skinny_waves", int(os.environ.get("SK_WAVES", "0")))
+    L.tune_set(b"skinny_grid", int(os.environ.get("SK_GRID", "0")))
     for fp8 in (False, True):
         for name, N, K, flags in shapes:
             wb = 1 if fp8 else 2
