@@ -665,7 +665,8 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const bool of32 = out_dtype == TEO_F32;
         // narrow LDS-DMA tiles (gemm_narrow.hip, round 5): forced here; the automatic rule sits below, after the families it competes with
         if (tune().gemm_narrow == 2 && !swiglu)
-            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, tune().gemm_narrow_bm == 128 ? 128 : 64, st);
+            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, tune().gemm_narrow_bm == 128 ? 128 : 64, st,
+                                      tune().gemm_narrow_bm == 128 && tune().gemm_narrow_waves == 8);
         if (tune().gemm_quad == 2 && !swiglu) return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);      // forced (its rule: below)
         // automatic: wherever the 64-row register-staged kernel was the choice (few tiles: the tower's out_proj / fc2, every tower GEMM and
         // the LLaMA o / down projections of config C2) the 64 x 128 LDS-DMA tile runs instead -- tools/vit_gemm_probe.py (round 5, us):

@@ -119,8 +119,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mfm
 
 // bm: 64 -> 64 x 128 tiles, 3 stages (72 KB: two workgroups per CU); 128 -> 128 x 128 tiles, 2 stages (64 KB: two per CU).
 // No SwiGLU form (the shapes this family serves carry bias / activation / residual epilogues)
+// bm = 128 with waves8: the same 128 x 128 tile on EIGHT waves (2 x 4 of 64 x 32), 3 stages (96 KB: one workgroup per CU, two waves per
+// SIMD) -- round 6, for problems with at most ONE such tile per CU (LLaMA o / down at M <= 1024, the tower's fc2 / out_proj): a lone
+// four-wave workgroup leaves every SIMD one wave whose MFMA chain waits for its own fragment reads (0.95 us per K step measured on a
+// 128 x 128 tile alone on its CU); with two waves per SIMD one reads while the other multiplies.
 int gemm_narrow_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                       int act, bool of32, bool f16, int bm, hipStream_t st) {
+                       int act, bool of32, bool f16, int bm, hipStream_t st, bool waves8) {
     const int bn = 128;
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
     const int nwg = tiles_m * tiles_n;
@@ -134,11 +138,11 @@ int gemm_narrow_launch(const void* A, const void* W, const void* bias, const voi
     }
 #define TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, OF) { if (f16) TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, true) else TEO_GN_LAUNCH_T(TBM, TBN, WM, WN, NS, OF, false) }
 #define TEO_GN_LAUNCH(TBM, TBN, WM, WN, NS) { if (of32) TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, true) else TEO_GN_LAUNCH_F(TBM, TBN, WM, WN, NS, false) }
-    if (bm == 64) TEO_GN_LAUNCH(64, 128, 2, 2, 3) else TEO_GN_LAUNCH(128, 128, 2, 2, 2)
+    if (bm == 64) TEO_GN_LAUNCH(64, 128, 2, 2, 3) else if (waves8) TEO_GN_LAUNCH(128, 128, 2, 4, 3) else TEO_GN_LAUNCH(128, 128, 2, 2, 2)
 #undef TEO_GN_LAUNCH
 #undef TEO_GN_LAUNCH_F
 #undef TEO_GN_LAUNCH_T
-    note_kernel(bm == 64 ? "gemm_narrow_64" : "gemm_narrow_128");
+    note_kernel(bm == 64 ? "gemm_narrow_64" : (waves8 ? "gemm_narrow_128w8" : "gemm_narrow_128"));
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_narrow");
     return TEO_OK;
 }

@@ -278,3 +278,26 @@ def test_tune_blocks_are_independent_and_validated():
         assert seen["other"] == 128 and a.get("attn_chunk") == 0
     finally:
         a.close(); b.close()
+
+
+def test_hand_scheduled_kernels_have_no_spills_and_no_scratch():
+    """the K loops of gemm_quad.hip / gemm_narrow.hip count their `s_waitcnt vmcnt(N)` by hand (only the LDS-DMA pieces may be
+    in flight; the asm-volatile MFMAs are invisible to the hazard recogniser).  A compiler that spilled a register or used scratch in those
+    kernels would put loads / stores into the loop that the counts do not know about -- wrong data with no signal.  The compiler's own
+    AMDHSA metadata (hipcc -S with the Makefile's flags, tools/kernel_meta.py) must say 0 spills and 0 scratch bytes for EVERY
+    instantiation, on every build; the register budget the layouts were designed for is checked with it."""
+    import shutil
+    import pytest
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this machine")
+    from tools.kernel_meta import kernel_meta
+    for src, want in (("gemm_quad.hip", 8), ("gemm_narrow.hip", 12)):
+        ks = kernel_meta(os.path.join(ROOT, "teochat_amd", "csrc", src))
+        assert len(ks) >= want, (src, len(ks))
+        for k in ks:
+            assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+        if src == "gemm_quad.hip":
+            # eight waves (two per SIMD): at most 256 registers per lane incl. the AGPR-pinned accumulators; four waves (one per SIMD): 512
+            for k in ks:
+                assert k["vgpr_count"] <= (256 if k["max_flat_workgroup_size"] == 512 else 512), k
+                assert k["agpr_count"] >= 100, k                      # the accumulators really live in AGPRs

@@ -18,7 +18,8 @@ FAM = (("auto", {}), ("plain", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0}),
        ("128 sk", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2}), ("128x256", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0}),
        ("128x256 sk", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}), ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0}),
        ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2}),
-       ("narrow 64", {"gemm_narrow": 2, "gemm_narrow_bm": 64}), ("narrow 128", {"gemm_narrow": 2, "gemm_narrow_bm": 128}), ("no narrow", {"gemm_narrow": 0}),
+       ("narrow 64", {"gemm_narrow": 2, "gemm_narrow_bm": 64}), ("narrow 128", {"gemm_narrow": 2, "gemm_narrow_bm": 128}), ("narrow 128 w8", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_waves": 8}),
+       ("no narrow", {"gemm_narrow": 0}),
        ("quad 256x160", {"gemm_quad": 2}), ("quad 256x160 four waves", {"gemm_quad": 2, "gemm_quad_waves": 4}), ("no quad", {"gemm_quad": 0}))
 ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
 L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws")
@@ -44,7 +45,10 @@ for name, M, N, K, act, with_res in (("vit qkv", 2056, 3072, 1024, 0, False), ("
                                      ("vit fc2 T2", 514, 1024, 4096, 0, True), ("vit fc2 T16", 4112, 1024, 4096, 0, True), ("vit out T16", 4112, 1024, 1024, 0, True),
                                      ("vit fc1 T16", 4112, 4096, 1024, L.ACT_GELU_ERF, False), ("vit qkv T16", 4112, 3072, 1024, 0, False),
                                      ("llama o", 2168, 4096, 4096, 0, True), ("llama down", 2168, 4096, 11008, 0, True), ("llama o T2", 638, 4096, 4096, 0, True), ("llama down T2", 638, 4096, 11008, 0, True),
-                                     ("llama qkv T2", 638, 12288, 4096, 0, False), ("lm_head-like", 638, 32000, 4096, 0, False)):
+                                     ("llama qkv T2", 638, 12288, 4096, 0, False), ("lm_head-like", 638, 32000, 4096, 0, False),
+                                     ("llama o T3", 893, 4096, 4096, 0, True), ("llama down T3", 893, 4096, 11008, 0, True), ("llama o T4-", 1022, 4096, 4096, 0, True),
+                                     ("llama down T4-", 1022, 4096, 11008, 0, True), ("llama o T5", 1403, 4096, 4096, 0, True), ("llama down T5", 1403, 4096, 11008, 0, True),
+                                     ("llama o T1", 383, 4096, 4096, 0, True), ("llama down T1", 383, 4096, 11008, 0, True)):
     A = torch.randn(M, K, device="cuda").to(bf)
     Ws = [(torch.randn(N, K, device="cuda") * 0.02).to(bf) for _ in range(8)]
     bias = torch.randn(N, device="cuda").to(bf)
