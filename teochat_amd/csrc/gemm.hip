@@ -671,9 +671,16 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         // automatic: wherever the 64-row register-staged kernel was the choice (few tiles: the tower's out_proj / fc2, every tower GEMM and
         // the LLaMA o / down projections of config C2) the 64 x 128 LDS-DMA tile runs instead -- tools/vit_gemm_probe.py (round 5, us):
         // fc2 47.1 -> 36.5, out_proj 17.2 -> 14.6 (T = 8); at T = 2: fc2 42.6 -> 32.6, fc1 23.0 -> 18.6, LLaMA o 60.8 -> 39.2, down 148 -> 93
+        // round 6: with 192 .. 256 tiles of 128 x 128 (one per CU, three quarters of the chip or more), a long K loop and a wide N -- LLaMA
+        // o / down at M = 641 .. 1024 -- the EIGHT-wave 128 x 128 tile (two waves per SIMD on one tile per CU) beats the two four-wave 64 x 128
+        // tiles per CU: o 41.5-43.1 vs 53.2-55.0 us, down 107-109 vs 134-136 (tools/vit_gemm_probe.py); it loses at 160 tiles (M = 638: 41.0 /
+        // 103.4 vs 39.9 / 93.0) and on the tower's N = 1024 shapes (fc2 39.8 vs 37.0), which stay on the 64 x 128 tile
+        if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && tune().gemm_narrow_waves != 4 && bm == 64 && K >= 2048 && N >= 2048 &&
+            (long long)cdiv(M, 128) * tiles_n >= 192)
+            return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 128, st, true);
         if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && bm == 64)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, st);
-        const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = (long long)cdiv(M, 256) * cdiv(N, 256);
+        const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = gemm_big_tile_count(M, N);     // (counts a ragged last row block as 128 x 512 tiles)
         // 256 x 160 tiles (gemm_quad.hip, round 5): automatic, and only while no other family is forced, where the problem is ONE round of
         // them but more than one round of 128 x 256 tiles: M = 2056 .. 2304 against N = 4096 (272 wide tiles, 234 of these): LLaMA o / down at
         // config C3, the tower's fc1.  tools/vit_gemm_probe.py (us, real epilogues): o 79.7 -> 71.3, down 178.6 -> 170.7, fc1 + GELU 39.5 -> 34.2

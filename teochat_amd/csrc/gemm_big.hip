@@ -25,6 +25,8 @@ constexpr int GB_A_BYTES = GB_BM * GB_BK * 2;            // 32 KiB
 constexpr int GB_STAGE = GB_A_BYTES + GB_BN * GB_BK * 2; // 64 KiB
 constexpr int GB_SLAB_FLOATS = GB_BM * GB_BN;          // 256 KB of fp32 accumulators per workgroup
 constexpr int GB_PIECES = 8;                             // 1-KiB DMA pieces per wave per K tile (waves 0-3: A, waves 4-7: W)
+constexpr int GB_RAG_STAGE = (128 + 512) * GB_BK * 2;    // 80 KiB: the 128 x 512 tile over a ragged last row block (round 6)
+constexpr int GB_RAG_PIECES = 11;                        // its W pieces per wave (waves 2-7: 66 slots for 64 pieces)
 
 __device__ __forceinline__ int gb_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -42,11 +44,17 @@ template <bool SWIGLU, bool OUT_F32, bool HYBRID, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M,
                                                                int N, int K, int lda, int ldc, int act, int tiles_m, int tiles_n,
-                                                               int group, int dp_rounds, int per, float* slabs, int* flags, int cohort) {
+                                                               int group, int dp_rounds, int per, float* slabs, int* flags, int cohort,
+                                                               int rag_tiles) {
+    // rag_tiles > 0 (round 6): `tiles_m` counts the FULL 256-row tiles only; the last M % 256 <= 128 rows are covered by rag_tiles =
+    // tiles_n / 2 tiles of 128 x 512 appended to the tile list (tile index >= tiles_m * tiles_n): the same eight waves of 128 x 64, laid out
+    // 1 x 8 instead of 2 x 4, over a stage of 128 A rows + 512 W rows (80 KB) -- the same MFMA work, fragment reads and K loop per tile
+    // as a full tile, so every tile still costs the same (the stream-K partition stays unweighted), but the row padding is gone: L = 256 T +
+    // (prompt - T) always leaves 112 .. 127 rows in the last tile, which a ninth 256-row tile covered with half its MFMA work on padding
+    // (M = 2168: qkv 432 -> 408 tiles, gate/up 774 -> 731).  Same k-ascending MFMA chain per output element: bit-identical (tested).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int nk = K / GB_BK;
     const int q = gb_xcd_remap(blockIdx.x, gridDim.x);
@@ -59,8 +67,9 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
     // in step, so they share W panels and A row tiles through their L2 exactly as in a data-parallel round; the hand-off goes
     // to the same slot of the next link (slab q -> q + C).  Same sequential k-order per tile either way.
     int t_first = 0, k_first = 0, t_last = 0, k_end = nk, has_head = 0, has_tail = 0, n_full = 0, t_full0 = 0, nseg = 1;
+    const int t_reg = tiles_m * tiles_n, t_all = t_reg + rag_tiles;
     const int sk_tile0 = dp_rounds * 256;
-    const int sk_tiles = tiles_m * tiles_n - sk_tile0;
+    const int sk_tiles = t_all - sk_tile0;
     const int slot = cohort ? (q & (cohort - 1)) : 0, pstride = cohort ? cohort : 1;          // position p -> tile sk_tile0 + p * pstride + slot
     const int pred = q - pstride;
     if (HYBRID) {
@@ -87,35 +96,41 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
         else if (is_head) { pos = t_first; kb = k_first; }
         else if (j >= dp_rounds) pos = t_full0 + (j - dp_rounds);
         tile = pos < 0 ? j * 256 + q : sk_tile0 + pos * pstride + slot;
-        if (tile >= tiles_m * tiles_n) continue;                             // a column's unused slots (both owners skip alike: no hand-off)
+        if (tile >= t_all) continue;                                         // a column's unused slots (both owners skip alike: no hand-off)
     } else {
         tile = q;
     }
+    const bool rag = tile >= t_reg;                                          // (workgroup-uniform) a 128 x 512 tile over the ragged last rows
     // tiles walk `group` N panels at a time, N fastest (see gemm_wide.hip): with many row tiles the 32 workgroups of an XCD would
     // otherwise share one W panel and stream all of A (sq8192: every XCD reads the whole A once per round)
-    const int gsz = group * tiles_m, sup = tile / gsz, rem = tile - sup * gsz;
+    const int gsz = group * tiles_m, sup = rag ? 0 : tile / max(gsz, 1), rem = tile - sup * gsz;
     const int gn = min(group, tiles_n - sup * group);
     const int tm = rem / gn, tn = sup * group + rem % gn;
-    const int m0 = tm * GB_BM, n0 = tn * GB_BN;
+    const int m0 = rag ? tiles_m * GB_BM : tm * GB_BM, n0 = rag ? (tile - t_reg) * (2 * GB_BN) : tn * GB_BN;
+    const int wm = rag ? 0 : wid >> 2, wn = rag ? wid : wid & 3;              // the wave's 128 x 64 block of the tile
+    const int a_bytes = rag ? GB_A_BYTES / 2 : GB_A_BYTES, stage_bytes = rag ? GB_RAG_STAGE : GB_STAGE;
 
-    // DMA: wave w < 4 brings A rows 64 w .. 64 w + 63 (8 pieces of 8 rows), wave w >= 4 W rows 64 (w - 4) ..; lane l carries row
-    // (l >> 3) of a piece, logical chunk (l & 7) ^ (l >> 3).  32-bit element offsets from one wave-uniform base.
-    const bool isA = wid < 4;
+    // DMA, full tile: wave w < 4 brings A rows 64 w .. 64 w + 63 (8 pieces of 8 rows), wave w >= 4 W rows 64 (w - 4) ..; 128 x 512 tile:
+    // waves 0 / 1 the 128 A rows, waves 2 .. 7 eleven pieces each of the 64 W pieces (66 slots: the last wave brings piece 63 three times, same
+    // bytes).  Lane l carries row (l >> 3) of a piece, logical chunk (l & 7) ^ (l >> 3).  32-bit element offsets from one wave-uniform base.
+    const bool isA = rag ? wid < 2 : wid < 4;
     const bf16_t* base = isA ? A : W;
     const int ld = isA ? lda : K;
-    const int row0 = isA ? m0 + wid * 64 : n0 + (wid - 4) * 64;
     const int rmax = (isA ? M : N) - 1;
-    unsigned off[GB_PIECES];
+    const int np = (rag && !isA) ? GB_RAG_PIECES : GB_PIECES;
+    const int p0 = isA ? wid * 8 : (rag ? (wid - 2) * GB_RAG_PIECES : (wid - 4) * 8), pmax = isA ? (rag ? 15 : 31) : (rag ? 63 : 31);
+    unsigned off[GB_RAG_PIECES];
 #pragma unroll
-    for (int j = 0; j < GB_PIECES; ++j) {
+    for (int j = 0; j < GB_RAG_PIECES; ++j) {
         const int rl = lane >> 3, c = (lane & 7) ^ rl;
-        off[j] = (unsigned)min(row0 + j * 8 + rl, rmax) * (unsigned)ld + c * 8;
+        off[j] = (unsigned)min((isA ? m0 : n0) + min(p0 + j, pmax) * 8 + rl, rmax) * (unsigned)ld + c * 8;
     }
-    const int lds_piece0 = (isA ? wid * 8 : 32 + (wid - 4) * 8) * 1024;
+    const int lds_base = isA ? 0 : a_bytes;
 #define TEO_GB_STAGE(KT, ST)                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < GB_PIECES; ++j)                                                                    \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[j] + (unsigned)(KT) * GB_BK), \
-                                         (__attribute__((address_space(3))) void*)(smem + (ST) * GB_STAGE + lds_piece0 + j * 1024), 16, 0, 0);
+    _Pragma("unroll") for (int j = 0; j < GB_RAG_PIECES; ++j)                                                                \
+        if (j < np)                                                                                                          \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[j] + (unsigned)(KT) * GB_BK), \
+                                             (__attribute__((address_space(3))) void*)(smem + (ST) * stage_bytes + lds_base + min(p0 + j, pmax) * 1024), 16, 0, 0);
 
     if (HYBRID && is_head) {
         if (tid == 0) {
@@ -164,8 +179,8 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
         __builtin_amdgcn_s_barrier();
         if (!late && kt + 1 < ke) { TEO_GB_STAGE(kt + 1, st ^ 1) }
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* sA = smem + st * GB_STAGE;
-        const unsigned char* sB = sA + GB_A_BYTES;
+        const unsigned char* sA = smem + st * stage_bytes;
+        const unsigned char* sB = sA + a_bytes;
         TEO_GB_READ(af, wf, 0)
         __builtin_amdgcn_sched_barrier(0);
         if (kt > kb) { TEO_GB_MFMA(caf, cwf, 0, 4) }       // second half of tile kt-1, from registers, under the reads above
@@ -213,8 +228,25 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
 // tune().gemm_big_hybrid (default 1): data-parallel rounds + stream-K remainder when a workspace is given (1: if it fits MALL, 2: always)
 // ... or there are at most 1.5 tiles per workgroup (a pure stream-K grid whose workgroups mostly stay on one tile: down at M = 4208,
 // 272 tiles, 183 MB: 311 us against 421 us for three ragged rounds of 128 x 256 tiles)
+// tune().gemm_big_ragged (default 1): a last row block of <= 128 rows as 128 x 512 tiles (round 6): 0 = never (a padded 256-row tile), 1 = auto,
+// 2 = whenever the shape allows.  Auto = only where it turns the problem into ONE round of tiles: gate/up at M = 638 (config C2) is 258
+// padded tiles = a round and two tiles, 215 with the ragged form -- 104.9 us against 119.3 (hybrid) / 173.5 (two rounds).  Elsewhere the
+// tile count drops by 5.6 % but not the number of rounds, and a 128 x 512 tile moves 80 KB per K step instead of 64: measured
+// (tools/dispatch_probe.py, M = 2168 / 4208) qkv 193.8 vs 193.8 / 348 vs 356, gate/up 340-372 vs 333 / 620 vs 604 us -- a wash or a loss,
+// because the hybrid form's stream-K part grows when a data-parallel round disappears (731 tiles = 1 round + 475 instead of 2 + 262).
+int gemm_big_ragged_tiles(int M, int N) {
+    const int rows = M % GB_BM, tiles_n = (N + GB_BN - 1) / GB_BN, mode = tune().gemm_big_ragged;
+    if (!(mode && rows > 0 && rows <= GB_BM / 2 && tiles_n % 2 == 0 && M >= GB_BM)) return 0;
+    const long long t_rag = (long long)(M / GB_BM) * tiles_n + tiles_n / 2, t_full = (long long)(M / GB_BM + 1) * tiles_n;
+    return (mode == 2 || (t_rag <= 256 && t_full > 256)) ? tiles_n / 2 : 0;
+}
+long long gemm_big_tile_count(int M, int N) {
+    const int rt = gemm_big_ragged_tiles(M, N);
+    return (long long)(rt ? M / GB_BM : (M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN) + rt;
+}
+
 bool gemm_big_hybrid_fits(int M, int N, int K) {
-    const long long T = (long long)((M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN);
+    const long long T = gemm_big_tile_count(M, N);
     const long long bytes = ((long long)M + N) * K * 2;
     // round 3 (tools/split_probe.py): gate/up at M = 2168 (198 MB, 774 tiles = 3.02 rounds) runs 337 / 342 us (warm / cold weights) in
     // the hybrid form against 358 / 363 on the 128 x 256 kernel -- with only three rounds the ragged one costs more than the
@@ -224,9 +256,11 @@ bool gemm_big_hybrid_fits(int M, int N, int K) {
 
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                     int act, bool swiglu, bool of32, bool f16, hipStream_t st, void* sk_ws, size_t flags_offset) {
-    const int tiles_m = cdiv(M, GB_BM), tiles_n = cdiv(N, GB_BN);
-    const int T = tiles_m * tiles_n, nk = K / GB_BK;
-    const size_t lds = 2 * GB_STAGE;
+    const int tiles_n = cdiv(N, GB_BN);
+    const int rag_tiles = gemm_big_ragged_tiles(M, N);     // > 0: the last M % 256 <= 128 rows as tiles_n / 2 tiles of 128 x 512 (see the kernel)
+    const int tiles_m = rag_tiles ? M / GB_BM : cdiv(M, GB_BM);
+    const int T = tiles_m * tiles_n + rag_tiles, nk = K / GB_BK;
+    const size_t lds = rag_tiles ? 2 * (size_t)GB_RAG_STAGE : 2 * (size_t)GB_STAGE;
     const int group = tune().gemm_big_group ? tune().gemm_big_group : (tiles_m >= 16 ? 4 : 1);
     // hybrid form when the tile count is not a whole number of rounds -- and the operands fit the 256 MB Infinity Cache: the
     // stream-K part has every workgroup at its own (tile, k), nothing is shared through L2, and once A + W no longer sit in MALL its
@@ -250,10 +284,10 @@ int gemm_big_launch(const void* A, const void* W, const void* bias, const void* 
 #define TEO_GB_LAUNCH_HF(SW, OF, HY, FV)                                                                                          \
     {                                                                                                                             \
         static unsigned long long attr_mask = 0;                                                                                  \
-        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF, HY, FV>), (int)lds, &attr_mask, "gemm_big")) return e; \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_big_kernel<SW, OF, HY, FV>), 2 * GB_RAG_STAGE, &attr_mask, "gemm_big")) return e; \
         gemm_mfma_bf16_big_kernel<SW, OF, HY, FV><<<(HY) ? 256 : T, 512, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                                (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m,  \
-                                                                               tiles_n, group, dp_rounds, per, slabs, flg, cohort);     \
+                                                                               tiles_n, group, dp_rounds, per, slabs, flg, cohort, rag_tiles); \
     }
 #define TEO_GB_LAUNCH(SW, OF) { if (hybrid) TEO_GB_LAUNCH_H(SW, OF, true) else TEO_GB_LAUNCH_H(SW, OF, false) }
     if (swiglu) { if (of32) TEO_GB_LAUNCH(true, true) else TEO_GB_LAUNCH(true, false) }

@@ -22,6 +22,7 @@
     X(gemm_big_group, 0, v >= 0)                                                                             \
     X(gemm_big_hybrid, 1, (v >= 0 && v <= 2))                                                                \
     X(gemm_big_cohort, -1, (v == -1 || v == 0 || v == 8 || v == 16 || v == 32))                              \
+    X(gemm_big_ragged, 1, (v >= 0 && v <= 2))                                                                \
     X(gemm_narrow, 1, (v >= 0 && v <= 2))                                                                    \
     X(gemm_narrow_bm, 0, (v == 0 || v == 64 || v == 128))                                                                \
     X(gemm_narrow_waves, 0, (v == 0 || v == 4 || v == 8))                                                    \

@@ -1,8 +1,8 @@
 """Every 16-bit GEMM tile family against the register-staged 128 x 128 kernel on RANDOM shapes: the bit-identity claim of DESIGN section 5
 (same LDS image, same fragment reads, same k-ascending MFMA chain per output element -> the choice of family is a performance decision only)
 is tested at the model's shapes elsewhere; here it is fuzzed over ragged M / N (one row over a tile, N not a multiple of any tile width),
-short and long K (one K tile .. more than any ring), strided A (lda > K), every epilogue and both 16-bit formats, for the eight forced
-families incl. the two 256 x 160 forms of round 5.  The reference leg (plain 128 x 128 tile) is itself checked against fp64 on a sample."""
+short and long K (one K tile .. more than any ring), strided A (lda > K), every epilogue and both 16-bit formats, for the nine forced
+families incl. the two 256 x 160 forms of round 5 and the eight-wave 128 x 128 form of round 6.  The reference leg (plain 128 x 128 tile) is itself checked against fp64 on a sample."""
 import os
 import random
 
@@ -17,10 +17,13 @@ pytestmark = pytest.mark.gpu
 PLAIN = {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}
 FORCED = (("64x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 64}, "gemm_narrow_64"),
           ("128x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 128}, "gemm_narrow_128"),
+          ("128x128 LDS-DMA, eight waves", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_waves": 8}, "gemm_narrow_128w8"),      # round 6
           ("256x160 eight waves", {"gemm_quad": 2}, "gemm_quad_160"),
           ("256x160 four waves", {"gemm_quad": 2, "gemm_quad_waves": 4}, "gemm_quad_160_w4"),
           ("128x256", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}, "gemm_wide"),      # (both need
-          ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}, "gemm_big"),                 # K >= 128)
+          ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128, "gemm_big_ragged": 0}, "gemm_big"),   # K >= 128)
+          ("256x256 + 128x512 over a ragged last row block", {"gemm_big": 2, "gemm_big_hybrid": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128,
+                                                               "gemm_big_ragged": 2}, "gemm_big"),                                            # round 6
           ("64-row register-staged", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 64}, "gemm_mfma_64"),
           ("production dispatch", {}, None))
 
@@ -81,4 +84,4 @@ def test_every_tile_family_is_bitwise_the_plain_kernel_on_random_shapes(seed, dt
                 assert ran == kernel, (name, ran, M, N, K)
             assert torch.equal(got, want), (name, ran, M, N, K, extra, float((got.float() - want.float()).abs().max()))
     L.tune_reset()
-    assert {"gemm_narrow_64", "gemm_narrow_128", "gemm_quad_160", "gemm_quad_160_w4", "gemm_wide", "gemm_big", "gemm_mfma_64"} <= seen
+    assert {"gemm_narrow_64", "gemm_narrow_128", "gemm_narrow_128w8", "gemm_quad_160", "gemm_quad_160_w4", "gemm_wide", "gemm_big", "gemm_mfma_64"} <= seen

@@ -1426,8 +1426,9 @@ def test_gemm_256x256_hybrid_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
         assert L.tune_set(b"gemm_big", 2) == 0 and L.tune_set(b"gemm_big_hybrid", 2) == 0
         # round 5: the stream-K part as XCD-local cohorts (columns of 8 / 16 / 32 tiles walked in step, hand-off to the same slot of the
         # next chain link) next to the linear ranges (0) and the shipped choice (-1): the same bits from every arrangement
-        for cohort in (-1, 0, 8, 16, 32):
-            assert L.tune_set(b"gemm_big_cohort", cohort) == 0
+        # round 6: the same with the ragged last row block covered by 128 x 512 tiles (gemm_big_ragged = 2: whenever the shape allows)
+        for cohort, ragged in ((-1, 0), (0, 0), (8, 0), (16, 0), (32, 0), (-1, 2), (0, 2), (16, 2)):
+            assert L.tune_set(b"gemm_big_cohort", cohort) == 0 and L.tune_set(b"gemm_big_ragged", ragged) == 0
             bad = 0
             for it in range(4):
                 if it % 2:
@@ -1436,13 +1437,14 @@ def test_gemm_256x256_hybrid_is_bitwise_the_plain_kernel(M, N, K, flags, extra):
                 got = _gemm_ws(A, W, ws, bias=bias, res=res, act=act, flags=flags, out_dtype=od)
                 torch.cuda.synchronize()
                 bad += int(not torch.equal(got, want))
-            assert bad == 0, f"cohort {cohort}: {bad}/4 launches differ from the plain kernel"
+            assert bad == 0, f"cohort {cohort}, ragged {ragged}: {bad}/4 launches differ from the plain kernel"
             assert lib.teo_last_kernel().decode() in ("gemm_big_hybrid", "gemm_big_hybrid_cohort")
         st = C.c_int(0)
         L.check(lib.teo_gemm_workspace_status(G.p(ws), C.byref(st), G.stream()), "ws status")
         assert st.value == 0
     finally:
         L.tune_set(b"gemm_big_cohort", -1)
+        L.tune_set(b"gemm_big_ragged", 1)
         L.tune_set(b"gemm_big_hybrid", 1)
         L.tune_set(b"gemm_big", 1)
         L.tune_set(b"gemm_wide", 1)

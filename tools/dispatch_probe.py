@@ -14,9 +14,10 @@ lib = L.load()
 bf = torch.bfloat16
 FAM = (("auto", {}), ("128x128", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0}), ("128x128 sk", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2}),
        ("128x256", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0}), ("128x256 sk", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}),
-       ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0}), ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2}),
+       ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0, "gemm_big_ragged": 2}), ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2, "gemm_big_ragged": 2}),
+       ("256x256 no-ragged", {"gemm_big": 2, "gemm_big_hybrid": 0, "gemm_big_ragged": 0}), ("256x256 hybrid no-ragged", {"gemm_big": 2, "gemm_big_hybrid": 2, "gemm_big_ragged": 0}),
        ("narrow64", {"gemm_narrow": 2, "gemm_narrow_bm": 64}), ("narrow128", {"gemm_narrow": 2, "gemm_narrow_bm": 128}), ("quad160", {"gemm_quad": 2}))
-DEF = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1, "gemm_narrow": 1, "gemm_narrow_bm": 0, "gemm_quad": 1}
+DEF = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1, "gemm_narrow": 1, "gemm_narrow_bm": 0, "gemm_quad": 1, "gemm_big_ragged": 1}
 ws = torch.empty(lib.teo_gemm_workspace_bytes(), dtype=torch.uint8, device="cuda")
 L.check(lib.teo_gemm_workspace_init(G.p(ws), G.stream()), "ws")
 

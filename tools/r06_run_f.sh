@@ -14,3 +14,4 @@ prof vit8 $ROOT/tools/vit_probe.py 8 20
 prof c2 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --frames 2 --new 128
 cd $ROOT
 python3 tools/vit_probe.py 2 50; python3 tools/vit_probe.py 8 50
+timeout 900 python3 tools/vit_gemm_probe.py > $OUT/vit_gemm_probe.txt 2>&1; cat $OUT/vit_gemm_probe.txt | cut -c1-600
