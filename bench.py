@@ -356,11 +356,13 @@ def main():
                 dist.init_process_group(args.dist_backend, rank=rank, world_size=world, timeout=pg_timeout)
         # host-side exchanges (the communicator's unique id, the per-rank statistics of the line) go over their OWN gloo group: they
         # never touch the GPU and never interleave with the timed region's barrier / reductions on the default group
+        chk_group = None
         with deadline("new_group(gloo)"):
             try:
                 host_group = dist.new_group(backend="gloo", timeout=pg_timeout)
-            except Exception:  # noqa: BLE001 -- no gloo in this build: the default group carries the host objects too
-                host_group = None
+                chk_group = dist.new_group(backend="gloo", timeout=pg_timeout)      # the RCCL check's own: a helper thread that never comes
+            except Exception:  # noqa: BLE001 -- no gloo in this build: the default group carries the host objects too      back must not hold host_group
+                host_group = chk_group = None
 
     if os.environ.get("TEO_BENCH_FAIL_RANK") == str(rank) and world > 1:
         # test hook (tests/test_bench_contract_gpu.py): a rank other than 0 dies -> the launcher must end the job with a non-zero code
@@ -405,7 +407,6 @@ def main():
         box = {}
         # the check's host-side exchange (the communicator's unique id) runs on its OWN gloo group: if the helper thread is still inside
         # it at the deadline, the timed region's barrier / all_reduce on the default group stay ordered across ranks
-        chk_group = host_group
 
         def rccl_check():
             # runs on a helper thread with a deadline: a communicator that never forms (a rank missing, a fabric fault) must not
@@ -684,7 +685,7 @@ def main():
                                     f"the running library's sources are {src_now}: traffic not quoted until tools/pmc_*_traffic.sh is re-run")
             return blob, name, None
         return None, None, "no PMC summary under profiles/"
-    blob, name, traffic_note = pmc_summary(("r05_pmc_decode_traffic.json", "r04_pmc_decode_traffic.json"))
+    blob, name, traffic_note = pmc_summary(("r06_pmc_decode_traffic.json", "r05_pmc_decode_traffic.json", "r04_pmc_decode_traffic.json"))
     if blob is not None:
         traffic = blob.get("hbm_bytes_per_launch")
         traffic_all = blob.get("kernels")
@@ -741,7 +742,7 @@ def main():
             # the batched step's own PMC passes exist for config C5's per-GPU shape (8 conversations, fp8 weights: tools/pmc_batch_traffic.sh)
             traffic_all, traffic_src = None, None
             if B == 8 and args.weights == "fp8" and abs(ctx_prof - 2178) <= 64:       # same shape as the PMC passes
-                blob, name, traffic_note = pmc_summary(("r05_pmc_batch_traffic.json", "r04_pmc_batch_traffic.json"))
+                blob, name, traffic_note = pmc_summary(("r06_pmc_batch_traffic.json", "r05_pmc_batch_traffic.json", "r04_pmc_batch_traffic.json"))
                 if blob is not None:
                     key = {"attn_decode_partial": "attn_decode_whole", "gateup_gemv": "gateup_stream_fp8", "qkv_rope_gemv": "qkv_lmhead_stream_fp8",
                            "o_gemv": "o_tile_fp8", "down_gemv": "down_tile_fp8"}.get(dom)
@@ -834,7 +835,7 @@ def main():
     elif rank == 0 and world > 1:
         # measured at N = 1 only (the contract: rank 0, N = 1); an N > 1 line points at the committed N = 1 line instead of carrying null
         ref_line = None
-        for name in ("r05_bench.json", "r04_bench.json"):
+        for name in ("r06_bench.json", "r05_bench.json", "r04_bench.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 try:

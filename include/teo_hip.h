@@ -73,8 +73,11 @@ size_t teo_sizeof(const char* struct_name);
  *   prefill GEMM  : "gemm_bm" (tile rows of the plain kernel: 0 auto, 64, 128), "gemm_depth", "gemm_sk" (stream-K: 0 off, 1 auto, 2 force),
  *                   "gemm_wide" (0 off, 1 auto, 2 force), "gemm_wide_sched", "gemm_wide_group", "gemm_big" (0 off, 1 auto, 2 force),
  *                   "gemm_big_group", "gemm_big_hybrid" (0 off, 1 auto, 2 force), "gemm_big_cohort" (stream-K part of the hybrid form as
- *                   XCD-local cohorts: -1 auto, 0 linear ranges, 8 / 16 / 32 workgroups per cohort), "gemm_narrow" (64 / 128 x 128 LDS-DMA
+ *                   XCD-local cohorts: -1 auto, 0 linear ranges, 8 / 16 / 32 workgroups per cohort), "gemm_big_ragged" (a last row block of <= 128
+ *                   rows as 128 x 512 tiles instead of a padded 256-row tile: 0 never, 1 auto = where that makes the problem one round, 2 whenever
+ *                   the shape allows), "gemm_narrow" (64 / 128 x 128 LDS-DMA
  *                   tiles for few-tile / short-K shapes: 0 off, 1 auto, 2 force), "gemm_narrow_bm" (its tile rows: 0 auto, 64, 128),
+ *                   "gemm_narrow_waves" (the 128 x 128 tile on 4 waves or on 8: 0 auto, 4, 8),
  *                   "gemm_quad" (256 x 160 tiles, hand-scheduled K loop with the accumulators in AGPRs, for problems that are one round of them: 0 off, 1 auto,
  *                   2 force), "gemm_quad_waves" (8: two waves per SIMD, the default; 4: one wave per SIMD with the whole register file), "gemm_fp8_wide" (0..3),
  *                   "gemm_fp8_big" (0..2) -- all bit-identical families
@@ -86,7 +89,9 @@ size_t teo_sizeof(const char* struct_name);
  *                   heads fill the CUs, 2 whenever the shape allows; bit-identical to the split + combine pair at the same chunk)
  *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible), "skinny_ring"
  *                   (weight tiles in flight of the streaming form: 0 default, 1 one more), "skinny_unr" (tile kernel steps per register
- *                   set: 0 auto, 4, 8) -- bit-identical at K = 4096, fp32 order elsewhere
+ *                   set: 0 auto, 4, 8), "skinny_waves" (tile kernel waves per workgroup: 0 auto = 8, 8, 16 -- measured and lost in round 6,
+ *                   kept for the A/B), "skinny_grid" (persistent workgroups per CU of the streaming form: 0 auto = 1, 1..3 -- likewise) --
+ *                   bit-identical at K = 4096, fp32 order elsewhere
  * teo_tune_set returns TEO_ERR_ARG for an unknown key or a value outside the key's set (message in teo_last_error). */
 typedef struct teo_tune teo_tune;
 teo_tune* teo_tune_create(void);                      /* a block holding the shipped defaults; NULL when out of memory */
@@ -387,6 +392,15 @@ size_t teo_llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
 int teo_llama_prefill(const teo_llama_desc* d, const void* d_embeds, const int* d_positions, int S, int past,
                       int last_only, float* d_logits, void* d_workspace, size_t workspace_bytes,
                       teo_stream_t stream, void* d_hidden_states);
+/* teo_llama_prefill that also returns the attention maps: `output_attentions` of the kept forward signature (llava_llama.py:65,95 ->
+ * LlamaAttention's eager softmax).  d_attentions: [layers][heads][S][past + S] in the model dtype -- softmax over the visible (causal)
+ * keys of scale * q k^T from the rotated q and the cached k the attention kernel itself reads, statistics in fp32, one rounding, exact
+ * zeros for masked keys.  The fused attention kernels never materialise these maps; a plain kernel writes them beside the unchanged
+ * forward (logits, cache and hidden states are the ones teo_llama_prefill produces).  Not a performance path: layers x heads x S x (past + S)
+ * elements (C3: 32 x 32 x 2168 x 2168 x 2 B = 9.6 GB). */
+int teo_llama_prefill_attentions(const teo_llama_desc* d, const void* d_embeds, const int* d_positions, int S, int past,
+                                 int last_only, float* d_logits, void* d_workspace, size_t workspace_bytes, teo_stream_t stream,
+                                 void* d_hidden_states, void* d_attentions);
 
 /* Persistent decode state: greedy decode of one sequence with everything (token, position, stop flag) on the device. */
 typedef struct {

@@ -664,7 +664,17 @@ def quant_rows_e4m3(x):
     return (q * s).to(x.dtype)
 
 
-def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, mode="exact", act_quant=None):
+def attention_probs(q, k, visible, scale, R):
+    """`output_attentions` of the kept forward signature (llava_llama.py:65,95 -> tf llama/modeling_llama.py eager_attention_forward): the
+    maps a caller gets back -- softmax over the visible keys of scale * q k^T, statistics in fp32, rounded ONCE to the working type (R);
+    masked keys are exactly 0.  q [B,H,Sq,d], k [B,H,Sk,d] (the rotated, 16-bit-rounded operands the attention kernels read)."""
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    if visible is not None:
+        s = s.masked_fill(~visible, float("-inf"))
+    return R(torch.softmax(s, dim=-1))
+
+
+def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, mode="exact", act_quant=None, attentions=None):
     """tf LlamaDecoderLayer/LlamaAttention/LlamaMLP (called from llava_llama.py:88-99).
     act_quant="e4m3": the input of every Linear layer goes through quant_rows_e4m3 first (w8a8 prefill of config C5; the weights
     in `sd` are then expected to be the dequantised e4m3 weights)."""
@@ -692,6 +702,8 @@ def llama_layer(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache, R, m
         rep = H // Hk
         kk = kk[:, :, None].expand(B, Hk, rep, kk.shape[2], d).reshape(B, H, -1, d)
         vv = vv[:, :, None].expand(B, Hk, rep, vv.shape[2], d).reshape(B, H, -1, d)
+    if attentions is not None:
+        attentions.append(attention_probs(q, kk, visible, 1.0 / math.sqrt(d), R))
     o = attention_core(q, kk, vv, visible, 1.0 / math.sqrt(d), R, "tf431_llama" if OP_ORDER == "tf431" else mode)
     o = R(o.transpose(1, 2).reshape(B, S, D))
     h = R(h + _lin(o, sd[pre + "self_attn.o_proj.weight"]))
@@ -733,7 +745,8 @@ def _llama_layer_w8a8(h, i, sd, cfg: LlamaCfg, cos, sin, visible, cache: KVCache
 
 
 def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[KVCache], sd, cfg: LlamaCfg,
-                  rounding=None, last_only=False, return_hidden=False, decode_kernel=False, act_quant=None, hidden_states=None):
+                  rounding=None, last_only=False, return_hidden=False, decode_kernel=False, act_quant=None, hidden_states=None,
+                  attentions=None):
     """LlamaModel + lm_head.  inputs_embeds [B,S,D]; position_ids [B,S] or None (-> past..past+S);
     attention_mask [B, past+S] of 0/1 or None.  Returns fp logits [B,S,V] (or [B,1,V]).
     hidden_states: a list that receives what LlamaModel.forward collects under output_hidden_states=True (llava_llama.py:56-69 ->
@@ -758,7 +771,7 @@ def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[K
     for i in range(cfg.num_hidden_layers):
         if hidden_states is not None:
             hidden_states.append(h)
-        h = llama_layer(h, i, sd, cfg, cos, sin, visible, cache, R, mode, act_quant)
+        h = llama_layer(h, i, sd, cfg, cos, sin, visible, cache, R, mode, act_quant, attentions=attentions)
     if hidden_states is not None:
         hidden_states.append(R(rmsnorm(h, sd["model.norm.weight"], cfg.rms_norm_eps)))
     if last_only:
@@ -774,7 +787,7 @@ def llama_forward(inputs_embeds, position_ids, attention_mask, cache: Optional[K
 # H14/H16: multimodal forward and greedy generation
 # --------------------------------------------------------------------------------------
 def mm_forward(input_ids, images: List[torch.Tensor], sd, vcfg: VitCfg, lcfg: LlamaCfg, mm: MMCfg,
-               attention_mask=None, rounding=None, dtype=torch.float32, hidden_states=None):
+               attention_mask=None, rounding=None, dtype=torch.float32, hidden_states=None, attentions=None):
     """llava_llama.py:56-99 prefill: encode + splice + LLaMA.  images = flat list of [3,H,W]."""
     pix = torch.stack([im.to(dtype) for im in images])                           # llava_arch.py:194
     feats = encode_images(pix, sd, vcfg, mm, rounding)
@@ -782,7 +795,7 @@ def mm_forward(input_ids, images: List[torch.Tensor], sd, vcfg: VitCfg, lcfg: Ll
     emb_w = sd["model.embed_tokens.weight"].to(dtype)
     _, pos, mask, _, embeds, _ = prepare_inputs_labels_for_multimodal(
         input_ids, None, attention_mask, None, None, flat, emb_w, mm)
-    logits, cache = llama_forward(embeds, pos, mask, None, sd, lcfg, rounding, hidden_states=hidden_states)
+    logits, cache = llama_forward(embeds, pos, mask, None, sd, lcfg, rounding, hidden_states=hidden_states, attentions=attentions)
     return logits, cache, embeds
 
 

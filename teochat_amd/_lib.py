@@ -135,6 +135,8 @@ _SIGS = {
     "teo_llama_prefill_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc), C.c_int]),
     "teo_llama_prefill": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "teo_llama_prefill_attentions": (C.c_int, [C.POINTER(LlamaDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "teo_llama_decode_workspace_bytes": (C.c_size_t, [C.POINTER(LlamaDesc)]),
     "teo_llama_decode_begin": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),
     "teo_llama_decode_step": (C.c_int, [C.POINTER(LlamaDesc), C.POINTER(DecodeState), C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -59,7 +59,7 @@ size_t projector_workspace_bytes(const teo_proj_desc* d, int rows);
 int projector(const teo_proj_desc* d, const void* x, int rows, void* y, void* ws, size_t ws_bytes, hipStream_t st);
 size_t llama_prefill_workspace_bytes(const teo_llama_desc* d, int S);
 int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
-                  float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states);
+                  float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states, void* attentions);
 int llama_prefill_batch(const teo_llama_desc* d, const void* embeds, const int* seq_lens, int nseq, long long cache_stride,
                         int last_only, float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states);
 size_t llama_decode_workspace_bytes(const teo_llama_desc* d);
@@ -363,7 +363,17 @@ int teo_llama_prefill(const teo_llama_desc* d, const void* emb, const int* pos, 
     TuneScope tune_scope(d->tune);
     TEO_CHECK_ARG(S >= 0 && past >= 0, "teo_llama_prefill: S %d past %d", S, past);
     if (S) { NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace"); }
-    return llama_prefill(d, emb, pos, S, past, last_only, logits, ws, wsb, ST(s), hidden_states);
+    return llama_prefill(d, emb, pos, S, past, last_only, logits, ws, wsb, ST(s), hidden_states, nullptr);
+}
+
+int teo_llama_prefill_attentions(const teo_llama_desc* d, const void* emb, const int* pos, int S, int past, int last_only,
+                                 float* logits, void* ws, size_t wsb, teo_stream_t s, void* hidden_states, void* attentions) {
+    ENTER();
+    NEED(d, "desc"); NEED_DT(d->dtype); NEED(attentions, "attentions");
+    TuneScope tune_scope(d->tune);
+    TEO_CHECK_ARG(S >= 0 && past >= 0, "teo_llama_prefill_attentions: S %d past %d", S, past);
+    if (S) { NEED(emb, "embeds"); NEED(logits, "logits"); NEED(ws, "workspace"); }
+    return llama_prefill(d, emb, pos, S, past, last_only, logits, ws, wsb, ST(s), hidden_states, attentions);
 }
 
 int teo_llama_prefill_batch(const teo_llama_desc* d, const void* emb, const int* seq_lens, int nseq, long long cache_stride,

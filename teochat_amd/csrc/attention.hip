@@ -58,6 +58,63 @@ __global__ __launch_bounds__(64) void attn_simple_kernel(teo_attn_args a) {
     }
 }
 
+// `output_attentions` of the kept forward signature (llava_llama.py:65,95 -> LlamaAttention's eager softmax): the [heads][q_len][kv_len]
+// maps themselves, which the flash kernel never materialises.  NOT on the performance path -- a caller that asks for the maps gets them
+// from this plain kernel beside the (unchanged) attention: one wave per (query, head), scores = scale * q . k in fp32 from the operands the
+// attention kernel reads (rotated q, cached k), softmax statistics in fp32, ONE rounding to the output type, exact zeros for masked keys.
+template <typename T>
+__global__ __launch_bounds__(64) void attn_probs_kernel(teo_attn_args a, T* __restrict__ probs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qs = sm;                   // [head_dim]
+    float* sc = sm + a.head_dim;      // [kv_len]
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int hk = h / (a.heads / a.kv_heads);
+    const int hd = a.head_dim;
+    const T* q = (const T*)a.q + b * a.q_bs + h * a.q_hs + (long long)i * a.q_rs;
+    const T* k = (const T*)a.k + b * a.k_bs + hk * a.k_hs;
+    for (int d = lane; d < hd; d += 64) qs[d] = Elem<T>::ld(q + d);
+    __syncthreads();
+    const int lim = a.causal ? min(a.kv_len, i + (a.kv_len - a.q_len) + 1) : a.kv_len;
+    float mx = -INFINITY;
+    for (int j = lane; j < lim; j += 64) {
+        const T* kr = k + (long long)j * a.k_rs;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(qs[d], Elem<T>::ld(kr + d), s);
+        s *= a.scale;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < lim; j += 64) {
+        const float p = expf(sc[j] - mx);
+        sum += p;
+        sc[j] = p;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    T* out = probs + (((long long)b * a.heads + h) * a.q_len + i) * a.kv_len;
+    for (int j = lane; j < a.kv_len; j += 64) Elem<T>::st(out + j, j < lim ? sc[j] * inv : 0.f);
+}
+
+// probs: [batch][heads][q_len][kv_len] in the model dtype
+int attention_probs(const teo_attn_args* ap, int dtype, void* probs, hipStream_t st) {
+    const teo_attn_args& a = *ap;
+    if (a.q_len == 0 || a.batch == 0) return TEO_OK;
+    TEO_CHECK_ARG(a.heads % a.kv_heads == 0 && (a.kv_len >= a.q_len || !a.causal), "attention_probs: heads %d kv_heads %d q_len %d kv_len %d", a.heads, a.kv_heads, a.q_len, a.kv_len);
+    const size_t lds = (size_t)(a.head_dim + a.kv_len) * sizeof(float);
+    if (lds > 64 * 1024) {
+        set_error("attention_probs: kv_len + head_dim <= 16384 (got %d)", a.kv_len + a.head_dim);
+        return TEO_ERR_UNSUPPORTED;
+    }
+    dim3 grid(a.q_len, a.heads, a.batch);
+    if (dtype == TEO_F32) attn_probs_kernel<float><<<grid, 64, lds, st>>>(a, (float*)probs);
+    else if (dtype == TEO_F16) attn_probs_kernel<f16_t><<<grid, 64, lds, st>>>(a, (f16_t*)probs);
+    else attn_probs_kernel<bf16_t><<<grid, 64, lds, st>>>(a, (bf16_t*)probs);
+    TEO_LAUNCH_CHECK("attn_probs");
+    return TEO_OK;
+}
+
 bool attn_mfma_ok(const teo_attn_args& a, int dtype) {
     if ((dtype != TEO_BF16 && dtype != TEO_F16) || (a.flags & TEO_ATTN_FORCE_SIMPLE) || a.vt == nullptr) return false;
     if (a.head_dim != 64 && a.head_dim != 128) return false;

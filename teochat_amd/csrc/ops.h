@@ -21,6 +21,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
 
 int attention(const teo_attn_args* a, int dtype, hipStream_t st);
 int attention_flash32(const teo_attn_args& a, hipStream_t st, bool f16 = false);
+int attention_probs(const teo_attn_args* a, int dtype, void* probs, hipStream_t st);      // the softmax maps themselves (`output_attentions`)
 size_t attn_decode_ws_bytes(int heads, int hd, int S_max, int batch = 1);
 struct AttnBatch {          // per-conversation strides (elements) of a batched decode step; {1, 0, 0, 0} = one conversation
     int batch = 1;

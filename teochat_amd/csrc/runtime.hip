@@ -212,8 +212,9 @@ static int snapshot_rows(void* hs, int idx, const void* src, int S, int D, size_
     return he == hipSuccess ? TEO_OK : hip_fail(he, "prefill: hidden-state snapshot");
 }
 
+// attentions (optional, `output_attentions` of the kept forward signature, llava_llama.py:65,95): [layers][heads][S][past + S] in the model dtype
 int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positions, int S, int past, int last_only,
-                  float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states) {
+                  float* logits, void* ws, size_t ws_bytes, hipStream_t st, void* hidden_states, void* attentions) {
     if (S == 0) return TEO_OK;
     TEO_CHECK_ARG(past + S <= d->max_seq, "teo_llama_prefill: past %d + S %d exceeds max_seq %d", past, S, d->max_seq);
     const PrefillWs w = prefill_carve(d, S, ws, ws_bytes);
@@ -246,6 +247,8 @@ int llama_prefill(const teo_llama_desc* d, const void* embeds, const int* positi
         a.batch = 1; a.heads = H; a.kv_heads = Hk; a.head_dim = hd; a.q_len = S; a.kv_len = past + S;
         a.causal = 1;
         a.scale = 1.0f / sqrtf((float)hd);
+        if (attentions)      // the maps of this layer, from the operands the attention kernel is about to read (rotated q, cached k)
+            TEO_TRY(attention_probs(&a, dt, (unsigned char*)attentions + (size_t)l * H * S * (size_t)(past + S) * e, st));
         return attention(&a, dt, st);
         };
         if (fp8) {

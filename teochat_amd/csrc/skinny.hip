@@ -614,8 +614,10 @@ int skinny_gemm(const void* x, const void* W, const float* wscale, int w_fp8, co
             TEO_KLAUNCH((skinny_gemm_kernel<WW, UN, true, false, false, false, 16>), blocks, 1024, 0, st, (const WW*)W, (const bf16_t*)x, MB, N, K, ldx,  \
                         tiled, rt, wscale, (const bf16_t*)res, (const bf16_t*)nullptr, eps, out, ldo, ldr, of, fuse, sw8)
             // steps per register set: two sets cover the wave's whole K slice where the registers allow (every request of the launch out at once)
-            const int un = steps16 <= 4 ? 2 : (steps16 <= 8 ? 4 : 6);
-            if (w_fp8)         { if (un == 2) TEO_SK16(fp8_t, 2); else if (un == 4) TEO_SK16(fp8_t, 4); else TEO_SK16(fp8_t, 6); }
+            // (fp8: at most 4 -- its activation fragments are twice the weights, UNR = 6 spills 67 VGPRs under the 128-register cap of a
+            // 1024-thread workgroup: tools/kernel_meta.py)
+            const int un = steps16 <= 4 ? 2 : ((steps16 <= 8 || w_fp8) ? 4 : 6);
+            if (w_fp8)         { if (un == 2) TEO_SK16(fp8_t, 2); else TEO_SK16(fp8_t, 4); }
             else if (fuse.f16) { if (un == 2) TEO_SK16(f16_t, 2); else if (un == 4) TEO_SK16(f16_t, 4); else TEO_SK16(f16_t, 6); }
             else               { if (un == 2) TEO_SK16(bf16_t, 2); else if (un == 4) TEO_SK16(bf16_t, 4); else TEO_SK16(bf16_t, 6); }
 #undef TEO_SK16

@@ -419,10 +419,12 @@ class TeoEngine:
     def reset_cache(self):
         self.cache_len = 0
 
-    def prefill(self, embeds, positions=None, last_only=False, hidden_states=False):
+    def prefill(self, embeds, positions=None, last_only=False, hidden_states=False, attentions=False):
         """embeds [S, D] appended to the cache; returns fp32 logits [S, V] (or [1, V]).  With hidden_states: (logits, hs) where hs is
         [layers + 1, S, D] in the model dtype -- the input embeddings, the residual stream after every layer but the last, and the
-        final-normed states (HF's `output_hidden_states` tuple; llava_llama.py:88-99)."""
+        final-normed states (HF's `output_hidden_states` tuple; llava_llama.py:88-99).  With attentions: the attention maps
+        [layers, heads, S, past + S] in the model dtype are appended to the returned tuple (HF's `output_attentions`; a plain kernel
+        beside the unchanged forward: teo_llama_prefill_attentions)."""
         S = embeds.shape[0]
         past = self.cache_len
         if past + S > self.max_seq:
@@ -439,12 +441,21 @@ class TeoEngine:
             self._flush_handoff_checks("prefill")
             ws = self._workspace("prefill", need)
             hs = torch.empty(self.cfg.num_hidden_layers + 1, S, self.cfg.hidden_size, dtype=self.dtype, device=self.device) if hidden_states else None
-            L.check(self.lib.teo_llama_prefill(C.byref(self.llama_desc), _p(e), _p(pos), S, past, 1 if last_only else 0,
-                                               _p(logits), _p(ws), ws.numel(), st, _p(hs) if hs is not None else None), "teo_llama_prefill")
+            att = None
+            if attentions:
+                att = torch.empty(self.cfg.num_hidden_layers, self.cfg.num_attention_heads, S, past + S, dtype=self.dtype, device=self.device)
+                L.check(self.lib.teo_llama_prefill_attentions(C.byref(self.llama_desc), _p(e), _p(pos), S, past, 1 if last_only else 0,
+                                                              _p(logits), _p(ws), ws.numel(), st, _p(hs) if hs is not None else None, _p(att)),
+                        "teo_llama_prefill_attentions")
+            else:
+                L.check(self.lib.teo_llama_prefill(C.byref(self.llama_desc), _p(e), _p(pos), S, past, 1 if last_only else 0,
+                                                   _p(logits), _p(ws), ws.numel(), st, _p(hs) if hs is not None else None), "teo_llama_prefill")
             sid = C.c_void_p(self.stream.cuda_stream)
             self._check_handoffs("prefill", lambda f: self.lib.teo_llama_prefill_workspace_status(C.byref(self.llama_desc), S, _p(ws), ws.numel(),
                                                                                                   C.byref(f), sid), "teo_llama_prefill")
         self.cache_len = past + S
+        if attentions:
+            return (logits, hs, att) if hidden_states else (logits, att)
         return (logits, hs) if hidden_states else logits
 
     def prefill_batch(self, embeds_list, hidden_states=False):

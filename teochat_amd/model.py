@@ -321,7 +321,9 @@ class LlavaLlamaForCausalLM:
             in ALL L + 1 hidden-state tensors are ZERO, at B = 1 and at B > 1 alike.  The reference's LlamaModel returns the (masked)
             activations it computed there; a consumer that pools over the full [B, S, D] tensor without applying the attention mask
             gets different values.  Real positions equal the reference's (tests/golden/hidden_*.npz).
-          * `output_attentions` raises NotImplementedError (the fused attention kernels never materialise the maps).
+          * `output_attentions` (B = 1): one [1, H, S, past + S] map per layer in the model dtype, written by a plain kernel beside the
+            unchanged fused forward (teo_llama_prefill_attentions) -- softmax statistics in fp32, one rounding, exact zeros for masked keys;
+            at B > 1 or on a batched decode step it raises NotImplementedError.
           * B > 1: `use_cache=True` (explicit) keeps one device cache per conversation and returns a TeoBatchKVCache; the next call
             takes it with input_ids [B, 1] (one batched decode step, every row at its own true next position).  With use_cache
             left None (the training-shape forward) nothing is kept and `past_key_values` is None.
@@ -332,11 +334,12 @@ class LlavaLlamaForCausalLM:
                                                           labels, images)
         if inputs_embeds is None:
             inputs_embeds = self.get_model().embed_tokens(input_ids)
-        if output_attentions:
-            # the flash kernels never materialise the [H, S, S] probability maps; a caller that needs them is outside this path
-            raise NotImplementedError("output_attentions: attention maps are not materialised by the fused attention kernels")
         eng = self.engine
         B, S, _ = inputs_embeds.shape
+        if output_attentions and (B > 1 or isinstance(past_key_values, TeoBatchKVCache)):
+            # the maps come from a plain kernel beside the single-sequence prefill (teo_llama_prefill_attentions); the batched forms keep
+            # the fused kernels only
+            raise NotImplementedError("output_attentions is a single-sequence feature (B = 1)")
         if isinstance(past_key_values, TeoBatchKVCache):
             # batched continuation (HF generate over a batch re-enters forward with the cache and ONE new token per row,
             # llava_arch.py:154-163): one batched decode step over the BatchDecoder's slots
@@ -407,7 +410,16 @@ class LlavaLlamaForCausalLM:
             if position_ids is not None:
                 pr = position_ids[0] if position_ids.dim() == 2 else position_ids
                 pos = pr[lo:hi] if pr.shape[-1] == S else pr
-            out = eng.prefill(inputs_embeds[0, lo:hi], positions=pos, last_only=False, hidden_states=hs_all is not None)
+            out = eng.prefill(inputs_embeds[0, lo:hi], positions=pos, last_only=False, hidden_states=hs_all is not None,
+                              attentions=bool(output_attentions))
+            if output_attentions:
+                # [layers, H, hi - lo, past + hi - lo] over the real rows; padded query rows / key columns of the caller's [S, past + S]
+                # frame stay zero (the contract of padded positions everywhere in this forward)
+                att = out[-1]
+                out = out[0] if hs_all is None else out[:2]
+                att_all = torch.zeros(att.shape[0], 1, att.shape[1], S, past + S, dtype=att.dtype, device=att.device)
+                att_all[:, 0, :, lo:hi, :past] = att[..., :past]
+                att_all[:, 0, :, lo:hi, past + lo:past + hi] = att[..., past:]
             if hs_all is not None:
                 out, hs = out
                 hs_all[:, 0, lo:hi] = hs
@@ -415,14 +427,21 @@ class LlavaLlamaForCausalLM:
         pkv = TeoKVCache(eng) if (use_cache is None or use_cache) and B == 1 else None
         if keep_batch:
             pkv = TeoBatchKVCache(eng, self._batch_decoder)
-        return self._forward_result(logits, labels, pkv, hs_all, return_dict)
+        attn_t = None
+        if output_attentions:
+            if B == 1 and spans[0] is not None:
+                attn_t = tuple(att_all[i] for i in range(att_all.shape[0]))
+            else:
+                attn_t = tuple(torch.zeros(1, self.config.num_attention_heads, S, past + S, dtype=eng.dtype, device=eng.device)
+                               for _ in range(self.config.num_hidden_layers))
+        return self._forward_result(logits, labels, pkv, hs_all, return_dict, attn_t)
 
-    def _forward_result(self, logits, labels, pkv, hs_all, return_dict):
+    def _forward_result(self, logits, labels, pkv, hs_all, return_dict, attentions=None):
         eng = self.engine
         loss = None
         if labels is not None:
             loss = self._shifted_loss(logits, labels)
-        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv,
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=pkv, attentions=attentions,
                                      hidden_states=tuple(hs_all[i] for i in range(hs_all.shape[0])) if hs_all is not None else None)
         if return_dict is False:
             return out.to_tuple()

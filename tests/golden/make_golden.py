@@ -14,6 +14,7 @@ Fixtures (SURVEY.md section 8c list):
   splice.json      G3 prepare_inputs_labels_for_multimodal index plans / masks / positions / labels
   tinyA.npz/tinyB.npz  G4 ViT features, G5 projector, G6 LLaMA prefill+decode, G7 end-to-end logits
   hidden_tiny*.npz     `output_hidden_states=True` of the same forward (round 5)
+  attn_tiny*.npz       `output_attentions=True` of the same forward (round 6)
 """
 import ast
 import json
@@ -434,6 +435,26 @@ def gen_hidden(name):
     print("hidden", name, tuple(hs.shape), "lm_head(hidden[-1]) - logits:", out["logits_from_last"], "batch", tuple(hb.shape))
 
 
+def gen_attn(name):
+    """Round 6: `output_attentions=True` of the kept forward signature (llava_llama.py:65,95): what the reference's forward returns in
+    `attentions` for the G7 inputs -- one [1, H, S, S] map per layer (eager attention: softmax over the causal keys).  Stored: 16 evenly
+    spaced query rows of every (layer, head) with all their keys, and per-layer checksums (row sums, sum of p^2)."""
+    model, sd, (vcfg, lcfg, mm) = build_reference(name)
+    T, n_text = 2, 24
+    frames = O.synthetic_frames(T, vcfg.image_size, seed=0)
+    ids = TY.prompt_ids(name, n_text, T, lcfg.vocab_size, seed=1).unsqueeze(0)
+    res = model(input_ids=ids, images=frames, use_cache=True, output_attentions=True)
+    att = torch.stack(list(res.attentions))[:, 0]                # [L, H, S, S]
+    assert att.dim() == 4 and att.shape[0] == lcfg.num_hidden_layers and att.shape[1] == lcfg.num_attention_heads
+    S = att.shape[2]
+    sel = torch.linspace(0, S - 1, SEL_ROWS).long()
+    out = {"sd_checksum": np.float64(sd_checksum(sd)), "input_ids": ids.numpy(), "T": np.int64(T), "shape": np.array(att.shape, dtype=np.int64),
+           "sel": sel.numpy(), "attn_sel": att[:, :, sel].numpy(), "row_sum_max_dev": np.float64(float((att.sum(-1) - 1).abs().max())),
+           "sum_p2": att.double().pow(2).sum((1, 2, 3)).numpy(), "upper_triangle_max": np.float64(float(att.triu(1).abs().max()))}
+    np.savez_compressed(os.path.join(HERE, "attn_" + name + ".npz"), **out)
+    print("attn", name, tuple(att.shape), "row sums off by", out["row_sum_max_dev"], "above the diagonal:", out["upper_triangle_max"])
+
+
 from tests._tiny import train_batch  # noqa: E402  (shared with the tests that replay the fixture)
 
 
@@ -650,7 +671,7 @@ def gen_detection():
 if __name__ == "__main__":
     assert ref_import.available(), "reference tree required"
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["host", "splice", "numeric", "train", "hidden", "metrics", "detection"]
+    which = sys.argv[1:] or ["host", "splice", "numeric", "train", "hidden", "attn", "metrics", "detection"]
     if "host" in which:
         gen_host()
     if "splice" in which:
@@ -664,6 +685,8 @@ if __name__ == "__main__":
             gen_train(nm)
         if "hidden" in which:
             gen_hidden(nm)
+        if "attn" in which:
+            gen_attn(nm)
     if "metrics" in which:
         gen_metrics()
     if "detection" in which:

@@ -253,8 +253,8 @@ def test_edge_cases_generate_and_forward():
         model.generate(input_ids=ids, images=frames, max_new_tokens=5000)
     with pytest.raises(ValueError):
         model(input_ids=ids, images=[torch.zeros(2, 3, 224, 224, device=dev)])
-    with pytest.raises(NotImplementedError):
-        model(input_ids=ids, images=frames, output_attentions=True)
+    with pytest.raises(NotImplementedError):        # the attention maps are a single-sequence feature (served at B = 1 since round 6)
+        model(input_ids=torch.cat([ids, ids]), images=list(frames) + list(frames), output_attentions=True)
 
 
 @pytest.mark.gpu

@@ -181,6 +181,26 @@ def test_oracle_hidden_states_match_reference(name):
 
 
 @pytest.mark.parametrize("name", ["tinyA", "tinyB"])
+def test_oracle_attentions_match_reference(name):
+    """Round 6: `output_attentions=True` of the kept forward signature (llava_llama.py:65,95): the reference's per-layer [1, H, S, S] maps
+    (fixture attn_*.npz made by make_golden.py `attn`) against the oracle's attention_probs -- 16 query rows of every (layer, head) with
+    all their keys, rows that sum to 1, exact zeros above the diagonal, and the per-layer sum of p^2."""
+    g = TY.load_npz("attn_" + name)
+    vcfg, lcfg, mm = TY.cfgs(name)
+    sd = TY.state_dict(name)
+    assert abs(TY.sd_checksum(sd) - float(g["sd_checksum"])) < 1e-6 * float(g["sd_checksum"])
+    frames = O.synthetic_frames(int(g["T"]), vcfg.image_size, seed=0)
+    ids = torch.from_numpy(g["input_ids"])
+    att = []
+    O.mm_forward(ids, frames, sd, vcfg, lcfg, mm, attentions=att)
+    got = torch.stack(att)[:, 0]
+    assert list(got.shape) == g["shape"].tolist() and float(g["upper_triangle_max"]) == 0.0
+    np.testing.assert_allclose(got[:, :, torch.from_numpy(g["sel"])].numpy(), g["attn_sel"], atol=2e-6)
+    np.testing.assert_allclose(got.double().pow(2).sum((1, 2, 3)).numpy(), g["sum_p2"], rtol=1e-5)
+    assert float(got.triu(1).abs().max()) == 0.0 and float((got.sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["tinyA", "tinyB"])
 def test_oracle_training_shape_loss_matches_reference(name):
     """N4: batch of 2, right padding, labels -> the reference's loss and logits (tests/golden/train_*.npz)."""
     g = TY.load_npz("train_" + name)

@@ -2,11 +2,11 @@
 # HBM traffic of the kernels of the BATCHED decode step (config C5 per GPU: 8 conversations, fp8 weights) from PMC counters inside a real
 # bench.py run -- the batched counterpart of tools/pmc_decode_traffic.sh, same recipe (MI355X_MICROARCH.md section HBM: separate rocprofv3
 # --pmc passes with nothing but --kernel-trace beside them, FETCH_SIZE doubled on gfx950, WRITE_SIZE as is, TCC_EA0_RDREQ_sum x 128 B as the
-# cross-check; the program itself follows `--`).  Writes gpurun_out/r05p/r05_pmc_batch_traffic.json.
+# cross-check; the program itself follows `--`).  Writes gpurun_out/r06p/r06_pmc_batch_traffic.json.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 COMMIT=${1:-unknown}
-mkdir -p $ROOT/gpurun_out/r05p
+mkdir -p $ROOT/gpurun_out/r06p
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum; do
   rm -rf /tmp/pmcb8_$C
@@ -48,6 +48,6 @@ for key, (match, alg) in KERNELS.items():
         e["error"] = str(ex)
     out["kernels"][key] = e
 out["hbm_bytes_per_launch"] = out["kernels"].get("attn_decode_whole", {}).get("hbm_bytes_per_launch")        # the dominant kernel of this step
-json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r05p/r05_pmc_batch_traffic.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r06p/r06_pmc_batch_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:4000])
 PY

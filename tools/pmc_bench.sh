@@ -1,10 +1,10 @@
 #!/bin/bash
 # PMC passes over a real bench.py run (rounds 3-4): MFMA busy / wave wait buckets / L2 hit-miss per kernel of the step.
-# Counters only (no trace domains beside --kernel-trace), the program itself after `--`.  -> gpurun_out/r05p/pmc_bench.txt
+# Counters only (no trace domains beside --kernel-trace), the program itself after `--`.  -> gpurun_out/r06p/pmc_bench.txt
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r05p/pmc_bench.txt
-mkdir -p $ROOT/gpurun_out/r05p
+OUT=$ROOT/gpurun_out/r06p/pmc_bench.txt
+mkdir -p $ROOT/gpurun_out/r06p
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 P2="TCC_HIT_sum TCC_MISS_sum"

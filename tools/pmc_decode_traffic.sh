@@ -2,11 +2,11 @@
 # HBM traffic of EVERY kernel of the decode step from PMC counters, inside a real bench.py run (round 3).
 # Collected as MI355X_MICROARCH.md (section HBM) prescribes: separate rocprofv3 --pmc passes (nothing but --kernel-trace beside
 # them), FETCH_SIZE doubled on gfx950 (128-B requests are tallied at 64 B), WRITE_SIZE as is, TCC_EA0_RDREQ_sum x 128 B as the
-# cross-check.  The program itself follows `--` (no wrapper hop).  Writes gpurun_out/r05p/r05_pmc_decode_traffic.json.
+# cross-check.  The program itself follows `--` (no wrapper hop).  Writes gpurun_out/r06p/r06_pmc_decode_traffic.json.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 COMMIT=${1:-unknown}
-mkdir -p $ROOT/gpurun_out/r05p
+mkdir -p $ROOT/gpurun_out/r06p
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_sum; do
   rm -rf /tmp/pmcd_$C
@@ -52,6 +52,6 @@ for key, (match, alg) in KERNELS.items():
 gu = out["kernels"].get("gateup_gemv", {})
 out["hbm_bytes_per_launch"] = gu.get("hbm_bytes_per_launch")        # the dominant kernel: bench.py's roofline.traffic
 out["kernel"] = "gemv_kernel<bf16,bf16,R=2,U=4,NT,SWIGLU> N=22016 K=4096 (decode rmsnorm + gate/up + SwiGLU)"
-json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r05p/r05_pmc_decode_traffic.json", "w"), indent=1)
+json.dump(out, open(os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/r06p/r06_pmc_decode_traffic.json", "w"), indent=1)
 print(json.dumps(out)[:3000])
 PY

@@ -1,15 +1,16 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/refresh_profiles.sh   -> gpurun_out/r05p/{bench*.json, kernel_stats.md}
-# The bench lines and the rocprofv3 kernel summary that profiles/r05_* are copied from.
+# usage (on the GPU box): bash tools/refresh_profiles.sh   -> gpurun_out/r06p/{bench*.json, kernel_stats.md}
+# The bench lines and the rocprofv3 kernel summary that profiles/r06_* are copied from.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r05p
+OUT=$ROOT/gpurun_out/r06p
 mkdir -p $OUT
 cd $ROOT
 timeout 900 python3 bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
 run() { name=$1; shift; timeout 600 python3 bench.py --no-cpu-baseline "$@" 2> $OUT/bench_$name.err | tail -1 > $OUT/bench_$name.json; }
 run frames16 --frames 16
 run frames2new128 --frames 2 --new 128
+run frames2new16 --frames 2 --new 16          # the regime the reference's tasks live in: a few answer tokens, TTFT is the latency (eval/classification.py:15-41)
 run weightsfp8 --weights fp8
 run batch8 --batch 8
 run batch8weightsfp8 --batch 8 --weights fp8
