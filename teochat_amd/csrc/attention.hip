@@ -197,6 +197,27 @@ template <> struct Cvt16<float> {
 // two packed 16-bit products + fp32 accumulate: v_dot2_f32_bf16 / v_dot2_f32_f16 by the element type
 #define attn_dot2 dot2h<IsF16<T>::v>
 
+// acc[e] += p * v[e] over the 8 (16-bit) / 4 (fp32) values of a 16-byte V chunk.  IEEE half (round 6): v_fma_mix_f32 takes the half operand
+// straight from either word of the register (op_sel picks the word, op_sel_hi marks it f16) -- 8 instructions instead of 8 converts (four of
+// them SDWA forms with their s_nop hazards) + 8 FMAs; fma(float(v), p, acc) with one rounding: the same bits.  The fp16 decode attention
+// kernel measured 8.38 us against bf16's 8.04 inside real steps before it (profiles/r06_bench_fp16_kernel_stats.md).
+template <typename T>
+__device__ __forceinline__ void attn_pv_fma(const uint4& vr, float p, float (&acc)[Cvt16<T>::N]) {
+    if constexpr (IsF16<T>::v) {
+        const unsigned w[4] = {vr.x, vr.y, vr.z, vr.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * i]) : "v"(w[i]), "v"(p));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * i + 1]) : "v"(w[i]), "v"(p));
+        }
+    } else {
+        float vf[Cvt16<T>::N];
+        Cvt16<T>::cvt(vr, vf);
+#pragma unroll
+        for (int e = 0; e < Cvt16<T>::N; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+    }
+}
+
 // K/V rows are read once per step: non-temporal 16-byte loads (streamed past L2 like the GEMV weight stream)
 typedef __attribute__((ext_vector_type(4))) unsigned int kv_u32x4;
 __device__ __forceinline__ uint4 ld_kv(const void* p) {
@@ -355,14 +376,18 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const int* __r
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const float p = pstrip[wid][wid * KPW + i * RPI + grp];      // 0 for keys >= kv_len
-        float vf[VE];
-        Cvt16<T>::cvt(vr[i], vf);
-        if (ROPE && kw0 + i * RPI + grp == pos) {
+        if constexpr (ROPE) {
+            float vf[VE];
+            Cvt16<T>::cvt(vr[i], vf);
+            if (kw0 + i * RPI + grp == pos) {
 #pragma unroll
-            for (int e = 0; e < VE; ++e) vf[e] = vnew[e];
+                for (int e = 0; e < VE; ++e) vf[e] = vnew[e];
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
+        } else {
+            attn_pv_fma<T>(vr[i], p, acc);
         }
-#pragma unroll
-        for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
     }
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = cross_group_sum<LPR>(acc[e]);
@@ -595,9 +620,7 @@ __global__ __launch_bounds__(AW_WAVES * 64) void attn_decode_whole_kernel(const 
             uint4 vraw = SLOT[i];                                                                                      \
             vraw.x = isnew ? vnew_pk.x : vraw.x; vraw.y = isnew ? vnew_pk.y : vraw.y;                                  \
             vraw.z = isnew ? vnew_pk.z : vraw.z; vraw.w = isnew ? vnew_pk.w : vraw.w;                                  \
-            float vf[VE];                                                                                              \
-            Cvt16<T>::cvt(vraw, vf);                                                                                   \
-            _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] = fmaf(p, vf[e], acc[e]);                            \
+            attn_pv_fma<T>(vraw, p, acc);                                                                              \
         }                                                                                                              \
         _Pragma("unroll") for (int e = 0; e < VE; ++e) acc[e] = cross_group_sum<LPR>(acc[e]);                          \
         if ((QT) == 0) { _Pragma("unroll") for (int e = 0; e < VE; ++e) OUT[e] = acc[e]; }                             \
