@@ -588,7 +588,7 @@ int gemm_wide_sk_launch(const void* A, const void* W, const void* bias, const vo
                         int act, bool of32, bool f16, void* sk_ws, size_t flags_offset, hipStream_t st);          // gemm_wide.hip
 
 // 128 x 256 tiles on 256 slots (one 8-wave workgroup per CU) against 128 x 128 tiles on 512 slots: rounds of equal-length tiles
-static bool gemm_wide_wins(int M, int N, int K, bool forced) {
+static bool gemm_wide_wins(int M, int N, int K, bool forced, bool swiglu) {
     if (K < 2 * BK) return false;
     const long long t_wide = (long long)cdiv(M, 128) * cdiv(N, 256), t_plain = (long long)cdiv(M, 128) * cdiv(N, 128);
     if (forced) return true;
@@ -597,7 +597,11 @@ static bool gemm_wide_wins(int M, int N, int K, bool forced) {
     // a long K loop on half a round of wide tiles still beats a whole round of 128 x 128 ones (the tower's fc2 at T = 16: M = 4112, N = 1024,
     // K = 4096, 132 wide tiles: 52.6 us against 61-65 us on either 128 x 128 kernel; tools/vit_gemm_probe.py, round 5)
     if (K >= 4096 && t_wide >= 128 && t_wide <= 256) return true;
-    if (t_wide < 208 && !(K <= 1024 && t_wide >= 192)) return false;
+    // round 6 (tools/dispatch_monotone.py): gate/up below one round of wide tiles (M <= 256: 68.7 us at M = 128 against 78.4 on the 128 x 128 tile --
+    // the SwiGLU epilogue has no narrow family), and the short-K shapes from 144 wide tiles on (the tower's fc1 / the projector at T = 4 .. 5:
+    // 26.1-26.9 us against 27.7-28.7 on 128 x 128 tiles)
+    if (swiglu && t_wide >= 64 && t_wide <= 256) return true;
+    if (t_wide < 208 && !(K <= 1024 && t_wide >= 144)) return false;
     // cost in rounds of the plain kernel; its ragged last round runs faster when it leaves one workgroup per CU (x 0.66, measured)
     const long long rem = t_plain % 512;
     const double plain = (double)(t_plain / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.66 : 1.0));
@@ -680,7 +684,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 128, st, true);
         if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && bm == 64)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, st);
-        const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = gemm_big_tile_count(M, N);     // (counts a ragged last row block as 128 x 512 tiles)
+        const long long t_wide_ = (long long)cdiv(M, 128) * cdiv(N, 256), t_big = gemm_big_tile_count(M, N, K);  // (counts a ragged last row block as 128 x 512 tiles)
         // 256 x 160 tiles (gemm_quad.hip, round 5): automatic, and only while no other family is forced, where the problem is ONE round of
         // them but more than one round of 128 x 256 tiles: M = 2056 .. 2304 against N = 4096 (272 wide tiles, 234 of these): LLaMA o / down at
         // config C3, the tower's fc1.  tools/vit_gemm_probe.py (us, real epilogues): o 79.7 -> 71.3, down 178.6 -> 170.7, fc1 + GELU 39.5 -> 34.2
@@ -707,7 +711,11 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         // M = 897 .. 1024 (192 tiles) 97-99 us vs 137-139 on 128 x 128 tiles, o / down at M = 2817 .. 3328 (192 / 208 tiles) 102-108 / 252-257 vs
         // 122-142 / 300-365; and at EQUAL modelled cost the 256 x 256 tile is the one that measures ahead (gate/up at M = 2305 .. 2560: four
         // rounds of them 393 us, seven rounds of 128 x 256 tiles 434-443) -- hence <=
-        const long long t_big_min = K >= 2048 ? 192 : 224;
+        // (tools/dispatch_monotone.py, round 6: a GEMM with more rows cannot be faster -- every inversion it found was a threshold here.)  192 tiles for
+        // every K (the tower's qkv at T = 15 / 16: 32.8 vs 37.6 us; fc1 / the projector at T = 12: 46.8 vs 52.1, 48.2 vs 50.0); 160 for the SwiGLU
+        // epilogue, whose only other families are the 128 x 256 tile and the register-staged 128 x 128 one (gate/up at M = 257 .. 512, 172 tiles:
+        // 92-94 us against 103-150)
+        const long long t_big_min = swiglu ? 160 : 192;
         if (bm == 128 && K >= 2 * BK && (tune().gemm_big == 2 || (tune().gemm_big == 1 && tune().gemm_wide == 1 && t_big >= t_big_min && !sk_wide_shape &&
                                                                big_rounds * GEMM_BIG_ROUND_COST <= (double)cdiv(t_wide_, 256))))
             return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, st, sk_ws, GEMM_SK_SLAB_BYTES);
@@ -717,7 +725,7 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
                 (tune().gemm_sk == 2 || sk_wide_fit))
                 return gemm_wide_sk_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, sk_ws, GEMM_SK_SLAB_BYTES, st);
         }
-        if (tune().gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, tune().gemm_wide == 2))
+        if (tune().gemm_wide && bm == 128 && gemm_wide_wins(M, N, K, tune().gemm_wide == 2, swiglu))
             return gemm_wide_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, st);
         // stream-K where it was measured to win: just over ONE round of tiles (544 tiles on 512 slots at M = 2168, N = 4096:
         // o 114 -> 93 us, down 297 -> 250 us).  With several tiles per workgroup the contiguous ranges spread an XCD's

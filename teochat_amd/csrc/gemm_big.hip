@@ -234,30 +234,40 @@ __global__ __launch_bounds__(512) void gemm_mfma_bf16_big_kernel(const bf16_t* _
 // tile count drops by 5.6 % but not the number of rounds, and a 128 x 512 tile moves 80 KB per K step instead of 64: measured
 // (tools/dispatch_probe.py, M = 2168 / 4208) qkv 193.8 vs 193.8 / 348 vs 356, gate/up 340-372 vs 333 / 620 vs 604 us -- a wash or a loss,
 // because the hybrid form's stream-K part grows when a data-parallel round disappears (731 tiles = 1 round + 475 instead of 2 + 262).
-int gemm_big_ragged_tiles(int M, int N) {
+// (bytes / tile-count rule of the hybrid form: see gemm_big_hybrid_fits below)
+static bool gb_hybrid_rule(long long T, long long bytes) { return bytes <= (160ll << 20) || T <= 384 || (T <= 800 && bytes <= (208ll << 20)); }
+// K > 0 adds the second automatic case: the ragged form saves a whole ROUND of the plain (non-hybrid) kernel where the hybrid form does not
+// apply to the padded problem anyway -- gate/up at M = 4353 .. 4480 (1548 -> 1505 tiles: seven rounds -> six; 637 us against 654 padded, 710 on
+// the 128 x 256 tile the rounds model fell back to)
+int gemm_big_ragged_tiles(int M, int N, int K) {
     const int rows = M % GB_BM, tiles_n = (N + GB_BN - 1) / GB_BN, mode = tune().gemm_big_ragged;
     if (!(mode && rows > 0 && rows <= GB_BM / 2 && tiles_n % 2 == 0 && M >= GB_BM)) return 0;
     const long long t_rag = (long long)(M / GB_BM) * tiles_n + tiles_n / 2, t_full = (long long)(M / GB_BM + 1) * tiles_n;
-    return (mode == 2 || (t_rag <= 256 && t_full > 256)) ? tiles_n / 2 : 0;
+    bool take = mode == 2 || (t_rag <= 256 && t_full > 256);
+    if (!take && K > 0 && (t_rag + 255) / 256 < (t_full + 255) / 256) {
+        const bool hybrid_would_run = t_full > 256 && t_full % 256 != 0 && gb_hybrid_rule(t_full, ((long long)M + N) * K * 2);
+        take = !hybrid_would_run;
+    }
+    return take ? tiles_n / 2 : 0;
 }
-long long gemm_big_tile_count(int M, int N) {
-    const int rt = gemm_big_ragged_tiles(M, N);
+long long gemm_big_tile_count(int M, int N, int K) {
+    const int rt = gemm_big_ragged_tiles(M, N, K);
     return (long long)(rt ? M / GB_BM : (M + GB_BM - 1) / GB_BM) * ((N + GB_BN - 1) / GB_BN) + rt;
 }
 
 bool gemm_big_hybrid_fits(int M, int N, int K) {
-    const long long T = gemm_big_tile_count(M, N);
+    const long long T = gemm_big_tile_count(M, N, K);
     const long long bytes = ((long long)M + N) * K * 2;
     // round 3 (tools/split_probe.py): gate/up at M = 2168 (198 MB, 774 tiles = 3.02 rounds) runs 337 / 342 us (warm / cold weights) in
     // the hybrid form against 358 / 363 on the 128 x 256 kernel -- with only three rounds the ragged one costs more than the
     // unshared stream-K part; at M = 4208 (214 MB, 5.7 rounds) the hybrid form loses (712 vs 580 us)
-    return bytes <= (160ll << 20) || T <= 384 || (T <= 800 && bytes <= (208ll << 20));
+    return gb_hybrid_rule(T, bytes);
 }
 
 int gemm_big_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                     int act, bool swiglu, bool of32, bool f16, hipStream_t st, void* sk_ws, size_t flags_offset) {
     const int tiles_n = cdiv(N, GB_BN);
-    const int rag_tiles = gemm_big_ragged_tiles(M, N);     // > 0: the last M % 256 <= 128 rows as tiles_n / 2 tiles of 128 x 512 (see the kernel)
+    const int rag_tiles = gemm_big_ragged_tiles(M, N, K);  // > 0: the last M % 256 <= 128 rows as tiles_n / 2 tiles of 128 x 512 (see the kernel)
     const int tiles_m = rag_tiles ? M / GB_BM : cdiv(M, GB_BM);
     const int T = tiles_m * tiles_n + rag_tiles, nk = K / GB_BK;
     const size_t lds = rag_tiles ? 2 * (size_t)GB_RAG_STAGE : 2 * (size_t)GB_STAGE;

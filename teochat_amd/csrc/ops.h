@@ -62,8 +62,8 @@ int cross_entropy(const float* logits, long long ld, const long long* labels, fl
 bool patch_embed_ok(int C, int img, int P, int ldw, int D, int dtype, const void* px, const void* W, const void* out);
 int patch_embed(const void* px, const void* W, void* out, int T, int C, int img, int P, int ldw, int D, hipStream_t st, bool f16 = false);
 bool gemm_big_hybrid_fits(int M, int N, int K);
-int gemm_big_ragged_tiles(int M, int N);               // gemm_big.hip: 128 x 512 tiles over a last row block of <= 128 rows (0: none)
-long long gemm_big_tile_count(int M, int N);           // equal-cost tiles of the 256 x 256 family for an M x N problem
+int gemm_big_ragged_tiles(int M, int N, int K = 0);    // gemm_big.hip: 128 x 512 tiles over a last row block of <= 128 rows (0: none)
+long long gemm_big_tile_count(int M, int N, int K = 0); // equal-cost tiles of the 256 x 256 family for an M x N problem
 bool skinny_gemm_ok(int MB, int N, int K, int ldx, int w_fp8, unsigned flags, const void* x, const void* W);
 // Producer-side RMSNorm hand-off between the GEMMs of a batched decode step.  A residual-producing GEMM (o / down
 // projection, one row tile per workgroup) also emits xg_out = bf16(h * next_g) and ssq_out[b][workgroup] = its 16
