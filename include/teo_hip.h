@@ -86,7 +86,7 @@ size_t teo_sizeof(const char* struct_name);
  *                   same tiles, same arithmetic: bit-identical
  *   decode attn   : "attn_chunk" (keys per decode chunk: 0 auto, 32/64/128/256; fp32 order of the split merge + where P is rounded),
  *                   "attn_whole" (batched decode attention as one workgroup per (conversation, head): 0 off, 1 auto = when conversations x
- *                   heads fill the CUs, 2 whenever the shape allows; bit-identical to the split + combine pair at the same chunk)
+ *                   heads make whole rounds of the CUs (a multiple of the CU count, or at least 7/4 rounds), 2 whenever the shape allows; bit-identical to the split + combine pair at the same chunk)
  *   batched GEMM  : "skinny_tiles" (0 auto, 1/2/4/8), "skinny_nt", "skinny_stream" (0 off, 1 auto, 2 whenever eligible), "skinny_ring"
  *                   (weight tiles in flight of the streaming form: 0 default, 1 one more), "skinny_unr" (tile kernel steps per register
  *                   set: 0 auto, 4, 8), "skinny_waves" (tile kernel waves per workgroup: 0 auto = 8, 8, 16 -- measured and lost in round 6,

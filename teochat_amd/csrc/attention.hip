@@ -801,7 +801,12 @@ int attn_decode(const void* q, void* kc, void* vc, void* vtc, const float* rope_
         const size_t lds = ((size_t)8 * cw + (size_t)nsw * (hd + 2) + 784) * sizeof(float);
         const int cus = device_cu_count();
         const bool fits = ni >= 1 && ni <= 8 && (hd & (hd - 1)) == 0 && hd <= 256 && lds <= 96 * 1024 && nsw <= 256 && (cw == 32 || cw == 64 || cw == 128);
-        if (fits && (tune().attn_whole == 2 || (tune().attn_whole == 1 && bt.batch > 1 && bt.batch * heads >= (cus > 0 ? cus : 256)))) {
+        // one workgroup per (conversation, head): whole rounds of the CUs only -- with 9..13 conversations x 32 heads the CUs that get a second
+        // workgroup finish 1.3x later than the rest and the split form wins (B = 9: 4.45 vs 4.85 ms per step, B = 10: 4.55 vs 4.99,
+        // B = 13: 5.25 vs 5.34; from 7/4 rounds on the imbalance amortises: B = 14: 5.52 vs 5.56; profiles/r06_batch_sweep_attn_{whole,split}.md)
+        const int ncu = cus > 0 ? cus : 256, wgs = bt.batch * heads;
+        const bool balanced = wgs >= ncu && (wgs % ncu == 0 || 4 * wgs >= 7 * ncu);
+        if (fits && (tune().attn_whole == 2 || (tune().attn_whole == 1 && bt.batch > 1 && balanced))) {
             const int rcw = attn_whole_launch(q, kc, vc, vtc, rope_cos, rope_sin, o, d_pos, S_max, heads, kv_heads, hd, scale, cw, lpr, dtype, bt, lds, st);
             if (rcw != TEO_ERR_UNSUPPORTED) return rcw;
         }

@@ -602,7 +602,7 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
         const double wide = (double)cdiv(t_wide, 256) * 0.80;   // measured: a wide fp8 round costs ~0.8 of a 128 x 128 round (o: 76 vs 81 us, gate/up 219 vs 272)
         const bool sk_shape = sk_ws && tune().gemm_fp8_wide && !swiglu && K >= 2 * F8_BK && t_wide > 256 && (tune().gemm_fp8_wide == 3 || t_wide <= 256 + 256 / 6);
         const long long t_big = (long long)cdiv(M, F8B_BM) * cdiv(N, F8B_BN);
-        if (K >= 2 * F8_BK && (tune().gemm_fp8_big == 2 || (tune().gemm_fp8_big == 1 && tune().gemm_fp8_wide == 1 && t_big >= 224 && !sk_shape &&
+        if (K >= 2 * F8_BK && (tune().gemm_fp8_big == 2 || (tune().gemm_fp8_big == 1 && tune().gemm_fp8_wide == 1 && t_big >= 160 && !sk_shape &&
                                                   cdiv(t_big, 256) * F8_BIG_ROUND_COST < (double)cdiv(t_wide, 256)))) {
             const int tiles_m = cdiv(M, F8B_BM), tiles_n = cdiv(N, F8B_BN);
             const size_t lds = 2 * F8B_STAGE;
@@ -640,7 +640,7 @@ int gemm_fp8(const void* A8, const float* a_scale, const void* W8, const float* 
             note_kernel("gemm_fp8_wide_sk"); TEO_LAUNCH_CHECK("gemm_mfma_fp8_wide_sk");
             return TEO_OK;
         }
-        if (K >= 2 * F8_BK && (tune().gemm_fp8_wide >= 2 || (tune().gemm_fp8_wide == 1 && t_wide >= 256 && wide < plain))) {
+        if (K >= 2 * F8_BK && (tune().gemm_fp8_wide >= 2 || (tune().gemm_fp8_wide == 1 && wide < plain && (t_wide >= 256 || (t_wide >= 144 && t_plain > 256))))) {
             const int tiles_m = cdiv(M, F8W_BM), tiles_n = cdiv(N, F8W_BN);
             const size_t lds = 3 * F8W_STAGE;
 #define TEO_F8W_LAUNCH(SW, OF)                                                                                                  \

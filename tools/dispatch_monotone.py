@@ -4,7 +4,9 @@ tower's four) and flag every row count whose time exceeds that of a LARGER row c
 rule picking a worse tile family than its neighbour's (the complement of tools/shape_sweep.py, which walks the shapes a caller can produce
 through the whole phases; this walks the rule boundaries themselves).  Weights rotate over 8 copies so that they come from HBM.
 
-usage (GPU box): python tools/dispatch_monotone.py [--lo 128] [--hi 4736] [--step 64] [--out gpurun_out/dispatch_monotone.txt]"""
+--fp8 walks the four LLaMA GEMMs of the w8a8 prefill (teo_gemm_fp8_ws) instead.
+
+usage (GPU box): python tools/dispatch_monotone.py [--fp8] [--lo 128] [--hi 4736] [--step 64] [--out gpurun_out/dispatch_monotone.txt]"""
 import argparse
 import ctypes as C
 import os
@@ -44,18 +46,27 @@ def main():
     ap.add_argument("--step", type=int, default=64)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dispatch_monotone.txt"))
     ap.add_argument("--tol", type=float, default=0.08)
+    ap.add_argument("--fp8", action="store_true")
     args = ap.parse_args()
     shapes = (("qkv", 12288, 4096, 0, L.ACT_NONE, False, False), ("o", 4096, 4096, 0, L.ACT_NONE, False, True),
               ("gateup", 22016, 4096, L.GEMM_SWIGLU16, L.ACT_NONE, False, False), ("down", 4096, 11008, 0, L.ACT_NONE, False, True),
               ("v.qkv", 3072, 1024, 0, L.ACT_NONE, True, False), ("v.out", 1024, 1024, 0, L.ACT_NONE, True, True),
               ("v.fc1", 4096, 1024, 0, L.ACT_GELU_ERF, True, False), ("v.fc2", 1024, 4096, 0, L.ACT_NONE, True, True))
+    if args.fp8:
+        shapes = tuple(s for s in shapes if not s[0].startswith("v."))
     Ms = list(range(args.lo, args.hi + 1, args.step))
     lines, flagged = [], []
     for name, N, K, flags, act, with_bias, with_res in shapes:
         Ws = [(torch.randn(N, K, device=dev) * 0.02).to(bf) for _ in range(8 if N * K * 2 > 16e6 else 16)]
+        if args.fp8:
+            Ws = [(W.float() * 100).to(torch.float8_e4m3fn).view(torch.uint8) for W in Ws]
+            w_scale = torch.rand(N, device=dev) * 0.01 + 0.005
+            a_scale = torch.rand(Ms[-1], device=dev) + 0.5
         Nc = N // 2 if flags else N
         bias = torch.randn(N, device=dev).to(bf) if with_bias else None
         Amax = torch.randn(Ms[-1], K, device=dev).to(bf)
+        if args.fp8:
+            Amax = (Amax.float() * 50).to(torch.float8_e4m3fn).view(torch.uint8)
         Cmax = torch.empty(Ms[-1], Nc, dtype=bf, device=dev)
         Rmax = torch.randn(Ms[-1], Nc, device=dev).to(bf) if with_res else None
         rows = []
@@ -65,6 +76,11 @@ def main():
             def run():
                 W = Ws[cnt[0] % len(Ws)]
                 cnt[0] += 1
+                if args.fp8:
+                    L.check(lib.teo_gemm_fp8_ws(Amax.data_ptr(), a_scale.data_ptr(), W.data_ptr(), w_scale.data_ptr(),
+                                                Rmax.data_ptr() if Rmax is not None else None, Cmax.data_ptr(), M, N, K, K, Nc, flags, L.TEO_BF16,
+                                                ws.data_ptr(), cur), "gemm_fp8")
+                    return
                 L.check(lib.teo_gemm_ws(Amax.data_ptr(), W.data_ptr(), bias.data_ptr() if bias is not None else None,
                                         Rmax.data_ptr() if Rmax is not None else None, Cmax.data_ptr(), M, N, K, K, Nc, act, flags, L.TEO_BF16, L.TEO_BF16,
                                         ws.data_ptr(), cur), "gemm")
