@@ -69,8 +69,8 @@ def main():
             Amax = (Amax.float() * 50).to(torch.float8_e4m3fn).view(torch.uint8)
         Cmax = torch.empty(Ms[-1], Nc, dtype=bf, device=dev)
         Rmax = torch.randn(Ms[-1], Nc, device=dev).to(bf) if with_res else None
-        rows = []
-        for M in Ms:
+
+        def time_M(M, trials=2):
             cnt = [0]
 
             def run():
@@ -86,7 +86,27 @@ def main():
                                         ws.data_ptr(), cur), "gemm")
             run()
             kern = lib.teo_last_kernel().decode().replace("gemm_", "")
-            rows.append((M, min(event_us(run) for _ in range(2)), kern))
+            return min(event_us(run) for _ in range(trials)), kern
+
+        rows = []
+        for M in Ms:
+            t, kern = time_M(M)
+            rows.append((M, t, kern))
+        # a point that looks inverted is timed again, back to back with the larger row count it lost to (clock ramps between kernel variants
+        # show up as one-off 10 % outliers): it stays flagged only if the repeat agrees
+        for _ in range(2):
+            best = (float("inf"), None)
+            redo = []
+            for i in range(len(rows) - 1, -1, -1):
+                if best[1] is not None and rows[i][1] > (1.0 + args.tol) * best[0]:
+                    redo.append((i, best[1]))
+                if rows[i][1] < best[0]:
+                    best = (rows[i][1], i)
+            for i, j in redo:
+                ti, _ = time_M(rows[i][0], 3)
+                tj, _ = time_M(rows[j][0], 3)
+                rows[i] = (rows[i][0], min(rows[i][1], ti), rows[i][2])
+                rows[j] = (rows[j][0], min(rows[j][1], tj), rows[j][2])
         # inversions: t(M) against the minimum over all larger M
         suffix_min = [0.0] * len(rows)
         best = (float("inf"), None)

@@ -19,3 +19,8 @@ timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/r06p/b
 timeout 1500 python3 tools/shape_sweep.py --out gpurun_out/r06p/shape_sweep.json > gpurun_out/r06p/shape_sweep.log 2>&1
 timeout 600 python3 tools/fp16_probe.py > gpurun_out/r06p/fp16_probe.txt 2>&1
 timeout 300 python3 tools/vit_probe.py 8 50 > gpurun_out/r06p/vit_probe.txt 2>&1; timeout 300 python3 tools/vit_probe.py 2 50 >> gpurun_out/r06p/vit_probe.txt 2>&1
+# property walks: a GEMM with more rows cannot be faster (bf16 and w8a8 prefill GEMMs), a batched step with more conversations cannot be faster
+timeout 600 python3 tools/dispatch_monotone.py --out gpurun_out/r06p/dispatch_monotone.txt > /dev/null 2>&1
+timeout 600 python3 tools/dispatch_monotone.py --fp8 --out gpurun_out/r06p/dispatch_monotone_fp8.txt > /dev/null 2>&1
+timeout 900 python3 tools/batch_sweep.py --weights bf16 --batches 1,2,3,4,6,8,9,10,11,12,13,14,15,16 --out gpurun_out/r06p/batch_sweep_bf16.json > gpurun_out/r06p/batch_sweep_bf16.log 2>&1
+timeout 900 python3 tools/batch_sweep.py --weights fp8 --batches 1,2,3,4,6,8,9,10,11,12,13,14,15,16 --out gpurun_out/r06p/batch_sweep_fp8.json > gpurun_out/r06p/batch_sweep_fp8.log 2>&1
