@@ -29,6 +29,8 @@
 namespace teo {
 
 constexpr int GQ_BM = 256, GQ_BK = 64;
+// s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14 -- "vmcnt(N) lgkmcnt(0)" with expcnt left alone
+#define GQ_WAIT_VM_LGKM0(N) ((((N) & 15) | (7 << 4) | ((((N) >> 4) & 3) << 14)))
 
 __device__ __forceinline__ int gq_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -41,16 +43,25 @@ template <bool F16> __device__ __forceinline__ void gq_mfma(teo_f32x4& c, const 
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-// WM: waves along M (2: four waves of 128 x 16 NI, one per SIMD; 4: EIGHT waves of 64 x 16 NI, two per SIMD)
-template <int NI, int NS, int WM, bool OUT_F32, bool F16>
-__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2, WM / 2))) void gemm_mfma_bf16_quad_kernel(
+// TBM: rows of the workgroup tile (256; 64 / 128: the few-tile shapes' form, see gemm_pipe_launch below).
+// WM: waves along M (2: four waves of (TBM / 2) x 16 NI, one per SIMD; 4: EIGHT waves of (TBM / 4) x 16 NI, two per SIMD)
+// OCC: waves per SIMD the register budget is cut for (WM / 2 for one workgroup per CU; 2 with WM = 2: two four-wave workgroups per CU)
+template <int TBM, int NI, int NS, int WM, int OCC, bool OUT_F32, bool F16>
+__global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2, OCC))) void gemm_mfma_bf16_quad_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M, int N, int K,
     int lda, int ldc, int act, int tiles_m, int tiles_n) {
-    constexpr int NW = WM * 2, MI = 16 / WM;     // waves; 16-row A fragments per wave (8 or 4)
-    constexpr int TN = 32 * NI, STG = (GQ_BM + TN) * 128, PT = 32 + 4 * NI, NPW = (PT + NW - 1) / NW;
-    static_assert(NS >= 2 && (NI * MI) % 4 == 0, "MFMA groups of four");
+    constexpr int NW = WM * 2, MI = TBM / 16 / WM;     // waves; 16-row A fragments per wave (8 or 4 at 256 rows)
+    constexpr int PA = TBM / 8;                  // DMA pieces of A per stage
+    constexpr int TN = 32 * NI, STG = (TBM + TN) * 128, PT = PA + 4 * NI, NPW = (PT + NW - 1) / NW;
+    static_assert(NS >= 2 && (NI * MI) % 4 == 0 && MI >= 1 && MI <= 8 && NI <= 8, "MFMA groups of four");
     constexpr int G = NI * MI / 4;               // MFMA groups of 4 per phase (NI x MI fragment pairs)
     constexpr int R = MI + NI;                   // fragment reads per phase
+    // 256-row tiles: 4 MFMAs, then two reads, group after group (LDS and MFMA busy side by side through the phase).  The small tiles have 2 / 4
+    // groups per phase: their reads go FIRST and into the first half of the groups, so that every read has at least four MFMAs behind it
+    // before the phase's wait (with "MFMAs, then reads" the last group's reads would be issued right in front of the wait)
+    constexpr bool RF = TBM != GQ_BM;
+    constexpr int RG = RF ? (G + 1) / 2 : G;     // groups that issue reads
+    constexpr int RPG = (R + RG - 1) / RG;       // fragment reads per such group (2 at 256 x 160; 6 at 64 x 128, 4 at 128 x 128)
     constexpr int PPG = (NPW + G - 1) / G;       // DMA pieces per group
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -60,16 +71,16 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2
     const int nk = K / GQ_BK;
     const int tile = gq_xcd_remap(blockIdx.x, gridDim.x);      // m fastest: the workgroups an XCD runs together share a W panel
     const int tm = tile % tiles_m, tn = tile / tiles_m;
-    const int m0 = tm * GQ_BM, n0 = tn * TN;
+    const int m0 = tm * TBM, n0 = tn * TN;
 
-    // DMA pieces of a stage: 32 of A (8 rows each), then 4 NI of W; wave w brings pieces w NPW .. w NPW + NPW - 1.  Lane l brings row
+    // DMA pieces of a stage: TBM / 8 of A (8 rows each), then 4 NI of W; wave w brings pieces w NPW .. w NPW + NPW - 1.  Lane l brings row
     // (l >> 3) of the piece, logical chunk (l & 7) ^ (l >> 3), to LDS byte piece * 1024 + l * 16 of the stage
     const bf16_t* src[NPW];
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
         const int p = min(wid * NPW + j, PT - 1);   // (eight waves: 56 slots for 52 pieces -- the last wave brings piece 51 again, same bytes)
         const int rl = lane >> 3, c = (lane & 7) ^ rl;
-        src[j] = p < 32 ? A + (long long)min(m0 + p * 8 + rl, M - 1) * lda + c * 8 : W + (long long)min(n0 + (p - 32) * 8 + rl, N - 1) * K + c * 8;
+        src[j] = p < PA ? A + (long long)min(m0 + p * 8 + rl, M - 1) * lda + c * 8 : W + (long long)min(n0 + (p - PA) * 8 + rl, N - 1) * K + c * 8;
     }
 #define TEO_GQ_PIECE(KT, ST, J)                                                                                                  \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[J] + (long long)(KT) * GQ_BK),         \
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2
         const int isw_ = (RI) >= MI;                                                                              \
         const int r_ = (isw_ ? rw0 + ((RI) - MI) * 16 : ra0 + (RI) * 16);                                         \
         F[isw_ ? (RI) - MI : 8 + (RI)] =                                                                          \
-            *reinterpret_cast<const teo_h16x8*>(smem + (ST) * STG + (isw_ ? GQ_BM * 128 : 0) + r_ * 128 + ((((KS) * 4 + fg) ^ (r_ & 7)) << 4)); \
+            *reinterpret_cast<const teo_h16x8*>(smem + (ST) * STG + (isw_ ? TBM * 128 : 0) + r_ * 128 + ((((KS) * 4 + fg) ^ (r_ & 7)) << 4)); \
     }
 #define TEO_GQ_MFMA4(F, GI)                                                                                       \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                            \
@@ -109,30 +120,43 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int r = 0; r < R; ++r) { TEO_GQ_READ(xf, 0, 0, r) }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), as a builtin: hipcc's wait pass does not read inline asm, and a wait it cannot see
+                                                // in the loop's preheader makes it put its own lgkmcnt(0) in front of the loop's first MFMA
     int st = 0;
     // MORE: a tile kt + NS exists (its pieces go into the stage this tile releases); MORE1: a tile kt + 1 exists
 #define TEO_GQ_KTILE(MORE, MORE1)                                                                                 \
     {                                                                                                             \
         const int stn = st + 1 == NS ? 0 : st + 1;                                                                \
         _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                           \
+            if (RF) {                                                                                             \
+                _Pragma("unroll") for (int t = 0; t < RPG; ++t)                                                   \
+                    if (g * RPG + t < R) { TEO_GQ_READ(yf, st, 1, g * RPG + t) }                                  \
+            }                                                                                                     \
             TEO_GQ_MFMA4(xf, g)                                                                                   \
-            if (2 * g < R) { TEO_GQ_READ(yf, st, 1, 2 * g) }                                                      \
-            if (2 * g + 1 < R) { TEO_GQ_READ(yf, st, 1, 2 * g + 1) }                                              \
+            if (!RF) {                                                                                            \
+                _Pragma("unroll") for (int t = 0; t < RPG; ++t)                                                   \
+                    if (g * RPG + t < R) { TEO_GQ_READ(yf, st, 1, g * RPG + t) }                                  \
+            }                                                                                                     \
         }                                                                                                         \
-        if (MORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * NPW) : "memory");                \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        /* builtin waits (hipcc's wait pass cannot read an asm one and would add its own lgkmcnt(0) behind the next reads) */ \
+        if (MORE) __builtin_amdgcn_s_waitcnt(GQ_WAIT_VM_LGKM0((NS - 2) * NPW));                                   \
+        else __builtin_amdgcn_s_waitcnt(GQ_WAIT_VM_LGKM0(0));                                                     \
+        asm volatile("" ::: "memory");                                                                            \
         __builtin_amdgcn_s_barrier();                                                                             \
         _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                           \
+            if (RF && MORE1) {                                                                                    \
+                _Pragma("unroll") for (int t = 0; t < RPG; ++t)                                                   \
+                    if (g * RPG + t < R) { TEO_GQ_READ(xf, stn, 0, g * RPG + t) }                                 \
+            }                                                                                                     \
             TEO_GQ_MFMA4(yf, g)                                                                                   \
             _Pragma("unroll") for (int t = 0; t < PPG; ++t)                                                       \
                 if (g * PPG + t < NPW && MORE) { TEO_GQ_PIECE(kt + NS, st, g * PPG + t) }                         \
-            if (MORE1) {                                                                                          \
-                if (2 * g < R) { TEO_GQ_READ(xf, stn, 0, 2 * g) }                                                 \
-                if (2 * g + 1 < R) { TEO_GQ_READ(xf, stn, 0, 2 * g + 1) }                                         \
+            if (!RF && MORE1) {                                                                                   \
+                _Pragma("unroll") for (int t = 0; t < RPG; ++t)                                                   \
+                    if (g * RPG + t < R) { TEO_GQ_READ(xf, stn, 0, g * RPG + t) }                                 \
             }                                                                                                     \
         }                                                                                                         \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* landed long ago: tells hipcc's wait pass so */      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0): landed long ago; as a builtin hipcc's wait pass sees it */ \
         st = stn;                                                                                                 \
     }
     int kt = 0;
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2
     // rows by a rolled loop, 8-byte stores covering a row's 160 contiguous bytes: bit-identical, o 73.1 -> 89.8 us, down 175.9 -> 187.2, fc1 + GELU
     // 51.2 -> 52.2.  The activation's cost here is VALU issue with ONE wave per SIMD, not code size: 160 erf per lane, no second wave to
     // alternate with -- which is why the eight-wave layout is the default.)
-    gemm_epilogue<NI, MI, 4, false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (MI * 16), n0 + wn * (NI * 16), fr, fg);
+    gemm_epilogue<NI, MI, (MI % 4 == 0 ? 4 : MI), false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (MI * 16), n0 + wn * (NI * 16), fr, fg);
 }
 
 // 256 x 160 tiles, 3 stages (156 KB: one workgroup per CU), eight or four waves (tune().gemm_quad_waves).  No SwiGLU form (gate / up run
@@ -165,8 +189,8 @@ int gemm_quad_launch(const void* A, const void* W, const void* bias, const void*
 #define TEO_GQ_LAUNCH_W(OF, FV, WMV)                                                                                              \
     {                                                                                                                             \
         static unsigned long long attr_mask = 0;                                                                                  \
-        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<NI, NS, WMV, OF, FV>), (int)lds, &attr_mask, "gemm_quad")) return e; \
-        gemm_mfma_bf16_quad_kernel<NI, NS, WMV, OF, FV><<<nwg, (WMV) * 128, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<GQ_BM, NI, NS, WMV, (WMV) / 2, OF, FV>), (int)lds, &attr_mask, "gemm_quad")) return e; \
+        gemm_mfma_bf16_quad_kernel<GQ_BM, NI, NS, WMV, (WMV) / 2, OF, FV><<<nwg, (WMV) * 128, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                           (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
     }
 #define TEO_GQ_LAUNCH_T(OF, FV) { if (eight) TEO_GQ_LAUNCH_W(OF, FV, 4) else TEO_GQ_LAUNCH_W(OF, FV, 2) }
@@ -177,6 +201,36 @@ int gemm_quad_launch(const void* A, const void* W, const void* bias, const void*
 #undef TEO_GQ_LAUNCH_W
     note_kernel(eight ? "gemm_quad_160" : "gemm_quad_160_w4");
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_quad");
+    return TEO_OK;
+}
+
+// The same K loop on the few-tile shapes' tiles (round 6): 64 x 128 (four waves of 32 x 64, ring of 3 = 72 KB: two workgroups per CU) and
+// 128 x 128 (four waves of 64 x 64, ring of 3 = 96 KB: one per CU).  Why: where a launch has at most one or two workgroups per CU (LLaMA o /
+// down below ~1000 rows, the tower's fc2 / out_proj / qkv at T <= 4) a SIMD holds ONE wave, and gemm_narrow.hip's loop as hipcc schedules it
+// is ds_read x 4 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, four times per K tile: the whole LDS latency is exposed four times (0.5 us per K
+// tile of a 64 x 128 tile alone on its CU; 16 MFMAs are 0.1 us).  Here the reads of k-half 1 fly under the MFMAs of k-half 0 and the
+// next tile's under k-half 1's.  Same LDS image, fragment reads and k-ascending chain: bit-identical to every other family.
+int gemm_pipe_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
+                     int act, bool of32, bool f16, int bm, hipStream_t st) {
+    constexpr int NI = 4, NS = 3, TN = 32 * NI;
+    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, TN);
+    const int nwg = tiles_m * tiles_n;
+#define TEO_GP_LAUNCH_W(OF, FV, BMV, OCCV)                                                                                        \
+    {                                                                                                                             \
+        constexpr size_t lds = (size_t)NS * ((BMV) + TN) * 128;                                                                   \
+        static unsigned long long attr_mask = 0;                                                                                  \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<BMV, NI, NS, 2, OCCV, OF, FV>), (int)lds, &attr_mask, "gemm_pipe")) return e; \
+        gemm_mfma_bf16_quad_kernel<BMV, NI, NS, 2, OCCV, OF, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+                                                                          (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
+    }
+#define TEO_GP_LAUNCH_T(OF, FV) { if (bm == 128) TEO_GP_LAUNCH_W(OF, FV, 128, 1) else TEO_GP_LAUNCH_W(OF, FV, 64, 2) }
+#define TEO_GP_LAUNCH_F(OF) { if (f16) TEO_GP_LAUNCH_T(OF, true) else TEO_GP_LAUNCH_T(OF, false) }
+    if (of32) TEO_GP_LAUNCH_F(true) else TEO_GP_LAUNCH_F(false)
+#undef TEO_GP_LAUNCH_F
+#undef TEO_GP_LAUNCH_T
+#undef TEO_GP_LAUNCH_W
+    note_kernel(bm == 128 ? "gemm_pipe_128" : "gemm_pipe_64");
+    TEO_LAUNCH_CHECK("gemm_mfma_bf16_pipe");
     return TEO_OK;
 }
 
