@@ -51,7 +51,8 @@ int teo_version(void);
 const char* teo_last_error(void);
 /* Diagnostics: which kernel family the most recent teo_gemm* / teo_attention call of this thread dispatched to
  * ("gemm_simple", "gemm_mfma_128", "gemm_mfma_128_sk", "gemm_wide", "gemm_wide_sk", "gemm_big", "gemm_big_hybrid", "gemm_fp8_*",
- * "gemm_big_hybrid_cohort", "gemm_narrow_64", "gemm_narrow_128", "gemm_quad_160", "gemm_quad_160_w4", "attn_flash32", "attn_simple").  Lets the parity tests state which production kernel they checked. */
+ * "gemm_big_hybrid_cohort", "gemm_narrow_64", "gemm_narrow_128", "gemm_narrow_128w8", "gemm_pipe_64x64", "gemm_pipe_64", "gemm_pipe_64_r4", "gemm_pipe_128x96",
+ * "gemm_pipe_128", "gemm_quad_160", "gemm_quad_160_w4", "attn_flash32", "attn_simple").  Lets the parity tests state which production kernel they checked. */
 const char* teo_last_kernel(void);
 /* Size of a struct of this header as the LIBRARY was built with it (0 for an unknown name): a binding checks its own layout against it
  * at load time -- "teo_vit_desc", "teo_proj_desc", "teo_llama_desc", "teo_decode_state", "teo_decode_batch_state", "teo_attn_args". */
@@ -78,6 +79,10 @@ size_t teo_sizeof(const char* struct_name);
  *                   the shape allows), "gemm_narrow" (64 / 128 x 128 LDS-DMA
  *                   tiles for few-tile / short-K shapes: 0 off, 1 auto, 2 force), "gemm_narrow_bm" (its tile rows: 0 auto, 64, 128),
  *                   "gemm_narrow_waves" (the 128 x 128 tile on 4 waves or on 8: 0 auto, 4, 8),
+ *                   "gemm_narrow_pipe" (the software-pipelined small tiles -- 64 x 64, 64 x 128, 128 x 96, 128 x 128, sized for one workgroup per
+ *                   CU -- in place of the LDS-DMA tiles: 0 off, 1 auto (default), 2 with "gemm_narrow" = 2: the forced narrow tile runs in this
+ *                   form), "gemm_pipe_bn" (forced form: tile columns, 0 = 128, 64 with 64 rows, 96 with 128 rows), "gemm_pipe_stages" (forced
+ *                   form: ring depth, 0 = 3, 3, 4),
  *                   "gemm_quad" (256 x 160 tiles, hand-scheduled K loop with the accumulators in AGPRs, for problems that are one round of them: 0 off, 1 auto,
  *                   2 force), "gemm_quad_waves" (8: two waves per SIMD, the default; 4: one wave per SIMD with the whole register file), "gemm_fp8_wide" (0..3),
  *                   "gemm_fp8_big" (0..2) -- all bit-identical families

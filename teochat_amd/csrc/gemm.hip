@@ -679,6 +679,35 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         // o / down at M = 641 .. 1024 -- the EIGHT-wave 128 x 128 tile (two waves per SIMD on one tile per CU) beats the two four-wave 64 x 128
         // tiles per CU: o 41.5-43.1 vs 53.2-55.0 us, down 107-109 vs 134-136 (tools/vit_gemm_probe.py); it loses at 160 tiles (M = 638: 41.0 /
         // 103.4 vs 39.9 / 93.0) and on the tower's N = 1024 shapes (fc2 39.8 vs 37.0), which stay on the 64 x 128 tile
+        // round 6, late: the software-pipelined K loop on tiles sized for about ONE workgroup per CU (gemm_quad.hip gemm_pipe_launch; every
+        // candidate on every shape, weights from HBM: profiles/r06_pipe_candidates.txt; us, against the LDS-DMA tiles of gemm_narrow.hip).
+        // t64 / t128 / t96 / tq: tiles of 64 x 64 / 64 x 128 / 128 x 96 / 128 x 128.
+        //   t64 <= 288 (more with a short K loop): 64 x 64 -- LLaMA o / down at M <= 256 20 / 55 against 34 / 86; the tower at T <= 4: fc2 32-33 ->
+        //       15-18, out_proj 10.8 -> 6.3-6.6, qkv 11 -> 6.1-8.7, fc1 16 -> 9-11.6;
+        //   t128 <= 256: 64 x 128, ring of 4 (one per CU) for a long K loop -- o / down at M = 257 .. 512 28-31 / 79 against 35 / 86; fc2 at
+        //       T = 5 .. 7 27-31 against 33-35; out_proj at T = 5 .. 7 and qkv at T = 2 9.1-11.5 against 11.2-12.7;
+        //   t96 <= 256: 128 x 96 -- the tower's fc2 / out_proj at T = 8 .. 11 (187 .. 253 tiles) 31-36 / 12.4-13.4 against 41-43 / 15.3-16.1, qkv
+        //       at T = 3 .. 4 11 against 13.5-14; LLaMA o / down at M = 513 .. 640 (215 tiles, ring of 4) 30-36 / 77-90 against 41 / 90-92;
+        //   else, wide N and long K from 192 tiles of 128 x 128 on (o / down at M = 641 .. 1024): 128 x 128 -- 39-42 / 94-102 against 43-44 /
+        //       97-104 on the eight-wave LDS-DMA tile.
+        //   Not taken: a short K loop with an activation epilogue and more than 256 tiles of 64 x 128 (fc1 + GELU at T = 3 .. 4: one wave per
+        //   SIMD evaluates its 64-128 erf alone; the old 64 x 128 kernel's two workgroups per CU alternate: 18-19 against 20-25), and the
+        //   tower's N = 1024 shapes beyond 256 tiles of 128 x 96 (T >= 12: within 5 % either way).
+        if (tune().gemm_narrow == 1 && tune().gemm_narrow_pipe == 1 && tune().gemm_bm == 0 && tune().gemm_narrow_waves == 0 && bm == 64) {
+            const long long cm64 = cdiv(M, 64), cm128 = cdiv(M, 128);
+            const long long t64 = cm64 * cdiv(N, 64), t128 = cm64 * cdiv(N, 128), t96 = cm128 * cdiv(N, 96), tq = cm128 * tiles_n;
+            const bool long_wide = K >= 2048 && N >= 2048;
+            if (t64 <= 288 || (K <= 1024 && (t64 <= 384 || (N >= 2048 && t64 <= 512))))
+                return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, 64, 4, st);
+            if (t128 <= 256)
+                return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 64, 128, K >= 2048 ? 4 : 3, st);
+            if (!(K <= 1024 && act != TEO_ACT_NONE)) {
+                if (t96 <= 256)
+                    return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 128, 96, long_wide ? 4 : 3, st);
+                if (long_wide && tq >= 192)
+                    return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 128, 128, 3, st);
+            }
+        }
         if (tune().gemm_narrow == 1 && tune().gemm_bm == 0 && tune().gemm_narrow_waves != 4 && bm == 64 && K >= 2048 && N >= 2048 &&
             (long long)cdiv(M, 128) * tiles_n >= 192)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, 128, st, true);

@@ -125,10 +125,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mfm
 // 128 x 128 tile alone on its CU); with two waves per SIMD one reads while the other multiplies.
 int gemm_narrow_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                        int act, bool of32, bool f16, int bm, hipStream_t st, bool waves8) {
-    // the software-pipelined form of the same tiles (gemm_quad.hip gemm_pipe_launch): 1 both tile heights, 2 the 64-row tile only, 3 the 128-row only
-    const int pipe = tune().gemm_narrow_pipe;
-    if (pipe == 1 || (pipe == 2 && bm == 64) || (pipe == 3 && bm == 128))
-        return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, bm, st);
+    // forced: the software-pipelined form of the same tiles (gemm_quad.hip gemm_pipe_launch; its automatic rule is in gemm.hip)
+    if (tune().gemm_narrow_pipe == 2)
+        return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, bm, tune().gemm_pipe_bn, tune().gemm_pipe_stages, st);
     const int bn = 128;
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
     const int nwg = tiles_m * tiles_n;

@@ -204,32 +204,47 @@ int gemm_quad_launch(const void* A, const void* W, const void* bias, const void*
     return TEO_OK;
 }
 
-// The same K loop on the few-tile shapes' tiles (round 6): 64 x 128 (four waves of 32 x 64, ring of 3 = 72 KB: two workgroups per CU) and
-// 128 x 128 (four waves of 64 x 64, ring of 3 = 96 KB: one per CU).  Why: where a launch has at most one or two workgroups per CU (LLaMA o /
-// down below ~1000 rows, the tower's fc2 / out_proj / qkv at T <= 4) a SIMD holds ONE wave, and gemm_narrow.hip's loop as hipcc schedules it
-// is ds_read x 4 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, four times per K tile: the whole LDS latency is exposed four times (0.5 us per K
-// tile of a 64 x 128 tile alone on its CU; 16 MFMAs are 0.1 us).  Here the reads of k-half 1 fly under the MFMAs of k-half 0 and the
-// next tile's under k-half 1's.  Same LDS image, fragment reads and k-ascending chain: bit-identical to every other family.
+// The same K loop on the few-tile shapes' tiles (round 6): 64 x 64 and 64 x 128 (four waves of 32 x 32 / 32 x 64) and 128 x 128 (four waves of
+// 64 x 64), rings of 3 or 4 stages.  Why: where a launch has at most one or two workgroups per CU (LLaMA o / down below ~1000 rows, every tower
+// GEMM at T <= 4, fc2 / out_proj at every T) a SIMD holds ONE wave, and gemm_narrow.hip's loop as hipcc schedules it is
+// ds_read x 4 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, four times per K tile: the whole LDS latency is exposed four times (0.5 us per K tile of a
+// 64 x 128 tile alone on its CU; its 16 MFMAs are 0.1 us).  Here the reads of k-half 1 fly under the MFMAs of k-half 0 and the next tile's under
+// k-half 1's.  And the tile is chosen so that the launch has about one workgroup per CU: a CU's LDS-DMA stream stops scaling at 50-70 GB/s
+// (a ring of 6 stages is no faster than one of 4), so a problem with 64 tiles of 64 x 128 runs on 64 CUs' worth of memory parallelism -- as
+// 128 tiles of 64 x 64 it is 30 % faster (LLaMA o at M <= 256: 33.5 -> 29 (pipelined) -> 21 us; the tower's fc2 at T = 2: 31 -> 22 -> 15).
+// Same LDS image, fragment reads and k-ascending chain: bit-identical to every other family (tests/test_gemm_fuzz_gpu.py).
+// bm 64: tn 64 (ring of 4 = 64 KB: two per CU) or 128 (ring of 3 = 72 KB: two per CU; ring of 4 = 96 KB: one per CU, for launches of at most
+// one workgroup per CU with a long K loop); bm 128: tn 128, ring of 3 = 96 KB
 int gemm_pipe_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                     int act, bool of32, bool f16, int bm, hipStream_t st) {
-    constexpr int NI = 4, NS = 3, TN = 32 * NI;
-    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, TN);
+                     int act, bool of32, bool f16, int bm, int tn, int ns, hipStream_t st) {
+    if (bm != 128) bm = 64;
+    if (bm == 128) tn = tn == 96 ? 96 : 128;
+    else if (tn != 64) tn = 128;
+    ns = (bm == 128) ? (tn == 96 && ns == 4 ? 4 : 3) : (tn == 64 ? 4 : (ns == 4 ? 4 : 3));
+    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, tn);
     const int nwg = tiles_m * tiles_n;
-#define TEO_GP_LAUNCH_W(OF, FV, BMV, OCCV)                                                                                        \
+#define TEO_GP_LAUNCH_W(OF, FV, BMV, NIV, NSV, OCCV)                                                                              \
     {                                                                                                                             \
-        constexpr size_t lds = (size_t)NS * ((BMV) + TN) * 128;                                                                   \
+        constexpr size_t lds = (size_t)(NSV) * ((BMV) + 32 * (NIV)) * 128;                                                        \
         static unsigned long long attr_mask = 0;                                                                                  \
-        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<BMV, NI, NS, 2, OCCV, OF, FV>), (int)lds, &attr_mask, "gemm_pipe")) return e; \
-        gemm_mfma_bf16_quad_kernel<BMV, NI, NS, 2, OCCV, OF, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<BMV, NIV, NSV, 2, OCCV, OF, FV>), (int)lds, &attr_mask, "gemm_pipe")) return e; \
+        gemm_mfma_bf16_quad_kernel<BMV, NIV, NSV, 2, OCCV, OF, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                           (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
     }
-#define TEO_GP_LAUNCH_T(OF, FV) { if (bm == 128) TEO_GP_LAUNCH_W(OF, FV, 128, 1) else TEO_GP_LAUNCH_W(OF, FV, 64, 2) }
+#define TEO_GP_LAUNCH_T(OF, FV)                                                                                                   \
+    {                                                                                                                             \
+        if (bm == 128 && tn == 96) { if (ns == 4) TEO_GP_LAUNCH_W(OF, FV, 128, 3, 4, 1) else TEO_GP_LAUNCH_W(OF, FV, 128, 3, 3, 1) } \
+        else if (bm == 128) TEO_GP_LAUNCH_W(OF, FV, 128, 4, 3, 1)                                                                 \
+        else if (tn == 64) TEO_GP_LAUNCH_W(OF, FV, 64, 2, 4, 2)                                                                   \
+        else if (ns == 4) TEO_GP_LAUNCH_W(OF, FV, 64, 4, 4, 2)                                                                    \
+        else TEO_GP_LAUNCH_W(OF, FV, 64, 4, 3, 2)                                                                                 \
+    }
 #define TEO_GP_LAUNCH_F(OF) { if (f16) TEO_GP_LAUNCH_T(OF, true) else TEO_GP_LAUNCH_T(OF, false) }
     if (of32) TEO_GP_LAUNCH_F(true) else TEO_GP_LAUNCH_F(false)
 #undef TEO_GP_LAUNCH_F
 #undef TEO_GP_LAUNCH_T
 #undef TEO_GP_LAUNCH_W
-    note_kernel(bm == 128 ? "gemm_pipe_128" : "gemm_pipe_64");
+    note_kernel(bm == 128 ? (tn == 96 ? "gemm_pipe_128x96" : "gemm_pipe_128") : (tn == 64 ? "gemm_pipe_64x64" : (ns == 4 ? "gemm_pipe_64_r4" : "gemm_pipe_64")));
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_pipe");
     return TEO_OK;
 }

@@ -18,6 +18,12 @@ PLAIN = {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_qu
 FORCED = (("64x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 64}, "gemm_narrow_64"),
           ("128x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 128}, "gemm_narrow_128"),
           ("128x128 LDS-DMA, eight waves", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_waves": 8}, "gemm_narrow_128w8"),      # round 6
+          ("64x64 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 64, "gemm_narrow_pipe": 2, "gemm_pipe_bn": 64}, "gemm_pipe_64x64"),            # round 6
+          ("64x128 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 64, "gemm_narrow_pipe": 2}, "gemm_pipe_64"),
+          ("64x128 software-pipelined, ring of 4", {"gemm_narrow": 2, "gemm_narrow_bm": 64, "gemm_narrow_pipe": 2, "gemm_pipe_stages": 4}, "gemm_pipe_64_r4"),
+          ("128x128 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_pipe": 2}, "gemm_pipe_128"),
+          ("128x96 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_pipe": 2, "gemm_pipe_bn": 96}, "gemm_pipe_128x96"),
+          ("128x96 software-pipelined, ring of 4", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_pipe": 2, "gemm_pipe_bn": 96, "gemm_pipe_stages": 4}, "gemm_pipe_128x96"),
           ("256x160 eight waves", {"gemm_quad": 2}, "gemm_quad_160"),
           ("256x160 four waves", {"gemm_quad": 2, "gemm_quad_waves": 4}, "gemm_quad_160_w4"),
           ("128x256", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}, "gemm_wide"),      # (both need
@@ -84,4 +90,4 @@ def test_every_tile_family_is_bitwise_the_plain_kernel_on_random_shapes(seed, dt
                 assert ran == kernel, (name, ran, M, N, K)
             assert torch.equal(got, want), (name, ran, M, N, K, extra, float((got.float() - want.float()).abs().max()))
     L.tune_reset()
-    assert {"gemm_narrow_64", "gemm_narrow_128", "gemm_narrow_128w8", "gemm_quad_160", "gemm_quad_160_w4", "gemm_wide", "gemm_big", "gemm_mfma_64"} <= seen
+    assert {"gemm_narrow_64", "gemm_narrow_128", "gemm_narrow_128w8", "gemm_pipe_64", "gemm_pipe_64_r4", "gemm_pipe_64x64", "gemm_pipe_128", "gemm_pipe_128x96", "gemm_quad_160", "gemm_quad_160_w4", "gemm_wide", "gemm_big", "gemm_mfma_64"} <= seen

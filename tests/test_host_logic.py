@@ -291,7 +291,7 @@ def test_hand_scheduled_kernels_have_no_spills_and_no_scratch():
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("no hipcc on this machine")
     from tools.kernel_meta import kernel_meta
-    for src, want in (("gemm_quad.hip", 8), ("gemm_narrow.hip", 12)):
+    for src, want in (("gemm_quad.hip", 24), ("gemm_narrow.hip", 12)):
         ks = kernel_meta(os.path.join(ROOT, "teochat_amd", "csrc", src))
         assert len(ks) >= want, (src, len(ks))
         for k in ks:
@@ -300,4 +300,5 @@ def test_hand_scheduled_kernels_have_no_spills_and_no_scratch():
             # eight waves (two per SIMD): at most 256 registers per lane incl. the AGPR-pinned accumulators; four waves (one per SIMD): 512
             for k in ks:
                 assert k["vgpr_count"] <= (256 if k["max_flat_workgroup_size"] == 512 else 512), k
-                assert k["agpr_count"] >= 100, k                      # the accumulators really live in AGPRs
+                big = "<256," in k["name"] or "ILi256E" in k["name"]
+                assert k["agpr_count"] >= (100 if big else 16), k     # the accumulators really live in AGPRs (256 x 160: 100 / 160; the small tiles 16 .. 64)

@@ -121,13 +121,18 @@ FAMILIES = (("production dispatch", {}),
             ("128x128 stream-K", {"gemm_wide": 0, "gemm_big": 0, "gemm_sk": 2, "gemm_narrow": 0}),
             ("64x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 64}),           # round 5 (SwiGLU GEMMs have no such form: they fall
             ("128x128 LDS-DMA", {"gemm_narrow": 2, "gemm_narrow_bm": 128}),         # through to the production dispatch under these knobs)
+            ("64x64 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 64, "gemm_narrow_pipe": 2, "gemm_pipe_bn": 64}),      # round 6
+            ("64x128 software-pipelined, ring of 4", {"gemm_narrow": 2, "gemm_narrow_bm": 64, "gemm_narrow_pipe": 2, "gemm_pipe_stages": 4}),
+            ("128x128 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_pipe": 2}),
+            ("128x96 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_pipe": 2, "gemm_pipe_bn": 96}),
             ("256x160 eight waves", {"gemm_quad": 2}),
             ("256x160 four waves", {"gemm_quad": 2, "gemm_quad_waves": 4}),
             ("128x256 tile", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0}),
             ("128x256 stream-K", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 2}),
             ("256x256 tile", {"gemm_big": 2, "gemm_big_hybrid": 0}),
             ("256x256 hybrid", {"gemm_big": 2, "gemm_big_hybrid": 2}))
-DEFAULTS = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1, "gemm_narrow": 1, "gemm_narrow_bm": 0, "gemm_quad": 1, "gemm_quad_waves": 8}
+DEFAULTS = {"gemm_wide": 1, "gemm_big": 1, "gemm_sk": 1, "gemm_big_hybrid": 1, "gemm_narrow": 1, "gemm_narrow_bm": 0, "gemm_quad": 1, "gemm_quad_waves": 8,
+            "gemm_narrow_pipe": 1, "gemm_pipe_bn": 0, "gemm_pipe_stages": 0}
 
 
 def gemm_all_families(gw, A, W, ref, tag, report, families=FAMILIES, **kw):
@@ -167,7 +172,7 @@ def test_llama_layer_walk_at_7b_shapes(fmt):
     qkv = R(n1 @ Wqkv.t())
     d_n1, d_Wqkv = G.dev(n1, bf), G.dev(Wqkv, bf)
     seen = gemm_all_families(gw, d_n1, d_Wqkv, qkv, "qkv GEMM M=2168 N=12288 K=4096", report)
-    assert {"gemm_mfma_128", "gemm_wide", "gemm_big", "gemm_narrow_64", "gemm_narrow_128"} <= seen, seen
+    assert {"gemm_mfma_128", "gemm_wide", "gemm_big", "gemm_narrow_64", "gemm_narrow_128", "gemm_pipe_64x64", "gemm_pipe_64_r4", "gemm_pipe_128", "gemm_pipe_128x96"} <= seen, seen
     # RoPE + KV append
     pos = torch.arange(S)
     c, s_ = O.rope_cos_sin(pos, hd, 10000.0, torch.float32)

@@ -23,7 +23,7 @@ def _engine(name="tinyB", dtype=torch.bfloat16):
 
 
 def test_two_engines_keep_their_own_knobs():
-    """Engine A forces the 128-row plain tile, engine B keeps the dispatch's choice (the 64 x 128 LDS-DMA tile for this small projector GEMM).  Calls
+    """Engine A forces the 128-row plain tile, engine B keeps the dispatch's choice (the software-pipelined 64 x 64 tile for this small projector GEMM).  Calls
     are interleaved; each engine's projector runs the family ITS block names every time (teo_last_kernel), the thread's bound block is a
     third, different choice that neither engine sees, and the values are bit-identical across families."""
     lib = G.lib()
@@ -36,7 +36,7 @@ def test_two_engines_keep_their_own_knobs():
     assert lib.teo_last_kernel().decode() == "gemm_mfma_128"
     for _ in range(3):
         yb = b.project(feats)
-        assert lib.teo_last_kernel().decode() == "gemm_narrow_64"
+        assert lib.teo_last_kernel().decode() == "gemm_pipe_64x64"
         ya = a.project(feats)
         assert lib.teo_last_kernel().decode() == "gemm_mfma_128"
         assert torch.equal(ya, ya0) and torch.equal(ya, yb)
@@ -49,7 +49,7 @@ def test_two_engines_keep_their_own_knobs():
     # an engine's knob change drops its captured decode graph (the capture keeps kernel choices) and only its own
     a.tune_reset()
     a.project(feats)
-    assert lib.teo_last_kernel().decode() == "gemm_narrow_64"
+    assert lib.teo_last_kernel().decode() == "gemm_pipe_64x64"
 
 
 def test_two_threads_do_not_share_knobs():
@@ -113,4 +113,4 @@ def test_nothing_outlives_a_released_block():
     assert lib.teo_last_kernel().decode() == "gemm_mfma_128"
     L.tune_release()
     G.gemm(A, W)
-    assert lib.teo_last_kernel().decode() == "gemm_narrow_64"        # 12 tiles of 128 x 128: the dispatch's own choice is the 64-row LDS-DMA tile
+    assert lib.teo_last_kernel().decode() == "gemm_pipe_64x64"       # 48 tiles of 64 x 64: the dispatch's own choice is the software-pipelined small tile

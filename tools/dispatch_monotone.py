@@ -2,7 +2,7 @@
 """A GEMM with more rows cannot be faster: walk M in steps of 64 through the production dispatch for the four LLaMA prefill GEMMs (and the
 tower's four) and flag every row count whose time exceeds that of a LARGER row count by more than 8 % -- each such inversion is a dispatch
 rule picking a worse tile family than its neighbour's (the complement of tools/shape_sweep.py, which walks the shapes a caller can produce
-through the whole phases; this walks the rule boundaries themselves).  Weights rotate over 8 copies so that they come from HBM.
+through the whole phases; this walks the rule boundaries themselves).  Weights rotate over enough copies (>= 600 MB) that they come from HBM, not from the Infinity Cache.
 
 --fp8 walks the four LLaMA GEMMs of the w8a8 prefill (teo_gemm_fp8_ws) instead.
 
@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dispatch_monotone.txt"))
     ap.add_argument("--tol", type=float, default=0.08)
     ap.add_argument("--fp8", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="knob=value in the calling thread's tune block")
+    ap.add_argument("--only", default="", help="comma-separated shape names (qkv,o,gateup,down,v.qkv,v.out,v.fc1,v.fc2)")
     args = ap.parse_args()
     shapes = (("qkv", 12288, 4096, 0, L.ACT_NONE, False, False), ("o", 4096, 4096, 0, L.ACT_NONE, False, True),
               ("gateup", 22016, 4096, L.GEMM_SWIGLU16, L.ACT_NONE, False, False), ("down", 4096, 11008, 0, L.ACT_NONE, False, True),
@@ -54,10 +56,15 @@ def main():
               ("v.fc1", 4096, 1024, 0, L.ACT_GELU_ERF, True, False), ("v.fc2", 1024, 4096, 0, L.ACT_NONE, True, True))
     if args.fp8:
         shapes = tuple(s for s in shapes if not s[0].startswith("v."))
+    if args.only:
+        shapes = tuple(s for s in shapes if s[0] in args.only.split(","))
+    for kv in args.tune:
+        k, v = kv.split("=")
+        L.tune_set(k.encode(), int(v))
     Ms = list(range(args.lo, args.hi + 1, args.step))
     lines, flagged = [], []
     for name, N, K, flags, act, with_bias, with_res in shapes:
-        Ws = [(torch.randn(N, K, device=dev) * 0.02).to(bf) for _ in range(8 if N * K * 2 > 16e6 else 16)]
+        Ws = [(torch.randn(N, K, device=dev) * 0.02).to(bf) for _ in range(max(8, -(-600_000_000 // (N * K * 2))))]       # > 2 x the 256 MB Infinity Cache: every launch streams its weights from HBM
         if args.fp8:
             Ws = [(W.float() * 100).to(torch.float8_e4m3fn).view(torch.uint8) for W in Ws]
             w_scale = torch.rand(N, device=dev) * 0.01 + 0.005

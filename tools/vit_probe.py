@@ -1,5 +1,5 @@
 """ViT tower + projector alone (T frames), for rocprofv3 --kernel-trace --stats: where the tower's time goes.
-usage: python tools/vit_probe.py [T] [iters]"""
+usage: python tools/vit_probe.py [T] [iters] [knob=value ...]      (knobs: the engine's teo_tune block, e.g. gemm_narrow_pipe=0)"""
 import os
 import sys
 import time
@@ -16,6 +16,9 @@ def main():
     tok, model, _, _ = load_pretrained_model("synthetic:teochat-7b", None, "synthetic:teochat-7b", device="cuda:0", dtype=torch.bfloat16,
                                              max_seq=512)
     eng = model.engine
+    for kv in sys.argv[3:]:
+        k, v = kv.split("=")
+        eng.tune_set(k, int(v))
     px = torch.randn(T, 3, 224, 224, device="cuda:0", dtype=torch.bfloat16)
     for _ in range(3):
         f = eng.vit_features(px)
@@ -31,7 +34,7 @@ def main():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     flops_vit = T * 155.3e9
-    print(f"T={T}: tower {1e3 * (t1 - t0) / iters:.3f} ms ({flops_vit / ((t1 - t0) / iters) / 1e12:.0f} TFLOP/s), projector {1e3 * (t2 - t1) / iters:.3f} ms")
+    print(f"T={T}{(' ' + ' '.join(sys.argv[3:])) if len(sys.argv) > 3 else ''}: tower {1e3 * (t1 - t0) / iters:.3f} ms ({flops_vit / ((t1 - t0) / iters) / 1e12:.0f} TFLOP/s), projector {1e3 * (t2 - t1) / iters:.3f} ms")
 
 
 if __name__ == "__main__":
