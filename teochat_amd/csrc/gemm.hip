@@ -744,7 +744,9 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         // every K (the tower's qkv at T = 15 / 16: 32.8 vs 37.6 us; fc1 / the projector at T = 12: 46.8 vs 52.1, 48.2 vs 50.0); 160 for the SwiGLU
         // epilogue, whose only other families are the 128 x 256 tile and the register-staged 128 x 128 one (gate/up at M = 257 .. 512, 172 tiles:
         // 92-94 us against 103-150)
-        const long long t_big_min = swiglu ? 160 : 192;
+        // (late round 6, weights from HBM: 156 for the other epilogues too -- the tower's fc1 at T = 10 .. 11 (160 / 176 tiles) 47 us against 49-53 on the
+        // two-stage 128 x 128 LDS-DMA tile, qkv at T = 13 .. 15 (156 .. 180 tiles of 256 x 256: 13-15 x 12) 32-33 against 33-35)
+        const long long t_big_min = swiglu ? 160 : 156;
         if (bm == 128 && K >= 2 * BK && (tune().gemm_big == 2 || (tune().gemm_big == 1 && tune().gemm_wide == 1 && t_big >= t_big_min && !sk_wide_shape &&
                                                                big_rounds * GEMM_BIG_ROUND_COST <= (double)cdiv(t_wide_, 256))))
             return gemm_big_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, swiglu, of32, f16, st, sk_ws, GEMM_SK_SLAB_BYTES);
