@@ -668,9 +668,18 @@ int gemm(const void* A, const void* W, const void* bias, const void* res, void* 
         const size_t lds = 4 * TILE_BYTES;
         const bool of32 = out_dtype == TEO_F32;
         // narrow LDS-DMA tiles (gemm_narrow.hip, round 5): forced here; the automatic rule sits below, after the families it competes with
+        if (tune().gemm_narrow == 2 && tune().gemm_narrow_pipe == 2 && swiglu)          // forced: the software-pipelined small tiles with the SwiGLU epilogue
+            return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, tune().gemm_narrow_bm == 128 ? 128 : 64, tune().gemm_pipe_bn,
+                                    tune().gemm_pipe_stages, st, true);
         if (tune().gemm_narrow == 2 && !swiglu)
             return gemm_narrow_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, tune().gemm_narrow_bm == 128 ? 128 : 64, st,
                                       tune().gemm_narrow_bm == 128 && tune().gemm_narrow_waves == 8);
+        // gate/up + SwiGLU at M <= 128 (a text-only prompt): one or two row tiles of 128 x 256 leave two thirds of the CUs idle (86 / 172 tiles: 66-68 us);
+        // the software-pipelined small tiles carry the SwiGLU epilogue too -- 64 x 128 at M <= 64 (344 tiles: 42 us), 128 x 128 at M <= 128 (172
+        // tiles: 50 us); from M = 129 on the 128 x 256 / 256 x 256 tiles are ahead again (tools/dispatch_monotone.py, round 6)
+        if (swiglu && M <= 128 && K >= 2048 && tune().gemm_narrow == 1 && tune().gemm_narrow_pipe == 1 && tune().gemm_bm == 0 && tune().gemm_wide == 1 &&
+            tune().gemm_big == 1)
+            return gemm_pipe_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, M <= 64 ? 64 : 128, 128, 4, st, true);
         if (tune().gemm_quad == 2 && !swiglu) return gemm_quad_launch(A, W, bias, res, C, M, N, K, lda, ldc, act, of32, f16, st);      // forced (its rule: below)
         // automatic: wherever the 64-row register-staged kernel was the choice (few tiles: the tower's out_proj / fc2, every tower GEMM and
         // the LLaMA o / down projections of config C2) the 64 x 128 LDS-DMA tile runs instead -- tools/vit_gemm_probe.py (round 5, us):

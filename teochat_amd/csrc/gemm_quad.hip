@@ -46,7 +46,7 @@ template <bool F16> __device__ __forceinline__ void gq_mfma(teo_f32x4& c, const 
 // TBM: rows of the workgroup tile (256; 64 / 128: the few-tile shapes' form, see gemm_pipe_launch below).
 // WM: waves along M (2: four waves of (TBM / 2) x 16 NI, one per SIMD; 4: EIGHT waves of (TBM / 4) x 16 NI, two per SIMD)
 // OCC: waves per SIMD the register budget is cut for (WM / 2 for one workgroup per CU; 2 with WM = 2: two four-wave workgroups per CU)
-template <int TBM, int NI, int NS, int WM, int OCC, bool OUT_F32, bool F16>
+template <int TBM, int NI, int NS, int WM, int OCC, bool OUT_F32, bool F16, bool SWIGLU = false>
 __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2, OCC))) void gemm_mfma_bf16_quad_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ bias, const bf16_t* res, void* Cv, int M, int N, int K,
     int lda, int ldc, int act, int tiles_m, int tiles_n) {
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(WM * 128) __attribute__((amdgpu_waves_per_eu(WM / 2
     // rows by a rolled loop, 8-byte stores covering a row's 160 contiguous bytes: bit-identical, o 73.1 -> 89.8 us, down 175.9 -> 187.2, fc1 + GELU
     // 51.2 -> 52.2.  The activation's cost here is VALU issue with ONE wave per SIMD, not code size: 160 erf per lane, no second wave to
     // alternate with -- which is why the eight-wave layout is the default.)
-    gemm_epilogue<NI, MI, (MI % 4 == 0 ? 4 : MI), false, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (MI * 16), n0 + wn * (NI * 16), fr, fg);
+    static_assert(!SWIGLU || NI % 2 == 0, "(gate 16 | up 16) column blocks per wave");
+    gemm_epilogue<NI, MI, (MI % 4 == 0 ? 4 : MI), SWIGLU, OUT_F32, F16>(acc, bv, bias != nullptr, res, Cv, M, N, ldc, act, m0 + wm * (MI * 16), n0 + wn * (NI * 16), fr, fg);
 }
 
 // 256 x 160 tiles, 3 stages (156 KB: one workgroup per CU), eight or four waves (tune().gemm_quad_waves).  No SwiGLU form (gate / up run
@@ -216,24 +217,26 @@ int gemm_quad_launch(const void* A, const void* W, const void* bias, const void*
 // bm 64: tn 64 (ring of 4 = 64 KB: two per CU) or 128 (ring of 3 = 72 KB: two per CU; ring of 4 = 96 KB: one per CU, for launches of at most
 // one workgroup per CU with a long K loop); bm 128: tn 128, ring of 3 = 96 KB
 int gemm_pipe_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                     int act, bool of32, bool f16, int bm, int tn, int ns, hipStream_t st) {
+                     int act, bool of32, bool f16, int bm, int tn, int ns, hipStream_t st, bool swiglu) {
     if (bm != 128) bm = 64;
+    if (swiglu && tn == 96) tn = 128;                    // the SwiGLU epilogue pairs 16-column blocks: an even number of them per wave
     if (bm == 128) tn = tn == 96 ? 96 : 128;
     else if (tn != 64) tn = 128;
     ns = (bm == 128) ? (tn == 96 && ns == 4 ? 4 : 3) : (tn == 64 ? 4 : (ns == 4 ? 4 : 3));
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, tn);
     const int nwg = tiles_m * tiles_n;
-#define TEO_GP_LAUNCH_W(OF, FV, BMV, NIV, NSV, OCCV)                                                                              \
+#define TEO_GP_LAUNCH_S(OF, FV, BMV, NIV, NSV, OCCV, SWV)                                                                         \
     {                                                                                                                             \
         constexpr size_t lds = (size_t)(NSV) * ((BMV) + 32 * (NIV)) * 128;                                                        \
         static unsigned long long attr_mask = 0;                                                                                  \
-        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<BMV, NIV, NSV, 2, OCCV, OF, FV>), (int)lds, &attr_mask, "gemm_pipe")) return e; \
-        gemm_mfma_bf16_quad_kernel<BMV, NIV, NSV, 2, OCCV, OF, FV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
+        if (int e = lds_attr_once(reinterpret_cast<const void*>(&gemm_mfma_bf16_quad_kernel<BMV, NIV, NSV, 2, OCCV, OF, FV, SWV>), (int)lds, &attr_mask, "gemm_pipe")) return e; \
+        gemm_mfma_bf16_quad_kernel<BMV, NIV, NSV, 2, OCCV, OF, FV, SWV><<<nwg, 256, lds, st>>>((const bf16_t*)A, (const bf16_t*)W, (const bf16_t*)bias, \
                                                                           (const bf16_t*)res, C, M, N, K, lda, ldc, act, tiles_m, tiles_n); \
     }
+#define TEO_GP_LAUNCH_W(OF, FV, BMV, NIV, NSV, OCCV) { if (swiglu) TEO_GP_LAUNCH_S(OF, FV, BMV, NIV, NSV, OCCV, true) else TEO_GP_LAUNCH_S(OF, FV, BMV, NIV, NSV, OCCV, false) }
 #define TEO_GP_LAUNCH_T(OF, FV)                                                                                                   \
     {                                                                                                                             \
-        if (bm == 128 && tn == 96) { if (ns == 4) TEO_GP_LAUNCH_W(OF, FV, 128, 3, 4, 1) else TEO_GP_LAUNCH_W(OF, FV, 128, 3, 3, 1) } \
+        if (bm == 128 && tn == 96) { if (ns == 4) TEO_GP_LAUNCH_S(OF, FV, 128, 3, 4, 1, false) else TEO_GP_LAUNCH_S(OF, FV, 128, 3, 3, 1, false) } \
         else if (bm == 128) TEO_GP_LAUNCH_W(OF, FV, 128, 4, 3, 1)                                                                 \
         else if (tn == 64) TEO_GP_LAUNCH_W(OF, FV, 64, 2, 4, 2)                                                                   \
         else if (ns == 4) TEO_GP_LAUNCH_W(OF, FV, 64, 4, 4, 2)                                                                    \
@@ -244,6 +247,7 @@ int gemm_pipe_launch(const void* A, const void* W, const void* bias, const void*
 #undef TEO_GP_LAUNCH_F
 #undef TEO_GP_LAUNCH_T
 #undef TEO_GP_LAUNCH_W
+#undef TEO_GP_LAUNCH_S
     note_kernel(bm == 128 ? (tn == 96 ? "gemm_pipe_128x96" : "gemm_pipe_128") : (tn == 64 ? "gemm_pipe_64x64" : (ns == 4 ? "gemm_pipe_64_r4" : "gemm_pipe_64")));
     TEO_LAUNCH_CHECK("gemm_mfma_bf16_pipe");
     return TEO_OK;

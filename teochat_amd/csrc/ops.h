@@ -93,7 +93,7 @@ int gemm_narrow_launch(const void* A, const void* W, const void* bias, const voi
 int gemm_quad_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool of32, bool f16, hipStream_t st);                 // gemm_quad.hip: 256 x 160 tiles, 4 waves
 int gemm_pipe_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
-                     int act, bool of32, bool f16, int bm, int tn, int ns, hipStream_t st);   // gemm_quad.hip: the same K loop on 64 x 64 / 64 x 128 / 128 x 128 tiles
+                     int act, bool of32, bool f16, int bm, int tn, int ns, hipStream_t st, bool swiglu = false);   // gemm_quad.hip: the same K loop on 64 x 64 / 64 x 128 / 128 x 128 tiles
 constexpr size_t GEMM_SK_SLAB_BYTES = (size_t)64 << 20;   // slab area of the stream-K workspaces (largest user: 256 x 256 KB)
 constexpr int GEMM_SK_FLAG_INTS = 1024;          // hand-off flags (<= 512 used) + the sticky error word
 constexpr int GEMM_SK_ERR_SLOT = GEMM_SK_FLAG_INTS - 1;   // set to 1 by a hand-off that timed out (results of that GEMM are invalid)

@@ -91,3 +91,48 @@ def test_every_tile_family_is_bitwise_the_plain_kernel_on_random_shapes(seed, dt
             assert torch.equal(got, want), (name, ran, M, N, K, extra, float((got.float() - want.float()).abs().max()))
     L.tune_reset()
     assert {"gemm_narrow_64", "gemm_narrow_128", "gemm_narrow_128w8", "gemm_pipe_64", "gemm_pipe_64_r4", "gemm_pipe_64x64", "gemm_pipe_128", "gemm_pipe_128x96", "gemm_quad_160", "gemm_quad_160_w4", "gemm_wide", "gemm_big", "gemm_mfma_64"} <= seen
+
+
+SWIGLU_FORCED = (("128x256", {"gemm_wide": 2, "gemm_big": 0, "gemm_sk": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128}, "gemm_wide"),
+                 ("256x256", {"gemm_big": 2, "gemm_big_hybrid": 0, "gemm_narrow": 0, "gemm_quad": 0, "gemm_bm": 128, "gemm_big_ragged": 0}, "gemm_big"),
+                 ("64x64 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 64, "gemm_narrow_pipe": 2, "gemm_pipe_bn": 64}, "gemm_pipe_64x64"),
+                 ("64x128 software-pipelined, ring of 4", {"gemm_narrow": 2, "gemm_narrow_bm": 64, "gemm_narrow_pipe": 2, "gemm_pipe_stages": 4}, "gemm_pipe_64_r4"),
+                 ("128x128 software-pipelined", {"gemm_narrow": 2, "gemm_narrow_bm": 128, "gemm_narrow_pipe": 2}, "gemm_pipe_128"),
+                 ("production dispatch", {}, None))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_swiglu_epilogue_is_bitwise_the_same_in_every_family_that_carries_it(dt):
+    """gate/up + SwiGLU (TEO_GEMM_SWIGLU16: W rows interleaved as 16 gate | 16 up, out[m, j] = silu(gate_j) * up_j; tf LlamaMLP reached from
+    llava_llama.py:88-99) on random shapes incl. the M <= 128 ones the small software-pipelined tiles take in production (round 6): every family
+    against the register-staged 128 x 128 kernel, bitwise, and that kernel against an fp64 evaluation."""
+    rng = random.Random(77 + (dt == torch.float16))
+    lib = G.lib()
+    seen = set()
+    for _ in range(8):
+        M = rng.choice([1, 5, 64, 65, 100, 128, 129, 200, 257, 640])
+        N = 32 * rng.choice([1, 2, 3, 5, 8, 9, 16, 33, 64, 172])
+        K = 64 * rng.choice([2, 3, 4, 8, 32, 64])
+        g = torch.Generator().manual_seed(M * 13 + N + K)
+        A = torch.randn(M, K, generator=g).to(dt).cuda()
+        W = (torch.randn(N, K, generator=g) * (2.0 / K ** 0.5)).to(dt).cuda()
+        _set(PLAIN)
+        want = G.gemm(A, W, flags=L.GEMM_SWIGLU16)
+        assert lib.teo_last_kernel().decode() == "gemm_mfma_128" and want.shape == (M, N // 2)
+        if M * N <= 70000:
+            full = A.double().cpu() @ W.double().cpu().t()
+            blk = full.view(M, N // 32, 2, 16)
+            ref = (torch.nn.functional.silu(blk[:, :, 0]) * blk[:, :, 1]).reshape(M, N // 2)
+            err = (want.double().cpu() - ref).abs()
+            tol = (2.0 ** (-7 if dt == torch.bfloat16 else -10)) * ref.abs() + 2e-3
+            assert bool((err <= tol).all()), (M, N, K, float(err.max()))
+        for name, knobs, kernel in SWIGLU_FORCED:
+            _set(knobs)
+            got = G.gemm(A, W, flags=L.GEMM_SWIGLU16)
+            ran = lib.teo_last_kernel().decode()
+            seen.add(ran)
+            if kernel is not None:
+                assert ran == kernel, (name, ran, M, N, K)
+            assert torch.equal(got, want), (name, ran, M, N, K, float((got.float() - want.float()).abs().max()))
+    L.tune_reset()
+    assert {"gemm_wide", "gemm_big", "gemm_pipe_64x64", "gemm_pipe_64_r4", "gemm_pipe_128"} <= seen, seen
