@@ -148,17 +148,27 @@ __global__ __launch_bounds__(256, 2) void attn_flash32_kernel(teo_attn_args a, i
         const int d = (wv * NPV + i) * 8 + (lane >> 3);
         vsrc[i] = VT + (long long)d * a.vt_rs + ((lane & 7) ^ ((d >> 1) & 7)) * 8;
     }
+    // The DMA pieces are INLINE ASM (round 6, late): to hipcc's wait pass a builtin LDS-DMA is a pending FLAT operation, and while one is pending
+    // every wait it derives for a fragment register is forced to lgkmcnt(0) -- in the steady state (pieces of the next tiles requested at the
+    // top of the iteration) each K / V^T fragment read was followed by a full wait in front of its MFMA, where the prologue (nothing pending)
+    // compiles to a 2-deep read pipeline with lgkmcnt(2) / (1).  Invisible to the pass, the pieces only add events to the in-order vmcnt queue
+    // (the loop's own vmcnt(0) is written in TEO_FA_PUBLISH); M0 = LDS byte address of the wave's 1 KB piece.
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem);
+#define TEO_FA_DMA16(GPTR, LDS_OFF)                                                                               \
+    {                                                                                                             \
+        const bf16_t* gp_ = (GPTR);                                                                               \
+        const unsigned la_ = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(LDS_OFF));                          \
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp_), "s"(la_) : "memory"); \
+    }
 #define TEO_FA_DMA_K(T_, SLOT)                                                                                        \
     _Pragma("unroll") for (int i = 0; i < NPK; ++i) {                                                             \
         /* rows past kv_len - 1 (only in the tile that crosses it) re-read the last row: their scores are masked */ \
         const unsigned back_ = (unsigned)max((T_) * 64 + krow[i] - (a.kv_len - 1), 0);                            \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(K + (koff[i] + (unsigned)(T_) * ktile - back_ * k_rs32)), \
-                                         (__attribute__((address_space(3))) void*)(smem + (SLOT) * KT_BYTES + (wv * NPK + i) * 1024), 16, 0, 0); \
+        TEO_FA_DMA16(K + (koff[i] + (unsigned)(T_) * ktile - back_ * k_rs32), (SLOT) * KT_BYTES + (wv * NPK + i) * 1024)      \
     }
 #define TEO_FA_DMA_V(T_, SLOT)                                                                                        \
     _Pragma("unroll") for (int i = 0; i < NPV; ++i)                                                               \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[i] + (T_) * 64),    \
-                                         (__attribute__((address_space(3))) void*)(smem + VBASE + (SLOT) * VT_BYTES + (wv * NPV + i) * 1024), 16, 0, 0);
+        TEO_FA_DMA16(vsrc[i] + (T_) * 64, VBASE + (SLOT) * VT_BYTES + (wv * NPV + i) * 1024)
     // the tile that crosses kv_len: keys >= kv_len of the V^T image are zeroed after it landed (P is 0 there, the cache row may hold anything)
 #define TEO_FA_TAIL_FIX(T_, SLOT)                                                                                 \
     if ((T_) < ntiles && (T_) * 64 + 64 > a.kv_len) {                                                             \
