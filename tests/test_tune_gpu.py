@@ -114,3 +114,40 @@ def test_nothing_outlives_a_released_block():
     L.tune_release()
     G.gemm(A, W)
     assert lib.teo_last_kernel().decode() == "gemm_pipe_64x64"       # 48 tiles of 64 x 64: the dispatch's own choice is the software-pipelined small tile
+
+
+@pytest.mark.parametrize("M,N,K,extra,want", [
+    (257, 1024, 4096, "bias_res", "gemm_pipe_64x64"),        # tower fc2 at T = 1: 5 x 16 = 80 tiles of 64 x 64
+    (514, 3072, 1024, "bias", "gemm_pipe_64x64"),            # tower qkv at T = 2: 432 tiles of 64 x 64, short K loop and wide N (limit 512)
+    (514, 4096, 1024, "bias_gelu", "gemm_narrow_64"),        # tower fc1 + GELU at T = 2: 576 / 288 tiles, short K with an activation -> the LDS-DMA tile stays
+    (1285, 1024, 4096, "bias_res", "gemm_pipe_64_r4"),       # tower fc2 at T = 5: 21 x 8 = 168 tiles of 64 x 128, long K -> ring of 4
+    (2056, 1024, 4096, "bias_res", "gemm_pipe_128x96"),      # tower fc2 at T = 8: 17 x 11 = 187 tiles of 128 x 96
+    (2056, 1024, 1024, "bias_res", "gemm_pipe_128x96"),      # tower out_proj at T = 8
+    (200, 4096, 4096, "res", "gemm_pipe_64x64"),             # LLaMA o at M <= 256
+    (638, 4096, 11008, "res", "gemm_pipe_128x96"),           # LLaMA down at C2's row count: 5 x 43 = 215 tiles
+    (900, 4096, 4096, "res", "gemm_pipe_128"),               # LLaMA o at M = 641 .. 1024
+    (100, 22016, 4096, "swiglu", "gemm_pipe_128"),           # gate/up + SwiGLU on a text-only prompt
+    (2168, 4096, 4096, "res", "gemm_quad_160"),              # C3: unchanged
+])
+def test_production_dispatch_takes_the_small_pipelined_tiles_where_round_six_measured_them_ahead(M, N, K, extra, want):
+    """The few-tile rule of gemm.hip (round 6, late; profiles/r06_pipe_candidates.txt): the tile is chosen for about one workgroup per CU.  Pins the
+    rule at the shapes the model produces (CLIP tower at T = 1 / 2 / 5 / 8: modeling_image.py:136-151; LLaMA o / down / gate-up: llava_llama.py:88-99)
+    and checks the result against the register-staged 128 x 128 kernel, bitwise."""
+    lib = G.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    W = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    swiglu = extra == "swiglu"
+    bias = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).cuda() if "bias" in extra else None
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda() if "res" in extra else None
+    kw = dict(bias=bias, res=res, act=L.ACT_GELU_ERF if "gelu" in extra else L.ACT_NONE, flags=L.GEMM_SWIGLU16 if swiglu else 0)
+    L.tune_reset()
+    got = G.gemm(A, W, **kw)
+    ran = lib.teo_last_kernel().decode()
+    for k, v in (("gemm_wide", 0), ("gemm_big", 0), ("gemm_sk", 0), ("gemm_narrow", 0), ("gemm_quad", 0), ("gemm_bm", 128)):
+        assert L.tune_set(k.encode(), v) == 0
+    ref = G.gemm(A, W, **kw)
+    assert lib.teo_last_kernel().decode() == "gemm_mfma_128"
+    L.tune_reset()
+    assert torch.equal(got, ref), (ran, float((got.float() - ref.float()).abs().max()))
+    assert ran == want, (ran, want, M, N, K)
