@@ -86,6 +86,8 @@ size_t teo_sizeof(const char* struct_name);
  *                   "gemm_quad" (256 x 160 tiles, hand-scheduled K loop with the accumulators in AGPRs, for problems that are one round of them: 0 off, 1 auto,
  *                   2 force), "gemm_quad_waves" (8: two waves per SIMD, the default; 4: one wave per SIMD with the whole register file), "gemm_fp8_wide" (0..3),
  *                   "gemm_fp8_big" (0..2) -- all bit-identical families
+ *   rope / caches : "rope_vt_fused" (prefill: RoPE + K append and V / V^T append as one launch where the 16-byte paths apply: 0 two launches, 1 one -- default;
+ *                   bit-identical)
  *   prefill attn  : "flash_order" (causal workgroup order of the flash kernel: 0 heavy-first, 1 second dispatch pass mirrored), "flash_pipe"
  *                   (software pipeline inside the wave: -1 auto = causal kernels, 0 one tile at a time, 1 wherever the form exists) --
  *                   same tiles, same arithmetic: bit-identical

@@ -205,8 +205,8 @@ int gemm_quad_launch(const void* A, const void* W, const void* bias, const void*
     return TEO_OK;
 }
 
-// The same K loop on the few-tile shapes' tiles (round 6): 64 x 64 and 64 x 128 (four waves of 32 x 32 / 32 x 64) and 128 x 128 (four waves of
-// 64 x 64), rings of 3 or 4 stages.  Why: where a launch has at most one or two workgroups per CU (LLaMA o / down below ~1000 rows, every tower
+// The same K loop on the few-tile shapes' tiles (round 6): 64 x 64 and 64 x 128 (four waves of 32 x 32 / 32 x 64), 128 x 96 and 128 x 128 (four waves
+// of 64 x 48 / 64 x 64), rings of 3 or 4 stages; the even-NI tiles also with the SwiGLU epilogue (gate/up at M <= 128).  Why: where a launch has at most one or two workgroups per CU (LLaMA o / down below ~1000 rows, every tower
 // GEMM at T <= 4, fc2 / out_proj at every T) a SIMD holds ONE wave, and gemm_narrow.hip's loop as hipcc schedules it is
 // ds_read x 4 -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, four times per K tile: the whole LDS latency is exposed four times (0.5 us per K tile of a
 // 64 x 128 tile alone on its CU; its 16 MFMAs are 0.1 us).  Here the reads of k-half 1 fly under the MFMAs of k-half 0 and the next tile's under
@@ -215,7 +215,7 @@ int gemm_quad_launch(const void* A, const void* W, const void* bias, const void*
 // 128 tiles of 64 x 64 it is 30 % faster (LLaMA o at M <= 256: 33.5 -> 29 (pipelined) -> 21 us; the tower's fc2 at T = 2: 31 -> 22 -> 15).
 // Same LDS image, fragment reads and k-ascending chain: bit-identical to every other family (tests/test_gemm_fuzz_gpu.py).
 // bm 64: tn 64 (ring of 4 = 64 KB: two per CU) or 128 (ring of 3 = 72 KB: two per CU; ring of 4 = 96 KB: one per CU, for launches of at most
-// one workgroup per CU with a long K loop); bm 128: tn 128, ring of 3 = 96 KB
+// one workgroup per CU with a long K loop); bm 128: tn 96 (ring of 3 = 84 KB or 4 = 112 KB) or 128 (ring of 3 = 96 KB): one per CU
 int gemm_pipe_launch(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K, int lda, int ldc,
                      int act, bool of32, bool f16, int bm, int tn, int ns, hipStream_t st, bool swiglu) {
     if (bm != 128) bm = 64;

@@ -51,14 +51,14 @@ __global__ void rope_kv_append_kernel(T* __restrict__ qkv, int ld, const int* __
 // bf16, head_dim % 16 == 0: one thread rotates 8 pairs (16-byte loads of both halves, 32-byte cos / sin rows) or copies
 // 2 x 16 bytes of V.  grid (S, ceil((heads + 2 kv_heads) * hd/16 / 256)); the V^T scatter is left to vt_append_kernel.
 template <bool F16>
-__global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(bf16_t* __restrict__ qkv, int ld, const int* __restrict__ positions,
-                                                                 const float* __restrict__ cs, const float* __restrict__ sn,
-                                                                 bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int past,
-                                                                 int S_max, int heads, int kv_heads, int hd, int copy_v) {
+__device__ __forceinline__ void rope_kv_append_vec_body(bf16_t* __restrict__ qkv, int ld, const int* __restrict__ positions,
+                                                        const float* __restrict__ cs, const float* __restrict__ sn,
+                                                        bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int past,
+                                                        int S_max, int heads, int kv_heads, int hd, int copy_v, int bx, int by) {
     // copy_v == 0 (round 5): the V rows are appended by vt_append_vec_kernel, which has them in hand for the V^T scatter anyway -- V is
     // read once per layer instead of twice
-    const int s = blockIdx.x, half = hd >> 1, tph = half >> 3;
-    const int t = blockIdx.y * 256 + threadIdx.x;
+    const int s = bx, half = hd >> 1, tph = half >> 3;
+    const int t = by * 256 + threadIdx.x;
     const int hh = t / tph, i0 = (t % tph) * 8;
     if (hh >= heads + (copy_v ? 2 : 1) * kv_heads) return;
     const int pos = positions ? positions[s] : past + s;
@@ -90,6 +90,13 @@ __global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(bf16_t* __restr
     *reinterpret_cast<uint4*>(dst + i0) = make_uint4(o1[0], o1[1], o1[2], o1[3]);
     *reinterpret_cast<uint4*>(dst + i0 + half) = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
+template <bool F16>
+__global__ __launch_bounds__(256) void rope_kv_append_vec_kernel(bf16_t* __restrict__ qkv, int ld, const int* __restrict__ positions,
+                                                                 const float* __restrict__ cs, const float* __restrict__ sn,
+                                                                 bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int past,
+                                                                 int S_max, int heads, int kv_heads, int hd, int copy_v) {
+    rope_kv_append_vec_body<F16>(qkv, ld, positions, cs, sn, kc, vc, past, S_max, heads, kv_heads, hd, copy_v, blockIdx.x, blockIdx.y);
+}
 
 // tiled V -> V^T append for long prefills: block = (64 positions, one kv head); 128-byte rows out
 template <typename T>
@@ -115,10 +122,10 @@ __global__ __launch_bounds__(256) void vt_append_kernel(const T* __restrict__ qk
 // bf16 variant with 16-byte global accesses on both sides: block = (64 positions, one kv head, 128 dims per pass).
 // Positions >= S inside the last 8-position store chunk are written as zeros (slots past the sequence end, rewritten by
 // whoever appends there).  Needs (past + s0) % 8 == 0 for the aligned 16-byte stores.
-__global__ __launch_bounds__(256) void vt_append_vec_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ vtc, int S,
-                                                            int past, int S_max, int v_off, int hd, bf16_t* __restrict__ vc) {
+__device__ __forceinline__ void vt_append_vec_body(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ vtc, int S,
+                                                   int past, int S_max, int v_off, int hd, bf16_t* __restrict__ vc, int bx, int by) {
     __shared__ bf16_t tile[64][136];                       // row stride 272 B: 16-byte aligned rows, column reads spread over banks
-    const int s0 = blockIdx.x * 64, hk = blockIdx.y;
+    const int s0 = bx * 64, hk = by;
     for (int d0 = 0; d0 < hd; d0 += 128) {
         const int dw = min(128, hd - d0), nc = dw >> 3;    // 16-byte chunks per row
         for (int id = threadIdx.x; id < 64 * nc; id += 256) {
@@ -142,6 +149,21 @@ __global__ __launch_bounds__(256) void vt_append_vec_kernel(const bf16_t* __rest
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void vt_append_vec_kernel(const bf16_t* __restrict__ qkv, int ld, bf16_t* __restrict__ vtc, int S,
+                                                            int past, int S_max, int v_off, int hd, bf16_t* __restrict__ vc) {
+    vt_append_vec_body(qkv, ld, vtc, S, past, S_max, v_off, hd, vc, blockIdx.x, blockIdx.y);
+}
+// ONE launch for both (round 6, late): the first n_rope workgroups rotate q / k and append K, the rest append V and scatter V^T -- the two halves
+// touch disjoint columns of the qkv rows and were two dependent launches of 6-13 us each per layer
+template <bool F16>
+__global__ __launch_bounds__(256) void rope_kv_vt_fused_kernel(bf16_t* __restrict__ qkv, int ld, const int* __restrict__ positions,
+                                                               const float* __restrict__ cs, const float* __restrict__ sn,
+                                                               bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ vtc, int S, int past,
+                                                               int S_max, int heads, int kv_heads, int hd, int rope_by, int n_rope, int vt_bx) {
+    const int b = blockIdx.x;
+    if (b < n_rope) rope_kv_append_vec_body<F16>(qkv, ld, positions, cs, sn, kc, vc, past, S_max, heads, kv_heads, hd, 0, b / rope_by, b % rope_by);
+    else vt_append_vec_body(qkv, ld, vtc, S, past, S_max, (heads + kv_heads) * hd, hd, vc, (b - n_rope) % vt_bx, (b - n_rope) / vt_bx);
 }
 
 int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, const float* sn, void* kc, void* vc,
@@ -167,6 +189,18 @@ int rope_kv_append(void* qkv, int ld, const int* positions, const float* cs, con
         const bool vvec = tiled_vt && hd % 8 == 0 && ld % 8 == 0 && past % 8 == 0 && S_max % 8 == 0 &&
                           ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(vtc)) & 15) == 0;
         const bool v_by_vt = vec && vvec && (reinterpret_cast<uintptr_t>(vc) & 15) == 0;
+        if (vec && v_by_vt && tune().rope_vt_fused != 0) {
+            const int nthr = (heads + kv_heads) * (hd / 16), rope_by = cdiv(nthr, 256), n_rope = S * rope_by, vt_bx = cdiv(S, 64);
+            const int grid = n_rope + vt_bx * kv_heads;
+            if (dtype == TEO_F16)
+                rope_kv_vt_fused_kernel<true><<<grid, 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, S, past, S_max,
+                                                                    heads, kv_heads, hd, rope_by, n_rope, vt_bx);
+            else
+                rope_kv_vt_fused_kernel<false><<<grid, 256, 0, st>>>((bf16_t*)qkv, ld, positions, cs, sn, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vtc, S, past, S_max,
+                                                                     heads, kv_heads, hd, rope_by, n_rope, vt_bx);
+            TEO_LAUNCH_CHECK("rope_kv_append");
+            return TEO_OK;
+        }
         if (vec) {
             const int nthr = (heads + (v_by_vt ? 1 : 2) * kv_heads) * (hd / 16);
             if (dtype == TEO_F16)

@@ -28,6 +28,7 @@
     X(gemm_narrow_waves, 0, (v == 0 || v == 4 || v == 8))                                                    \
     X(gemm_narrow_pipe, 1, (v >= 0 && v <= 2))                                                               \
     X(gemm_pipe_stages, 0, (v == 0 || v == 3 || v == 4))                                                    \
+    X(rope_vt_fused, 1, (v == 0 || v == 1))                                                                  \
     X(gemm_pipe_bn, 0, (v == 0 || v == 64 || v == 96 || v == 128))                                                 \
     X(gemm_quad, 1, (v >= 0 && v <= 2))                                                                      \
     X(gemm_quad_waves, 8, (v == 4 || v == 8))                                                                \

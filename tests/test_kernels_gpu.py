@@ -308,6 +308,38 @@ def test_rope_kv_append(dtype, S, past):
     assert float(kc[:, :past].abs().sum()) == 0 and float(kc[:, past + S:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,past", [(300, 0), (129, 64), (16, 8)])
+def test_rope_kv_vt_one_launch_equals_the_two_launches(dtype, S, past):
+    """Round 6: RoPE + K append and V / V^T append run as ONE launch (`rope_vt_fused`, default on) where the 16-byte paths apply; same kernels' bodies,
+    so q (in place), the K / V caches and the V^T cache must equal the two-launch form bit for bit -- at LLaMA's head geometry, ragged row counts
+    and a non-zero past (apply_rotary_pos_emb + cache append, tf LlamaAttention.forward reached from llava_llama.py:88-99)."""
+    from teochat_amd.engine import rope_tables
+    H, Hk, hd, S_max = 32, 32, 128, 512
+    ld = (H + 2 * Hk) * hd
+    qkv = rnd(S, ld, seed=S + past).to(dtype)
+    cs, sn = rope_tables(hd, 10000.0, S_max)
+    d_pos, d_cs, d_sn = torch.arange(past, past + S).to(torch.int32).cuda(), cs.cuda(), sn.cuda()
+    outs = []
+    try:
+        for knob in (1, 0):
+            assert L.tune_set(b"rope_vt_fused", knob) == 0
+            d_qkv = qkv.clone().cuda()
+            kc = torch.zeros(Hk, S_max, hd, dtype=dtype, device="cuda")
+            vc, vtc = torch.zeros_like(kc), torch.zeros(Hk, hd, S_max, dtype=dtype, device="cuda")
+            L.check(G.lib().teo_rope_kv_append(G.p(d_qkv), ld, G.p(d_pos), G.p(d_cs), G.p(d_sn), G.p(kc), G.p(vc), G.p(vtc), S, past, S_max, H, Hk, hd,
+                                               G.DT[dtype], G.stream()), "rope")
+            torch.cuda.synchronize()
+            outs.append((d_qkv, kc, vc, vtc))
+    finally:
+        L.tune_reset()
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    v = qkv[:, (H + Hk) * hd:].view(S, Hk, hd)
+    assert torch.equal(outs[0][2][:, past:past + S].cpu().transpose(0, 1), v) and torch.equal(outs[0][3][:, :, past:past + S].cpu().permute(2, 0, 1), v)
+    assert float(outs[0][1][:, :past].float().abs().sum()) == 0 and bool((outs[0][0][:, :H * hd] != qkv.cuda()[:, :H * hd]).any())
+
+
 # ---------------------------------------------------------------------------------------------- data movement
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embed_splice_bit_exact(dtype):
